@@ -1,0 +1,93 @@
+"""ctypes binding of libcatchhip.so (include/catchhip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no
+GPU is visible, every entry point raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcatchhip.so")
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+c_vp = ctypes.c_void_p
+c_vpp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); must list every symbol declared in catchhip.h
+PROTOTYPES = {
+    "catchhip_abi_version": (ctypes.c_int, []),
+    "catchhip_last_error": (ctypes.c_char_p, []),
+    "catchhip_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "catchhip_ctx_create": (ctypes.c_int, [ctypes.c_int, c_vpp]),
+    "catchhip_ctx_destroy": (ctypes.c_int, [c_vp]),
+    "catchhip_ctx_sync": (ctypes.c_int, [c_vp]),
+    "catchhip_ctx_last_kernel_ms": (ctypes.c_int, [
+        c_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), c_i64p]),
+    "catchhip_targets_create": (ctypes.c_int, [
+        c_vp, c_u8p, c_i64p, c_i32p, ctypes.c_int64, ctypes.c_int32, c_vpp]),
+    "catchhip_targets_destroy": (ctypes.c_int, [c_vp]),
+    "catchhip_probes_create": (ctypes.c_int, [
+        c_vp, c_u8p, c_i64p, ctypes.c_int64, c_i32p, c_i32p, c_i32p,
+        ctypes.c_int64, ctypes.c_int32, c_vpp]),
+    "catchhip_probes_destroy": (ctypes.c_int, [c_vp]),
+    "catchhip_cover_scan": (ctypes.c_int, [
+        c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_int32, c_vpp, c_i64p]),
+    "catchhip_rows_fetch": (ctypes.c_int, [
+        c_vp, c_vp, c_i32p, c_i32p, c_i64p, c_i64p]),
+    "catchhip_rows_from_host": (ctypes.c_int, [
+        c_vp, c_i32p, c_i32p, c_i64p, c_i64p, ctypes.c_int64, c_i64p,
+        ctypes.c_int32, c_vpp]),
+    "catchhip_rows_destroy": (ctypes.c_int, [c_vp]),
+    "catchhip_tolerant_bp": (ctypes.c_int, [
+        c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+        c_i64p]),
+    "catchhip_setcover_greedy": (ctypes.c_int, [
+        c_vp, c_vp, ctypes.c_int64, c_i64p, c_f64p, c_i64p, c_i64p]),
+    "catchhip_comm_unique_id": (ctypes.c_int, [c_u8p]),
+    "catchhip_comm_init": (ctypes.c_int, [
+        c_vp, c_u8p, ctypes.c_int32, ctypes.c_int32]),
+    "catchhip_comm_destroy": (ctypes.c_int, [c_vp]),
+    "catchhip_ndf_hamming": (ctypes.c_int, [
+        c_vp, c_u8p, ctypes.c_int64, ctypes.c_int32, c_i32p, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_int32, c_u8p]),
+}
+
+_lib = None
+
+
+class CatchHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libcatchhip.so (raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CatchHipError(
+                "libcatchhip.so is not built (%s); run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C catch_amd/csrc`.  There is no CPU fallback."
+                % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().catchhip_last_error()
+        msg = msg.decode("utf-8", "replace") if msg else ""
+        if rc == -1:
+            raise ValueError("catchhip: " + msg)
+        if rc == -4:
+            raise IndexError("catchhip: " + msg)
+        raise CatchHipError("catchhip error %d: %s" % (rc, msg))

@@ -1,0 +1,332 @@
+// Context, error handling, input upload and bit-plane packing.
+#include <stdarg.h>
+
+#include "internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void chip_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *catchhip_last_error(void) { return g_err; }
+extern "C" int catchhip_abi_version(void) { return CATCHHIP_ABI_VERSION; }
+
+extern "C" int catchhip_device_count(int *count) {
+    ARG_CHECK(count != nullptr);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        chip_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return CATCHHIP_EHIP;
+    }
+    *count = n;
+    return 0;
+}
+
+extern "C" int catchhip_ctx_create(int device, catchhip_ctx **out) {
+    ARG_CHECK(out != nullptr);
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    catchhip_ctx *c = new catchhip_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        chip_set_error("hipStreamCreate failed");
+        return CATCHHIP_EHIP;
+    }
+    for (int i = 0; i < 2 * NPHASE; ++i) (void)hipEventCreate(&c->ev[i]);
+    if (hipHostMalloc((void **)&c->h_pin, 64 * sizeof(u64), hipHostMallocDefault) != hipSuccess) {
+        chip_set_error("hipHostMalloc failed");
+        delete c;
+        return CATCHHIP_ENOMEM;
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" int catchhip_ctx_destroy(catchhip_ctx *c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)catchhip_comm_destroy(c);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 2 * NPHASE; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+extern "C" int catchhip_ctx_sync(catchhip_ctx *c) {
+    ARG_CHECK(c != nullptr);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int catchhip_ctx_last_kernel_ms(catchhip_ctx *c, int phase, double *ms, i64 *launches) {
+    ARG_CHECK(c != nullptr && phase >= 0 && phase < NPHASE);
+    if (ms) *ms = c->phase_ms[phase];
+    if (launches) *launches = c->phase_launches[phase];
+    return 0;
+}
+
+// ------------------------------------------------------------------------
+// bit-plane packing: 32 bases per u32 word, 3 planes (code bit 0, 1, 2) with
+// A=0 C=1 G=2 T=3 other(N)=4.  Base i of a stream lives in bit (i & 31) of
+// word (i >> 5).  One wavefront packs 64 bases per step with three ballots.
+// ------------------------------------------------------------------------
+__device__ __forceinline__ u32 dna_code(u8 c) {
+    return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+}
+
+// targets: SoA planes (plane b at planes + b*nwords)
+__global__ void __launch_bounds__(256)
+pack_targets_kernel(const u8 *__restrict__ bytes, i64 n, u32 *__restrict__ planes, i64 nwords) {
+    const int lane = threadIdx.x & 63;
+    const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
+    const i64 nchunks = (n + 63) >> 6;
+    for (i64 ch = wave; ch < nchunks; ch += nwaves) {
+        i64 i = ch * 64 + lane;
+        u32 c = (i < n) ? dna_code(bytes[i]) : 0u;
+        u64 b0 = __ballot(c & 1u), b1 = __ballot(c & 2u), b2 = __ballot(c & 4u);
+        if (lane < 6) {
+            u64 b = lane < 2 ? b0 : (lane < 4 ? b1 : b2);
+            u32 w = (lane & 1) ? (u32)(b >> 32) : (u32)b;
+            i64 wi = ch * 2 + (lane & 1);
+            if (wi < nwords) planes[(size_t)(lane >> 1) * nwords + wi] = w;
+        }
+    }
+}
+
+// probes: [probe][word][4] (x = plane0, y = plane1, z = plane2, w = 0), one
+// wavefront per probe (probes are short: L <= 256)
+__global__ void __launch_bounds__(256)
+pack_probes_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, i64 nprobes,
+                   int pwords, u32 *__restrict__ planes) {
+    const int lane = threadIdx.x & 63;
+    const i64 p = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (p >= nprobes) return;
+    const u32 o = probe_off[p];
+    const int L = (int)(probe_off[p + 1] - o);
+    for (int ch = 0; ch * 64 < L; ++ch) {
+        int i = ch * 64 + lane;
+        u32 c = (i < L) ? dna_code(bytes[o + i]) : 0u;
+        u64 b0 = __ballot(c & 1u), b1 = __ballot(c & 2u), b2 = __ballot(c & 4u);
+        if (lane < 8) {
+            int half = lane >> 2, comp = lane & 3;
+            int wi = ch * 2 + half;
+            u64 b = comp == 0 ? b0 : (comp == 1 ? b1 : (comp == 2 ? b2 : 0ull));
+            u32 w = half ? (u32)(b >> 32) : (u32)b;
+            if (wi < pwords) planes[((size_t)p * pwords + wi) * 4 + comp] = w;
+        }
+    }
+}
+
+static void alphabet_scan(const u8 *b, i64 n, bool *dna5, bool *has_n) {
+    bool present[256] = {false};
+    for (i64 i = 0; i < n; ++i) present[b[i]] = true;
+    *dna5 = true;
+    *has_n = false;
+    for (int c = 0; c < 256; ++c) {
+        if (!present[c]) continue;
+        if (c == 'A' || c == 'C' || c == 'G' || c == 'T') continue;
+        *has_n = true;
+        if (c != 'N') *dna5 = false;
+    }
+}
+
+extern "C" int catchhip_targets_create(catchhip_ctx *ctx, const u8 *bytes, const i64 *seq_off,
+                                       const i32 *seq_genome, i64 nseq, i32 ngenomes,
+                                       catchhip_targets **out) {
+    ARG_CHECK(ctx && out && seq_off && nseq >= 0 && ngenomes >= 0);
+    ARG_CHECK(nseq == 0 || (bytes != nullptr && seq_genome != nullptr) || seq_off[nseq] == 0);
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    i64 total = seq_off[nseq];
+    ARG_CHECK(seq_off[0] == 0 && total >= 0);
+    if (total >= ((i64)1 << 32) - 4096) {
+        chip_set_error("targets larger than 2^32 bases per group are not supported");
+        return CATCHHIP_EINVAL;
+    }
+    catchhip_targets *t = new catchhip_targets();
+    t->ctx = ctx;
+    t->total = total;
+    t->nseq = nseq;
+    t->ngenomes = ngenomes;
+    t->h_seq_off.assign(seq_off, seq_off + nseq + 1);
+    t->h_seq_genome.assign(seq_genome, seq_genome + nseq);
+    t->min_seq_len = nseq ? ((i64)1 << 62) : 0;
+    std::vector<u32> so32((size_t)nseq + 1);
+    for (i64 i = 0; i <= nseq; ++i) so32[i] = (u32)seq_off[i];
+    t->h_genome_off.assign((size_t)ngenomes + 1, -1);
+    i32 prev = -1;
+    for (i64 i = 0; i < nseq; ++i) {
+        i64 len = seq_off[i + 1] - seq_off[i];
+        i32 g = seq_genome[i];
+        if (len < 0 || g < prev || g < 0 || g >= ngenomes) {
+            delete t;
+            chip_set_error("targets: bad seq_off / seq_genome (must be non-decreasing)");
+            return CATCHHIP_EINVAL;
+        }
+        if (len < t->min_seq_len) t->min_seq_len = len;
+        if (g != prev) t->h_genome_off[g] = seq_off[i];
+        prev = g;
+    }
+    // genomes without sequences get an empty range
+    t->h_genome_off[ngenomes] = total;
+    for (i32 g = ngenomes - 1; g >= 0; --g)
+        if (t->h_genome_off[g] < 0) t->h_genome_off[g] = t->h_genome_off[g + 1];
+    std::vector<u32> go32((size_t)ngenomes + 1);
+    for (i32 g = 0; g <= ngenomes; ++g) go32[g] = (u32)t->h_genome_off[g];
+    alphabet_scan(bytes, total, &t->dna5, &t->has_n);
+
+    int rc = 0;
+    do {
+        if ((rc = t->bytes.alloc((size_t)total + 256))) break;
+        if ((rc = t->seq_off.alloc((size_t)nseq + 1))) break;
+        if ((rc = t->seq_genome.alloc((size_t)nseq))) break;
+        if ((rc = t->genome_off.alloc((size_t)ngenomes + 1))) break;
+        hipStream_t s = ctx->stream;
+        if (hipMemsetAsync(t->bytes.p, 0, (size_t)total + 256, s) != hipSuccess ||
+            (total && hipMemcpyAsync(t->bytes.p, bytes, (size_t)total, hipMemcpyHostToDevice, s) != hipSuccess) ||
+            hipMemcpyAsync(t->seq_off.p, so32.data(), sizeof(u32) * (nseq + 1), hipMemcpyHostToDevice, s) != hipSuccess ||
+            (nseq && hipMemcpyAsync(t->seq_genome.p, seq_genome, sizeof(i32) * nseq, hipMemcpyHostToDevice, s) != hipSuccess) ||
+            hipMemcpyAsync(t->genome_off.p, go32.data(), sizeof(u32) * (ngenomes + 1), hipMemcpyHostToDevice, s) != hipSuccess) {
+            chip_set_error("targets upload failed");
+            rc = CATCHHIP_EHIP;
+            break;
+        }
+        if (t->dna5) {
+            // room for a whole scan tile of overhang beyond the last base
+            t->nwords = (total + 8192) / 32 + 64;
+            if ((rc = t->planes.alloc((size_t)t->nwords * 3))) break;
+            if (hipMemsetAsync(t->planes.p, 0, sizeof(u32) * t->nwords * 3, s) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
+            if (total) {
+                i64 chunks = (total + 63) / 64;
+                unsigned blocks = (unsigned)(chunks < 4 * 2048 ? div_up(chunks, 4) : 2048);
+                hipLaunchKernelGGL(pack_targets_kernel, dim3(blocks), dim3(256), 0, s, t->bytes.p, total,
+                                   t->planes.p, t->nwords);
+            }
+        }
+        if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
+            chip_set_error("targets pack failed");
+            rc = CATCHHIP_EHIP;
+            break;
+        }
+    } while (0);
+    if (rc) { delete t; return rc; }
+    *out = t;
+    return 0;
+}
+
+extern "C" int catchhip_targets_destroy(catchhip_targets *t) {
+    if (t) { (void)hipSetDevice(t->ctx->device); delete t; }
+    return 0;
+}
+
+extern "C" int catchhip_probes_create(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off,
+                                      i64 nprobes, const i32 *set_id, const i32 *ent_probe,
+                                      const i32 *ent_pos, i64 nent, i32 k, catchhip_probes **out) {
+    ARG_CHECK(ctx && out && probe_off && nprobes >= 0 && nent >= 0);
+    ARG_CHECK(nprobes == 0 || (bytes && set_id));
+    ARG_CHECK(nent == 0 || (ent_probe && ent_pos && k > 0));
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    i64 total = probe_off[nprobes];
+    ARG_CHECK(probe_off[0] == 0 && total >= 0 && total < ((i64)1 << 31));
+    catchhip_probes *p = new catchhip_probes();
+    p->ctx = ctx;
+    p->nprobes = nprobes;
+    p->total = total;
+    p->nent = nent;
+    p->k = k;
+    p->L = nprobes ? (i32)(probe_off[1] - probe_off[0]) : 0;
+    std::vector<u32> po32((size_t)nprobes + 1);
+    for (i64 i = 0; i <= nprobes; ++i) po32[i] = (u32)probe_off[i];
+    for (i64 i = 0; i < nprobes; ++i) {
+        i64 len = probe_off[i + 1] - probe_off[i];
+        if (set_id[i] < 0) { delete p; chip_set_error("probes: negative set id"); return CATCHHIP_EINVAL; }
+        if (set_id[i] > p->max_set_id) p->max_set_id = set_id[i];
+        if (len <= 0) { delete p; chip_set_error("probes: empty probe"); return CATCHHIP_EINVAL; }
+        if (len != p->L) p->L = -1;
+    }
+    // anchors must lie inside their probe
+    std::vector<i32> per_probe((size_t)nprobes, 0);
+    bool pigeon = (p->L > 0 && k > 0 && p->L % k == 0);
+    for (i64 e = 0; e < nent; ++e) {
+        i32 q = ent_probe[e], a = ent_pos[e];
+        if (q < 0 || q >= nprobes || a < 0 || a + k > probe_off[q + 1] - probe_off[q]) {
+            delete p;
+            chip_set_error("probes: anchor %lld out of range", (long long)e);
+            return CATCHHIP_EINVAL;
+        }
+        if (pigeon) {
+            if (a % k != 0) pigeon = false;
+            else per_probe[q]++;
+        }
+    }
+    if (pigeon) {
+        // unique entries + every multiple of k present <=> count == L/k each
+        i32 want = p->L / k;
+        for (i64 i = 0; i < nprobes && pigeon; ++i)
+            if (per_probe[i] != want) pigeon = false;
+        if (nent != (i64)want * nprobes) pigeon = false;
+    }
+    p->pigeonhole = pigeon && nprobes > 0;
+    alphabet_scan(bytes, total, &p->dna5, &p->has_n);
+
+    int rc = 0;
+    do {
+        hipStream_t s = ctx->stream;
+        if ((rc = p->bytes.alloc((size_t)total + 256))) break;
+        if ((rc = p->probe_off.alloc((size_t)nprobes + 1))) break;
+        if ((rc = p->set_id.alloc((size_t)nprobes))) break;
+        if ((rc = p->ent_probe.alloc((size_t)nent))) break;
+        if ((rc = p->ent_pos.alloc((size_t)nent))) break;
+        if (hipMemsetAsync(p->bytes.p, 0, (size_t)total + 256, s) != hipSuccess ||
+            (total && hipMemcpyAsync(p->bytes.p, bytes, (size_t)total, hipMemcpyHostToDevice, s) != hipSuccess) ||
+            hipMemcpyAsync(p->probe_off.p, po32.data(), sizeof(u32) * (nprobes + 1), hipMemcpyHostToDevice, s) != hipSuccess ||
+            (nprobes && hipMemcpyAsync(p->set_id.p, set_id, sizeof(i32) * nprobes, hipMemcpyHostToDevice, s) != hipSuccess) ||
+            (nent && hipMemcpyAsync(p->ent_probe.p, ent_probe, sizeof(i32) * nent, hipMemcpyHostToDevice, s) != hipSuccess) ||
+            (nent && hipMemcpyAsync(p->ent_pos.p, ent_pos, sizeof(i32) * nent, hipMemcpyHostToDevice, s) != hipSuccess)) {
+            chip_set_error("probes upload failed");
+            rc = CATCHHIP_EHIP;
+            break;
+        }
+        if (p->dna5 && p->L > 0 && p->L <= 256) {
+            p->pwords = (p->L + 31) / 32;
+            size_t nw = (size_t)nprobes * p->pwords * 4;
+            if ((rc = p->planes.alloc(nw + 1024))) break;
+            if (hipMemsetAsync(p->planes.p, 0, sizeof(u32) * (nw + 1024), s) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
+            unsigned blocks = (unsigned)div_up(nprobes, 4);
+            hipLaunchKernelGGL(pack_probes_kernel, dim3(blocks), dim3(256), 0, s, p->bytes.p, p->probe_off.p,
+                               nprobes, p->pwords, p->planes.p);
+        }
+        if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
+            chip_set_error("probes pack failed");
+            rc = CATCHHIP_EHIP;
+            break;
+        }
+    } while (0);
+    if (rc) { delete p; return rc; }
+    *out = p;
+    return 0;
+}
+
+extern "C" int catchhip_probes_destroy(catchhip_probes *p) {
+    if (p) { (void)hipSetDevice(p->ctx->device); delete p; }
+    return 0;
+}
+
+extern "C" int catchhip_rows_destroy(catchhip_rows *r) {
+    if (r) { (void)hipSetDevice(r->ctx->device); delete r; }
+    return 0;
+}

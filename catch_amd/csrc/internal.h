@@ -1,0 +1,188 @@
+// Internal declarations shared by the translation units of libcatchhip.so.
+// gfx950 (MI355X, CDNA4) only: 64-lane wavefronts are assumed throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/catchhip.h"
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+#define WAVE 64
+
+void chip_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                         \
+    do {                                                                      \
+        hipError_t e__ = (expr);                                              \
+        if (e__ != hipSuccess) {                                              \
+            chip_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,      \
+                           hipGetErrorString(e__));                           \
+            return CATCHHIP_EHIP;                                             \
+        }                                                                     \
+    } while (0)
+
+#define TRY(expr)                                                             \
+    do {                                                                      \
+        int r__ = (expr);                                                     \
+        if (r__ != 0) return r__;                                             \
+    } while (0)
+
+#define ARG_CHECK(cond)                                                       \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            chip_set_error("%s:%d: invalid argument: %s", __FILE__, __LINE__, \
+                           #cond);                                            \
+            return CATCHHIP_EINVAL;                                           \
+        }                                                                     \
+    } while (0)
+
+// Device buffer owning a hipMalloc'd region (freed in the destructor).
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int alloc(size_t count) {
+        release();
+        n = count;
+        size_t bytes = (count ? count : 1) * sizeof(T);
+        hipError_t e = hipMalloc((void **)&p, bytes);
+        if (e != hipSuccess) {
+            p = nullptr;
+            chip_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+            return CATCHHIP_ENOMEM;
+        }
+        return 0;
+    }
+    // grow (content not preserved)
+    int reserve(size_t count) {
+        if (count <= n && p) return 0;
+        return alloc(count);
+    }
+    void swap(DevBuf &o) {
+        T *tp = p; p = o.p; o.p = tp;
+        size_t tn = n; n = o.n; o.n = tn;
+    }
+};
+
+enum { PHASE_SCAN = 0, PHASE_ROWS = 1, PHASE_GREEDY = 2, PHASE_NDF = 3, NPHASE = 4 };
+
+struct catchhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2 * NPHASE] = {};
+    double phase_ms[NPHASE] = {};
+    i64 phase_launches[NPHASE] = {};
+    // pinned staging word(s) for small device->host reads
+    u64 *h_pin = nullptr;
+    // RCCL (optional)
+    void *comm = nullptr;
+    int nranks = 1, rank = 0;
+    int num_cus = 256;
+};
+
+struct catchhip_targets {
+    catchhip_ctx *ctx = nullptr;
+    i64 total = 0;    // total bases (concatenated)
+    i64 nseq = 0;
+    i32 ngenomes = 0;
+    i64 min_seq_len = 0;
+    bool dna5 = false;   // alphabet subset of {A,C,G,T,N}
+    bool has_n = false;  // contains a symbol other than A,C,G,T
+    DevBuf<u8> bytes;        // raw characters
+    DevBuf<u32> seq_off;     // nseq+1, global offsets (u32: total < 2^32)
+    DevBuf<i32> seq_genome;  // nseq
+    DevBuf<u32> genome_off;  // ngenomes+1 global offset of each genome's first base
+    i64 nwords = 0;          // 32-base words per plane (+ padding)
+    DevBuf<u32> planes;      // 3 planes, SoA: plane b at planes + b*nwords
+    std::vector<i64> h_seq_off;
+    std::vector<i32> h_seq_genome;
+    std::vector<i64> h_genome_off;
+};
+
+struct catchhip_probes {
+    catchhip_ctx *ctx = nullptr;
+    i64 nprobes = 0;
+    i64 total = 0;
+    i64 nent = 0;
+    i32 k = 0;
+    i32 L = 0;            // common probe length, or -1 if lengths differ
+    bool dna5 = false;
+    bool has_n = false;
+    bool pigeonhole = false;  // anchors are exactly {0,k,2k,..,L-k} for every probe
+    i64 max_set_id = 0;
+    DevBuf<u8> bytes;
+    DevBuf<u32> probe_off;   // nprobes+1
+    DevBuf<i32> set_id;      // nprobes
+    DevBuf<i32> ent_probe, ent_pos;
+    i32 pwords = 0;          // 32-base words per probe (ceil(L/32))
+    DevBuf<u32> planes;      // [probe][plane(3)][pwords]
+};
+
+// rows: cover intervals in GLOBAL coordinates of a targets object
+struct catchhip_rows {
+    catchhip_ctx *ctx = nullptr;
+    i64 n = 0;
+    i64 total = 0;       // size of the global coordinate space
+    i32 ngenomes = 0;
+    DevBuf<i32> set_id;
+    DevBuf<i32> univ;
+    DevBuf<u32> gs, ge;
+    DevBuf<u32> genome_off;  // ngenomes+1
+    std::vector<i64> h_genome_off;
+};
+
+// ---- timing helpers -----------------------------------------------------
+struct PhaseTimer {
+    catchhip_ctx *c;
+    int phase;
+    PhaseTimer(catchhip_ctx *ctx, int ph) : c(ctx), phase(ph) {
+        c->phase_launches[ph] = 0;
+        c->phase_ms[ph] = 0.0;
+        (void)hipEventRecord(c->ev[2 * ph], c->stream);
+    }
+    void launch(i64 k = 1) { c->phase_launches[phase] += k; }
+    // records the stop event; call finish() after a stream sync to read it
+    void stop() { (void)hipEventRecord(c->ev[2 * phase + 1], c->stream); }
+    void finish() {
+        float ms = 0.f;
+        (void)hipEventSynchronize(c->ev[2 * phase + 1]);
+        if (hipEventElapsedTime(&ms, c->ev[2 * phase], c->ev[2 * phase + 1]) == hipSuccess)
+            c->phase_ms[phase] = ms;
+    }
+};
+
+// ---- device primitives (primitives.hip) ---------------------------------
+// exclusive prefix sum of n u32 values (in place allowed: out may equal in);
+// if total != nullptr, *total (device u64) receives the grand total.
+int chip_exclusive_scan_u32(catchhip_ctx *ctx, const u32 *in, u32 *out, i64 n,
+                            DevBuf<u32> &tmp);
+// LSD radix sort of (u64 key, u32 value) pairs on bits [0, key_bits).
+// Result ends in keys/vals (the alt buffers are scratch of the same size).
+int chip_radix_sort_pairs(catchhip_ctx *ctx, DevBuf<u64> &keys, DevBuf<u64> &keys_alt,
+                          DevBuf<u32> &vals, DevBuf<u32> &vals_alt, i64 n, int key_bits);
+
+static inline int ceil_log2_u64(u64 x) {
+    int b = 0;
+    while (b < 64 && ((u64)1 << b) < x) ++b;
+    return b;
+}
+static inline i64 div_up(i64 a, i64 b) { return (a + b - 1) / b; }

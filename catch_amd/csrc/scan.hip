@@ -1,0 +1,663 @@
+// K1: probe -> target coverage scan.
+//
+//  * scan_fast_kernel: the tiled Hamming kernel.  Valid when every probe has
+//    the same length L, anchors are the pigeonhole anchors {0,k,..,L-k} with
+//    L/k > mismatches, lcf_thres == L, island == 0 and every target sequence
+//    is at least L long: then a probe covers offset o iff
+//    Hamming(probe, seq[o:o+L]) <= mismatches (character equality, N == N),
+//    and the cover range is exactly (o, o+L).  Targets and probes are 3
+//    bit-planes of 32 bases per word; each lane owns OPL offsets and keeps
+//    their L-base windows in VGPRs, a probe tile is staged in LDS and read
+//    with wave-uniform (broadcast) ds_read_b128, mismatches are counted with
+//    XOR/OR + v_bcnt, and a wave skips a probe after the first 32 bases when
+//    no lane can still be within the mismatch budget (__ballot).
+//  * general path (any alphabet, any anchors, truncated alignments,
+//    lcf_thres < L, island): seed join (hash every target k-mer, binary
+//    search in the sorted anchor-hash table) + one lane per seed hit that
+//    evaluates the reference's cover function on the raw bytes.
+//  * rows: cover_extension / clip / (set, start) radix sort / merge.
+#include <algorithm>
+
+#include "internal.h"
+
+// ------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------
+// index s with off[s] <= x < off[s+1]  (off has n+1 entries, off[0] = 0)
+__device__ __forceinline__ u32 find_segment(const u32 *__restrict__ off, u32 n, u32 x) {
+    u32 lo = 0, hi = n;  // answer in [lo, hi)
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (off[mid] <= x) lo = mid; else hi = mid;
+    }
+    // skip empty segments: off[lo] <= x and we need x < off[lo+1]
+    while (lo + 1 < n && off[lo + 1] <= x) ++lo;
+    return lo;
+}
+
+struct HitBuf {
+    u32 *a;      // probe (unique index)
+    u32 *b;      // global start
+    u32 *c;      // global end (general path) -- may be null in fast path
+    u32 *count;  // device counter
+    u32 cap;
+};
+
+// ------------------------------------------------------------------------
+// fast kernel
+// ------------------------------------------------------------------------
+#define SF_THREADS 256
+#define SF_OPL 4                       // offsets per lane
+#define SF_TILE (SF_THREADS * SF_OPL)  // offsets per workgroup
+#define SF_PT 256                      // probes per LDS stage
+
+template <int NW, bool USE_N>
+__global__ void __launch_bounds__(SF_THREADS)
+scan_fast_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total,
+                 const u32 *__restrict__ seq_off, u32 nseq,
+                 const uint4 *__restrict__ pplanes, u32 nprobes, u32 probes_per_block,
+                 int L, int mm, u32 tailmask, HitBuf hb) {
+    __shared__ uint4 lds[SF_PT * NW];
+    const int tid = threadIdx.x;
+    const u32 tile0 = blockIdx.x * SF_TILE;
+    const u32 p_begin = blockIdx.y * probes_per_block;
+    const u32 p_end = min(nprobes, p_begin + probes_per_block);
+
+    // L-base windows of this lane's offsets, 3 planes x NW words each
+    u32 T0[SF_OPL][NW], T1[SF_OPL][NW], T2[SF_OPL][NW];
+#pragma unroll
+    for (int w = 0; w < SF_OPL; ++w) {
+        u32 o = tile0 + w * SF_THREADS + tid;
+        u32 wi = o >> 5, sh = o & 31;
+        const u32 *p0 = tplanes + wi, *p1 = tplanes + nwords + wi, *p2 = tplanes + 2 * nwords + wi;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            T0[w][j] = __builtin_amdgcn_alignbit(p0[j + 1], p0[j], sh);
+            T1[w][j] = __builtin_amdgcn_alignbit(p1[j + 1], p1[j], sh);
+            if (USE_N) T2[w][j] = __builtin_amdgcn_alignbit(p2[j + 1], p2[j], sh);
+            else T2[w][j] = 0;
+        }
+    }
+
+    for (u32 ps = p_begin; ps < p_end; ps += SF_PT) {
+        const u32 cnt = min((u32)SF_PT, p_end - ps);
+        __syncthreads();
+        for (u32 i = tid; i < cnt * NW; i += SF_THREADS) lds[i] = pplanes[(size_t)ps * NW + i];
+        __syncthreads();
+
+        for (u32 q = 0; q < cnt; ++q) {
+            const uint4 q0 = lds[q * NW];
+            u32 c[SF_OPL];
+            bool any = false;
+#pragma unroll
+            for (int w = 0; w < SF_OPL; ++w) {
+                u32 x = (T0[w][0] ^ q0.x) | (T1[w][0] ^ q0.y);
+                if (USE_N) x |= (T2[w][0] ^ q0.z);
+                if (NW == 1) x &= tailmask;
+                c[w] = __popc(x);
+                any |= (c[w] <= (u32)mm);
+            }
+            if (__ballot(any) == 0ull) continue;  // wave-uniform early out
+#pragma unroll
+            for (int j = 1; j < NW; ++j) {
+                const uint4 qj = lds[q * NW + j];
+#pragma unroll
+                for (int w = 0; w < SF_OPL; ++w) {
+                    u32 x = (T0[w][j] ^ qj.x) | (T1[w][j] ^ qj.y);
+                    if (USE_N) x |= (T2[w][j] ^ qj.z);
+                    if (j == NW - 1) x &= tailmask;
+                    c[w] += __popc(x);
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < SF_OPL; ++w) {
+                if (c[w] <= (u32)mm) {
+                    u32 o = tile0 + w * SF_THREADS + tid;
+                    if (o < total && o + (u32)L <= total) {
+                        u32 s = find_segment(seq_off, nseq, o);
+                        if (o + (u32)L <= seq_off[s + 1]) {  // window inside one sequence
+                            u32 slot = atomicAdd(hb.count, 1u);
+                            if (slot < hb.cap) { hb.a[slot] = ps + q; hb.b[slot] = o; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+typedef void (*scan_fast_fn)(const u32 *, i64, u32, const u32 *, u32, const uint4 *, u32, u32, int,
+                             int, u32, HitBuf);
+
+template <bool USE_N> static scan_fast_fn pick_fast(int nw) {
+    switch (nw) {
+    case 1: return scan_fast_kernel<1, USE_N>;
+    case 2: return scan_fast_kernel<2, USE_N>;
+    case 3: return scan_fast_kernel<3, USE_N>;
+    case 4: return scan_fast_kernel<4, USE_N>;
+    case 5: return scan_fast_kernel<5, USE_N>;
+    case 6: return scan_fast_kernel<6, USE_N>;
+    case 7: return scan_fast_kernel<7, USE_N>;
+    case 8: return scan_fast_kernel<8, USE_N>;
+    }
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------
+// general path
+// ------------------------------------------------------------------------
+__device__ __forceinline__ u64 kmer_hash(const u8 *__restrict__ p, int k) {
+    u64 h = 0xcbf29ce484222325ull;
+    for (int i = 0; i < k; ++i) h = (h ^ (u64)p[i]) * 0x100000001b3ull;
+    return h;
+}
+
+__global__ void __launch_bounds__(256)
+anchor_hash_kernel(const u8 *__restrict__ pbytes, const u32 *__restrict__ probe_off,
+                   const i32 *__restrict__ ent_probe, const i32 *__restrict__ ent_pos, u32 nent,
+                   int k, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+    u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nent) return;
+    keys[e] = kmer_hash(pbytes + probe_off[ent_probe[e]] + ent_pos[e], k);
+    vals[e] = e;
+}
+
+// one lane per target position i: every anchor whose k-mer hash equals the
+// hash of seq[i:i+k] becomes a seed hit (entry, i)  (catch/probe.py:1062-1069)
+__global__ void __launch_bounds__(256)
+seed_join_kernel(const u8 *__restrict__ tbytes, u32 total, const u32 *__restrict__ seq_off,
+                 u32 nseq, int k, const u64 *__restrict__ keys, const u32 *__restrict__ vals,
+                 u32 nent, HitBuf hb) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total || i + (u32)k > total) return;
+    u32 s = find_segment(seq_off, nseq, i);
+    if (i + (u32)k > seq_off[s + 1]) return;  // k-mer must lie inside one sequence
+    u64 h = kmer_hash(tbytes + i, k);
+    u32 lo = 0, hi = nent;
+    while (lo < hi) {
+        u32 mid = (lo + hi) >> 1;
+        if (keys[mid] < h) lo = mid + 1; else hi = mid;
+    }
+    for (u32 j = lo; j < nent && keys[j] == h; ++j) {
+        u32 slot = atomicAdd(hb.count, 1u);
+        if (slot < hb.cap) { hb.a[slot] = vals[j]; hb.b[slot] = i; }
+    }
+}
+
+#define MAX_MM 32
+// one lane per seed hit: the reference's cover function on the aligned window
+// (catch/probe.py:1070-1108 + :1328-1344 + longest_common_substring.py:59-159)
+__global__ void __launch_bounds__(256)
+extend_kernel(const u8 *__restrict__ tbytes, const u32 *__restrict__ seq_off, u32 nseq,
+              const u8 *__restrict__ pbytes, const u32 *__restrict__ probe_off,
+              const i32 *__restrict__ ent_probe, const i32 *__restrict__ ent_pos, int k,
+              int mm, int lcf_thres, int island, const u32 *__restrict__ seed_ent,
+              const u32 *__restrict__ seed_pos, u32 nseeds, HitBuf out) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseeds) return;
+    const u32 e = seed_ent[t], gi = seed_pos[t];
+    const i32 p = ent_probe[e];
+    const i64 a = ent_pos[e];
+    const u8 *pf = pbytes + probe_off[p];
+    const i64 L = (i64)(probe_off[p + 1] - probe_off[p]);
+    const u32 s = find_segment(seq_off, nseq, gi);
+    const i64 lo = seq_off[s], G = (i64)seq_off[s + 1] - lo;
+    const i64 i = (i64)gi - lo;
+    const i64 off = i - a;
+    const i64 sub_l = off > 0 ? off : 0;
+    const i64 sub_r = (off + L < G) ? off + L : G;
+    const i64 W = sub_r - sub_l;              // compared length (both truncated)
+    const i64 ps = off < 0 ? -off : 0;        // probe index of window position 0
+    const i64 ks = off < 0 ? i : a;           // anchor start in window coordinates
+    const i64 ke = ks + k;
+    const u8 *x = pf + ps;                    // probe window
+    const u8 *y = tbytes + lo + sub_l;        // target window
+    // the seed is a k-mer *equality* in the reference (dict lookup): verify it
+    for (i64 j = ks; j < ke; ++j)
+        if (x[j] != y[j]) return;
+    if (mm < 0) return;                       // range(k+1) empty: length -1 < any threshold
+    i64 before[MAX_MM + 1], after[MAX_MM + 1];
+    int nb = 0, na = 0;
+    for (i64 j = ks - 1; j >= 0 && nb <= mm; --j)
+        if (x[j] != y[j]) before[nb++] = (ks - 1) - j;
+    for (i64 j = ke; j < W && na <= mm; ++j)
+        if (x[j] != y[j]) after[na++] = j - ke;
+    i64 best_len = -1, best_start = -1;
+    for (int q = 0; q <= mm; ++q) {
+        i64 bl = (q >= nb) ? ks : before[q];
+        i64 al = (mm - q >= na) ? (W - ke) : after[mm - q];
+        i64 len = bl + k + al;
+        if (len > best_len) { best_len = len; best_start = ks - bl; }
+    }
+    i64 thr = lcf_thres;
+    if (L < thr) thr = L;
+    if (G < thr) thr = G;
+    if (best_len < thr) return;
+    if (island > 0) {
+        i64 exact = (nb > 0 ? before[0] : ks) + k + (na > 0 ? after[0] : (W - ke));
+        if (mm == 0) exact = best_len;
+        if (exact < island) return;
+    }
+    u32 gs = (u32)(lo + sub_l + best_start);
+    u32 slot = atomicAdd(out.count, 1u);
+    if (slot < out.cap) { out.a[slot] = (u32)p; out.b[slot] = gs; out.c[slot] = gs + (u32)best_len; }
+}
+
+// ------------------------------------------------------------------------
+// rows: extension / clip / sort / merge
+// ------------------------------------------------------------------------
+// key = (owner set id << 32) | clipped start, val = clipped end
+// (catch/filter/set_cover_filter.py:424-439; the genome offset is implicit in
+// the global coordinate)
+__global__ void __launch_bounds__(256)
+rows_key_kernel(const u32 *__restrict__ hp, const u32 *__restrict__ hs, const u32 *__restrict__ he,
+                u32 fixed_len, u32 n, const u32 *__restrict__ seq_off, u32 nseq,
+                const i32 *__restrict__ set_id, u32 ext, u64 *__restrict__ keys,
+                u32 *__restrict__ vals) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u32 gs = hs[t];
+    u32 ge = he ? he[t] : gs + fixed_len;
+    u32 s = find_segment(seq_off, nseq, gs);
+    u32 lo = seq_off[s], hi = seq_off[s + 1];
+    u32 es = (gs - lo > ext) ? gs - ext : lo;
+    u32 ee = (hi - ge > ext) ? ge + ext : hi;
+    u32 sid = set_id ? (u32)set_id[hp[t]] : hp[t];
+    keys[t] = ((u64)sid << 32) | es;
+    vals[t] = ee;
+}
+
+// After the sort: rows of one (set, segment) group are adjacent and ordered by
+// start.  The thread standing on the first row of a group walks it, merging
+// overlapping and touching intervals (catch/utils/interval.py:288-316);
+// `bounds` (genome offsets, or sequence offsets for the tolerant-bp variant)
+// define the segments.  head[i] = 1 on the first row of every merged interval,
+// whose merged end goes to mend[i].
+__global__ void __launch_bounds__(256)
+rows_merge_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u32 n,
+                  const u32 *__restrict__ bounds, u32 nb, u32 *__restrict__ head,
+                  u32 *__restrict__ mend, u32 *__restrict__ seg) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u64 key = keys[t];
+    u32 sid = (u32)(key >> 32), st = (u32)key;
+    u32 sg = find_segment(bounds, nb, st);
+    seg[t] = sg;
+    bool first;
+    if (t == 0) first = true;
+    else {
+        u64 pk = keys[t - 1];
+        first = ((u32)(pk >> 32) != sid) || (find_segment(bounds, nb, (u32)pk) != sg);
+    }
+    if (!first) return;
+    u32 hi_bound = bounds[sg + 1];
+    u32 cur_head = t, cur_end = vals[t];
+    head[t] = 1;
+    for (u32 j = t + 1; j < n; ++j) {
+        u64 kj = keys[j];
+        u32 sj = (u32)kj;
+        if ((u32)(kj >> 32) != sid || sj >= hi_bound) break;  // next group
+        u32 ej = vals[j];
+        if (sj <= cur_end) { head[j] = 0; if (ej > cur_end) cur_end = ej; }
+        else { mend[cur_head] = cur_end; cur_head = j; cur_end = ej; head[j] = 1; }
+    }
+    mend[cur_head] = cur_end;
+}
+
+__global__ void __launch_bounds__(256)
+rows_compact_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ head,
+                    const u32 *__restrict__ mend, const u32 *__restrict__ seg,
+                    const u32 *__restrict__ idx, u32 n, i32 *__restrict__ o_set,
+                    i32 *__restrict__ o_univ, u32 *__restrict__ o_gs, u32 *__restrict__ o_ge) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n || !head[t]) return;
+    u32 d = idx[t];
+    o_set[d] = (i32)(keys[t] >> 32);
+    o_univ[d] = (i32)seg[t];
+    o_gs[d] = (u32)keys[t];
+    o_ge[d] = mend[t];
+}
+
+__global__ void __launch_bounds__(256)
+rows_bp_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ head,
+               const u32 *__restrict__ mend, u32 n, unsigned long long *__restrict__ bp) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n || !head[t]) return;
+    atomicAdd(&bp[(u32)(keys[t] >> 32)], (unsigned long long)(mend[t] - (u32)keys[t]));
+}
+
+// ------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------
+struct RawHits {
+    DevBuf<u32> a, b, c, count;
+    u32 n = 0;
+    bool has_end = false;
+};
+
+static int read_count(catchhip_ctx *ctx, const u32 *d, u32 *out) {
+    HIP_TRY(hipMemcpyAsync(ctx->h_pin, d, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = *(volatile u32 *)ctx->h_pin;
+    return 0;
+}
+
+static bool fast_path_ok(const catchhip_probes *P, const catchhip_targets *T, int mm, int lcf_thres,
+                         int island) {
+    if (!P->dna5 || !T->dna5) return false;
+    if (P->L <= 0 || P->L > 256 || P->pwords < 1 || P->pwords > 8) return false;
+    if (!P->pigeonhole) return false;
+    if (mm < 0 || P->L / P->k <= mm) return false;   // some anchor survives any <= mm mismatches
+    if (lcf_thres != P->L || island != 0) return false;
+    if (T->nseq == 0 || T->min_seq_len < P->L) return false;
+    return true;
+}
+
+static int run_fast(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm,
+                    RawHits &H, PhaseTimer &tm) {
+    const bool use_n = P->has_n || T->has_n;
+    scan_fast_fn fn = use_n ? pick_fast<true>(P->pwords) : pick_fast<false>(P->pwords);
+    if (!fn) { chip_set_error("fast scan: unsupported probe length"); return CATCHHIP_EINVAL; }
+    const u32 ntiles = (u32)div_up(T->total, SF_TILE);
+    // enough workgroups to fill 256 CUs several times over
+    u32 want_chunks = (u32)div_up((i64)ctx->num_cus * 16, ntiles);
+    u32 ppb = (u32)div_up(P->nprobes, want_chunks ? want_chunks : 1);
+    ppb = (u32)(div_up(ppb, SF_PT) * SF_PT);
+    u32 nchunks = (u32)div_up(P->nprobes, ppb);
+    if (nchunks > 65535) { ppb = (u32)(div_up(div_up(P->nprobes, 65535), SF_PT) * SF_PT); nchunks = (u32)div_up(P->nprobes, ppb); }
+    const u32 tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
+    u32 cap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(P->nprobes * 64, (i64)1 << 28));
+    TRY(H.count.alloc(1));
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        TRY(H.a.reserve(cap));
+        TRY(H.b.reserve(cap));
+        HIP_TRY(hipMemsetAsync(H.count.p, 0, sizeof(u32), ctx->stream));
+        HitBuf hb = {H.a.p, H.b.p, nullptr, H.count.p, cap};
+        hipLaunchKernelGGL(fn, dim3(ntiles, nchunks), dim3(SF_THREADS), 0, ctx->stream, T->planes.p,
+                           T->nwords, (u32)T->total, T->seq_off.p, (u32)T->nseq,
+                           (const uint4 *)P->planes.p, (u32)P->nprobes, ppb, (int)P->L, mm, tailmask, hb);
+        tm.launch();
+        HIP_TRY(hipGetLastError());
+        u32 n;
+        TRY(read_count(ctx, H.count.p, &n));
+        if (n <= cap) { H.n = n; H.has_end = false; return 0; }
+        cap = n;  // overflow: rerun with the exact size
+    }
+    chip_set_error("fast scan: hit buffer overflow");
+    return CATCHHIP_ENOMEM;
+}
+
+static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm,
+                       int lcf_thres, int island, RawHits &H, PhaseTimer &tm) {
+    H.n = 0;
+    H.has_end = true;
+    if (P->nent == 0 || T->total == 0) return 0;
+    if (mm > MAX_MM) { chip_set_error("mismatches > %d not supported", MAX_MM); return CATCHHIP_EINVAL; }
+    const u32 nent = (u32)P->nent;
+    DevBuf<u64> keys, keys_alt;
+    DevBuf<u32> vals, vals_alt;
+    TRY(keys.alloc(nent));
+    TRY(vals.alloc(nent));
+    hipLaunchKernelGGL(anchor_hash_kernel, dim3((unsigned)div_up(nent, 256)), dim3(256), 0, ctx->stream,
+                       P->bytes.p, P->probe_off.p, P->ent_probe.p, P->ent_pos.p, nent, (int)P->k, keys.p,
+                       vals.p);
+    tm.launch();
+    TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nent, 64));
+    // seed hits
+    DevBuf<u32> sa, sb, scount;
+    TRY(scount.alloc(1));
+    u32 cap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(T->total * 2, (i64)1 << 28));
+    u32 nseeds = 0;
+    for (int attempt = 0;; ++attempt) {
+        TRY(sa.reserve(cap));
+        TRY(sb.reserve(cap));
+        HIP_TRY(hipMemsetAsync(scount.p, 0, sizeof(u32), ctx->stream));
+        HitBuf hb = {sa.p, sb.p, nullptr, scount.p, cap};
+        hipLaunchKernelGGL(seed_join_kernel, dim3((unsigned)div_up(T->total, 256)), dim3(256), 0, ctx->stream,
+                           T->bytes.p, (u32)T->total, T->seq_off.p, (u32)T->nseq, (int)P->k, keys.p, vals.p,
+                           nent, hb);
+        tm.launch();
+        HIP_TRY(hipGetLastError());
+        TRY(read_count(ctx, scount.p, &nseeds));
+        if (nseeds <= cap) break;
+        if (attempt >= 2) { chip_set_error("seed join: hit buffer overflow"); return CATCHHIP_ENOMEM; }
+        cap = nseeds;
+    }
+    if (nseeds == 0) return 0;
+    // extension: at most one range per seed
+    TRY(H.a.reserve(nseeds));
+    TRY(H.b.reserve(nseeds));
+    TRY(H.c.reserve(nseeds));
+    TRY(H.count.alloc(1));
+    HIP_TRY(hipMemsetAsync(H.count.p, 0, sizeof(u32), ctx->stream));
+    HitBuf ob = {H.a.p, H.b.p, H.c.p, H.count.p, nseeds};
+    hipLaunchKernelGGL(extend_kernel, dim3((unsigned)div_up(nseeds, 256)), dim3(256), 0, ctx->stream, T->bytes.p,
+                       T->seq_off.p, (u32)T->nseq, P->bytes.p, P->probe_off.p, P->ent_probe.p, P->ent_pos.p,
+                       (int)P->k, mm, lcf_thres, island, sa.p, sb.p, nseeds, ob);
+    tm.launch();
+    HIP_TRY(hipGetLastError());
+    TRY(read_count(ctx, H.count.p, &H.n));
+    return 0;
+}
+
+// Sorted + merged rows from raw hits.  bounds = genome offsets (sets) or
+// sequence offsets (tolerant bp).
+struct MergedRows {
+    DevBuf<u64> keys, keys_alt;
+    DevBuf<u32> vals, vals_alt, head, mend, seg, idx, tmp;
+    u32 n = 0;       // sorted raw rows
+    u32 nmerged = 0; // merged rows
+};
+
+static int build_rows(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,
+                      const RawHits &H, u32 ext, bool use_set_id, const u32 *bounds, u32 nbounds,
+                      i64 max_set_id, MergedRows &M, PhaseTimer &tm) {
+    M.n = H.n;
+    M.nmerged = 0;
+    if (H.n == 0) return 0;
+    const u32 n = H.n;
+    TRY(M.keys.alloc(n));
+    TRY(M.vals.alloc(n));
+    hipLaunchKernelGGL(rows_key_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, ctx->stream, H.a.p, H.b.p,
+                       H.has_end ? H.c.p : (const u32 *)nullptr, (u32)(P->L > 0 ? P->L : 0), n, T->seq_off.p,
+                       (u32)T->nseq, use_set_id ? P->set_id.p : (const i32 *)nullptr, ext, M.keys.p, M.vals.p);
+    tm.launch();
+    int bits = 32 + ceil_log2_u64((u64)max_set_id + 1);
+    if (bits > 64) bits = 64;
+    TRY(chip_radix_sort_pairs(ctx, M.keys, M.keys_alt, M.vals, M.vals_alt, n, bits));
+    tm.launch(3 * ((bits + 7) / 8));
+    TRY(M.head.alloc(n));
+    TRY(M.mend.alloc(n));
+    TRY(M.seg.alloc(n));
+    TRY(M.idx.alloc(n));
+    HIP_TRY(hipMemsetAsync(M.head.p, 0, sizeof(u32) * n, ctx->stream));
+    hipLaunchKernelGGL(rows_merge_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, ctx->stream, M.keys.p,
+                       M.vals.p, n, bounds, nbounds, M.head.p, M.mend.p, M.seg.p);
+    TRY(chip_exclusive_scan_u32(ctx, M.head.p, M.idx.p, n, M.tmp));
+    tm.launch(3);
+    // merged count = idx[n-1] + head[n-1]
+    HIP_TRY(hipMemcpyAsync(ctx->h_pin, M.idx.p + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync((u32 *)ctx->h_pin + 1, M.head.p + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    M.nmerged = ((volatile u32 *)ctx->h_pin)[0] + ((volatile u32 *)ctx->h_pin)[1];
+    return 0;
+}
+
+extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,
+                                   i32 mismatches, i32 lcf_thres, i32 island, i32 cover_extension, i32 mode,
+                                   catchhip_rows **out, i64 *nrows) {
+    ARG_CHECK(ctx && P && T && out && cover_extension >= 0);
+    ARG_CHECK(P->ctx == ctx && T->ctx == ctx);
+    *out = nullptr;
+    if (nrows) *nrows = 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const bool fast_ok = fast_path_ok(P, T, mismatches, lcf_thres, island);
+    if (mode == CATCHHIP_SCAN_FAST && !fast_ok) {
+        chip_set_error("cover_scan: fast-path preconditions do not hold");
+        return CATCHHIP_EINVAL;
+    }
+    const bool use_fast = fast_ok && mode != CATCHHIP_SCAN_GENERAL;
+
+    catchhip_rows *R = new catchhip_rows();
+    R->ctx = ctx;
+    R->total = T->total;
+    R->ngenomes = T->ngenomes;
+    R->h_genome_off = T->h_genome_off;
+    int rc = 0;
+    do {
+        if ((rc = R->genome_off.alloc((size_t)T->ngenomes + 1))) break;
+        if (hipMemcpyAsync(R->genome_off.p, T->genome_off.p, sizeof(u32) * (T->ngenomes + 1),
+                           hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
+        RawHits H;
+        {
+            PhaseTimer tm(ctx, PHASE_SCAN);
+            if (P->nprobes > 0 && T->total > 0) {
+                rc = use_fast ? run_fast(ctx, P, T, mismatches, H, tm)
+                              : run_general(ctx, P, T, mismatches, lcf_thres, island, H, tm);
+            }
+            tm.stop();
+            if (rc) break;
+            tm.finish();
+        }
+        MergedRows M;
+        PhaseTimer tm(ctx, PHASE_ROWS);
+        const i64 max_sid = P->max_set_id;
+        if ((rc = build_rows(ctx, P, T, H, (u32)cover_extension, true, T->genome_off.p, (u32)T->ngenomes,
+                             max_sid, M, tm))) break;
+        R->n = M.nmerged;
+        if ((rc = R->set_id.alloc(R->n))) break;
+        if ((rc = R->univ.alloc(R->n))) break;
+        if ((rc = R->gs.alloc(R->n))) break;
+        if ((rc = R->ge.alloc(R->n))) break;
+        if (M.n) {
+            hipLaunchKernelGGL(rows_compact_kernel, dim3((unsigned)div_up(M.n, 256)), dim3(256), 0, ctx->stream,
+                               M.keys.p, M.head.p, M.mend.p, M.seg.p, M.idx.p, M.n, R->set_id.p, R->univ.p,
+                               R->gs.p, R->ge.p);
+            tm.launch();
+        }
+        tm.stop();
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+            chip_set_error("cover_scan: row build failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = CATCHHIP_EHIP;
+            break;
+        }
+        tm.finish();
+    } while (0);
+    if (rc) { delete R; return rc; }
+    *out = R;
+    if (nrows) *nrows = R->n;
+    return 0;
+}
+
+extern "C" int catchhip_tolerant_bp(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,
+                                    i32 mismatches, i32 lcf_thres, i32 island, i64 *bp_out) {
+    ARG_CHECK(ctx && P && T && bp_out);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (P->nprobes == 0 || T->total == 0) return 0;
+    const bool use_fast = fast_path_ok(P, T, mismatches, lcf_thres, island);
+    RawHits H;
+    {
+        PhaseTimer tm(ctx, PHASE_SCAN);
+        int rc = use_fast ? run_fast(ctx, P, T, mismatches, H, tm)
+                          : run_general(ctx, P, T, mismatches, lcf_thres, island, H, tm);
+        tm.stop();
+        if (rc) return rc;
+        tm.finish();
+    }
+    if (H.n == 0) return 0;
+    MergedRows M;
+    PhaseTimer tm(ctx, PHASE_ROWS);
+    // merge per (probe, sequence): probe.find_probe_covers_in_sequence merges per sequence
+    TRY(build_rows(ctx, P, T, H, 0u, false, T->seq_off.p, (u32)T->nseq, P->nprobes, M, tm));
+    DevBuf<unsigned long long> bp;
+    TRY(bp.alloc((size_t)P->nprobes));
+    HIP_TRY(hipMemsetAsync(bp.p, 0, sizeof(unsigned long long) * P->nprobes, ctx->stream));
+    hipLaunchKernelGGL(rows_bp_kernel, dim3((unsigned)div_up(M.n, 256)), dim3(256), 0, ctx->stream, M.keys.p,
+                       M.head.p, M.mend.p, M.n, bp.p);
+    tm.launch();
+    tm.stop();
+    std::vector<unsigned long long> h((size_t)P->nprobes);
+    HIP_TRY(hipMemcpyAsync(h.data(), bp.p, sizeof(unsigned long long) * P->nprobes, hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    tm.finish();
+    for (i64 i = 0; i < P->nprobes; ++i) bp_out[i] += (i64)h[i];
+    return 0;
+}
+
+extern "C" int catchhip_rows_fetch(catchhip_ctx *ctx, const catchhip_rows *R, i32 *set_id, i32 *universe,
+                                   i64 *start, i64 *end) {
+    ARG_CHECK(ctx && R);
+    if (R->n == 0) return 0;
+    ARG_CHECK(set_id && universe && start && end);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<u32> gs((size_t)R->n), ge((size_t)R->n);
+    HIP_TRY(hipMemcpyAsync(set_id, R->set_id.p, sizeof(i32) * R->n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(universe, R->univ.p, sizeof(i32) * R->n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(gs.data(), R->gs.p, sizeof(u32) * R->n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ge.data(), R->ge.p, sizeof(u32) * R->n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (i64 i = 0; i < R->n; ++i) {
+        i64 base = R->h_genome_off[universe[i]];
+        start[i] = (i64)gs[i] - base;
+        end[i] = (i64)ge[i] - base;
+    }
+    return 0;
+}
+
+extern "C" int catchhip_rows_from_host(catchhip_ctx *ctx, const i32 *set_id, const i32 *universe,
+                                       const i64 *start, const i64 *end, i64 nrows, const i64 *genome_len,
+                                       i32 ngenomes, catchhip_rows **out) {
+    ARG_CHECK(ctx && out && nrows >= 0 && ngenomes >= 0 && (ngenomes == 0 || genome_len));
+    ARG_CHECK(nrows == 0 || (set_id && universe && start && end));
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    catchhip_rows *R = new catchhip_rows();
+    R->ctx = ctx;
+    R->ngenomes = ngenomes;
+    R->n = nrows;
+    R->h_genome_off.assign((size_t)ngenomes + 1, 0);
+    for (i32 g = 0; g < ngenomes; ++g) {
+        if (genome_len[g] < 0) { delete R; chip_set_error("rows_from_host: negative genome length"); return CATCHHIP_EINVAL; }
+        R->h_genome_off[g + 1] = R->h_genome_off[g] + genome_len[g];
+    }
+    R->total = R->h_genome_off[ngenomes];
+    if (R->total >= ((i64)1 << 32) - 4096) { delete R; chip_set_error("rows_from_host: coordinate space too large"); return CATCHHIP_EINVAL; }
+    std::vector<u32> gs((size_t)nrows), ge((size_t)nrows), go((size_t)ngenomes + 1);
+    for (i32 g = 0; g <= ngenomes; ++g) go[g] = (u32)R->h_genome_off[g];
+    for (i64 i = 0; i < nrows; ++i) {
+        i32 u = universe[i];
+        bool ok = u >= 0 && u < ngenomes && start[i] >= 0 && end[i] > start[i] && end[i] <= genome_len[u] && set_id[i] >= 0;
+        if (ok && i > 0) {
+            if (set_id[i] < set_id[i - 1]) ok = false;
+            else if (set_id[i] == set_id[i - 1]) {
+                if (u < universe[i - 1]) ok = false;
+                else if (u == universe[i - 1] && start[i] <= end[i - 1]) ok = false;  // must be disjoint, non-touching
+            }
+        }
+        if (!ok) { delete R; chip_set_error("rows_from_host: row %lld is invalid or out of order", (long long)i); return CATCHHIP_EINVAL; }
+        gs[i] = (u32)(R->h_genome_off[u] + start[i]);
+        ge[i] = (u32)(R->h_genome_off[u] + end[i]);
+    }
+    int rc = 0;
+    do {
+        if ((rc = R->set_id.alloc(nrows))) break;
+        if ((rc = R->univ.alloc(nrows))) break;
+        if ((rc = R->gs.alloc(nrows))) break;
+        if ((rc = R->ge.alloc(nrows))) break;
+        if ((rc = R->genome_off.alloc((size_t)ngenomes + 1))) break;
+        hipStream_t s = ctx->stream;
+        if ((nrows && (hipMemcpyAsync(R->set_id.p, set_id, sizeof(i32) * nrows, hipMemcpyHostToDevice, s) != hipSuccess ||
+                       hipMemcpyAsync(R->univ.p, universe, sizeof(i32) * nrows, hipMemcpyHostToDevice, s) != hipSuccess ||
+                       hipMemcpyAsync(R->gs.p, gs.data(), sizeof(u32) * nrows, hipMemcpyHostToDevice, s) != hipSuccess ||
+                       hipMemcpyAsync(R->ge.p, ge.data(), sizeof(u32) * nrows, hipMemcpyHostToDevice, s) != hipSuccess)) ||
+            hipMemcpyAsync(R->genome_off.p, go.data(), sizeof(u32) * (ngenomes + 1), hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            chip_set_error("rows_from_host: upload failed");
+            rc = CATCHHIP_EHIP;
+        }
+    } while (0);
+    if (rc) { delete R; return rc; }
+    *out = R;
+    return 0;
+}

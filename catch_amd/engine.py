@@ -1,0 +1,256 @@
+"""Thin Python objects over the C-ABI handles of libcatchhip.so.
+
+Only marshals NumPy host buffers in and out (stdlib + NumPy, no torch); all
+compute happens in the HIP kernels behind include/catchhip.h.
+"""
+import ctypes
+
+import numpy as np
+
+from catch_amd import _lib
+from catch_amd._lib import c_f64p, c_i32p, c_i64p, c_u8p, check
+
+SCAN_AUTO, SCAN_GENERAL, SCAN_FAST = 0, 1, 2
+PHASE_SCAN, PHASE_ROWS, PHASE_GREEDY, PHASE_NDF = 0, 1, 2, 3
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _concat(strs):
+    off = np.zeros(len(strs) + 1, dtype=np.int64)
+    if strs:
+        np.cumsum([len(s) for s in strs], out=off[1:])
+    buf = np.frombuffer("".join(strs).encode("latin-1"), dtype=np.uint8)
+    if buf.size == 0:
+        buf = np.zeros(1, dtype=np.uint8)
+    return np.ascontiguousarray(buf), off
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = _lib.lib().catchhip_device_count(ctypes.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class Context:
+    """One HIP device + stream (catchhip_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        self._L = _lib.lib()
+        check(self._L.catchhip_ctx_create(int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            self._L.catchhip_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self._L.catchhip_ctx_sync(self._h))
+
+    def kernel_ms(self, phase):
+        ms = ctypes.c_double(0.0)
+        n = ctypes.c_int64(0)
+        check(self._L.catchhip_ctx_last_kernel_ms(self._h, phase,
+                                                  ctypes.byref(ms),
+                                                  ctypes.byref(n)))
+        return ms.value, n.value
+
+    # -- RCCL -----------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = np.zeros(128, dtype=np.uint8)
+        check(_lib.lib().catchhip_comm_unique_id(_ptr(buf, c_u8p)))
+        return buf.tobytes()
+
+    def comm_init(self, unique_id, nranks, rank):
+        buf = np.frombuffer(unique_id, dtype=np.uint8).copy()
+        check(self._L.catchhip_comm_init(self._h, _ptr(buf, c_u8p), nranks,
+                                         rank))
+
+    # -- near-duplicate filter --------------------------------------------
+    def ndf_hamming(self, probe_strs, L, positions, dist_thres):
+        n = len(probe_strs)
+        buf, _ = _concat(probe_strs)
+        pos = np.ascontiguousarray(positions, dtype=np.int32)
+        ntables, k = pos.shape
+        keep = np.zeros(max(n, 1), dtype=np.uint8)
+        check(self._L.catchhip_ndf_hamming(self._h, _ptr(buf, c_u8p), n, L,
+                                           _ptr(pos, c_i32p), ntables, k,
+                                           dist_thres, _ptr(keep, c_u8p)))
+        return keep[:n].astype(bool)
+
+
+class Targets:
+    """Device-resident target sequences (catchhip_targets).
+    genomes: list of genomes, each a list of sequence strings."""
+
+    def __init__(self, ctx, genomes):
+        self.ctx = ctx
+        seqs, sg = [], []
+        for j, g in enumerate(genomes):
+            for s in g:
+                seqs.append(s)
+                sg.append(j)
+        buf, off = _concat(seqs)
+        sgn = np.asarray(sg, dtype=np.int32)
+        if sgn.size == 0:
+            sgn = np.zeros(1, dtype=np.int32)
+        self.nseq = len(seqs)
+        self.ngenomes = len(genomes)
+        self.total = int(off[-1])
+        self._h = ctypes.c_void_p()
+        check(ctx._L.catchhip_targets_create(
+            ctx._h, _ptr(buf, c_u8p), _ptr(off, c_i64p), _ptr(sgn, c_i32p),
+            self.nseq, self.ngenomes, ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self.ctx._L.catchhip_targets_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Probes:
+    """Device-resident unique probes + anchor table (catchhip_probes)."""
+
+    def __init__(self, ctx, uniq, owner, ent_probe, ent_pos, k):
+        self.ctx = ctx
+        self.n = len(uniq)
+        buf, off = _concat(uniq)
+        owner = np.ascontiguousarray(owner, dtype=np.int32)
+        ep = np.ascontiguousarray(ent_probe, dtype=np.int32)
+        eo = np.ascontiguousarray(ent_pos, dtype=np.int32)
+        if owner.size == 0:
+            owner = np.zeros(1, dtype=np.int32)
+        nent = int(ep.size) if self.n else 0
+        if ep.size == 0:
+            ep = np.zeros(1, dtype=np.int32)
+            eo = np.zeros(1, dtype=np.int32)
+        self._h = ctypes.c_void_p()
+        check(ctx._L.catchhip_probes_create(
+            ctx._h, _ptr(buf, c_u8p), _ptr(off, c_i64p), self.n,
+            _ptr(owner, c_i32p), _ptr(ep, c_i32p), _ptr(eo, c_i32p), nent,
+            int(k or 0), ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self.ctx._L.catchhip_probes_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Rows:
+    """Device-resident cover rows (catchhip_rows)."""
+
+    def __init__(self, ctx, handle, n):
+        self.ctx = ctx
+        self._h = handle
+        self.n = int(n)
+
+    @staticmethod
+    def scan(ctx, probes, targets, mismatches, lcf_thres, island=0,
+             cover_extension=0, mode=SCAN_AUTO):
+        h = ctypes.c_void_p()
+        n = ctypes.c_int64(0)
+        check(ctx._L.catchhip_cover_scan(
+            ctx._h, probes._h, targets._h, int(mismatches), int(lcf_thres),
+            int(island), int(cover_extension), int(mode), ctypes.byref(h),
+            ctypes.byref(n)))
+        return Rows(ctx, h, n.value)
+
+    @staticmethod
+    def from_host(ctx, set_id, universe, start, end, genome_len):
+        si = np.ascontiguousarray(set_id, dtype=np.int32)
+        un = np.ascontiguousarray(universe, dtype=np.int32)
+        st = np.ascontiguousarray(start, dtype=np.int64)
+        en = np.ascontiguousarray(end, dtype=np.int64)
+        gl = np.ascontiguousarray(genome_len, dtype=np.int64)
+        n = int(si.size)
+        ng = int(gl.size)
+        if n == 0:
+            si = np.zeros(1, np.int32); un = np.zeros(1, np.int32)
+            st = np.zeros(1, np.int64); en = np.zeros(1, np.int64)
+        if ng == 0:
+            gl = np.zeros(1, np.int64)
+        h = ctypes.c_void_p()
+        check(ctx._L.catchhip_rows_from_host(
+            ctx._h, _ptr(si, c_i32p), _ptr(un, c_i32p), _ptr(st, c_i64p),
+            _ptr(en, c_i64p), n, _ptr(gl, c_i64p), ng, ctypes.byref(h)))
+        return Rows(ctx, h, n)
+
+    def fetch(self):
+        n = max(self.n, 1)
+        si = np.zeros(n, np.int32); un = np.zeros(n, np.int32)
+        st = np.zeros(n, np.int64); en = np.zeros(n, np.int64)
+        check(self.ctx._L.catchhip_rows_fetch(
+            self.ctx._h, self._h, _ptr(si, c_i32p), _ptr(un, c_i32p),
+            _ptr(st, c_i64p), _ptr(en, c_i64p)))
+        return si[:self.n], un[:self.n], st[:self.n], en[:self.n]
+
+    def greedy(self, num_sets, ranks=None, universe_p=None):
+        """catchhip_setcover_greedy -> picked set ids in pick order."""
+        num_sets = int(num_sets)
+        out = np.zeros(max(num_sets, 1), dtype=np.int64)
+        n_out = ctypes.c_int64(0)
+        rk = None if ranks is None else np.ascontiguousarray(ranks, np.int64)
+        up = (None if universe_p is None
+              else np.ascontiguousarray(universe_p, np.float64))
+        check(self.ctx._L.catchhip_setcover_greedy(
+            self.ctx._h, self._h, num_sets,
+            None if rk is None else _ptr(rk, c_i64p),
+            None if up is None else _ptr(up, c_f64p),
+            _ptr(out, c_i64p), ctypes.byref(n_out)))
+        return [int(x) for x in out[:n_out.value]]
+
+    def close(self):
+        if self._h:
+            self.ctx._L.catchhip_rows_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tolerant_bp(ctx, probes, targets, mismatches, lcf_thres, island, out):
+    """catchhip_tolerant_bp: out (int64, one per unique probe) += bp."""
+    check(ctx._L.catchhip_tolerant_bp(ctx._h, probes._h, targets._h,
+                                      int(mismatches), int(lcf_thres),
+                                      int(island), _ptr(out, c_i64p)))
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on the device selected by CATCHHIP_DEVICE /
+    LOCAL_RANK (one process per GPU)."""
+    global _default_ctx
+    if _default_ctx is None:
+        import os
+        dev = int(os.environ.get("CATCHHIP_DEVICE",
+                                 os.environ.get("LOCAL_RANK", "0")))
+        _default_ctx = Context(dev)
+    return _default_ctx

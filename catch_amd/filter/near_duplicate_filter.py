@@ -1,0 +1,71 @@
+"""Near-duplicate filters on the MI355X: drop-in for
+catch/filter/near_duplicate_filter.py.
+
+NearDuplicateFilterWithHammingDistance(dist_thres, probe_length) keeps the
+reference's constructor (:115), draws the LSH sampling positions from Python's
+`random` in exactly the reference's order (catch/utils/lsh.py:284-287 -> :224
+-> :28: per table, k calls of random.randint(0, dim-1)), and resolves the
+multiplicity-ordered greedy pass (:60-103) on the GPU
+(catchhip_ndf_hamming).  Output: kept probes (subset of the input objects) in
+priority order; the reference returns them in CPython-set order, which callers
+never rely on (catch/filter/probe_designer.py:288,308).
+
+requires_probe_groupings is set so that grouped input is handled in-process
+(HIP contexts do not survive the fork of catch/filter/base_filter.py:121-158).
+"""
+import math
+import operator
+import random
+from collections import defaultdict
+
+from catch_amd import engine
+from catch_amd.filter.base_filter import BaseFilter
+
+
+class NearDuplicateFilter(BaseFilter):
+    def __init__(self, k, reporting_prob=0.80):
+        self.k = k
+        self.reporting_prob = reporting_prob
+
+    def _order_by_multiplicity(self, input):
+        occurrences = defaultdict(int)
+        for p in input:
+            occurrences[p] += 1
+        # stable sort, ties keep first-seen order (:64-66)
+        return [p for p, _ in sorted(occurrences.items(),
+                                     key=operator.itemgetter(1),
+                                     reverse=True)]
+
+
+class NearDuplicateFilterWithHammingDistance(NearDuplicateFilter):
+    def __init__(self, dist_thres, probe_length):
+        super().__init__(k=20)
+        self.dim = probe_length
+        self.dist_thres = dist_thres
+
+    def num_tables(self):
+        """catch/utils/lsh.py:268-276."""
+        P1 = 1.0 - float(self.dist_thres) / float(self.dim)
+        if P1 == 1.0:
+            return 1
+        return int(math.ceil(math.log(1.0 - self.reporting_prob,
+                                      1.0 - math.pow(P1, self.k))))
+
+    def _draw_positions(self):
+        return [[random.randint(0, self.dim - 1) for _ in range(self.k)]
+                for _ in range(self.num_tables())]
+
+    def _filter(self, input):
+        input = list(input)
+        order = self._order_by_multiplicity(input)
+        positions = self._draw_positions()
+        if not order:
+            return []
+        for p in order:
+            # lsh.py:30 asserts len(x) == dim; probe.py:79-80 raises
+            if len(p.seq_str) != self.dim:
+                raise ValueError("Sequences must be of same length")
+        ctx = engine.default_context()
+        keep = ctx.ndf_hamming([p.seq_str for p in order], self.dim,
+                               positions, self.dist_thres)
+        return [p for p, kp in zip(order, keep) if kp]

@@ -1,0 +1,240 @@
+"""SetCoverFilter on the MI355X: drop-in for catch/filter/set_cover_filter.py.
+
+Same constructor and `BaseFilter.filter()` contract as the reference class
+(catch/filter/set_cover_filter.py:199-357, :902-930); the work of
+`_make_sets` (:359-470), `_make_ranks` (:614-735) and
+`set_cover.approx_multiuniverse` (catch/utils/set_cover.py:147-615) runs in
+the HIP kernels of libcatchhip.so through `catch_amd.engine`.  There is no
+CPU fallback: without the library or a GPU the filter raises.
+
+Not supported (raises NotImplementedError): custom hybridization functions
+loaded from a Python file (`custom_cover_range_fn`, :288-299) -- an arbitrary
+Python callable cannot run inside a kernel.
+"""
+import logging
+
+import numpy as np
+
+from catch_amd import engine
+from catch_amd import probe
+from catch_amd.filter.base_filter import BaseFilter
+from catch_amd.utils import seq_io
+
+logger = logging.getLogger(__name__)
+
+
+def set_max_num_processes_for_set_cover_instances(max_num_processes=8):
+    """catch/filter/set_cover_filter.py:66-79.  Accepted for CLI
+    compatibility; set-cover instances are solved on the GPU."""
+    global _sc_max_num_processes
+    _sc_max_num_processes = max_num_processes
+
+
+set_max_num_processes_for_set_cover_instances()
+
+_RC = str.maketrans("ACGT", "TGCA")
+
+
+def _reverse_complement(s):
+    """A<->T, C<->G, everything else maps to itself (:515-521)."""
+    return s[::-1].translate(_RC)
+
+
+class SetCoverFilter(BaseFilter):
+    """Selects candidate probes with the greedy multi-universe set cover."""
+
+    def __init__(self,
+                 mismatches,
+                 lcf_thres,
+                 island_of_exact_match=0,
+                 mismatches_tolerant=None,
+                 lcf_thres_tolerant=None,
+                 island_of_exact_match_tolerant=None,
+                 custom_cover_range_fn=None,
+                 custom_cover_range_tolerant_fn=None,
+                 identify=False,
+                 avoided_genomes=[],
+                 coverage=1.0,
+                 cover_extension=0,
+                 kmer_probe_map_k=20,
+                 kmer_probe_map_use_native_dict=False):
+        if (custom_cover_range_fn is not None
+                or custom_cover_range_tolerant_fn is not None):
+            raise NotImplementedError(
+                "custom hybridization functions cannot run on the GPU path")
+        self.mismatches = mismatches
+        self.lcf_thres = lcf_thres
+        self.island_of_exact_match = island_of_exact_match
+        # tolerant parameters default to the strict ones when falsy (:308-313)
+        if not mismatches_tolerant:
+            mismatches_tolerant = mismatches
+        if not lcf_thres_tolerant:
+            lcf_thres_tolerant = lcf_thres
+        if not island_of_exact_match_tolerant:
+            island_of_exact_match_tolerant = island_of_exact_match
+        self.mismatches_tolerant = mismatches_tolerant
+        self.lcf_thres_tolerant = lcf_thres_tolerant
+        self.island_of_exact_match_tolerant = island_of_exact_match_tolerant
+
+        if identify:
+            if (coverage <= 1.0 and coverage >= 0.25) or \
+               (coverage > 1 and coverage >= 5000):
+                logger.warning(("Identification is enabled but the required "
+                                "coverage is high; generally coverage should "
+                                "be small when performing identification"))
+        self.identify = identify
+        self.avoided_genomes = avoided_genomes
+        self.coverage = coverage
+        self.cover_extension = cover_extension
+        self.kmer_probe_map_k = kmer_probe_map_k
+        self.kmer_probe_map_use_native_dict = kmer_probe_map_use_native_dict
+        self.requires_probe_groupings = True
+        self._force_num_processes = None   # accepted, unused (:355-357)
+        self.scan_mode = engine.SCAN_AUTO
+        self.last_timings = {}
+
+    # ------------------------------------------------------------------
+    def _context(self):
+        return engine.default_context()
+
+    def _make_sets(self, candidate_probes, target_genomes, ctx=None,
+                   targets=None):
+        """Device rows for one group (:359-470).  Returns (rows, owner) where
+        rows is an engine.Rows (set ids = indices into candidate_probes)."""
+        ctx = ctx or self._context()
+        strs = [p.seq_str for p in candidate_probes]
+        k, uniq, owner, ep, eo = probe.anchor_table(
+            strs, self.mismatches, self.lcf_thres,
+            min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
+        own_targets = targets is None
+        if own_targets:
+            targets = engine.Targets(ctx, [g.seqs for g in target_genomes])
+        probes = engine.Probes(ctx, uniq, owner, ep, eo, k)
+        try:
+            rows = engine.Rows.scan(ctx, probes, targets, self.mismatches,
+                                    self.lcf_thres,
+                                    self.island_of_exact_match,
+                                    self.cover_extension, self.scan_mode)
+        finally:
+            probes.close()
+            if own_targets:
+                targets.close()
+        return rows
+
+    def _tolerant_bp_over(self, ctx, probes_dev, n_uniq, sequences):
+        """Sum over `sequences` and their reverse complements of the bp each
+        unique probe covers under the tolerant model (:472-529)."""
+        bp = np.zeros(max(n_uniq, 1), dtype=np.int64)
+        if not sequences:
+            return bp
+        # one genome per sequence: coverage is merged per sequence anyway
+        genomes = []
+        for s in sequences:
+            genomes.append([s])
+            genomes.append([_reverse_complement(s)])
+        t = engine.Targets(ctx, genomes)
+        try:
+            engine.tolerant_bp(ctx, probes_dev, t, self.mismatches_tolerant,
+                               self.lcf_thres_tolerant,
+                               self.island_of_exact_match_tolerant, bp)
+        finally:
+            t.close()
+        return bp
+
+    def _make_ranks(self, candidate_probes, target_genomes_grouped, ctx=None):
+        """Rank per candidate (:614-735): (0, #groups hit) under --identify,
+        (1, avoided bp) for probes that touch an avoided genome, densified."""
+        n = len(candidate_probes)
+        need = self.identify or len(self.avoided_genomes) > 0
+        if not need:
+            return np.zeros(n, dtype=np.int64)
+        ctx = ctx or self._context()
+        strs = [p.seq_str for p in candidate_probes]
+        k, uniq, _owner, ep, eo = probe.anchor_table(
+            strs, self.mismatches_tolerant, self.lcf_thres_tolerant,
+            min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
+        ident = np.arange(len(uniq), dtype=np.int32)
+        pd = engine.Probes(ctx, uniq, ident, ep, eo, k)
+        try:
+            if self.identify:
+                hits = np.zeros(len(uniq), dtype=np.int64)
+                for genomes in target_genomes_grouped:
+                    seqs = [s for g in genomes for s in g.seqs]
+                    bp = self._tolerant_bp_over(ctx, pd, len(uniq), seqs)
+                    hits += (bp[:len(uniq)] >= 1)
+                rank_a = np.zeros(len(uniq), dtype=np.int64)
+                rank_b = hits
+            else:
+                rank_a = np.zeros(len(uniq), dtype=np.int64)
+                rank_b = np.zeros(len(uniq), dtype=np.int64)
+            total = np.zeros(len(uniq), dtype=np.int64)
+            for path in self.avoided_genomes:
+                for sequence in seq_io.iterate_fasta(path):
+                    total += self._tolerant_bp_over(ctx, pd, len(uniq),
+                                                    [sequence])[:len(uniq)]
+            avoided = total > 0
+            rank_a = np.where(avoided, 1, rank_a)
+            rank_b = np.where(avoided, total, rank_b)
+        finally:
+            pd.close()
+        tuples = sorted(set(zip(rank_a.tolist(), rank_b.tolist())))
+        tidx = {t: i for i, t in enumerate(tuples)}
+        uidx = {s: i for i, s in enumerate(uniq)}
+        return np.fromiter(
+            (tidx[(int(rank_a[uidx[s]]), int(rank_b[uidx[s]]))] for s in strs),
+            dtype=np.int64, count=n)
+
+    def _make_universe_p(self, target_genomes):
+        """:761-792."""
+        if self.coverage <= 1.0:
+            return [self.coverage for _ in target_genomes]
+        out = []
+        for gnm in target_genomes:
+            desired = min(self.coverage, gnm.size())
+            out.append(float(desired) / gnm.size())
+        return out
+
+    def _filter(self, input, target_genomes_grouped):
+        """input = [p_1, ..., p_m] candidate probes per group; returns the
+        selected probes per group (:902-930)."""
+        ctx = self._context()
+        selected_probes = []
+        timings = dict(scan_ms=0.0, rows_ms=0.0, greedy_ms=0.0, picks=0,
+                       rows=0, scan_launches=0, greedy_launches=0)
+        for group_i, (possible_probes, target_genomes) in enumerate(
+                zip(input, target_genomes_grouped)):
+            possible_probes = list(possible_probes)
+            if len(possible_probes) == 0:
+                selected_probes.append([])
+                continue
+            logger.info("Building set cover sets input (group %d of %d)",
+                        group_i + 1, len(input))
+            rows = self._make_sets(possible_probes, target_genomes, ctx)
+            try:
+                ms, nl = ctx.kernel_ms(engine.PHASE_SCAN)
+                timings["scan_ms"] += ms
+                timings["scan_launches"] += nl
+                timings["rows_ms"] += ctx.kernel_ms(engine.PHASE_ROWS)[0]
+                timings["rows"] += rows.n
+                ranks = self._make_ranks(possible_probes,
+                                         target_genomes_grouped, ctx)
+                universe_p = self._make_universe_p(target_genomes)
+                logger.info("Solving set cover instance (group %d of %d)",
+                            group_i + 1, len(input))
+                ids = rows.greedy(len(possible_probes), ranks, universe_p)
+                ms, nl = ctx.kernel_ms(engine.PHASE_GREEDY)
+                timings["greedy_ms"] += ms
+                timings["greedy_launches"] += nl
+                timings["picks"] += len(ids)
+            finally:
+                rows.close()
+            num_bad = int(np.count_nonzero(ranks[ids] > 0)) if len(ids) else 0
+            if num_bad > 0:
+                logger.warning(("Group %d: forced to choose %d less-than-ideal "
+                                "probe%s (i.e., probes that 'hit' more than "
+                                "one grouping during identification or probes "
+                                "that cover an avoided genome)"), group_i + 1,
+                               num_bad, "" if num_bad == 1 else "s")
+            selected_probes.append([possible_probes[i] for i in ids])
+        self.last_timings = timings
+        return selected_probes

@@ -1,0 +1,39 @@
+"""Genome value type at the filter boundary (mirrors catch/genome.py:9-143:
+`.seqs` list of sequence strings, `.size()`)."""
+from collections import OrderedDict
+
+
+class Genome:
+    def __init__(self, seqs, chrs=None):
+        if len(seqs) > 1 and chrs is None:
+            raise ValueError(("When there is more than one sequence, chrs "
+                              "should also be specified"))
+        self.seqs = seqs
+        self.chrs = chrs
+        self._size = None
+
+    def divided_into_chrs(self):
+        return len(self.seqs) > 1
+
+    def size(self, only_unambig=False):
+        if only_unambig:
+            return sum(seq.count(b) for seq in self.seqs for b in "ATCG")
+        if self._size is None:
+            self._size = sum(len(seq) for seq in self.seqs)
+        return self._size
+
+    def __hash__(self):
+        return hash(tuple(self.seqs))
+
+    def __eq__(self, other):
+        return (isinstance(other, Genome) and self.seqs == other.seqs
+                and self.chrs == other.chrs)
+
+    @staticmethod
+    def from_chrs(seqs_by_chr):
+        seqs = list(seqs_by_chr.values())
+        return Genome(seqs, OrderedDict(seqs_by_chr))
+
+    @staticmethod
+    def from_one_seq(seq):
+        return Genome([seq])

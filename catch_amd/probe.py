@@ -1,0 +1,149 @@
+"""Probe value type and the host side of the seed ("anchor") table.
+
+Mirrors the pieces of catch/probe.py that the filters touch: `Probe`
+(:38-353: `.seq`, `.seq_str`, hash/eq by sequence, `mismatches`), the anchor
+selection of construct_kmer_probe_map_to_find_probe_covers (:507-577, with the
+pigeonhole rule :414-504 and the random rule :356-405, which must consume
+np.random exactly like the reference for results to be reproducible), and the
+module-level pool knob `set_max_num_processes_for_probe_finding_pools`
+(:766-779; a no-op here: the scan runs on the GPU).
+"""
+import numpy as np
+
+
+class Probe:
+    """Immutable probe sequence; equality and hash are by sequence string."""
+
+    __slots__ = ("seq_str", "_seq", "is_flanking_n_string", "header")
+
+    def __init__(self, seq):
+        if isinstance(seq, str):
+            self.seq_str = seq
+            self._seq = None
+        else:
+            self._seq = seq
+            self.seq_str = "".join(seq)
+        self.is_flanking_n_string = False
+        self.header = None
+
+    @property
+    def seq(self):
+        if self._seq is None:
+            self._seq = np.fromiter(self.seq_str, dtype="U1",
+                                    count=len(self.seq_str))
+        return self._seq
+
+    @staticmethod
+    def from_str(seq_str):
+        return Probe(seq_str)
+
+    def mismatches(self, other):
+        """catch/probe.py:55-88 (offset 0)."""
+        if len(self.seq_str) != len(other.seq_str):
+            raise ValueError("Sequences must be of same length")
+        a = np.frombuffer(self.seq_str.encode("latin-1"), dtype=np.uint8)
+        b = np.frombuffer(other.seq_str.encode("latin-1"), dtype=np.uint8)
+        return int(np.count_nonzero(a != b))
+
+    def reverse_complement(self):
+        rc_map = {"A": "T", "T": "A", "C": "G", "G": "C"}
+        return Probe("".join(rc_map.get(b, b) for b in self.seq_str[::-1]))
+
+    def __hash__(self):
+        return hash(self.seq_str)
+
+    def __eq__(self, other):
+        return isinstance(other, Probe) and self.seq_str == other.seq_str
+
+    def __len__(self):
+        return len(self.seq_str)
+
+    def __getitem__(self, i):
+        return self.seq_str[i]
+
+    def __str__(self):
+        return self.seq_str
+
+    def __repr__(self):
+        return self.seq_str
+
+
+def set_max_num_processes_for_probe_finding_pools(max_num_processes=8):
+    """catch/probe.py:766-779.  Accepted for CLI compatibility; unused."""
+    global _pfp_max_num_processes
+    _pfp_max_num_processes = max_num_processes
+
+
+set_max_num_processes_for_probe_finding_pools()
+
+
+def pigeonhole_kmer_length(probe_length, mismatches):
+    """k of _construct_pigeonholed_kmer_probe_map (catch/probe.py:473-491)."""
+    if mismatches == 0:
+        return probe_length
+    k = int(probe_length / mismatches)
+    if k == float(probe_length) / mismatches:
+        k -= 1
+    while probe_length % k != 0:
+        k -= 1
+    return k
+
+
+def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
+                 num_kmers_per_probe=20):
+    """Anchors of construct_kmer_probe_map_to_find_probe_covers
+    (catch/probe.py:507-577) for `probe_strs` (duplicates allowed).
+
+    Returns (k, uniq, owner, ent_probe, ent_pos):
+      uniq       unique probe strings, first-seen order
+      owner      for each unique string the LAST input index holding it (the
+                 set id that receives its coverage, catch/filter/
+                 set_cover_filter.py:408-412)
+      ent_probe, ent_pos   int32 arrays: unique (unique-probe, position)
+                 anchors, every anchor k long.
+    Random mode (mismatches/lcf_thres None, differing lengths,
+    lcf_thres < probe length, or pigeonhole k < min_k) draws
+    np.random.choice(n_kmers, size=20, replace=True) once per input probe in
+    input order, like catch/probe.py:391-401.
+    """
+    first = {}
+    last = {}
+    for i, p in enumerate(probe_strs):
+        if p not in first:
+            first[p] = len(first)
+        last[p] = i
+    uniq = list(first.keys())
+    owner = np.fromiter((last[p] for p in uniq), dtype=np.int32,
+                        count=len(uniq))
+    if not uniq:
+        return None, uniq, owner, np.zeros(0, np.int32), np.zeros(0, np.int32)
+    L = len(probe_strs[0])
+    differ = any(len(p) != L for p in probe_strs)
+    use_random = (mismatches is None or lcf_thres is None or differ
+                  or lcf_thres < L)
+    kk = None
+    if not use_random:
+        kk = pigeonhole_kmer_length(L, mismatches)
+        if kk < min_k:
+            use_random = True
+    if use_random:
+        kk = k
+        pairs = set()
+        for p in probe_strs:
+            if kk > len(p):
+                raise ValueError("k is larger than the length of a probe")
+            n_kmers = len(p) - kk + 1
+            pi = first[p]
+            for pos in np.random.choice(n_kmers, size=num_kmers_per_probe,
+                                        replace=True):
+                pairs.add((pi, int(pos)))
+        pairs = sorted(pairs)
+        ent_probe = np.fromiter((a for a, _ in pairs), dtype=np.int32,
+                                count=len(pairs))
+        ent_pos = np.fromiter((b for _, b in pairs), dtype=np.int32,
+                              count=len(pairs))
+    else:
+        per = L // kk
+        ent_probe = np.repeat(np.arange(len(uniq), dtype=np.int32), per)
+        ent_pos = np.tile(np.arange(0, L, kk, dtype=np.int32), len(uniq))
+    return kk, uniq, owner, ent_probe, ent_pos

@@ -1,0 +1,164 @@
+/*
+ * catchhip.h -- C ABI of libcatchhip.so: the MI355X (gfx950) implementation of
+ * the probe-coverage / set-cover / near-duplicate hot path of
+ * broadinstitute/catch v1.5.2.
+ *
+ * The reference is pure Python and has no FFI of its own: the functions below
+ * are what a ctypes binding for this path binds (INTEGRATION.md shows the
+ * stub).  Each entry point cites the reference code (relative to the
+ * reference repository root) whose behaviour it replaces.  Plain pointers and
+ * sizes only; every buffer named `const T* x` is a caller-owned HOST buffer
+ * unless the comment says "device".  All functions return 0 on success and a
+ * negative CATCHHIP_E* code on failure; catchhip_last_error() gives the
+ * message for the calling thread.  One host thread per context.
+ *
+ * Coordinates.  A `targets` object is a list of sequences, concatenated in
+ * the order given; consecutive sequences with the same genome index form one
+ * genome (= one "universe" of the set cover, catch/filter/
+ * set_cover_filter.py:414-453).  Cover rows are reported in genome
+ * coordinates (position within the genome's concatenated sequences), exactly
+ * as SetCoverFilter._make_sets builds them.
+ */
+#ifndef CATCHHIP_H
+#define CATCHHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CATCHHIP_ABI_VERSION 1
+
+#define CATCHHIP_OK 0
+#define CATCHHIP_EINVAL (-1)   /* bad argument */
+#define CATCHHIP_EHIP (-2)     /* HIP runtime error */
+#define CATCHHIP_ENOMEM (-3)   /* allocation failed */
+#define CATCHHIP_ERANK (-4)    /* rank list exhausted (reference: IndexError) */
+#define CATCHHIP_ECOMM (-5)    /* RCCL error */
+
+typedef struct catchhip_ctx catchhip_ctx;
+typedef struct catchhip_targets catchhip_targets;
+typedef struct catchhip_probes catchhip_probes;
+typedef struct catchhip_rows catchhip_rows;
+
+int catchhip_abi_version(void);
+const char *catchhip_last_error(void);
+
+/* ---- context: one HIP device + one stream ----------------------------- */
+int catchhip_device_count(int *count);
+int catchhip_ctx_create(int device, catchhip_ctx **out);
+int catchhip_ctx_destroy(catchhip_ctx *ctx);
+int catchhip_ctx_sync(catchhip_ctx *ctx);
+/* Elapsed GPU milliseconds spent in the kernels of the most recent call of
+ * the named phase (HIP events on the context's stream).  phase: 0 = cover
+ * scan kernels (K1 hit search), 1 = row build (sort/merge), 2 = greedy
+ * set-cover kernels, 3 = near-duplicate kernels. *launches = kernel launches
+ * timed. */
+int catchhip_ctx_last_kernel_ms(catchhip_ctx *ctx, int phase, double *ms,
+                                int64_t *launches);
+
+/* ---- inputs ------------------------------------------------------------ */
+/* Target sequences (catch/genome.py Genome.seqs of every genome of a group).
+ * bytes: concatenation of the nseq sequences (raw characters, compared by
+ * equality exactly as the reference compares str characters);
+ * seq_off[nseq+1]; seq_genome[nseq] non-decreasing genome index in
+ * [0, ngenomes). Uploads and bit-packs on the device. */
+int catchhip_targets_create(catchhip_ctx *ctx, const uint8_t *bytes,
+                            const int64_t *seq_off, const int32_t *seq_genome,
+                            int64_t nseq, int32_t ngenomes,
+                            catchhip_targets **out);
+int catchhip_targets_destroy(catchhip_targets *t);
+
+/* Candidate probes + their seed ("anchor") table, i.e. the content of the
+ * reference's kmer_probe_map (catch/probe.py:507-577 builds it,
+ * :580-763 stores it): nprobes UNIQUE probe sequences (bytes/probe_off),
+ * set_id[nprobes] = the set-cover set id that owns each unique probe
+ * (catch/filter/set_cover_filter.py:408-412), and nent unique
+ * (ent_probe, ent_pos) anchors of common length k. */
+int catchhip_probes_create(catchhip_ctx *ctx, const uint8_t *bytes,
+                           const int64_t *probe_off, int64_t nprobes,
+                           const int32_t *set_id, const int32_t *ent_probe,
+                           const int32_t *ent_pos, int64_t nent, int32_t k,
+                           catchhip_probes **out);
+int catchhip_probes_destroy(catchhip_probes *p);
+
+/* ---- K1: coverage scan -------------------------------------------------- */
+#define CATCHHIP_SCAN_AUTO 0     /* fast kernel when its preconditions hold */
+#define CATCHHIP_SCAN_GENERAL 1  /* force the seed-join + extension path */
+#define CATCHHIP_SCAN_FAST 2     /* force the tiled Hamming kernel (EINVAL if
+                                    preconditions do not hold) */
+/* Replaces SetCoverFilter._make_sets (catch/filter/set_cover_filter.py
+ * :359-470) = for every target sequence, probe.find_probe_covers_in_sequence
+ * (catch/probe.py:1008-1271) under the default hybridization model
+ * probe_covers_sequence_by_longest_common_substring(mismatches, lcf_thres,
+ * island) (catch/probe.py:1274-1346, catch/utils/longest_common_substring.py
+ * :59-159), then cover_extension / clip / genome offset (:424-453) and
+ * IntervalSet normalisation (catch/utils/interval.py:25-44, :288-316).
+ * Result: device-resident rows (set id, universe, start, end) sorted by
+ * (set id, universe, start); *nrows = number of rows. */
+int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *probes,
+                        const catchhip_targets *targets, int32_t mismatches,
+                        int32_t lcf_thres, int32_t island,
+                        int32_t cover_extension, int32_t mode,
+                        catchhip_rows **out, int64_t *nrows);
+/* Copy rows to the host (arrays of length nrows). */
+int catchhip_rows_fetch(catchhip_ctx *ctx, const catchhip_rows *rows,
+                        int32_t *set_id, int32_t *universe, int64_t *start,
+                        int64_t *end);
+/* Build a rows object from host arrays (sorted by (set, universe, start),
+ * disjoint non-touching within (set, universe)); genome_len[ngenomes] gives
+ * the coordinate range of each universe.  Lets the greedy solver run on
+ * externally supplied instances (the reference's set_cover unit tests). */
+int catchhip_rows_from_host(catchhip_ctx *ctx, const int32_t *set_id,
+                            const int32_t *universe, const int64_t *start,
+                            const int64_t *end, int64_t nrows,
+                            const int64_t *genome_len, int32_t ngenomes,
+                            catchhip_rows **out);
+int catchhip_rows_destroy(catchhip_rows *r);
+
+/* Replaces SetCoverFilter._compute_tolerant_bp_covered_within_sequence
+ * (catch/filter/set_cover_filter.py:472-529) for every sequence of
+ * `targets` (the caller adds reverse-complement sequences to `targets`):
+ * bp_out[i] += sum over sequences of the total length of the merged cover
+ * ranges of unique probe i (bp_out has nprobes entries, host). */
+int catchhip_tolerant_bp(catchhip_ctx *ctx, const catchhip_probes *probes,
+                         const catchhip_targets *targets, int32_t mismatches,
+                         int32_t lcf_thres, int32_t island, int64_t *bp_out);
+
+/* ---- K2: greedy multi-universe set cover ------------------------------- */
+/* Replaces set_cover.approx_multiuniverse(sets, costs == 1, universe_p,
+ * ranks, use_intervalsets=True) (catch/utils/set_cover.py:147-615) as called
+ * by catch/filter/set_cover_filter.py:113-144.  num_sets = number of
+ * candidate probes (set ids 0..num_sets-1); ranks[num_sets] (NULL = all
+ * equal); universe_p[ngenomes] float64 coverage fraction per universe
+ * (NULL = 1.0).  out_ids (capacity num_sets) receives the chosen set ids in
+ * pick order; *n_out their number. */
+int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *rows,
+                             int64_t num_sets, const int64_t *ranks,
+                             const double *universe_p, int64_t *out_ids,
+                             int64_t *n_out);
+
+/* Multi-GPU form: every rank holds the full rows; rank r evaluates the gains
+ * of sets s with s % nranks == r and the per-pick winner is agreed with one
+ * RCCL all-reduce(MAX) of a 64-bit key.  Requires catchhip_comm_init. */
+int catchhip_comm_unique_id(uint8_t *id128);
+int catchhip_comm_init(catchhip_ctx *ctx, const uint8_t *id128, int32_t nranks,
+                       int32_t rank);
+int catchhip_comm_destroy(catchhip_ctx *ctx);
+
+/* ---- K3: near-duplicate filter (Hamming LSH) --------------------------- */
+/* Replaces NearDuplicateFilter._filter for NearDuplicateFilterWithHamming
+ * Distance (catch/filter/near_duplicate_filter.py:47-142) with
+ * lsh.NearNeighborLookup (catch/utils/lsh.py:239-320): n UNIQUE probes of
+ * equal length L given in priority order (multiplicity descending, stable);
+ * positions[ntables*k] the sampled positions per table; keep[n] (host,
+ * uint8) receives 1 for probes that the sequential greedy pass includes. */
+int catchhip_ndf_hamming(catchhip_ctx *ctx, const uint8_t *bytes, int64_t n,
+                         int32_t L, const int32_t *positions, int32_t ntables,
+                         int32_t k, int32_t dist_thres, uint8_t *keep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CATCHHIP_H */

@@ -1,0 +1,480 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY (never part of the product path).
+
+ctypes front end to oracle/liboracle.so (the plain-C CPU restatement of the
+broadinstitute/catch v1.5.2 hot path) plus the small pure-Python pieces of the
+restatement (anchor-table construction, rank computation, near-duplicate
+filter).  Only tests/, bench.py's `cpu_baseline` leg and
+__graft_entry__.smoke() may import this module, and only as the checker.
+
+Pinned against golden vectors recorded from the live reference
+(tests/golden/*.json, generator tests/golden/make_golden.py); see
+tests/test_oracle_golden.py.  Reference citations are relative to
+/root/reference.
+"""
+import ctypes
+import math
+import os
+import random
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (Makefile in this directory)."""
+    src = os.path.join(_HERE, "catch_oracle.c")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.orc_free.argtypes = [ctypes.c_void_p]
+        L.orc_k_lcf_around_anchor.argtypes = [
+            _u8p, ctypes.c_int64, _u8p, ctypes.c_int64, ctypes.c_int64,
+            ctypes.c_int64, ctypes.c_int64, _i64p, _i64p]
+        L.orc_lcf_cover.argtypes = [
+            _u8p, ctypes.c_int64, _u8p, ctypes.c_int64, ctypes.c_int64,
+            ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+            ctypes.c_int64, ctypes.c_int64, _i64p, _i64p]
+        L.orc_lcf_cover.restype = ctypes.c_int
+        L.orc_merge_overlapping.argtypes = [_i64p, _i64p, ctypes.c_int64]
+        L.orc_merge_overlapping.restype = ctypes.c_int64
+        L.orc_scan_sequence.argtypes = [
+            _u8p, ctypes.c_int64, _u8p, _i64p, _i32p, _i32p, ctypes.c_int64,
+            ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+            ctypes.c_int, ctypes.POINTER(_i32p), ctypes.POINTER(_i64p),
+            ctypes.POINTER(_i64p)]
+        L.orc_scan_sequence.restype = ctypes.c_int64
+        L.orc_make_sets.argtypes = [
+            _u8p, _i64p, _i32p, ctypes.c_int64, _u8p, _i64p, _i32p, _i32p,
+            ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+            ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(_i32p),
+            ctypes.POINTER(_i32p), ctypes.POINTER(_i64p), ctypes.POINTER(_i64p)]
+        L.orc_make_sets.restype = ctypes.c_int64
+        L.orc_approx_multiuniverse.argtypes = [
+            _i32p, _i32p, _i64p, _i64p, ctypes.c_int64, ctypes.c_int64,
+            ctypes.c_int64, _f64p, _f64p, _i64p, _i64p]
+        L.orc_approx_multiuniverse.restype = ctypes.c_int64
+        _lib = L
+    return _lib
+
+
+def _bytes_arr(s):
+    if isinstance(s, str):
+        s = s.encode("latin-1")
+    a = np.frombuffer(bytes(s), dtype=np.uint8)
+    if a.size == 0:
+        a = np.zeros(1, dtype=np.uint8)[:0]
+    return np.ascontiguousarray(a)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _take(ptr, n, dtype):
+    if n == 0:
+        out = np.zeros(0, dtype=dtype)
+    else:
+        out = np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+    lib().orc_free(ctypes.cast(ptr, ctypes.c_void_p))
+    return out
+
+
+# --------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------
+def k_lcf_around_anchor(a, b, anchor_start, anchor_end, k):
+    """catch/utils/longest_common_substring.py:59-159 -> (length, start)."""
+    aa, bb = _bytes_arr(a), _bytes_arr(b)
+    ol, os_ = ctypes.c_int64(), ctypes.c_int64()
+    lib().orc_k_lcf_around_anchor(_p(aa, _u8p), aa.size, _p(bb, _u8p), bb.size,
+                                  anchor_start, anchor_end, k,
+                                  ctypes.byref(ol), ctypes.byref(os_))
+    return int(ol.value), int(os_.value)
+
+
+def lcf_cover(probe_seq, sequence, kmer_start, kmer_end, full_probe_len,
+              full_sequence_len, mismatches, lcf_thres, island=0):
+    """catch/probe.py:1328-1344 -> (start, end) or None."""
+    aa, bb = _bytes_arr(probe_seq), _bytes_arr(sequence)
+    s, e = ctypes.c_int64(), ctypes.c_int64()
+    ok = lib().orc_lcf_cover(_p(aa, _u8p), aa.size, _p(bb, _u8p), bb.size,
+                             kmer_start, kmer_end, full_probe_len,
+                             full_sequence_len, mismatches, lcf_thres, island,
+                             ctypes.byref(s), ctypes.byref(e))
+    return (int(s.value), int(e.value)) if ok else None
+
+
+def merge_overlapping(intervals):
+    """catch/utils/interval.py:288-316."""
+    n = len(intervals)
+    if n == 0:
+        return []
+    st = np.array([x[0] for x in intervals], dtype=np.int64)
+    en = np.array([x[1] for x in intervals], dtype=np.int64)
+    m = lib().orc_merge_overlapping(_p(st, _i64p), _p(en, _i64p), n)
+    return [(int(st[i]), int(en[i])) for i in range(m)]
+
+
+# --------------------------------------------------------------------------
+# anchor (k-mer seed) table: catch/probe.py:356-577
+# --------------------------------------------------------------------------
+def pigeonhole_k(probe_length, mismatches, min_k):
+    """catch/probe.py:470-494; returns k or None when k < min_k."""
+    if mismatches == 0:
+        k = probe_length
+    else:
+        k = int(probe_length / mismatches)
+        if k == float(probe_length) / mismatches:
+            k -= 1
+        while probe_length % k != 0:
+            k -= 1
+    if k < min_k:
+        return None
+    return k
+
+
+def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
+                 num_kmers_per_probe=20):
+    """construct_kmer_probe_map_to_find_probe_covers (catch/probe.py:507-577).
+    probe_strs may contain duplicates (the reference iterates every Probe
+    object, so in random mode np.random is consumed once per input probe,
+    :391-401, and equal probes pool their positions because Probe hashes by
+    sequence).  Returns (k, entries): entries = sorted unique
+    (unique_probe_index, position) pairs, unique indices in first-seen order
+    (see _unique_last)."""
+    if len(probe_strs) == 0:
+        return None, []
+    uidx = {}
+    for p in probe_strs:
+        uidx.setdefault(p, len(uidx))
+    L = len(probe_strs[0])
+    differ = any(len(p) != L for p in probe_strs)
+    use_random = (mismatches is None or lcf_thres is None or differ
+                  or lcf_thres < L)
+    kk = None
+    if not use_random:
+        kk = pigeonhole_k(L, mismatches, min_k)
+        if kk is None:
+            use_random = True
+    entries = set()
+    if use_random:
+        for p in probe_strs:
+            if k > len(p):
+                raise ValueError("k is larger than the length of a probe")
+            n_kmers = len(p) - k + 1
+            for pos in np.random.choice(n_kmers, size=num_kmers_per_probe,
+                                        replace=True):
+                entries.add((uidx[p], int(pos)))
+        kk = k
+    else:
+        for p in probe_strs:
+            for pos in range(0, L, kk):
+                entries.add((uidx[p], pos))
+    return kk, sorted(entries)
+
+
+def _pack_probes(probe_strs):
+    off = np.zeros(len(probe_strs) + 1, dtype=np.int64)
+    for i, p in enumerate(probe_strs):
+        off[i + 1] = off[i] + len(p)
+    buf = _bytes_arr("".join(probe_strs))
+    return buf, off
+
+
+def _pack_entries(entries):
+    ep = np.array([e[0] for e in entries], dtype=np.int32)
+    eo = np.array([e[1] for e in entries], dtype=np.int32)
+    return ep, eo
+
+
+# --------------------------------------------------------------------------
+# scan: catch/probe.py:1008-1271
+# --------------------------------------------------------------------------
+def scan_sequence(sequence, probe_strs, entries, k, mismatches, lcf_thres,
+                  island=0, merge=True):
+    """find_probe_covers_in_sequence -> {probe_index: [(start, end), ...]}."""
+    seq = _bytes_arr(sequence)
+    buf, off = _pack_probes(probe_strs)
+    ep, eo = _pack_entries(entries)
+    op, os_, oe = _i32p(), _i64p(), _i64p()
+    n = lib().orc_scan_sequence(_p(seq, _u8p), seq.size, _p(buf, _u8p),
+                                _p(off, _i64p), _p(ep, _i32p), _p(eo, _i32p),
+                                len(entries), k, mismatches, lcf_thres, island,
+                                1 if merge else 0, ctypes.byref(op),
+                                ctypes.byref(os_), ctypes.byref(oe))
+    pr = _take(op, n, np.int32)
+    st = _take(os_, n, np.int64)
+    en = _take(oe, n, np.int64)
+    out = {}
+    for i in range(n):
+        out.setdefault(int(pr[i]), []).append((int(st[i]), int(en[i])))
+    return out
+
+
+def make_sets(probe_strs, entries, k, genomes, mismatches, lcf_thres,
+              island=0, cover_extension=0):
+    """SetCoverFilter._make_sets (catch/filter/set_cover_filter.py:359-470).
+    genomes: list of genomes, each a list of sequence strings.
+    Returns int arrays (probe, universe, start, end) sorted by
+    (probe, universe, start), IntervalSet-normalised."""
+    seqs, seq_genome = [], []
+    for j, g in enumerate(genomes):
+        for s in g:
+            seqs.append(s)
+            seq_genome.append(j)
+    soff = np.zeros(len(seqs) + 1, dtype=np.int64)
+    for i, s in enumerate(seqs):
+        soff[i + 1] = soff[i] + len(s)
+    sbuf = _bytes_arr("".join(seqs))
+    sg = np.array(seq_genome, dtype=np.int32)
+    buf, off = _pack_probes(probe_strs)
+    ep, eo = _pack_entries(entries)
+    op, ou, os_, oe = _i32p(), _i32p(), _i64p(), _i64p()
+    n = lib().orc_make_sets(_p(sbuf, _u8p), _p(soff, _i64p), _p(sg, _i32p),
+                            len(seqs), _p(buf, _u8p), _p(off, _i64p),
+                            _p(ep, _i32p), _p(eo, _i32p), len(entries), k,
+                            mismatches, lcf_thres, island, cover_extension,
+                            ctypes.byref(op), ctypes.byref(ou),
+                            ctypes.byref(os_), ctypes.byref(oe))
+    return (_take(op, n, np.int32), _take(ou, n, np.int32),
+            _take(os_, n, np.int64), _take(oe, n, np.int64))
+
+
+# --------------------------------------------------------------------------
+# greedy multi-universe set cover: catch/utils/set_cover.py:147-615
+# --------------------------------------------------------------------------
+def approx_multiuniverse(row_set, row_univ, row_start, row_end, num_sets,
+                         num_universes, costs=None, universe_p=None,
+                         ranks=None):
+    """Rows sorted by (set, universe, start), normalised per (set, universe).
+    Returns the picked set ids in pick order."""
+    rs = np.ascontiguousarray(row_set, dtype=np.int32)
+    ru = np.ascontiguousarray(row_univ, dtype=np.int32)
+    st = np.ascontiguousarray(row_start, dtype=np.int64)
+    en = np.ascontiguousarray(row_end, dtype=np.int64)
+    P, U = int(num_sets), int(num_universes)
+    c = (np.ones(P, dtype=np.float64) if costs is None
+         else np.ascontiguousarray(costs, dtype=np.float64))
+    up = (np.ones(U, dtype=np.float64) if universe_p is None
+          else np.ascontiguousarray(universe_p, dtype=np.float64))
+    rk = (np.ones(P, dtype=np.int64) if ranks is None
+          else np.ascontiguousarray(ranks, dtype=np.int64))
+    out = np.zeros(max(P, 1), dtype=np.int64)
+    n = lib().orc_approx_multiuniverse(_p(rs, _i32p), _p(ru, _i32p),
+                                       _p(st, _i64p), _p(en, _i64p), rs.size,
+                                       P, U, _p(c, _f64p), _p(up, _f64p),
+                                       _p(rk, _i64p), _p(out, _i64p))
+    if n < 0:
+        raise IndexError("rank list exhausted (reference raises IndexError)")
+    return [int(x) for x in out[:n]]
+
+
+# --------------------------------------------------------------------------
+# SetCoverFilter end to end: catch/filter/set_cover_filter.py:794-930
+# --------------------------------------------------------------------------
+_RC = {ord('A'): 'T', ord('T'): 'A', ord('C'): 'G', ord('G'): 'C'}
+
+
+def reverse_complement(s):
+    """catch/filter/set_cover_filter.py:515-521 (non-ACGT map to themselves)."""
+    return "".join(_RC.get(ord(b), b) for b in s[::-1])
+
+
+def _unique_last(probe_strs):
+    """Unique probe strings in first-seen order; owner index = LAST index with
+    that string (catch/filter/set_cover_filter.py:408-412)."""
+    owner = {}
+    for i, p in enumerate(probe_strs):
+        owner[p] = i
+    uniq = list(owner.keys())
+    return uniq, [owner[p] for p in uniq]
+
+
+def tolerant_bp(uniq, entries, k, sequence, mismatches, lcf_thres, island,
+                rc_too=True):
+    """_compute_tolerant_bp_covered_within_sequence (:472-529)."""
+    out = {}
+    seqs = [sequence] + ([reverse_complement(sequence)] if rc_too else [])
+    for s in seqs:
+        for pi, ranges in scan_sequence(s, uniq, entries, k, mismatches,
+                                        lcf_thres, island, True).items():
+            out[pi] = out.get(pi, 0) + sum(e - st for st, e in ranges)
+    return out
+
+
+def make_ranks(probe_strs, genomes_grouped, params, avoided_sequences):
+    """_make_ranks (:614-735). avoided_sequences: list of sequence strings in
+    the order seq_io.iterate_fasta yields them over all avoided FASTA files."""
+    identify = params.get("identify", False)
+    uniq, _ = _unique_last(probe_strs)
+    uidx = {p: i for i, p in enumerate(uniq)}
+    need = identify or len(avoided_sequences) > 0
+    if need:
+        m_t, l_t, i_t = (params["mismatches_tolerant"],
+                         params["lcf_thres_tolerant"],
+                         params["island_tolerant"])
+        kk = params.get("kmer_probe_map_k", 20)
+        k, entries = anchor_table(probe_strs, m_t, l_t, min_k=kk, k=kk)
+    rank_val = {}
+    if identify:
+        hits = [0] * len(uniq)
+        for group in genomes_grouped:
+            tot = {}
+            for g in group:
+                for s in g:
+                    for pi, bp in tolerant_bp(uniq, entries, k, s, m_t, l_t,
+                                              i_t, True).items():
+                        tot[pi] = tot.get(pi, 0) + bp
+            for pi, bp in tot.items():
+                if bp >= 1:
+                    hits[pi] += 1
+        for pi in range(len(uniq)):
+            rank_val[pi] = (0, hits[pi])
+    else:
+        for pi in range(len(uniq)):
+            rank_val[pi] = (0, 0)
+    tot = {}
+    for s in avoided_sequences:
+        for pi, bp in tolerant_bp(uniq, entries, k, s, m_t, l_t, i_t,
+                                  True).items():
+            tot[pi] = tot.get(pi, 0) + bp
+    for pi, bp in tot.items():
+        if bp > 0:
+            rank_val[pi] = (1, bp)
+    all_t = sorted(set(rank_val.values()))
+    tidx = {t: i for i, t in enumerate(all_t)}
+    return [tidx[rank_val[uidx[p]]] for p in probe_strs]
+
+
+def universe_p(coverage, genome_sizes):
+    """_make_universe_p (:761-792)."""
+    if coverage <= 1.0:
+        return [coverage for _ in genome_sizes]
+    return [float(min(coverage, sz)) / sz for sz in genome_sizes]
+
+
+def set_cover_filter(probes_grouped, genomes_grouped, mismatches, lcf_thres,
+                     island=0, mismatches_tolerant=None,
+                     lcf_thres_tolerant=None, island_tolerant=None,
+                     identify=False, avoided_sequences=(), coverage=1.0,
+                     cover_extension=0, kmer_probe_map_k=20,
+                     return_intermediate=False):
+    """SetCoverFilter.__init__ + _filter (catch/filter/set_cover_filter.py
+    :199-357, :902-930).  probes_grouped: list of lists of probe strings;
+    genomes_grouped: list (per group) of genomes, each a list of sequence
+    strings.  Returns per-group sorted lists of selected probe indices."""
+    if not mismatches_tolerant:
+        mismatches_tolerant = mismatches
+    if not lcf_thres_tolerant:
+        lcf_thres_tolerant = lcf_thres
+    if not island_tolerant:
+        island_tolerant = island
+    params = dict(identify=identify, mismatches_tolerant=mismatches_tolerant,
+                  lcf_thres_tolerant=lcf_thres_tolerant,
+                  island_tolerant=island_tolerant,
+                  kmer_probe_map_k=kmer_probe_map_k)
+    selected, inter = [], []
+    for gi, (probe_strs, genomes) in enumerate(zip(probes_grouped,
+                                                   genomes_grouped)):
+        probe_strs = list(probe_strs)
+        P = len(probe_strs)
+        if P == 0:
+            rows = (np.zeros(0, np.int32), np.zeros(0, np.int32),
+                    np.zeros(0, np.int64), np.zeros(0, np.int64))
+            k, entries = None, []
+        else:
+            uniq, owner = _unique_last(probe_strs)
+            k, entries = anchor_table(probe_strs, mismatches, lcf_thres,
+                                      min_k=kmer_probe_map_k,
+                                      k=kmer_probe_map_k)
+            up_, uu, us, ue = make_sets(uniq, entries, k, genomes, mismatches,
+                                        lcf_thres, island, cover_extension)
+            own = np.array(owner, dtype=np.int32)
+            rs = own[up_] if up_.size else up_
+            order = np.lexsort((us, uu, rs))
+            rows = (rs[order], uu[order], us[order], ue[order])
+        ranks = make_ranks(probe_strs, genomes_grouped, params,
+                           list(avoided_sequences)) if P else []
+        up = universe_p(coverage, [sum(len(s) for s in g) for g in genomes])
+        picks = approx_multiuniverse(rows[0], rows[1], rows[2], rows[3], P,
+                                     len(genomes), None, up,
+                                     ranks) if P else []
+        selected.append(sorted(picks))
+        inter.append(dict(k=k, entries=entries, rows=rows, ranks=ranks,
+                          universe_p=up, picks=picks))
+    if return_intermediate:
+        return selected, inter
+    return selected
+
+
+# --------------------------------------------------------------------------
+# near-duplicate filter (Hamming): catch/filter/near_duplicate_filter.py
+# :47-142 + catch/utils/lsh.py:16-45, :218-320
+# --------------------------------------------------------------------------
+def lsh_num_tables(dist_thres, dim, k, reporting_prob=0.80):
+    """catch/utils/lsh.py:268-276."""
+    P1 = 1.0 - float(dist_thres) / float(dim)
+    if P1 == 1.0:
+        return 1
+    return int(math.ceil(math.log(1.0 - reporting_prob,
+                                  1.0 - math.pow(P1, k))))
+
+
+def lsh_draw_positions(num_tables, k, dim):
+    """Positions in the order the reference draws them: per table, k calls of
+    random.randint(0, dim-1) (lsh.py:284-287 -> :224 -> :28)."""
+    return [[random.randint(0, dim - 1) for _ in range(k)]
+            for _ in range(num_tables)]
+
+
+def ndf_hamming(probe_strs, dist_thres, positions):
+    """NearDuplicateFilter._filter with the Hamming family; `positions` is the
+    per-table list of sampled positions.  Returns the kept probe strings in
+    inclusion order (= multiplicity-sorted order)."""
+    occ = {}
+    for p in probe_strs:
+        occ[p] = occ.get(p, 0) + 1
+    # stable sort by count desc (near_duplicate_filter.py:64-66)
+    order = [p for p, _ in sorted(occ.items(), key=lambda kv: kv[1],
+                                  reverse=True)]
+    tables = []
+    for pos in positions:
+        ht = {}
+        for p in occ.keys():
+            ht.setdefault(tuple(p[i] for i in pos), []).append(p)
+        tables.append(ht)
+    arr = {p: np.frombuffer(p.encode("latin-1"), dtype=np.uint8)
+           for p in occ.keys()}
+    include, exclude, kept = set(), set(), []
+    for p in order:
+        if p in exclude:
+            continue
+        include.add(p)
+        kept.append(p)
+        for pos, ht in zip(positions, tables):
+            for q in ht[tuple(p[i] for i in pos)]:
+                if q in include:
+                    continue
+                if len(q) != len(p):
+                    raise ValueError("Sequences must be of same length")
+                if int(np.count_nonzero(arr[p] != arr[q])) <= dist_thres:
+                    exclude.add(q)
+    return kept

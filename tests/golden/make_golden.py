@@ -1,0 +1,517 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the LIVE reference.
+
+Runs only in the authoring container (needs /root/reference, which never
+travels to the GPU box).  Nothing from the reference is copied: this script
+imports broadinstitute/catch v1.5.2 read-only, wraps the functions on the hot
+path with recorders, runs the reference's own unit-test suites for that path
+(so every known-answer case those tests assert is captured as
+inputs -> outputs *data*), then runs the reference on seeded synthetic inputs
+made by catch_amd/utils/synthetic.py.  Output: gzip'd JSON fixtures.
+
+    PYTHONDONTWRITEBYTECODE=1 PYTHONHASHSEED=0 python tests/golden/make_golden.py
+"""
+import gzip
+import importlib.util  # noqa: F401  (the reference's dynamic_load relies on it being imported)
+from collections import OrderedDict
+import json
+import os
+import random
+import sys
+import unittest
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(1, REPO)
+
+import numpy as np  # noqa: E402
+
+from catch import probe  # noqa: E402
+from catch import genome  # noqa: E402
+from catch.filter import set_cover_filter as scf  # noqa: E402
+from catch.filter import near_duplicate_filter as ndf  # noqa: E402
+from catch.filter import candidate_probes  # noqa: E402
+from catch.filter import duplicate_filter  # noqa: E402
+from catch.utils import longest_common_substring as lcs  # noqa: E402
+from catch.utils import set_cover  # noqa: E402
+from catch.utils import interval  # noqa: E402
+from catch.utils import lsh  # noqa: E402
+from catch.utils import seq_io  # noqa: E402
+
+from catch_amd.utils import synthetic  # noqa: E402
+
+REC = {"lcs": [], "lcf": [], "scan": [], "setcover": [], "scf": [], "ndf": [],
+       "merge": []}
+MAX_SEQ = 6000          # do not record scans of sequences longer than this
+MAX_PER_KIND = 4000
+
+
+def _s(x):
+    if isinstance(x, np.ndarray):
+        return "".join(x)
+    return str(x)
+
+
+# ---------------------------------------------------------------- lcs / lcf
+_orig_klcf = lcs.k_lcf_around_anchor
+
+
+def rec_klcf(a, b, anchor_start, anchor_end, k):
+    out = _orig_klcf(a, b, anchor_start, anchor_end, k)
+    if len(REC["lcs"]) < MAX_PER_KIND and len(a) <= 400:
+        REC["lcs"].append(dict(a=_s(a), b=_s(b), anchor_start=int(anchor_start),
+                               anchor_end=int(anchor_end), k=int(k),
+                               out=[int(out[0]), int(out[1])]))
+    return out
+
+
+_orig_factory = probe.probe_covers_sequence_by_longest_common_substring
+_in_worker_guard = {"pid": os.getpid()}
+
+
+def rec_factory(mismatches, lcf_thres, island_of_exact_match=0):
+    fn = _orig_factory(mismatches, lcf_thres, island_of_exact_match)
+
+    def lcf(probe_seq, sequence, kmer_start, kmer_end, full_probe_len,
+            full_sequence_len):
+        out = fn(probe_seq, sequence, kmer_start, kmer_end, full_probe_len,
+                 full_sequence_len)
+        if (os.getpid() == _in_worker_guard["pid"]
+                and len(REC["lcf"]) < MAX_PER_KIND and len(probe_seq) <= 400):
+            REC["lcf"].append(dict(
+                probe_seq=_s(probe_seq), sequence=_s(sequence),
+                kmer_start=int(kmer_start), kmer_end=int(kmer_end),
+                full_probe_len=int(full_probe_len),
+                full_sequence_len=int(full_sequence_len),
+                mismatches=int(mismatches), lcf_thres=int(lcf_thres),
+                island=int(island_of_exact_match),
+                out=None if out is None else [int(out[0]), int(out[1])]))
+        return out
+    lcf.orc_params = (mismatches, lcf_thres, island_of_exact_match)
+    return lcf
+
+
+# ---------------------------------------------------------------- merge
+_orig_merge = interval.merge_overlapping
+
+
+def rec_merge(intervals):
+    out = _orig_merge(intervals)
+    if (os.getpid() == _in_worker_guard["pid"] and len(REC["merge"]) < 500
+            and len(intervals) <= 64):
+        try:
+            REC["merge"].append(dict(
+                intervals=[[int(s), int(e)] for s, e in intervals],
+                out=[[int(s), int(e)] for s, e in out]))
+        except (TypeError, ValueError):
+            pass
+    return out
+
+
+# ---------------------------------------------------------------- scan
+_pool_state = {}
+_orig_open = probe.open_probe_finding_pool
+_orig_find = probe.find_probe_covers_in_sequence
+
+
+def rec_open(kmer_probe_map, cover_range_for_probe_in_subsequence_fn,
+             *args, **kwargs):
+    _pool_state.clear()
+    params = getattr(cover_range_for_probe_in_subsequence_fn, "orc_params",
+                     None)
+    _pool_state["params"] = params
+    _pool_state["k"] = int(kmer_probe_map.k)
+    ents = []
+    for kmer, lst in kmer_probe_map.native_dict.items():
+        for seq_str, pos in lst:
+            ents.append((seq_str, int(pos)))
+    _pool_state["entries"] = sorted(set(ents))
+    return _orig_open(kmer_probe_map, cover_range_for_probe_in_subsequence_fn,
+                      *args, **kwargs)
+
+
+def rec_find(sequence, merge_overlapping=True):
+    out = _orig_find(sequence, merge_overlapping=merge_overlapping)
+    if (_pool_state.get("params") is not None and len(sequence) <= MAX_SEQ
+            and len(REC["scan"]) < 600):
+        m, thres, island = _pool_state["params"]
+        probes = sorted(set(e[0] for e in _pool_state["entries"]))
+        pidx = {p: i for i, p in enumerate(probes)}
+        REC["scan"].append(dict(
+            sequence=sequence, probes=probes, k=_pool_state["k"],
+            entries=[[pidx[s], pos] for s, pos in _pool_state["entries"]],
+            mismatches=int(m), lcf_thres=int(thres), island=int(island),
+            merge=bool(merge_overlapping),
+            out={str(pidx[p.seq_str]): [[int(s), int(e)] for s, e in rngs]
+                 for p, rngs in out.items()}))
+    return out
+
+
+# ---------------------------------------------------------------- set cover
+_orig_amu = set_cover.approx_multiuniverse
+
+
+def _to_intervals(s):
+    if isinstance(s, tuple) and len(s) == 2 and all(
+            isinstance(x, (int, np.integer)) for x in s):
+        return [[int(s[0]), int(s[1])]]
+    if isinstance(s, interval.IntervalSet):
+        return [[int(a), int(b)] for a, b in s.intervals]
+    elems = sorted(int(v) for v in s)
+    out = []
+    for v in elems:
+        if out and out[-1][1] == v:
+            out[-1][1] = v + 1
+        elif out and out[-1][1] > v:
+            continue
+        else:
+            out.append([v, v + 1])
+    return out
+
+
+def rec_amu(sets, costs=None, universe_p=None, ranks=None, use_arrays=False,
+            use_intervalsets=False, logger_prefix=""):
+    out = _orig_amu(sets, costs=costs, universe_p=universe_p, ranks=ranks,
+                    use_arrays=use_arrays, use_intervalsets=use_intervalsets,
+                    logger_prefix=logger_prefix)
+    if os.getpid() != _in_worker_guard["pid"] or len(REC["setcover"]) >= 400:
+        return out
+    try:
+        # iteration order of the reference's `set(sets.keys())` defines ties
+        order = list(set(sets.keys()))
+        sid = {k: i for i, k in enumerate(order)}
+        uid = {}
+        rows = []
+        for k in order:
+            for u, s in sets[k].items():
+                if use_intervalsets and isinstance(s, tuple):
+                    ivs = [[int(s[0]), int(s[1])]]
+                else:
+                    if not use_intervalsets and not all(
+                            isinstance(v, (int, np.integer)) for v in s):
+                        return out
+                    ivs = _to_intervals(s)
+                ui = uid.setdefault(u, len(uid))
+                for a, b in ivs:
+                    rows.append([sid[k], ui, a, b])
+        rows.sort()
+        rec = dict(rows=rows, num_sets=len(order), num_universes=len(uid),
+                   costs=None if costs is None else
+                   [float(costs[k]) for k in order],
+                   universe_p=None if universe_p is None else
+                   [float(universe_p[u]) for u in uid.keys()],
+                   ranks=None if ranks is None else
+                   [int(ranks[k]) for k in order],
+                   out=sorted(sid[k] for k in out))
+        REC["setcover"].append(rec)
+    except Exception as e:  # unrepresentable instance: skip it
+        sys.stderr.write("skip setcover record: %r\n" % (e,))
+    return out
+
+
+# ---------------------------------------------------------------- SCF
+_orig_scf_filter = scf.SetCoverFilter._filter
+_orig_make_sets = scf.SetCoverFilter._make_sets
+_orig_make_ranks = scf.SetCoverFilter._make_ranks
+_orig_rand_map = probe._construct_rand_kmer_probe_map
+_scf_side = {}
+
+
+def rec_rand_map(*a, **k):
+    _scf_side["used_random"] = True
+    return _orig_rand_map(*a, **k)
+
+
+def rec_make_sets(self, candidate_probes_, target_genomes):
+    sets = _orig_make_sets(self, candidate_probes_, target_genomes)
+    rows = []
+    for set_id, d in sets.items():
+        for u, s in d.items():
+            ivs = [s] if isinstance(s, tuple) else list(s.intervals)
+            for a, b in ivs:
+                rows.append([int(set_id), int(u), int(a), int(b)])
+    rows.sort()
+    _scf_side.setdefault("rows", []).append(rows)
+    return sets
+
+
+def rec_make_ranks(self, candidate_probes_, target_genomes_grouped):
+    ranks = _orig_make_ranks(self, candidate_probes_, target_genomes_grouped)
+    _scf_side.setdefault("ranks", []).append(
+        [int(ranks[i]) for i in range(len(candidate_probes_))])
+    return ranks
+
+
+def rec_scf_filter(self, input, target_genomes_grouped):
+    _scf_side.clear()
+    state = np.random.get_state()
+    out = _orig_scf_filter(self, input, target_genomes_grouped)
+    sp = getattr(self.cover_range_fn, "orc_params", None)
+    tp = getattr(self.cover_range_tolerant_fn, "orc_params", None)
+    if sp is None or tp is None or len(REC["scf"]) >= 400:
+        return out
+    avoided = []
+    for path in self.avoided_genomes:
+        avoided.extend(list(seq_io.iterate_fasta(path)))
+    rec = dict(
+        mismatches=int(sp[0]), lcf_thres=int(sp[1]), island=int(sp[2]),
+        mismatches_tolerant=int(tp[0]), lcf_thres_tolerant=int(tp[1]),
+        island_tolerant=int(tp[2]), identify=bool(self.identify),
+        avoided_sequences=avoided, coverage=self.coverage,
+        cover_extension=int(self.cover_extension),
+        kmer_probe_map_k=int(self.kmer_probe_map_k),
+        probes=[[p.seq_str for p in g] for g in input],
+        genomes=[[list(g.seqs) for g in grp] for grp in target_genomes_grouped],
+        rows=_scf_side.get("rows"), ranks=_scf_side.get("ranks"),
+        out=[sorted(p.seq_str for p in g) for g in out])
+    if _scf_side.get("used_random"):
+        rec["np_random_state"] = [state[0], [int(x) for x in state[1]],
+                                  int(state[2]), int(state[3]),
+                                  float(state[4])]
+    REC["scf"].append(rec)
+    return out
+
+
+# ---------------------------------------------------------------- NDF
+_orig_ndf_filter = ndf.NearDuplicateFilter._filter
+
+
+class _RandProxy:
+    def __init__(self):
+        self.log = []
+
+    def randint(self, a, b):
+        v = random.randint(a, b)
+        self.log.append(int(v))
+        return v
+
+    def __getattr__(self, name):
+        return getattr(random, name)
+
+
+def rec_ndf_filter(self, input):
+    input = list(input)
+    is_hamming = isinstance(self.lsh_family, lsh.HammingDistanceFamily)
+    proxy = _RandProxy()
+    old = lsh.random
+    lsh.random = proxy
+    try:
+        out = _orig_ndf_filter(self, input)
+    finally:
+        lsh.random = old
+    if (is_hamming and os.getpid() == _in_worker_guard["pid"]
+            and len(REC["ndf"]) < 200 and len(input) <= 5000):
+        k = self.k
+        pos = [proxy.log[i:i + k] for i in range(0, len(proxy.log), k)]
+        REC["ndf"].append(dict(
+            probes=[p.seq_str for p in input], dist_thres=int(self.dist_thres),
+            k=int(k), reporting_prob=float(self.reporting_prob),
+            dim=int(self.lsh_family.dim), positions=pos,
+            out=sorted(p.seq_str for p in out)))
+    return out
+
+
+def install():
+    lcs.k_lcf_around_anchor = rec_klcf
+    probe.probe_covers_sequence_by_longest_common_substring = rec_factory
+    probe.open_probe_finding_pool = rec_open
+    probe.find_probe_covers_in_sequence = rec_find
+    probe._construct_rand_kmer_probe_map = rec_rand_map
+    set_cover.approx_multiuniverse = rec_amu
+    scf.SetCoverFilter._filter = rec_scf_filter
+    scf.SetCoverFilter._make_sets = rec_make_sets
+    scf.SetCoverFilter._make_ranks = rec_make_ranks
+    ndf.NearDuplicateFilter._filter = rec_ndf_filter
+    # subclasses call NearDuplicateFilter._filter(self, input) explicitly
+
+
+def run_reference_tests():
+    names = [
+        "catch.utils.tests.test_longest_common_substring",
+        "catch.utils.tests.test_interval",
+        "catch.utils.tests.test_set_cover",
+        "catch.filter.tests.test_set_cover_filter",
+        "catch.filter.tests.test_near_duplicate_filter",
+        "catch.tests.test_probe",
+    ]
+    loader = unittest.TestLoader()
+    for n in names:
+        suite = loader.loadTestsFromName(n)
+        # skip the slow randomized recall tests of test_probe (not exact)
+        def keep(t):
+            return not any(s in t.id() for s in (
+                "random_small_genome", "random_large_genome",
+                "RandomGenome", "random_genome", "custom_cover_range_fn"))
+        flat = []
+
+        def walk(s):
+            for t in s:
+                if isinstance(t, unittest.TestSuite):
+                    walk(t)
+                elif keep(t):
+                    flat.append(t)
+        walk(suite)
+        res = unittest.TextTestRunner(verbosity=0).run(unittest.TestSuite(flat))
+        print(n, "ran", res.testsRun, "failures", len(res.failures),
+              "errors", len(res.errors), flush=True)
+        if res.failures or res.errors:
+            raise SystemExit("reference tests failed under the recorder")
+
+
+# ---------------------------------------------------------------- synthetic
+def _run_scf(groups_genomes, L, stride, m, e, coverage, lcf_thres=None,
+             island=0, seed=None, identify=False, k_map=20, dedup=True):
+    """Reference pipeline: candidates -> DuplicateFilter -> SetCoverFilter."""
+    if seed is not None:
+        np.random.seed(seed)
+    tg = [[genome.Genome.from_chrs(OrderedDict((str(i), s) for i, s in enumerate(g)))
+           if len(g) > 1 else genome.Genome.from_one_seq(g[0]) for g in grp]
+          for grp in groups_genomes]
+    probes = []
+    for grp in tg:
+        c = []
+        for g in grp:
+            c += candidate_probes.make_candidate_probes_from_sequences(
+                g.seqs, probe_length=L, probe_stride=stride,
+                min_n_string_length=2)
+        if dedup:
+            c = duplicate_filter.DuplicateFilter().filter(c)
+        probes.append(c)
+    f = scf.SetCoverFilter(mismatches=m, lcf_thres=lcf_thres or L,
+                           island_of_exact_match=island, coverage=coverage,
+                           cover_extension=e, identify=identify,
+                           kmer_probe_map_k=k_map)
+    f.filter(probes, tg, input_is_grouped=True)
+    rec = REC["scf"].pop()
+    rec["synthetic"] = True
+    return rec
+
+
+def synthetic_cases():
+    out = []
+    rng = np.random.Generator(np.random.PCG64(77))
+    # 6 x 3 kb divergent genomes with Ns
+    small = [synthetic.make_species(rng, [3000], 6, 2, 0.04, 0.01)]
+    two = [synthetic.make_species(rng, [2500], 4, 2, 0.05, 0.01),
+           synthetic.make_species(rng, [1800, 900], 3, 1, 0.0, 0.02)]
+    cases = [
+        ("small_75_2_50", small, dict(L=75, stride=25, m=2, e=50, coverage=1.0)),
+        ("small_100_2_50", small, dict(L=100, stride=50, m=2, e=50, coverage=1.0)),
+        ("small_100_3_0_p90", small, dict(L=100, stride=50, m=3, e=0, coverage=0.9)),
+        ("small_75_2_10_p50", small, dict(L=75, stride=25, m=2, e=10, coverage=0.5)),
+        ("small_75_2_0_l60", small, dict(L=75, stride=25, m=2, e=0, coverage=1.0,
+                                         lcf_thres=60, seed=11)),
+        ("small_100_5_50", small, dict(L=100, stride=50, m=5, e=50, coverage=1.0,
+                                       seed=12)),
+        ("small_75_2_0_island", small, dict(L=75, stride=25, m=2, e=0,
+                                            coverage=1.0, island=30)),
+        ("small_75_1_0_bp", small, dict(L=75, stride=25, m=1, e=0, coverage=2000)),
+        ("two_100_2_50", two, dict(L=100, stride=50, m=2, e=50, coverage=1.0)),
+        ("two_75_2_20_identify", two, dict(L=75, stride=25, m=2, e=20,
+                                           coverage=0.3, identify=True)),
+        ("s1_75_2_50", synthetic.dataset("S1"),
+         dict(L=75, stride=25, m=2, e=50, coverage=1.0)),
+    ]
+    for name, groups, kw in cases:
+        rec = _run_scf(groups, **kw)
+        rec["name"] = name
+        out.append(rec)
+        print("synthetic", name, "probes", [len(g) for g in rec["probes"]],
+              "picks", [len(g) for g in rec["out"]], flush=True)
+    return out
+
+
+def candidate_cases():
+    out = []
+    rng = np.random.Generator(np.random.PCG64(5))
+    seqs = [g[0] for g in synthetic.make_species(rng, [1200], 4, 2, 0.05, 0.02)]
+    seqs.append("ACGT" * 30 + "NN" + "TTGACA" * 25 + "N" + "CAG" * 40 + "NNNNN"
+                + "GATTACA" * 20)
+    for L, stride in ((100, 50), (75, 25), (60, 60), (80, 33)):
+        ps = candidate_probes.make_candidate_probes_from_sequences(
+            seqs, probe_length=L, probe_stride=stride, min_n_string_length=2)
+        out.append(dict(seqs=seqs, probe_length=L, probe_stride=stride,
+                        out=[p.seq_str for p in ps]))
+    return out
+
+
+def ndf_cases():
+    out = []
+    rng = np.random.Generator(np.random.PCG64(9))
+    base = synthetic.make_species(rng, [4000], 8, 2, 0.03, 0.01, with_n=False)
+    for L, d, seed in ((75, 2, 123), (100, 2, 5), (100, 3, 6)):
+        ps = []
+        for g in base:
+            ps += candidate_probes.make_candidate_probes_from_sequences(
+                g, probe_length=L, probe_stride=L // 2)
+        random.seed(seed)
+        f = ndf.NearDuplicateFilterWithHammingDistance(d, L)
+        f.filter(ps)
+        rec = REC["ndf"].pop()
+        rec["seed"] = seed
+        out.append(rec)
+        print("ndf", L, d, len(rec["probes"]), "->", len(rec["out"]),
+              "tables", len(rec["positions"]), flush=True)
+    return out
+
+
+def random_lcs_cases(n=3000):
+    rnd = random.Random(4242)
+    out = []
+    for _ in range(n):
+        L = rnd.choice([30, 75, 100, 128, 140])
+        alpha = "ACGTN" if rnd.random() < 0.8 else "ACGT"
+        a = [rnd.choice(alpha) for _ in range(L)]
+        b = list(a)
+        for _ in range(rnd.choice([0, 1, 2, 3, 5, 8, 20])):
+            b[rnd.randrange(L)] = rnd.choice(alpha)
+        k = rnd.choice([10, 20, 25])
+        s = rnd.randrange(0, L - k + 1)
+        b[s:s + k] = a[s:s + k]
+        if rnd.random() < 0.2:
+            b = b[:rnd.randrange(s + k, L + 1)]
+        m = rnd.choice([0, 1, 2, 3, 5])
+        a, b = "".join(a), "".join(b)
+        ol = _orig_klcf(a, b, s, s + k, m)
+        out.append(dict(a=a, b=b, anchor_start=s, anchor_end=s + k, k=m,
+                        out=[int(ol[0]), int(ol[1])]))
+    return out
+
+
+def dump(name, obj):
+    path = os.path.join(HERE, name + ".json.gz")
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(json.dumps(obj, separators=(",", ":")).encode())
+    print("wrote", path, os.path.getsize(path), "bytes", flush=True)
+
+
+def main():
+    install()
+    run_reference_tests()
+    tests_scf = list(REC["scf"])
+    tests_ndf = list(REC["ndf"])
+    REC["scf"].clear()
+    REC["ndf"].clear()
+    syn = synthetic_cases()
+    ndf_syn = ndf_cases()
+    dump("lcs_anchor", dict(from_reference_tests=REC["lcs"],
+                            random=random_lcs_cases()))
+    dump("lcf_cover", REC["lcf"])
+    dump("merge", REC["merge"])
+    dump("scan", REC["scan"])
+    dump("setcover", REC["setcover"])
+    dump("scf_reference_tests", tests_scf)
+    dump("scf_synthetic", syn)
+    dump("ndf_hamming", dict(from_reference_tests=tests_ndf,
+                             synthetic=ndf_syn))
+    dump("candidate_probes", candidate_cases())
+    for k, v in REC.items():
+        print(k, len(v))
+
+
+if __name__ == "__main__":
+    main()
