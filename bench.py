@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Benchmark of the SetCoverFilter hot path (K1 coverage scan + row build +
+K2 greedy set cover) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one full pass of the hot path over the workload with the packed
+inputs already resident in HBM: for every group, catchhip_cover_scan (tiled
+Hamming scan, sort/merge into cover rows) and catchhip_setcover_greedy.
+Workload at N=1: BASELINE.json configs[1] -- ~100 Ebola+Lassa-like genomes,
+`design.py -pl 100 -ps 50 -m 2 -e 50` -- as the seeded synthetic set S2
+(catch_amd/utils/synthetic.py; the reference ships no input at this scale).
+For N>1 (launched by torch.distributed.run, one rank per GPU) every rank
+processes its own S2-shaped dataset (seed 2+rank): groups are independent
+set-cover instances, so they shard with no data-path collective (weak
+scaling).  `--shard probes` instead runs ONE dataset on all ranks with the
+candidate sets sharded and one RCCL all-reduce(MAX) per greedy pick.
+
+Prints one JSON line on rank 0 (see README/DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+
+from catch_amd import engine, probe  # noqa: E402
+from catch_amd.filter import candidate_probes  # noqa: E402
+from catch_amd.utils import synthetic  # noqa: E402
+
+PROBE_LEN, STRIDE, MISMATCHES, EXT = 100, 50, 2, 50
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TOPS = 78.6     # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, 32-bit int ops
+
+
+def make_workload(name, seed, scale):
+    groups = synthetic.dataset(name, seed=seed, scale=scale)
+    cands = []
+    for genomes in groups:
+        c = []
+        for g in genomes:
+            c += [p.seq_str for p in
+                  candidate_probes.make_candidate_probes_from_sequences(
+                      list(g), probe_length=PROBE_LEN, probe_stride=STRIDE)]
+        cands.append(list(dict.fromkeys(c)))     # DuplicateFilter
+    return groups, cands
+
+
+class ResidentGroup:
+    def __init__(self, ctx, genomes, cand):
+        self.n_sets = len(cand)
+        self.G = sum(len(s) for g in genomes for s in g)
+        k, uniq, owner, ep, eo = probe.anchor_table(cand, MISMATCHES, PROBE_LEN)
+        self.targets = engine.Targets(ctx, genomes)
+        self.probes = engine.Probes(ctx, uniq, owner, ep, eo, k)
+        self.n_unique = len(uniq)
+
+    def close(self):
+        self.probes.close()
+        self.targets.close()
+
+
+def one_step(ctx, groups, stats=None):
+    picks = []
+    for g in groups:
+        rows = engine.Rows.scan(ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN,
+                                0, EXT, engine.SCAN_AUTO)
+        if stats is not None:
+            ms, nl = ctx.kernel_ms(engine.PHASE_SCAN)
+            stats["scan_ms"] += ms
+            stats["scan_launches"] += nl
+            stats["rows_ms"] += ctx.kernel_ms(engine.PHASE_ROWS)[0]
+            stats["rows"] += rows.n
+        ids = rows.greedy(g.n_sets)
+        if stats is not None:
+            ms, nl = ctx.kernel_ms(engine.PHASE_GREEDY)
+            stats["greedy_ms"] += ms
+            stats["greedy_launches"] += nl
+            stats["picks"] += len(ids)
+            if stats.get("want_rows"):
+                stats.setdefault("row_data", []).append(rows.fetch())
+        rows.close()
+        picks.append(ids)
+    return picks
+
+
+def cpu_baseline(groups, cands, budget_s=12.0):
+    """The CPU oracle (oracle/, plain C, 1 thread) timed on the same
+    workload; reported beside the GPU number, never part of it."""
+    from oracle import oracle as orc
+    orc.build()
+    units = sum(len(c) * sum(len(s) for g in grp for s in g)
+                for c, grp in zip(cands, groups))
+    t0 = time.perf_counter()
+    reps = 0
+    sel = None
+    while True:
+        sel = orc.set_cover_filter(cands, groups, MISMATCHES, PROBE_LEN,
+                                   coverage=1.0, cover_extension=EXT)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 50:
+            break
+    return dict(value=units * reps / el, unit="probe*bp/s", cores=1,
+                kind="port", seconds_per_pass=el / reps,
+                sample="%d full passes of the bench workload through the "
+                       "plain-C oracle (seed-and-extend scan + interval-set "
+                       "greedy), single thread" % reps), sel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="S2")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--shard", choices=["groups", "probes"], default="groups")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist   # plumbing only: rendezvous/barrier
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    ctx = engine.Context(local_rank)
+    seed = 2 + (rank if args.shard == "groups" else 0)
+    groups, cands = make_workload(args.workload, seed, args.scale)
+    if world > 1 and args.shard == "probes":
+        ids = [engine.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(ids[0], world, rank)
+
+    t_up0 = time.perf_counter()
+    resident = [ResidentGroup(ctx, g, c) for g, c in zip(groups, cands)]
+    ctx.sync()
+    upload_s = time.perf_counter() - t_up0
+    units = sum(r.n_sets * r.G for r in resident)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_step(ctx, resident)
+    stats = dict(scan_ms=0.0, rows_ms=0.0, greedy_ms=0.0, scan_launches=0,
+                 greedy_launches=0, picks=0, rows=0)
+    barrier()
+    t0 = time.perf_counter()
+    picks = None
+    for _ in range(args.steps):
+        picks = one_step(ctx, resident, stats)
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        u = torch.tensor([float(units)], dtype=torch.float64)
+        if args.shard == "groups":
+            dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        total_units = float(u[0])
+        dist.barrier()
+    else:
+        total_units = float(units)
+
+    if rank == 0:
+        K = args.steps
+        P = sum(r.n_sets for r in resident)
+        G = sum(r.G for r in resident)
+        rows_per_step = stats["rows"] / K
+        # K1 algorithmic bytes: 0.375 B/base, T_p = 1024
+        k1_bytes = sum(0.375 * r.G * -(-r.n_unique // 1024)
+                       + 0.375 * PROBE_LEN * r.n_unique for r in resident) \
+            + 16.0 * rows_per_step
+        k1_ms = stats["scan_ms"] / K
+        k1_launch_ms = stats["scan_ms"] / max(stats["scan_launches"], 1)
+        k1_gbs = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        # VALU work of the brute-force form: 3*ceil(L/32) + 2*A 64-bit ops
+        # per probe x bp = 20 at L=100, A=4
+        k1_ops = 20.0 * sum(r.n_unique * r.G for r in resident)
+        # K2 (full recompute per pick): 12 B per row + bitmap words + apply
+        picks_per_step = stats["picks"] / K
+        k2_ms = stats["greedy_ms"] / K
+        words_per_row = (PROBE_LEN + 2 * EXT + 63) // 64 + 1
+        k2_bytes_pick = rows_per_step * (12.0 + 8.0 * words_per_row)
+        k2_gbs = (k2_bytes_pick * picks_per_step) / (k2_ms * 1e-3) / 1e9 \
+            if k2_ms > 0 else 0.0
+        dominant = "k2_greedy" if k2_ms >= k1_ms else "k1_scan"
+        if dominant == "k1_scan":
+            roof = dict(bound="hbm", kernel="scan_fast_kernel",
+                        achieved=k1_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=k1_gbs / HBM_PEAK_GBS, traffic=None,
+                        avg_launch_ms=k1_launch_ms)
+        else:
+            roof = dict(bound="hbm", kernel="gain_kernel+apply_kernel",
+                        achieved=k2_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=k2_gbs / HBM_PEAK_GBS, traffic=None,
+                        avg_launch_ms=(stats["greedy_ms"]
+                                       / max(stats["greedy_launches"], 1)))
+        out = {
+            "metric": "candidate-probe x target-bp / s through SetCoverFilter "
+                      "(K1 scan + K2 greedy)",
+            "value": total_units * K / elapsed,
+            "unit": "probe*bp/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak" if args.shard == "groups" else "strong",
+            "vs_baseline": None,
+            "dtype": "u32 bit-planes / u64 bitmap (integer)",
+            "data": "synthetic",
+            "config": {"workload": "%s (BASELINE configs[1]): %d genomes in "
+                                   "%d groups, G=%d bp, P=%d candidates, "
+                                   "-pl 100 -ps 50 -m 2 -e 50 -c 1.0"
+                                   % (args.workload,
+                                      sum(len(g) for g in groups),
+                                      len(groups), G, P),
+                       "per_rank": True, "shard": args.shard,
+                       "scale": args.scale},
+            "setcoverfilter_ms": elapsed / K * 1e3,
+            "picks": picks_per_step, "rows": rows_per_step,
+            "kernel_ms_per_step": {"k1_scan": k1_ms,
+                                   "rows_build": stats["rows_ms"] / K,
+                                   "k2_greedy": k2_ms},
+            "k1_probe_bp_per_s": (sum(r.n_unique * r.G for r in resident)
+                                  / (k1_ms * 1e-3)) if k1_ms > 0 else None,
+            "k1_valu": {"achieved_Tops": k1_ops / (k1_ms * 1e-3) / 1e12
+                        if k1_ms > 0 else None, "peak_Tops": VALU_PEAK_TOPS,
+                        "note": "brute-force op count; early exit skips most"},
+            "roofline": roof,
+            "roofline_k1": dict(bound="hbm", achieved=k1_gbs,
+                                peak=HBM_PEAK_GBS, unit="GB/s",
+                                frac=k1_gbs / HBM_PEAK_GBS,
+                                avg_launch_ms=k1_launch_ms),
+            "roofline_k2": dict(bound="hbm", achieved=k2_gbs,
+                                peak=HBM_PEAK_GBS, unit="GB/s",
+                                frac=k2_gbs / HBM_PEAK_GBS,
+                                ms_per_pick=k2_ms / max(picks_per_step, 1)),
+            "h2d_upload_s": upload_s,
+            "value_incl_h2d": total_units / (elapsed / K + upload_s),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, sel = cpu_baseline(groups, cands)
+            out["cpu_baseline"] = base
+            # the timed GPU result must equal the oracle's (parity guard)
+            out["parity_vs_oracle"] = [sorted(a) for a in picks] == \
+                [sorted(b) for b in sel]
+            out["speedup_vs_cpu_oracle"] = out["value"] / base["value"]
+        print(json.dumps(out))
+    for r in resident:
+        r.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

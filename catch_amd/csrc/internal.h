@@ -154,16 +154,24 @@ struct catchhip_rows {
 struct PhaseTimer {
     catchhip_ctx *c;
     int phase;
-    PhaseTimer(catchhip_ctx *ctx, int ph) : c(ctx), phase(ph) {
-        c->phase_launches[ph] = 0;
-        c->phase_ms[ph] = 0.0;
-        (void)hipEventRecord(c->ev[2 * ph], c->stream);
+    bool stopped = false;
+    PhaseTimer(catchhip_ctx *ctx, int ph) : c(ctx), phase(ph) { restart(); }
+    void restart() {
+        stopped = false;
+        c->phase_launches[phase] = 0;
+        c->phase_ms[phase] = 0.0;
+        (void)hipEventRecord(c->ev[2 * phase], c->stream);
     }
     void launch(i64 k = 1) { c->phase_launches[phase] += k; }
-    // records the stop event; call finish() after a stream sync to read it
-    void stop() { (void)hipEventRecord(c->ev[2 * phase + 1], c->stream); }
+    // records the stop event (first call wins); finish() reads it after a sync
+    void stop() {
+        if (stopped) return;
+        stopped = true;
+        (void)hipEventRecord(c->ev[2 * phase + 1], c->stream);
+    }
     void finish() {
         float ms = 0.f;
+        stop();
         (void)hipEventSynchronize(c->ev[2 * phase + 1]);
         if (hipEventElapsedTime(&ms, c->ev[2 * phase], c->ev[2 * phase + 1]) == hipSuccess)
             c->phase_ms[phase] = ms;

@@ -373,10 +373,12 @@ static int run_fast(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
         TRY(H.b.reserve(cap));
         HIP_TRY(hipMemsetAsync(H.count.p, 0, sizeof(u32), ctx->stream));
         HitBuf hb = {H.a.p, H.b.p, nullptr, H.count.p, cap};
+        tm.restart();  // time exactly the scan kernel (HIP events on this stream)
         hipLaunchKernelGGL(fn, dim3(ntiles, nchunks), dim3(SF_THREADS), 0, ctx->stream, T->planes.p,
                            T->nwords, (u32)T->total, T->seq_off.p, (u32)T->nseq,
                            (const uint4 *)P->planes.p, (u32)P->nprobes, ppb, (int)P->L, mm, tailmask, hb);
         tm.launch();
+        tm.stop();
         HIP_TRY(hipGetLastError());
         u32 n;
         TRY(read_count(ctx, H.count.p, &n));

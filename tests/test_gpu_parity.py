@@ -1,0 +1,350 @@
+"""Parity of the HIP path (through the C ABI of libcatchhip.so) with the CPU
+oracle and with golden vectors recorded from the live reference.
+Bit-exact: everything here is integer/index work."""
+import random
+
+import numpy as np
+import pytest
+
+from util import (candidates, load_golden, np_state_from_json, rows_as_tuples,
+                  small_species)
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    from catch_amd import engine
+    return engine
+
+
+def _probe_mod():
+    from catch_amd import probe
+    return probe
+
+
+def _scan_rows(ctx, probe_strs, genomes, m, thres, island=0, ext=0, mode=0,
+               min_k=20, entries=None, k=None):
+    """Rows (set, universe, start, end) from the HIP path."""
+    engine, probe = _engine(), _probe_mod()
+    if entries is None:
+        k, uniq, owner, ep, eo = probe.anchor_table(probe_strs, m, thres,
+                                                    min_k=min_k, k=min_k)
+    else:
+        uniq = list(probe_strs)
+        owner = np.arange(len(uniq), dtype=np.int32)
+        ep = np.array([e[0] for e in entries], dtype=np.int32)
+        eo = np.array([e[1] for e in entries], dtype=np.int32)
+    t = engine.Targets(ctx, genomes)
+    p = engine.Probes(ctx, uniq, owner, ep, eo, k)
+    rows = engine.Rows.scan(ctx, p, t, m, thres, island, ext, mode)
+    out = rows_as_tuples(*rows.fetch())
+    rows.close(); p.close(); t.close()
+    return out
+
+
+def _oracle_rows(oracle, probe_strs, genomes, m, thres, island=0, ext=0,
+                 min_k=20):
+    k, entries = oracle.anchor_table(probe_strs, m, thres, min_k=min_k, k=min_k)
+    uniq, owner = oracle._unique_last(probe_strs)
+    pr, un, st, en = oracle.make_sets(uniq, entries, k, genomes, m, thres,
+                                      island, ext)
+    own = np.array(owner, dtype=np.int32)
+    return rows_as_tuples(own[pr] if pr.size else pr, un, st, en)
+
+
+# ---------------------------------------------------------------- K1
+@pytest.mark.parametrize("L,stride,m,ext", [(75, 25, 2, 50), (100, 50, 2, 50),
+                                            (100, 50, 3, 0), (75, 25, 0, 10),
+                                            (64, 32, 1, 5), (32, 16, 0, 0),
+                                            (40, 20, 1, 3),
+                                            (130, 65, 4, 20)])
+def test_scan_fast_matches_oracle(ctx, oracle, L, stride, m, ext):
+    engine = _engine()
+    genomes = small_species()
+    probes = candidates(genomes, L, stride)
+    exp = _oracle_rows(oracle, probes, genomes, m, L, 0, ext)
+    got = _scan_rows(ctx, probes, genomes, m, L, 0, ext, engine.SCAN_FAST)
+    assert got == exp
+    # the seed-join + extension path must agree with the tiled Hamming kernel
+    got_g = _scan_rows(ctx, probes, genomes, m, L, 0, ext, engine.SCAN_GENERAL)
+    assert got_g == exp
+
+
+def test_scan_fast_no_n_two_planes(ctx, oracle):
+    engine = _engine()
+    genomes = small_species(seed=5, with_n=False)
+    probes = candidates(genomes, 100, 50)
+    exp = _oracle_rows(oracle, probes, genomes, 2, 100, 0, 50)
+    assert _scan_rows(ctx, probes, genomes, 2, 100, 0, 50, engine.SCAN_FAST) == exp
+
+
+@pytest.mark.parametrize("L,stride,m,thres,island,ext,seed", [
+    (75, 25, 2, 60, 0, 0, 11),      # lcf_thres < L  -> random anchors
+    (100, 50, 5, 100, 0, 50, 12),   # pigeonhole k < 20 -> random anchors
+    (75, 25, 2, 75, 30, 0, None),   # island of exact match
+    (100, 50, 3, 80, 25, 10, 13),
+    (75, 25, 1, 40, 0, 3, 14),
+])
+def test_scan_general_matches_oracle(ctx, oracle, L, stride, m, thres, island,
+                                     ext, seed):
+    genomes = small_species(seed=21)
+    probes = candidates(genomes, L, stride)
+    if seed is not None:
+        np.random.seed(seed)
+    exp = _oracle_rows(oracle, probes, genomes, m, thres, island, ext)
+    if seed is not None:
+        np.random.seed(seed)
+    got = _scan_rows(ctx, probes, genomes, m, thres, island, ext)
+    assert got == exp
+
+
+def test_scan_multi_chromosome_and_short_sequences(ctx, oracle):
+    """Genome coordinates across chromosomes (set_cover_filter.py:429-453),
+    sequences shorter than the probe and than k, empty sequences."""
+    rng = random.Random(3)
+    def rs(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+    base = rs(400)
+    genomes = [[base[:150], base[150:], rs(30)], [base[10:300]], [rs(8), ""],
+               [base[100:160]]]
+    probes = candidates([[base]], 50, 10)
+    for m, thres in ((1, 50), (2, 30)):
+        np.random.seed(1)
+        exp = _oracle_rows(oracle, probes, genomes, m, thres, 0, 7, min_k=10)
+        np.random.seed(1)
+        got = _scan_rows(ctx, probes, genomes, m, thres, 0, 7, min_k=10)
+        assert got == exp
+
+
+def test_scan_arbitrary_alphabet(ctx, oracle):
+    """Character equality on any byte alphabet (the reference's toy tests use
+    A-Z; lower case differs from upper case)."""
+    rng = random.Random(9)
+    alpha = "ABCDEFGHIJKLMNOPQRSTUVWXYZacgt"
+    seq = "".join(rng.choice(alpha) for _ in range(600))
+    genomes = [[seq], [seq[100:400].lower() + seq[400:]]]
+    probes = [seq[i:i + 20] for i in range(0, 580, 7)]
+    exp = _oracle_rows(oracle, probes, genomes, 1, 20, 0, 2, min_k=5)
+    got = _scan_rows(ctx, probes, genomes, 1, 20, 0, 2, min_k=5)
+    assert got == exp
+
+
+def test_scan_reference_test_vectors(ctx):
+    """The reference's own scan known answers (catch/tests/test_probe.py),
+    recorded as data."""
+    recs = [c for c in load_golden("scan") if c["merge"]]
+    assert len(recs) >= 20
+    for c in recs:
+        got = _scan_rows(ctx, c["probes"], [[c["sequence"]]], c["mismatches"],
+                         c["lcf_thres"], c["island"], 0,
+                         entries=c["entries"], k=c["k"])
+        exp = sorted((int(p), 0, s, e) for p, v in c["out"].items()
+                     for s, e in v)
+        assert got == exp, (c["probes"], c["sequence"][:60])
+
+
+def test_scan_empty_inputs(ctx):
+    engine = _engine()
+    assert _scan_rows(ctx, [], [["ACGT" * 30]], 1, 10) == []
+    assert _scan_rows(ctx, ["ACGTACGTAC"], [], 0, 10, min_k=5) == []
+    assert _scan_rows(ctx, ["ACGTACGTAC"], [[""]], 0, 10, min_k=5) == []
+    with pytest.raises(ValueError):
+        t = engine.Targets(ctx, [["AC"]])
+        p = engine.Probes(ctx, ["ACGTACGTAC"], [0], [0], [0], 5)
+        engine.Rows.scan(ctx, p, t, 2, 60, 0, 0, engine.SCAN_FAST)
+
+
+# ---------------------------------------------------------------- K2
+def test_greedy_reference_test_vectors(ctx):
+    """set_cover.approx_multiuniverse known answers
+    (catch/utils/tests/test_set_cover.py), unit-cost instances."""
+    engine = _engine()
+    recs = load_golden("setcover")
+    n = 0
+    for c in recs:
+        if c["costs"] is not None and any(x != 1.0 for x in c["costs"]):
+            continue
+        r = np.array(c["rows"], dtype=np.int64).reshape(-1, 4)
+        U = c["num_universes"]
+        glen = np.zeros(U, dtype=np.int64)
+        for u in range(U):
+            sel = r[:, 1] == u
+            glen[u] = r[sel, 3].max() if sel.any() else 0
+        rows = engine.Rows.from_host(ctx, r[:, 0], r[:, 1], r[:, 2], r[:, 3], glen)
+        got = rows.greedy(c["num_sets"], c["ranks"], c["universe_p"])
+        rows.close()
+        assert sorted(got) == c["out"], c
+        n += 1
+    assert n >= 20
+
+
+def test_greedy_random_instances_match_oracle(ctx, oracle):
+    engine = _engine()
+    rng = np.random.Generator(np.random.PCG64(123))
+    for trial in range(30):
+        P = int(rng.integers(1, 60))
+        U = int(rng.integers(1, 6))
+        glen = rng.integers(50, 400, size=U)
+        rows = []
+        for s in range(P):
+            for u in range(U):
+                if rng.random() < 0.6:
+                    ivs, pos = [], int(rng.integers(0, 30))
+                    for _ in range(int(rng.integers(1, 4))):
+                        ln = int(rng.integers(1, 40))
+                        if pos + ln > glen[u]:
+                            break
+                        ivs.append((pos, pos + ln))
+                        pos += ln + int(rng.integers(1, 50))
+                    rows += [(s, u, a, b) for a, b in ivs]
+        if not rows:
+            continue
+        r = np.array(sorted(rows), dtype=np.int64)
+        ranks = rng.integers(0, 3, size=P) if trial % 2 else None
+        up = [float(x) for x in rng.choice([1.0, 0.9, 0.5, 0.25, 0.0], size=U)] \
+            if trial % 3 else None
+        exp = oracle.approx_multiuniverse(r[:, 0], r[:, 1], r[:, 2], r[:, 3], P,
+                                          U, None, up, ranks)
+        dev = engine.Rows.from_host(ctx, r[:, 0], r[:, 1], r[:, 2], r[:, 3], glen)
+        got = dev.greedy(P, ranks, up)
+        dev.close()
+        assert got == exp, trial   # same picks in the same order
+
+
+# ---------------------------------------------------------------- SCF
+def _run_filter(c):
+    from catch_amd import genome, probe
+    from catch_amd.filter import set_cover_filter as scf
+    import tempfile, os
+    paths = []
+    if c["avoided_sequences"]:
+        fd, path = tempfile.mkstemp(suffix=".fasta")
+        with os.fdopen(fd, "w") as f:
+            for i, s in enumerate(c["avoided_sequences"]):
+                f.write(">a%d\n%s\n" % (i, s))
+        paths.append(path)
+    f = scf.SetCoverFilter(
+        mismatches=c["mismatches"], lcf_thres=c["lcf_thres"],
+        island_of_exact_match=c["island"],
+        mismatches_tolerant=c["mismatches_tolerant"],
+        lcf_thres_tolerant=c["lcf_thres_tolerant"],
+        island_of_exact_match_tolerant=c["island_tolerant"],
+        identify=c["identify"], avoided_genomes=paths, coverage=c["coverage"],
+        cover_extension=c["cover_extension"],
+        kmer_probe_map_k=c["kmer_probe_map_k"])
+    probes = [[probe.Probe.from_str(s) for s in g] for g in c["probes"]]
+    genomes = [[genome.Genome.from_one_seq(g[0]) if len(g) == 1 else
+                genome.Genome(list(g), chrs=dict((str(i), s) for i, s in enumerate(g)))
+                for g in grp] for grp in c["genomes"]]
+    if "np_random_state" in c:
+        np.random.set_state(np_state_from_json(c["np_random_state"]))
+    out = f.filter(probes, genomes, input_is_grouped=True)
+    for p in paths:
+        os.remove(p)
+    # identity: outputs are the very input objects
+    for g_out, g_in in zip(out, probes):
+        ids = set(id(p) for p in g_in)
+        assert all(id(p) in ids for p in g_out)
+    return [sorted(p.seq_str for p in g) for g in out]
+
+
+@pytest.mark.parametrize("name", ["scf_reference_tests", "scf_synthetic"])
+def test_set_cover_filter_golden(ctx, name):
+    """SetCoverFilter.filter() through the plugin surface: selected probe sets
+    identical to the reference's on the same inputs."""
+    recs = load_golden(name)
+    assert len(recs) >= 5
+    for c in recs:
+        assert _run_filter(c) == c["out"], (name, c.get("name"))
+
+
+def test_set_cover_filter_matches_oracle_medium(ctx, oracle):
+    """30-genome two-species input (S2 at scale 0.3): picks equal the oracle's."""
+    from catch_amd.utils import synthetic
+    groups = synthetic.dataset("S2", scale=0.3)
+    probes = [candidates(g, 100, 50) for g in groups]
+    exp = oracle.set_cover_filter(probes, groups, 2, 100, coverage=1.0,
+                                  cover_extension=50)
+    c = dict(mismatches=2, lcf_thres=100, island=0, mismatches_tolerant=2,
+             lcf_thres_tolerant=100, island_tolerant=0, identify=False,
+             avoided_sequences=[], coverage=1.0, cover_extension=50,
+             kmer_probe_map_k=20, probes=probes, genomes=groups)
+    got = _run_filter(c)
+    assert got == [sorted(probes[gi][i] for i in ids) for gi, ids in enumerate(exp)]
+
+
+def test_full_size_properties(ctx):
+    """BASELINE config 2 at full size (S2, ~1.56 Mbp): checks that do not need
+    the oracle -- the two independent device scans agree row for row, the
+    chosen probes cover every universe completely (coverage 1.0), no chosen
+    probe is redundant at the moment it was picked, and the run is
+    deterministic."""
+    engine, probe = _engine(), _probe_mod()
+    from catch_amd.utils import synthetic
+    groups = synthetic.dataset("S2")
+    for genomes in groups:
+        cand = candidates(genomes, 100, 50)
+        k, uniq, owner, ep, eo = probe.anchor_table(cand, 2, 100)
+        t = engine.Targets(ctx, genomes)
+        p = engine.Probes(ctx, uniq, owner, ep, eo, k)
+        rf = engine.Rows.scan(ctx, p, t, 2, 100, 0, 50, engine.SCAN_FAST)
+        rg = engine.Rows.scan(ctx, p, t, 2, 100, 0, 50, engine.SCAN_GENERAL)
+        a, b = rf.fetch(), rg.fetch()
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        picks = rf.greedy(len(cand))
+        assert picks == rf.greedy(len(cand))
+        assert len(set(picks)) == len(picks)
+        sid, un, st, en = a
+        glen = np.array([sum(len(s) for s in g) for g in genomes])
+        base = np.concatenate([[0], np.cumsum(glen)])
+        tot = int(base[-1])
+        def cover(mask):
+            d = np.zeros(tot + 1, dtype=np.int64)
+            np.add.at(d, base[un[mask]] + st[mask], 1)
+            np.add.at(d, base[un[mask]] + en[mask], -1)
+            return np.cumsum(d)[:-1] > 0
+        all_cov = cover(np.ones(sid.size, dtype=bool))
+        sel_cov = cover(np.isin(sid, picks))
+        assert np.array_equal(all_cov, sel_cov)
+        # dropping the last pick must leave something uncovered
+        less = cover(np.isin(sid, picks[:-1]))
+        assert less.sum() < sel_cov.sum()
+        rf.close(); rg.close(); p.close(); t.close()
+
+
+# ---------------------------------------------------------------- K3
+def test_ndf_hamming_golden(ctx):
+    from catch_amd import probe
+    from catch_amd.filter import near_duplicate_filter as ndf
+    g = load_golden("ndf_hamming")
+    recs = g["from_reference_tests"] + g["synthetic"]
+    assert len(recs) >= 3
+    for c in recs:
+        f = ndf.NearDuplicateFilterWithHammingDistance(c["dist_thres"], c["dim"])
+        f.k = c["k"]
+        f.reporting_prob = c["reporting_prob"]
+        f._draw_positions = lambda c=c: c["positions"]
+        inp = [probe.Probe.from_str(s) for s in c["probes"]]
+        out = f.filter(inp)
+        assert sorted(p.seq_str for p in out) == c["out"]
+        if "seed" in c:   # positions drawn from `random` like the reference
+            random.seed(c["seed"])
+            f2 = ndf.NearDuplicateFilterWithHammingDistance(c["dist_thres"], c["dim"])
+            assert f2._draw_positions() == c["positions"]
+
+
+def test_ndf_hamming_matches_oracle_large(ctx, oracle):
+    from catch_amd import probe
+    from catch_amd.filter import near_duplicate_filter as ndf
+    from catch_amd.utils import synthetic
+    rng = np.random.Generator(np.random.PCG64(31))
+    sp = synthetic.make_species(rng, [6000], 40, 4, 0.03, 0.01, with_n=True)
+    strs = candidates(sp, 100, 25, dedup=False)
+    random.seed(99)
+    pos = oracle.lsh_draw_positions(oracle.lsh_num_tables(3, 100, 20), 20, 100)
+    exp = oracle.ndf_hamming(strs, 3, pos)
+    f = ndf.NearDuplicateFilterWithHammingDistance(3, 100)
+    random.seed(99)
+    out = f.filter([probe.Probe.from_str(s) for s in strs])
+    assert [p.seq_str for p in out] == exp
+    assert len(exp) < len(set(strs))

@@ -1,0 +1,92 @@
+"""Pins the CPU oracle (oracle/) to golden vectors recorded from the live
+reference (tests/golden/make_golden.py).  No GPU needed."""
+import numpy as np
+import pytest
+
+from util import load_golden, np_state_from_json, rows_as_tuples
+
+
+def test_k_lcf_around_anchor_reference_test_vectors(oracle):
+    g = load_golden("lcs_anchor")
+    assert len(g["from_reference_tests"]) >= 25
+    for c in g["from_reference_tests"] + g["random"]:
+        got = oracle.k_lcf_around_anchor(c["a"], c["b"], c["anchor_start"],
+                                         c["anchor_end"], c["k"])
+        assert list(got) == c["out"], c
+
+
+def test_lcf_cover_reference_test_vectors(oracle):
+    recs = load_golden("lcf_cover")
+    assert len(recs) >= 15
+    for c in recs:
+        got = oracle.lcf_cover(c["probe_seq"], c["sequence"], c["kmer_start"],
+                               c["kmer_end"], c["full_probe_len"],
+                               c["full_sequence_len"], c["mismatches"],
+                               c["lcf_thres"], c["island"])
+        exp = None if c["out"] is None else tuple(c["out"])
+        assert got == exp, c
+
+
+def test_scan_reference_test_vectors(oracle):
+    recs = load_golden("scan")
+    assert len(recs) >= 20
+    for c in recs:
+        got = oracle.scan_sequence(c["sequence"], c["probes"],
+                                   [tuple(e) for e in c["entries"]], c["k"],
+                                   c["mismatches"], c["lcf_thres"], c["island"],
+                                   c["merge"])
+        exp = {int(k): [tuple(x) for x in v] for k, v in c["out"].items()}
+        assert got == exp, (c["probes"], c["sequence"][:80])
+
+
+def test_approx_multiuniverse_reference_test_vectors(oracle):
+    recs = load_golden("setcover")
+    assert len(recs) >= 28
+    for c in recs:
+        r = np.array(c["rows"], dtype=np.int64).reshape(-1, 4)
+        got = oracle.approx_multiuniverse(r[:, 0], r[:, 1], r[:, 2], r[:, 3],
+                                          c["num_sets"], c["num_universes"],
+                                          c["costs"], c["universe_p"],
+                                          c["ranks"])
+        assert sorted(got) == c["out"], c
+
+
+@pytest.mark.parametrize("name", ["scf_reference_tests", "scf_synthetic"])
+def test_set_cover_filter_end_to_end(oracle, name):
+    recs = load_golden(name)
+    assert len(recs) >= 5
+    for c in recs:
+        if "np_random_state" in c:
+            np.random.set_state(np_state_from_json(c["np_random_state"]))
+        sel, inter = oracle.set_cover_filter(
+            c["probes"], c["genomes"], c["mismatches"], c["lcf_thres"],
+            c["island"], c["mismatches_tolerant"], c["lcf_thres_tolerant"],
+            c["island_tolerant"], c["identify"], c["avoided_sequences"],
+            c["coverage"], c["cover_extension"], c["kmer_probe_map_k"],
+            return_intermediate=True)
+        for gi, ids in enumerate(sel):
+            got = sorted(c["probes"][gi][i] for i in ids)
+            assert got == c["out"][gi], (name, c.get("name"), gi)
+            if c.get("rows") is not None and len(c["probes"][gi]):
+                exp_rows = sorted(tuple(x) for x in c["rows"][gi])
+                assert rows_as_tuples(*inter[gi]["rows"]) == exp_rows
+            if c.get("ranks") is not None and len(c["probes"][gi]):
+                assert list(inter[gi]["ranks"]) == c["ranks"][gi]
+
+
+def test_ndf_hamming(oracle):
+    g = load_golden("ndf_hamming")
+    recs = g["from_reference_tests"] + g["synthetic"]
+    assert len(recs) >= 3
+    for c in recs:
+        assert oracle.lsh_num_tables(c["dist_thres"], c["dim"], c["k"],
+                                     c["reporting_prob"]) == len(c["positions"])
+        kept = oracle.ndf_hamming(c["probes"], c["dist_thres"], c["positions"])
+        assert sorted(kept) == c["out"]
+
+
+def test_merge_overlapping(oracle):
+    assert oracle.merge_overlapping([(1, 5), (3, 7), (9, 12)]) == [(1, 7), (9, 12)]
+    assert oracle.merge_overlapping([(1, 3), (3, 5)]) == [(1, 5)]
+    assert oracle.merge_overlapping([]) == []
+    assert oracle.merge_overlapping([(5, 6), (1, 2)]) == [(1, 2), (5, 6)]
