@@ -12,6 +12,72 @@ void chip_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// ---- caching device allocator (see internal.h) ---------------------------
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
+namespace {
+struct PoolBlock { int dev; size_t cls; };
+std::mutex g_pool_mu;
+std::multimap<std::pair<int, size_t>, void *> g_pool_free;
+std::unordered_map<void *, PoolBlock> g_pool_live;
+
+size_t pool_class(size_t b) {
+    if (b < 512) return 512;
+    if (b <= ((size_t)1 << 26)) {
+        size_t c = 512;
+        while (c < b) c <<= 1;
+        return c;
+    }
+    const size_t step = (size_t)1 << 26;  // 64 MiB granules above 64 MiB
+    return (b + step - 1) / step * step;
+}
+}  // namespace
+
+void *chip_pool_alloc(size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t cls = pool_class(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_free.find(std::make_pair(dev, cls));
+        if (it != g_pool_free.end()) {
+            void *p = it->second;
+            g_pool_free.erase(it);
+            g_pool_live[p] = PoolBlock{dev, cls};
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, cls);
+    if (e != hipSuccess) {
+        // give cached blocks back to the driver and retry once
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (auto &kv : g_pool_free)
+            if (kv.first.first == dev) (void)hipFree(kv.second);
+        for (auto it = g_pool_free.begin(); it != g_pool_free.end();)
+            it = (it->first.first == dev) ? g_pool_free.erase(it) : std::next(it);
+        e = hipMalloc(&p, cls);
+        if (e != hipSuccess) {
+            chip_set_error("hipMalloc(%zu bytes) failed: %s", cls, hipGetErrorString(e));
+            return nullptr;
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_live[p] = PoolBlock{dev, cls};
+    return p;
+}
+
+void chip_pool_free(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_live.find(p);
+    if (it == g_pool_live.end()) return;
+    g_pool_free.insert(std::make_pair(std::make_pair(it->second.dev, it->second.cls), p));
+    g_pool_live.erase(it);
+}
+
 extern "C" const char *catchhip_last_error(void) { return g_err; }
 extern "C" int catchhip_abi_version(void) { return CATCHHIP_ABI_VERSION; }
 

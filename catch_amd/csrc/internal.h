@@ -47,7 +47,16 @@ void chip_set_error(const char *fmt, ...);
         }                                                                     \
     } while (0)
 
-// Device buffer owning a hipMalloc'd region (freed in the destructor).
+// Caching device allocator (core.hip): hipMalloc/hipFree cost tens of
+// microseconds and hipFree synchronises the device, which would dominate the
+// millisecond-scale calls of this library.  Blocks are rounded up to a size
+// class and kept on per-device free lists until the process exits; a block is
+// only reused by work enqueued later on the context's single stream, after
+// the host has observed the previous user's results.
+void *chip_pool_alloc(size_t bytes);
+void chip_pool_free(void *p);
+
+// Device buffer owning a pooled region (returned to the pool in the destructor).
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
@@ -56,7 +65,7 @@ template <typename T> struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) chip_pool_free((void *)p);
         p = nullptr;
         n = 0;
     }
@@ -64,12 +73,8 @@ template <typename T> struct DevBuf {
         release();
         n = count;
         size_t bytes = (count ? count : 1) * sizeof(T);
-        hipError_t e = hipMalloc((void **)&p, bytes);
-        if (e != hipSuccess) {
-            p = nullptr;
-            chip_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-            return CATCHHIP_ENOMEM;
-        }
+        p = (T *)chip_pool_alloc(bytes);
+        if (!p) return CATCHHIP_ENOMEM;
         return 0;
     }
     // grow (content not preserved)

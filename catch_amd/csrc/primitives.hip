@@ -202,7 +202,6 @@ int chip_radix_sort_pairs(catchhip_ctx *ctx, DevBuf<u64> &keys, DevBuf<u64> &key
         vals.swap(vals_alt);
     }
     HIP_TRY(hipGetLastError());
-    // scratch (hist/tmp) is freed on return: make sure the stream is done with it
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // scratch (hist/tmp) returns to the pool; reuse is ordered by the stream
     return 0;
 }

@@ -197,7 +197,7 @@ class SetCoverFilter(BaseFilter):
     def _filter(self, input, target_genomes_grouped):
         """input = [p_1, ..., p_m] candidate probes per group; returns the
         selected probes per group (:902-930)."""
-        ctx = self._context()
+        ctx = None   # created on first use: empty input needs no device
         selected_probes = []
         timings = dict(scan_ms=0.0, rows_ms=0.0, greedy_ms=0.0, picks=0,
                        rows=0, scan_launches=0, greedy_launches=0)
@@ -207,6 +207,8 @@ class SetCoverFilter(BaseFilter):
             if len(possible_probes) == 0:
                 selected_probes.append([])
                 continue
+            if ctx is None:
+                ctx = self._context()
             logger.info("Building set cover sets input (group %d of %d)",
                         group_i + 1, len(input))
             rows = self._make_sets(possible_probes, target_genomes, ctx)

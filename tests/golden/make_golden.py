@@ -137,7 +137,7 @@ def rec_open(kmer_probe_map, cover_range_for_probe_in_subsequence_fn,
 def rec_find(sequence, merge_overlapping=True):
     out = _orig_find(sequence, merge_overlapping=merge_overlapping)
     if (_pool_state.get("params") is not None and len(sequence) <= MAX_SEQ
-            and len(REC["scan"]) < 600):
+            and len(REC["scan"]) < 900):
         m, thres, island = _pool_state["params"]
         probes = sorted(set(e[0] for e in _pool_state["entries"]))
         pidx = {p: i for i, p in enumerate(probes)}
@@ -199,6 +199,8 @@ def rec_amu(sets, costs=None, universe_p=None, ranks=None, use_arrays=False,
                 for a, b in ivs:
                     rows.append([sid[k], ui, a, b])
         rows.sort()
+        if len(rows) > 1500:   # keep the fixture small: skip the big randomized instances
+            return out
         rec = dict(rows=rows, num_sets=len(order), num_universes=len(uid),
                    costs=None if costs is None else
                    [float(costs[k]) for k in order],
@@ -333,11 +335,13 @@ def run_reference_tests():
     names = [
         "catch.utils.tests.test_longest_common_substring",
         "catch.utils.tests.test_interval",
+        "catch.tests.test_probe",
         "catch.utils.tests.test_set_cover",
         "catch.filter.tests.test_set_cover_filter",
         "catch.filter.tests.test_near_duplicate_filter",
-        "catch.tests.test_probe",
     ]
+    if "probe-only" in sys.argv:
+        names = names[:3]
     loader = unittest.TestLoader()
     for n in names:
         suite = loader.loadTestsFromName(n)
@@ -492,6 +496,12 @@ def dump(name, obj):
 def main():
     install()
     run_reference_tests()
+    if "probe-only" in sys.argv:
+        dump("lcs_anchor", dict(from_reference_tests=REC["lcs"],
+                                random=random_lcs_cases()))
+        dump("lcf_cover", REC["lcf"])
+        dump("scan", REC["scan"])
+        return
     tests_scf = list(REC["scf"])
     tests_ndf = list(REC["ndf"])
     REC["scf"].clear()
@@ -501,7 +511,6 @@ def main():
     dump("lcs_anchor", dict(from_reference_tests=REC["lcs"],
                             random=random_lcs_cases()))
     dump("lcf_cover", REC["lcf"])
-    dump("merge", REC["merge"])
     dump("scan", REC["scan"])
     dump("setcover", REC["setcover"])
     dump("scf_reference_tests", tests_scf)

@@ -1,0 +1,172 @@
+"""Host-side logic of the product (no GPU): anchor tables, candidate probes,
+plugin dispatch, FASTA rules, and that the C-ABI library loads and exports
+every symbol include/catchhip.h declares."""
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+from util import load_golden, np_state_from_json
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from catch_amd import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(REPO, "include", "catchhip.h")).read()
+    declared = set(re.findall(r"\b(catchhip_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"catchhip_ctx", "catchhip_targets", "catchhip_probes",
+                 "catchhip_rows"}
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), name
+        assert name in _lib.PROTOTYPES, name
+    assert set(_lib.PROTOTYPES) == declared
+    assert L.catchhip_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a GPU the product raises; it never routes through the oracle."""
+    from catch_amd import engine, _lib
+    if engine.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.CatchHipError):
+        engine.Context(0)
+    import catch_amd.filter.set_cover_filter as scf
+    src = open(scf.__file__).read() + open(engine.__file__).read()
+    assert "oracle" not in src
+
+
+def test_anchor_table_matches_reference_rows_inputs(oracle):
+    """anchor_table (product) == oracle's restatement, pigeonhole and random
+    (np.random consumed identically), duplicates pooled."""
+    from catch_amd import probe
+    rng = random.Random(5)
+    for L, m, thres, min_k in [(75, 2, 75, 20), (100, 2, 100, 20),
+                               (100, 5, 100, 20), (75, 2, 60, 20),
+                               (100, 0, 100, 20), (100, 4, 100, 20),
+                               (30, 1, 30, 3), (12, 3, 12, 3)]:
+        strs = ["".join(rng.choice("ACGT") for _ in range(L)) for _ in range(40)]
+        strs += strs[:5]          # duplicates
+        np.random.seed(42)
+        k1, uniq, owner, ep, eo = probe.anchor_table(strs, m, thres, min_k, min_k)
+        np.random.seed(42)
+        k2, entries = oracle.anchor_table(strs, m, thres, min_k, min_k)
+        u2, own2 = oracle._unique_last(strs)
+        assert k1 == k2 and uniq == u2 and list(owner) == own2
+        assert sorted(zip(ep.tolist(), eo.tolist())) == entries
+
+
+def test_pigeonhole_kmer_length_table():
+    """SURVEY App. A.2 table (measured on the reference)."""
+    from catch_amd import probe
+    assert probe.pigeonhole_kmer_length(75, 0) == 75
+    assert probe.pigeonhole_kmer_length(75, 1) == 25
+    assert probe.pigeonhole_kmer_length(75, 2) == 25
+    assert probe.pigeonhole_kmer_length(100, 1) == 50
+    assert probe.pigeonhole_kmer_length(100, 2) == 25
+    assert probe.pigeonhole_kmer_length(100, 3) == 25
+    assert probe.pigeonhole_kmer_length(100, 4) == 20
+    assert probe.pigeonhole_kmer_length(100, 5) < 20
+
+
+def test_candidate_probes_golden():
+    from catch_amd.filter import candidate_probes
+    recs = load_golden("candidate_probes")
+    assert recs
+    for c in recs:
+        got = candidate_probes.make_candidate_probes_from_sequences(
+            c["seqs"], c["probe_length"], c["probe_stride"])
+        assert [p.seq_str for p in got] == c["out"]
+    with pytest.raises(ValueError):
+        candidate_probes.make_candidate_probes_from_sequences(["ACGT"], 10, 5)
+    with pytest.raises(TypeError):
+        candidate_probes.make_candidate_probes_from_sequences("ACGT", 2, 1)
+
+
+def test_base_filter_dispatch():
+    from catch_amd.filter.base_filter import BaseFilter
+
+    class One(BaseFilter):
+        def _filter(self, input):
+            return [x for x in input if x % 2 == 0]
+
+    class Two(BaseFilter):
+        def _filter(self, input, target_genomes):
+            return [x for x in input if x in target_genomes]
+
+    class Grouped(BaseFilter):
+        requires_probe_groupings = True
+
+        def _filter(self, input, target_genomes):
+            return [list(reversed(g)) for g in input]
+
+    assert One().filter([1, 2, 3, 4]) == [2, 4]
+    assert One().filter([[1, 2], [4, 5]], input_is_grouped=True) == [[2], [4]]
+    assert Two().filter([1, 2, 3], [2, 3]) == [2, 3]
+    assert Grouped().filter([[1, 2], [3]], [[], []], input_is_grouped=True) == [[2, 1], [3]]
+    with pytest.raises(AssertionError):
+        Grouped().filter([1, 2], [[]])
+    with pytest.raises(Exception):
+        BaseFilter().filter([1])
+
+
+def test_duplicate_filter_and_probe_type():
+    from catch_amd import probe
+    from catch_amd.filter.duplicate_filter import DuplicateFilter
+    ps = [probe.Probe.from_str(s) for s in ["ACGT", "TTTT", "ACGT", "GGGG", "TTTT"]]
+    out = DuplicateFilter().filter(ps)
+    assert [p.seq_str for p in out] == ["ACGT", "TTTT", "GGGG"]
+    assert out[0] is ps[0]
+    a, b = probe.Probe.from_str("ACGTN"), probe.Probe.from_str("ACCTN")
+    assert a.mismatches(b) == 1 and len(a) == 5 and a[1] == "C"
+    assert "".join(a.seq) == "ACGTN"
+    assert a.reverse_complement().seq_str == "NACGT"
+    with pytest.raises(ValueError):
+        a.mismatches(probe.Probe.from_str("AC"))
+
+
+def test_seq_io_rules(tmp_path):
+    from catch_amd.utils import seq_io
+    fn = tmp_path / "x.fasta"
+    fn.write_text(">a desc\nacgtRYn-\nAC-GT\n\n>b\nNNNN\nacgu\n")
+    m = seq_io.read_fasta(str(fn))
+    assert list(m.items()) == [("a desc", "ACGTNNNACGT"), ("b", "NNNNACGU")]
+    assert list(seq_io.iterate_fasta(str(fn))) == ["acgtNNn-AC-GT", "NNNNacgu"]
+    gs = seq_io.read_genomes_from_fasta(str(fn))
+    assert [g.seqs for g in gs] == [["ACGTNNNACGT"], ["NNNNACGU"]]
+    assert gs[0].size() == 11
+
+
+def test_ndf_ordering_and_positions():
+    from catch_amd import probe
+    from catch_amd.filter import near_duplicate_filter as ndf
+    g = load_golden("ndf_hamming")
+    for c in g["synthetic"]:
+        f = ndf.NearDuplicateFilterWithHammingDistance(c["dist_thres"], c["dim"])
+        assert f.num_tables() == len(c["positions"])
+        random.seed(c["seed"])
+        assert f._draw_positions() == c["positions"]
+    f = ndf.NearDuplicateFilterWithHammingDistance(2, 4)
+    ps = [probe.Probe.from_str(s) for s in ["AAAA", "CCCC", "CCCC", "GGGG", "GGGG", "TTTT"]]
+    assert [p.seq_str for p in f._order_by_multiplicity(ps)] == ["CCCC", "GGGG", "AAAA", "TTTT"]
+
+
+def test_set_cover_filter_constructor_surface():
+    from catch_amd.filter import set_cover_filter as scf
+    f = scf.SetCoverFilter(2, 100, coverage=0.5, cover_extension=10)
+    assert f.requires_probe_groupings is True
+    assert (f.mismatches_tolerant, f.lcf_thres_tolerant) == (2, 100)
+    assert f.filter([[]], [[]], input_is_grouped=True) == [[]]
+    with pytest.raises(NotImplementedError):
+        scf.SetCoverFilter(2, 100, custom_cover_range_fn=("x.py", "fn"))
+    scf.set_max_num_processes_for_set_cover_instances(4)
+    from catch_amd.genome import Genome
+    g = [Genome.from_one_seq("A" * 50), Genome.from_one_seq("C" * 200)]
+    assert scf.SetCoverFilter(2, 100, coverage=100)._make_universe_p(g) == [1.0, 0.5]
+    assert scf.SetCoverFilter(2, 100, coverage=0.25)._make_universe_p(g) == [0.25, 0.25]
