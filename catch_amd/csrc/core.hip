@@ -143,6 +143,12 @@ extern "C" int catchhip_ctx_last_kernel_ms(catchhip_ctx *c, int phase, double *m
     return 0;
 }
 
+extern "C" int catchhip_ctx_last_counters(catchhip_ctx *c, i64 *out8) {
+    ARG_CHECK(c != nullptr && out8 != nullptr);
+    for (int i = 0; i < 8; ++i) out8[i] = c->counters[i];
+    return 0;
+}
+
 // ------------------------------------------------------------------------
 // bit-plane packing: 32 bases per u32 word, 3 planes (code bit 0, 1, 2) with
 // A=0 C=1 G=2 T=3 other(N)=4.  Base i of a stream lives in bit (i & 31) of

@@ -96,6 +96,7 @@ struct catchhip_ctx {
     hipEvent_t ev[2 * NPHASE] = {};
     double phase_ms[NPHASE] = {};
     i64 phase_launches[NPHASE] = {};
+    i64 counters[8] = {};
     // pinned staging word(s) for small device->host reads
     u64 *h_pin = nullptr;
     // RCCL (optional)

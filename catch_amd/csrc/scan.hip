@@ -382,7 +382,7 @@ static int run_fast(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
         HIP_TRY(hipGetLastError());
         u32 n;
         TRY(read_count(ctx, H.count.p, &n));
-        if (n <= cap) { H.n = n; H.has_end = false; return 0; }
+        if (n <= cap) { H.n = n; H.has_end = false; ctx->counters[0] = n; ctx->counters[1] = 0; return 0; }
         cap = n;  // overflow: rerun with the exact size
     }
     chip_set_error("fast scan: hit buffer overflow");
@@ -439,6 +439,8 @@ static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchh
     tm.launch();
     HIP_TRY(hipGetLastError());
     TRY(read_count(ctx, H.count.p, &H.n));
+    ctx->counters[0] = H.n;
+    ctx->counters[1] = nseeds;
     return 0;
 }
 

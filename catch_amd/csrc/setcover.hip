@@ -40,8 +40,9 @@ struct GreedyState {
     u32 done;      // 0 running, 1 finished, 2 rank list exhausted
     u32 iters;
     u32 lmax;      // longest row
-    u32 pad;
+    u32 smax;      // largest (set, universe) element count
     unsigned long long prof[8];  // shader-clock ticks per phase (thread 0)
+    unsigned long long n_wrows, n_recount, n_words;  // work counters
 };
 
 #define ID_BITS 24
@@ -51,7 +52,11 @@ struct GreedyState {
 #define LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#ifdef CATCHHIP_PROFILE   // per-phase shader-clock accounting (make CXXFLAGS+=-DCATCHHIP_PROFILE)
 #define PROF(i) do { if (tid == 0) { unsigned long long t_ = __builtin_readcyclecounter(); st->prof[i] += t_ - t_prev; t_prev = t_; } } while (0)
+#else
+#define PROF(i) do { (void)t_prev; } while (0)
+#endif
 
 __device__ __forceinline__ u32 range_popcount(const u64 *__restrict__ bm, u32 s, u32 e) {
     u32 w0 = s >> 6, w1 = (e - 1) >> 6;
@@ -63,10 +68,29 @@ __device__ __forceinline__ u32 range_popcount(const u64 *__restrict__ bm, u32 s,
     return c + (u32)__popcll(bm[w1] & m1);
 }
 // same, reading through L2 (words may have been cleared by atomics this launch)
+// The common case (rows of <= 5 words, i.e. <= 257 bases) issues all its loads
+// before the first use, so the words arrive in ONE memory round trip; a plain
+// loop would pay one dependent L2/MALL round trip (~1k cycles) per word.
+#define RP_MAXW 5
 __device__ __forceinline__ u32 range_popcount_l2(const unsigned long long *bm, u32 s, u32 e) {
     u32 w0 = s >> 6, w1 = (e - 1) >> 6;
     u64 m0 = ~0ull << (s & 63);
     u64 m1 = ~0ull >> (63 - ((e - 1) & 63));
+    const u32 nw = w1 - w0 + 1;
+    if (nw <= RP_MAXW) {
+        u64 v[RP_MAXW];
+#pragma unroll
+        for (u32 j = 0; j < RP_MAXW; ++j) v[j] = (j < nw) ? LD(&bm[w0 + j]) : 0ull;
+        u32 c = 0;
+#pragma unroll
+        for (u32 j = 0; j < RP_MAXW; ++j) {
+            u64 m = ~0ull;
+            if (j == 0) m &= m0;
+            if (j == nw - 1) m &= m1;
+            if (j < nw) c += (u32)__popcll(v[j] & m);
+        }
+        return c;
+    }
     if (w0 == w1) return (u32)__popcll(LD(&bm[w0]) & m0 & m1);
     u32 c = (u32)__popcll(LD(&bm[w0]) & m0);
     for (u32 w = w0 + 1; w < w1; ++w) c += (u32)__popcll(LD(&bm[w]));
@@ -186,28 +210,41 @@ __global__ void greedy_start_kernel(GreedyState *st) {
 // initial per-row counts (every row lies wholly inside the fresh universe)
 __global__ void __launch_bounds__(256)
 rowcnt_init_kernel(const u32 *__restrict__ gs, const u32 *__restrict__ ge, const u32 *__restrict__ row_seg,
-                   u32 nrows, u32 *__restrict__ rowcnt, u32 *__restrict__ segcnt) {
+                   u32 nrows, u32 *__restrict__ segcnt) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrows) return;
-    u32 c = ge[r] - gs[r];
-    rowcnt[r] = c;
-    atomicAdd(&segcnt[row_seg[r]], c);
+    atomicAdd(&segcnt[row_seg[r]], ge[r] - gs[r]);
 }
 
 __global__ void __launch_bounds__(256)
 seg_init_kernel(const u32 *__restrict__ segcnt, const u32 *__restrict__ seg_univ,
                 const u32 *__restrict__ seg_set, const u32 *__restrict__ left, u32 nseg,
-                u32 *__restrict__ segcontrib, u32 *__restrict__ gain, u32 *__restrict__ segmax,
+                u32 *__restrict__ segcontrib, GreedyState *__restrict__ st,
                 u64 *__restrict__ ukeys, u32 *__restrict__ uvals) {
     u32 q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nseg) return;
-    u32 u = seg_univ[q], c = segcnt[q], l = left[u];
-    u32 contrib = c < l ? c : l;
-    segcontrib[q] = contrib;
-    atomicAdd(&gain[seg_set[q]], contrib);
-    atomicMax(&segmax[u], c);
-    ukeys[q] = u;   // for the per-universe segment index
-    uvals[q] = q;
+    u32 c = 0;
+    if (q < nseg) {
+        u32 u = seg_univ[q], l = left[u];
+        c = segcnt[q];
+        segcontrib[q] = c < l ? c : l;
+        ukeys[q] = u;   // for the per-universe segment index
+        uvals[q] = q;
+    }
+    // largest segment count (bounds when min(left, count) can bind): one
+    // atomic per wavefront instead of one contended atomic per segment
+    for (int d = 32; d > 0; d >>= 1) { u32 o = __shfl_down(c, d, WAVE); c = o > c ? o : c; }
+    if ((threadIdx.x & 63) == 0 && c) atomicMax(&st->smax, c);
+}
+
+// initial gain of every set = sum of its segments' contributions (no atomics)
+__global__ void __launch_bounds__(256)
+gain_init_kernel(const u32 *__restrict__ segcontrib, const u32 *__restrict__ set_seg_ptr, u32 nsets,
+                 u32 *__restrict__ gain) {
+    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsets) return;
+    u32 g = 0;
+    for (u32 q = set_seg_ptr[s]; q < set_seg_ptr[s + 1]; ++q) g += segcontrib[q];
+    gain[s] = g;
 }
 
 __global__ void __launch_bounds__(256)
@@ -216,6 +253,44 @@ pos_key_kernel(const u32 *__restrict__ gs, u32 nrows, u64 *__restrict__ keys, u3
     if (r >= nrows) return;
     keys[r] = gs[r];
     vals[r] = r;
+}
+
+// position-sorted row table {gs, ge, row, set} and its coarse bucket index
+__global__ void __launch_bounds__(256)
+pent_fill_kernel(const u32 *__restrict__ pos_row, const u32 *__restrict__ gs, const u32 *__restrict__ ge,
+                 const i32 *__restrict__ row_set, const u32 *__restrict__ row_seg, u32 nrows,
+                 uint4 *__restrict__ pent, u32 *__restrict__ prowcnt) {
+    u32 y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= nrows) return;
+    u32 r = pos_row[y];
+    pent[y] = make_uint4(gs[r], ge[r], row_seg[r], (u32)row_set[r]);
+    prowcnt[y] = ge[r] - gs[r];   // every row lies wholly inside the fresh universe
+}
+
+// rows in set order with what the apply / re-count phases need in one load
+__global__ void __launch_bounds__(256)
+wrow_fill_kernel(const u32 *__restrict__ gs, const u32 *__restrict__ ge, const i32 *__restrict__ row_set,
+                 const i32 *__restrict__ row_univ, const u32 *__restrict__ row_seg,
+                 const u32 *__restrict__ can, u32 nrows, uint4 *__restrict__ wrow) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    u32 prev = (r > 0 && row_set[r - 1] == row_set[r] && row_univ[r - 1] == row_univ[r]) ? ge[r - 1] : 0u;
+    // bit 31 of the segment field: this universe may stay partly uncovered
+    // (can > 0), so min(left, count) has to be evaluated exactly
+    wrow[r] = make_uint4(gs[r], ge[r], prev, row_seg[r] | (can[row_univ[r]] ? 0x80000000u : 0u));
+}
+
+__global__ void __launch_bounds__(256)
+bucket_kernel(const u64 *__restrict__ pos_key, u32 nrows, u32 nbuckets, int shift, u32 *__restrict__ bucket) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    u64 want = (u64)b << shift;
+    u32 lo = 0, hi = nrows;
+    while (lo < hi) {
+        u32 mid = (lo + hi) >> 1;
+        if (pos_key[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    bucket[b] = lo;
 }
 
 __global__ void __launch_bounds__(256)
@@ -235,25 +310,27 @@ useg_ptr_kernel(const u64 *__restrict__ ukeys, u32 nseg, u32 nuniv, u32 *__restr
 // ------------------------------------------------------------------------
 struct GreedyArgs {
     unsigned long long *bm;
-    const u32 *gs, *ge;
-    const i32 *row_set, *row_univ;
-    const u32 *row_seg;
+    const uint4 *wrow;    // rows in set order: {gs, ge, prev_ge (same universe, else 0), segment}
     const u32 *set_ptr, *set_seg_ptr;
     const u32 *seg_univ, *seg_set;
-    const u64 *pos_key;   // sorted row starts
-    const u32 *pos_row;   // row index per sorted slot
+    const uint4 *pent;    // rows sorted by start: {gs, ge, segment, set}
+    u32 *prowcnt;         // |row ∩ universe| per sorted slot
+    const u32 *bucket;    // first sorted slot with gs >= (b << BUCKET_SHIFT)
     const u32 *useg_ptr, *useg;
-    const u32 *can, *segmax, *rank;
-    u32 *usize, *left, *rowcnt, *segcnt, *segcontrib, *gain;
-    u32 *picked, *picks, *ubind, *blockdirty, *dirty;
-    unsigned long long *blockmax;
+    const u32 *can, *rank;
+    u32 *usize, *left, *segcnt, *segcontrib, *gain;
+    u32 *picked, *picks, *dirty;
     GreedyState *st;
-    u32 nrows, nsets, nuniv, nblocks;
+    u32 nrows, nsets, nuniv, chunk;
 };
 
 #define GW_THREADS 1024
 #define GW_WAVES (GW_THREADS / WAVE)
-#define GW_MAXBIND 2048
+#define GW_MAXBIND 1024
+#define GW_MAXWSEG 4096    // winner segments with LDS accumulators
+#define GW_MAXDIRTY 4096   // dirty segments staged in LDS
+#define GW_CAND 4          // candidate rows fetched per lane per step
+#define BUCKET_SHIFT 5
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
 #pragma unroll
@@ -264,217 +341,287 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
-// key of block b over the sets of the current rank that are not picked
-__device__ __forceinline__ void refresh_block(const GreedyArgs &a, u32 b, u32 cur_rank, int lane) {
-    unsigned long long k = 0;
-    const u32 base = b * GAIN_BLOCK;
-#pragma unroll
-    for (int j = 0; j < GAIN_BLOCK / WAVE; ++j) {
-        u32 s = base + j * WAVE + lane;
-        if (s < a.nsets && a.rank[s] == cur_rank && !LD(&a.picked[s])) {
-            unsigned long long g = LD(&a.gain[s]);
-            if (g) {
-                unsigned long long kk = (g << ID_BITS) | (unsigned long long)(ID_MASK - s);
-                k = kk > k ? kk : k;
-            }
-        }
+// contribution min(left, count) of segment q changed? patch the set's gain.
+__device__ __forceinline__ void patch_segment(const GreedyArgs &a, u32 q, u32 *s_cdirty) {
+    const u32 ss = a.seg_set[q];
+    if (LD(&a.picked[ss])) return;
+    const u32 l = LD(&a.left[a.seg_univ[q]]), c = LD(&a.segcnt[q]);
+    const u32 nc = c < l ? c : l;
+    const u32 oc = atomicExch(&a.segcontrib[q], nc);
+    if (oc != nc) {
+        atomicAdd(&a.gain[ss], nc - oc);
+        s_cdirty[ss / a.chunk] = 1u;
     }
-    k = wave_max_u64(k);
-    if (lane == 0) { ST(&a.blockmax[b], k); ST(&a.blockdirty[b], 0u); }
 }
 
 __global__ void __launch_bounds__(GW_THREADS)
 greedy_wg_kernel(GreedyArgs a) {
     __shared__ unsigned long long s_red[GW_WAVES];
     __shared__ unsigned long long s_key;
+    __shared__ u32 s_cdirty[GW_THREADS];  // this thread's chunk of sets must be re-scanned
     __shared__ u32 s_bind[GW_MAXBIND];
-    __shared__ u32 s_nbind, s_ndirty, s_need, s_rank, s_stop;
+    __shared__ u32 s_clr[GW_MAXWSEG];     // bits cleared per winner segment
+    __shared__ u32 s_dirty[GW_MAXDIRTY];
+    __shared__ u32 s_nbind, s_ndirty, s_need, s_rank, s_stop, s_npicks, s_iters;
+    __shared__ unsigned long long s_nwrows, s_nrecount, s_nwords;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     GreedyState *st = a.st;
 
-    if (tid == 0) { s_need = st->n_need; s_rank = st->cur_rank; s_stop = st->done; s_nbind = 0; }
+    if (tid == 0) {
+        s_need = st->n_need; s_rank = st->cur_rank; s_stop = st->done;
+        s_nbind = 0; s_ndirty = 0; s_npicks = 0; s_iters = 0;
+        s_nwrows = 0; s_nrecount = 0; s_nwords = 0;
+    }
+    s_cdirty[tid] = 1u;
     __syncthreads();
     if (s_stop) return;
-    for (u32 b = wave; b < a.nblocks; b += GW_WAVES) refresh_block(a, b, s_rank, lane);
-    DRAIN();
-    __syncthreads();
+    const u32 lmax = st->lmax, smax = st->smax;
+    u32 cnt_recount = 0, cnt_words = 0;   // per-thread work counters
+    const u32 c0 = tid * a.chunk;                                  // this thread's sets
+    const u32 c1 = min(a.nsets, c0 + a.chunk);
+    unsigned long long ckey = 0;                                   // best key in the chunk
+    u32 my_rank = 0xffffffffu;                                     // rank the chunk scan is valid for
+    u32 cur_rank = st->cur_rank, stop = 0;                         // uniform across the workgroup
+    const u32 nrank = st->nrank;
     unsigned long long t_prev = __builtin_readcyclecounter();
 
     for (;;) {
-        // ---- arg-max over the block maxima --------------------------------
-        unsigned long long k = 0;
-        for (u32 b = tid; b < a.nblocks; b += GW_THREADS) {
-            unsigned long long v = LD(&a.blockmax[b]);
-            k = v > k ? v : k;
-        }
-        k = wave_max_u64(k);
-        if (lane == 0) s_red[wave] = k;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long m = 0;
-            for (int w = 0; w < GW_WAVES; ++w) m = s_red[w] > m ? s_red[w] : m;
-            s_key = m;
-            st->iters++;
-            if ((m >> ID_BITS) == 0) {
-                // no set of this rank covers anything still needed: next rank
-                // (set_cover.py:522-526)
-                s_rank++;
-                st->cur_rank = s_rank;
-                if (s_rank >= st->nrank) { st->done = 2; s_stop = 1; }
-            } else {
-                u32 s = ID_MASK - (u32)(m & ID_MASK);
-                ST(&a.picked[s], 1u);
-                a.picks[st->npicks] = s;
-                st->npicks++;
+        // ---- A: arg-max.  Only chunks whose gains changed are re-scanned ----
+        if (s_cdirty[tid] || my_rank != cur_rank) {
+            s_cdirty[tid] = 0u;
+            my_rank = cur_rank;
+            unsigned long long k = 0;
+            for (u32 s0 = c0; s0 < c1; s0 += 16) {
+                // gains and ranks of 16 sets in flight together: one round trip
+                u32 g[16], rk[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const u32 sj = min(s0 + j, c1 - 1);
+                    g[j] = LD(&a.gain[sj]);
+                    rk[j] = a.rank[sj];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    // picked sets hold gain 0 (see below); other ranks are masked here
+                    if (s0 + j < c1 && g[j] && rk[j] == my_rank) {
+                        unsigned long long kk = ((unsigned long long)g[j] << ID_BITS) |
+                                                (unsigned long long)(ID_MASK - (s0 + j));
+                        k = kk > k ? kk : k;
+                    }
+                }
             }
-            s_nbind = 0;
-            s_ndirty = 0;
+            ckey = k;
         }
-        __syncthreads(); PROF(0);
-        if (s_stop) return;
-        const unsigned long long key = s_key;
+        {
+            unsigned long long k = wave_max_u64(ckey);
+            if (lane == 0) s_red[wave] = k;
+        }
+        __syncthreads();
+        // every wave folds the 16 partial maxima itself: no second barrier and no
+        // global access between the scan and the apply phase
+        unsigned long long key = wave_max_u64(lane < GW_WAVES ? s_red[lane] : 0ull);
+        key = __shfl(key, 0, WAVE);
+        PROF(0);
         if ((key >> ID_BITS) == 0) {
-            for (u32 b = wave; b < a.nblocks; b += GW_WAVES) refresh_block(a, b, s_rank, lane);
-            DRAIN();
-            __syncthreads();
+            // no set of this rank covers anything still needed: next rank
+            // (set_cover.py:522-526); chunks re-scan because my_rank != cur_rank
+            cur_rank++;
+            if (tid == 0) s_iters++;
+            if (cur_rank >= nrank) { stop = 2; break; }
+            __syncthreads();   // s_red is rewritten by the next scan
             continue;
         }
         const u32 s = ID_MASK - (u32)(key & ID_MASK);
-        const u32 r0 = a.set_ptr[s], r1 = a.set_ptr[s + 1];
-
-        // ---- apply: remove the winner's elements (set_cover.py:531-550) ----
-        for (u32 r = r0 + tid; r < r1; r += GW_THREADS) {
-            u32 x = a.gs[r], e = a.ge[r];
-            u32 w0 = x >> 6, w1 = (e - 1) >> 6;
-            u32 cleared = 0;
-            for (u32 w = w0; w <= w1; ++w) {
-                u64 m = ~0ull;
-                if (w == w0) m &= ~0ull << (x & 63);
-                if (w == w1) m &= ~0ull >> (63 - ((e - 1) & 63));
-                u64 old = atomicAnd(&a.bm[w], ~m);
-                cleared += (u32)__popcll(old & m);
-            }
-            if (cleared) atomicSub(&a.usize[a.row_univ[r]], cleared);
+        const u32 r0 = a.set_ptr[s], nw = a.set_ptr[s + 1] - r0;
+        const u32 q0 = a.set_seg_ptr[s], nq = a.set_seg_ptr[s + 1] - q0;
+        for (u32 i = tid; i < nq && i < GW_MAXWSEG; i += GW_THREADS) s_clr[i] = 0u;
+        if (tid == 0) {
+            s_iters++;
+            ST(&a.picked[s], 1u);
+            ST(&a.gain[s], 0u);          // never eligible again; its rows are skipped below
+            a.picks[s_npicks++] = s;
+            s_cdirty[s / a.chunk] = 1u;
+            s_nbind = 0;
+            s_ndirty = 0;
+            s_nwrows += nw;
         }
-        DRAIN();
-        __syncthreads(); PROF(1);
-        for (u32 q = a.set_seg_ptr[s] + tid; q < a.set_seg_ptr[s + 1]; q += GW_THREADS) {
-            u32 u = a.seg_univ[q];
+        __syncthreads();
+
+        // ---- B: apply: remove the winner's elements (set_cover.py:531-550) --
+        for (u32 i = tid; i < nw; i += GW_THREADS) {
+            const uint4 wr = a.wrow[r0 + i];
+            const u32 x = wr.x, e = wr.y;
+            const u32 w0 = x >> 6, w1 = (e - 1) >> 6, nwd = w1 - w0 + 1;
+            const u64 m0 = ~0ull << (x & 63), m1 = ~0ull >> (63 - ((e - 1) & 63));
+            u32 cleared = 0;
+            if (nwd <= RP_MAXW) {
+                // all returning atomics in flight together: one round trip
+                u64 old[RP_MAXW], msk[RP_MAXW];
+#pragma unroll
+                for (u32 j = 0; j < RP_MAXW; ++j) {
+                    u64 m = ~0ull;
+                    if (j == 0) m &= m0;
+                    if (j == nwd - 1) m &= m1;
+                    msk[j] = m;
+                    old[j] = (j < nwd) ? atomicAnd(&a.bm[w0 + j], ~m) : 0ull;
+                }
+#pragma unroll
+                for (u32 j = 0; j < RP_MAXW; ++j)
+                    if (j < nwd) cleared += (u32)__popcll(old[j] & msk[j]);
+            } else {
+                for (u32 w = w0; w <= w1; ++w) {
+                    u64 m = ~0ull;
+                    if (w == w0) m &= m0;
+                    if (w == w1) m &= m1;
+                    u64 old = atomicAnd(&a.bm[w], ~m);
+                    cleared += (u32)__popcll(old & m);
+                }
+            }
+            if (cleared) {
+                const u32 li = (wr.w & 0x7fffffffu) - q0;
+                if (li < GW_MAXWSEG) atomicAdd(&s_clr[li], cleared);
+                else atomicSub(&a.usize[a.seg_univ[wr.w & 0x7fffffffu]], cleared);
+            }
+        }
+        __syncthreads();
+        PROF(1);
+
+        // ---- C1: remaining need per touched universe (single writer) ---------
+        // (wave 0 only, so that its dependent loads overlap the other waves' C2 chain)
+        if (wave == 0) for (u32 i = lane; i < nq; i += WAVE) {
+            const u32 u = a.seg_univ[q0 + i];
             u32 n = LD(&a.usize[u]);
-            u32 c = a.can[u];
-            u32 nl = n > c ? n - c : 0u;
-            u32 ol = LD(&a.left[u]);
+            if (i < GW_MAXWSEG && s_clr[i]) { n -= s_clr[i]; ST(&a.usize[u], n); }
+            const u32 c = a.can[u];
+            const u32 nl = n > c ? n - c : 0u;
+            const u32 ol = LD(&a.left[u]);
             if (nl != ol) {
                 ST(&a.left[u], nl);
                 if (ol > 0 && nl == 0) atomicSub(&s_need, 1u);
                 // min(left, count) can only bind when part of the universe may
-                // stay uncovered and the need dropped below the largest count
-                if (c > 0 && nl < a.segmax[u]) {
+                // stay uncovered and the need fell below the largest count
+                if (c > 0 && nl < smax) {
                     u32 slot = atomicAdd(&s_nbind, 1u);
                     if (slot < GW_MAXBIND) s_bind[slot] = u;
-                    ST(&a.ubind[u], 1u);
+                }
+            }
+        }
+        // ---- C2: re-count the rows that overlap a cleared range --------------
+        // one 16-lane group per winner row; candidates come from the
+        // position-sorted row table through a coarse bucket index
+        if (wave != 0) {
+            const int sub = tid & 15;
+            for (u32 i = (tid - WAVE) >> 4; i < nw; i += (GW_THREADS - WAVE) / 16) {
+                const uint4 wr = a.wrow[r0 + i];
+                const u32 x = wr.x, e = wr.y, prev = wr.z;
+                const bool partial = (wr.w >> 31) != 0;   // min(left,count) may bind in this universe
+                const u32 lo_start = x > lmax ? x - lmax : 0u;      // earlier rows cannot reach x
+                u32 y = a.bucket[lo_start >> BUCKET_SHIFT] + sub;
+                bool more = true;
+                while (more) {
+                    uint4 c[GW_CAND];
+#pragma unroll
+                    for (int j = 0; j < GW_CAND; ++j) {
+                        const u32 yy = y + 16 * j;
+                        c[j] = a.pent[min(yy, a.nrows - 1)];
+                        if (yy >= a.nrows) c[j].x = c[j].y = 0xffffffffu;   // past the end
+                    }
+                    u32 nc[GW_CAND], oc[GW_CAND], pk[GW_CAND], cnw[GW_CAND];
+                    u64 v[GW_CAND][RP_MAXW];
+                    bool use[GW_CAND];
+                    // every load below is unconditional (clamped to a valid
+                    // address when unused) so that all candidates' words arrive
+                    // in one memory round trip instead of one per candidate
+#pragma unroll
+                    for (int j = 0; j < GW_CAND; ++j) {
+                        // overlaps the range and was not already visited from
+                        // the previous range of this universe
+                        use[j] = c[j].x < e && c[j].y > x && prev <= c[j].x;
+                        const u32 cs = use[j] ? c[j].x : 0u, ce = use[j] ? c[j].y : 1u;
+                        const u32 w0 = cs >> 6;
+                        cnw[j] = ((ce - 1) >> 6) - w0 + 1;
+#pragma unroll
+                        for (u32 t = 0; t < RP_MAXW; ++t) v[j][t] = LD(&a.bm[w0 + min(t, cnw[j] - 1)]);
+                        pk[j] = LD(&a.picked[use[j] ? c[j].w : 0u]);   // rows of chosen sets are dead
+                        oc[j] = a.prowcnt[use[j] ? y + 16 * j : 0u];
+                    }
+#pragma unroll
+                    for (int j = 0; j < GW_CAND; ++j) {
+                        nc[j] = 0;
+                        if (pk[j]) use[j] = false;
+                        if (!use[j]) continue;
+                        cnt_recount++;
+                        cnt_words += cnw[j];
+                        if (cnw[j] > RP_MAXW) { nc[j] = range_popcount_l2(a.bm, c[j].x, c[j].y); continue; }
+                        const u64 m0 = ~0ull << (c[j].x & 63), m1 = ~0ull >> (63 - ((c[j].y - 1) & 63));
+#pragma unroll
+                        for (u32 t = 0; t < RP_MAXW; ++t) {
+                            u64 m = ~0ull;
+                            if (t == 0) m &= m0;
+                            if (t == cnw[j] - 1) m &= m1;
+                            if (t < cnw[j]) nc[j] += (u32)__popcll(v[j][t] & m);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < GW_CAND; ++j) {
+                        if (use[j] && oc[j] != nc[j]) {
+                            const u32 d = oc[j] - nc[j];
+                            a.prowcnt[y + 16 * j] = nc[j];
+                            if (partial) {
+                                atomicSub(&a.segcnt[c[j].z], d);
+                                const u32 slot = atomicAdd(&s_ndirty, 1u);
+                                if (slot < GW_MAXDIRTY) s_dirty[slot] = c[j].z; else a.dirty[slot] = c[j].z;
+                            } else {
+                                // fully covered universes: contribution == count
+                                atomicSub(&a.gain[c[j].w], d);
+                                s_cdirty[c[j].w / a.chunk] = 1u;
+                            }
+                        }
+                    }
+                    more = c[GW_CAND - 1].x < e;   // sorted by start: stop once past the range
+                    y += 16 * GW_CAND;
                 }
             }
         }
         DRAIN();
-        __syncthreads(); PROF(2);
+        __syncthreads();
+        PROF(2);
 
-        // ---- re-count the rows that overlap a cleared range ----------------
-        const u32 lmax = st->lmax;
-        for (u32 wr = r0 + wave; wr < r1; wr += GW_WAVES) {
-            const u32 x = a.gs[wr], e = a.ge[wr];
-            const u32 lo_start = x > lmax ? x - lmax : 0u;  // rows starting before this cannot reach x
-            u32 lo = 0, hi = a.nrows;
-            while (lo < hi) {
-                u32 mid = (lo + hi) >> 1;
-                if ((u32)a.pos_key[mid] < lo_start) lo = mid + 1; else hi = mid;
-            }
-            for (u32 y = lo + lane; y < a.nrows; y += WAVE) {
-                if ((u32)a.pos_key[y] >= e) break;
-                const u32 r = a.pos_row[y];
-                if (a.ge[r] <= x) continue;
-                const u32 sr = (u32)a.row_set[r];
-                if (LD(&a.picked[sr])) continue;
-                const u32 nc = range_popcount_l2(a.bm, a.gs[r], a.ge[r]);
-                const u32 oc = atomicExch(&a.rowcnt[r], nc);  // a row reached from two ranges is patched once
-                if (oc != nc) {
-                    const u32 q = a.row_seg[r];
-                    atomicSub(&a.segcnt[q], oc - nc);
-                    a.dirty[atomicAdd(&s_ndirty, 1u)] = q;   // <= one entry per row per pick
-                }
-            }
-        }
-        DRAIN();
-        __syncthreads(); PROF(3);
-        // contribution min(left, count) of every segment whose count changed
-        {
+        // ---- D: universes with partial cover: exact min(left, count) ---------
+        if (s_ndirty | s_nbind) {
             const u32 nd = s_ndirty;
-            for (u32 i = tid; i < nd; i += GW_THREADS) {
-                const u32 q = a.dirty[i];
-                const u32 ss = a.seg_set[q];
-                const u32 l = LD(&a.left[a.seg_univ[q]]), c = LD(&a.segcnt[q]);
-                const u32 nc = c < l ? c : l;
-                const u32 oc = atomicExch(&a.segcontrib[q], nc);
-                if (oc != nc) { atomicAdd(&a.gain[ss], nc - oc); ST(&a.blockdirty[ss / GAIN_BLOCK], 1u); }
-            }
-        }
-        DRAIN();
-        __syncthreads(); PROF(4);
-
-        // ---- universes whose need became binding: re-evaluate min(left, count)
-        {
+            for (u32 i = tid; i < nd; i += GW_THREADS)
+                patch_segment(a, i < GW_MAXDIRTY ? s_dirty[i] : LD(&a.dirty[i]), s_cdirty);
             const u32 nb = s_nbind;
             if (nb > GW_MAXBIND) {
-                // overflow of the LDS list: walk every universe's flag instead
                 for (u32 u = wave; u < a.nuniv; u += GW_WAVES) {
-                    if (!LD(&a.ubind[u])) continue;
-                    const u32 l = LD(&a.left[u]);
-                    for (u32 z = a.useg_ptr[u] + lane; z < a.useg_ptr[u + 1]; z += WAVE) {
-                        u32 q = a.useg[z], ss = a.seg_set[q];
-                        if (LD(&a.picked[ss])) continue;
-                        u32 c = LD(&a.segcnt[q]);
-                        u32 nc = c < l ? c : l;
-                        u32 oc = atomicExch(&a.segcontrib[q], nc);
-                        if (oc != nc) { atomicAdd(&a.gain[ss], nc - oc); ST(&a.blockdirty[ss / GAIN_BLOCK], 1u); }
-                    }
-                    if (lane == 0) ST(&a.ubind[u], 0u);
+                    if (a.can[u] == 0 || LD(&a.left[u]) >= smax) continue;
+                    for (u32 z = a.useg_ptr[u] + lane; z < a.useg_ptr[u + 1]; z += WAVE)
+                        patch_segment(a, a.useg[z], s_cdirty);
                 }
             } else {
                 for (u32 i = wave; i < nb; i += GW_WAVES) {
                     const u32 u = s_bind[i];
-                    const u32 l = LD(&a.left[u]);
-                    for (u32 z = a.useg_ptr[u] + lane; z < a.useg_ptr[u + 1]; z += WAVE) {
-                        u32 q = a.useg[z], ss = a.seg_set[q];
-                        if (LD(&a.picked[ss])) continue;
-                        u32 c = LD(&a.segcnt[q]);
-                        u32 nc = c < l ? c : l;
-                        u32 oc = atomicExch(&a.segcontrib[q], nc);
-                        if (oc != nc) { atomicAdd(&a.gain[ss], nc - oc); ST(&a.blockdirty[ss / GAIN_BLOCK], 1u); }
-                    }
-                    if (lane == 0) ST(&a.ubind[u], 0u);
+                    for (u32 z = a.useg_ptr[u] + lane; z < a.useg_ptr[u + 1]; z += WAVE)
+                        patch_segment(a, a.useg[z], s_cdirty);
                 }
             }
+            DRAIN();
+            __syncthreads();
         }
-        if (tid == 0) ST(&a.blockdirty[s / GAIN_BLOCK], 1u);
-        DRAIN();
-        __syncthreads(); PROF(5);
-
-        // ---- refresh dirty blocks of the max structure ---------------------
-        for (u32 base = wave * WAVE; base < a.nblocks; base += GW_WAVES * WAVE) {
-            u32 b = base + lane;
-            bool dirty = (b < a.nblocks) && LD(&a.blockdirty[b]);
-            u64 mask = __ballot(dirty);
-            while (mask) {
-                int j = __ffsll((unsigned long long)mask) - 1;
-                mask &= mask - 1;
-                refresh_block(a, base + j, s_rank, lane);
-            }
-        }
-        DRAIN();
-        __syncthreads(); PROF(6);
-        if (tid == 0 && s_need == 0) { st->done = 1; st->n_need = 0; s_stop = 1; }
-        __syncthreads();
-        if (s_stop) return;
+        PROF(3);
+        if (s_need == 0) break;
+    }
+    atomicAdd(&s_nrecount, (unsigned long long)cnt_recount);
+    atomicAdd(&s_nwords, (unsigned long long)cnt_words);
+    __syncthreads();
+    if (tid == 0) {
+        st->done = stop == 2 ? 2u : 1u;
+        st->n_need = s_need;
+        st->cur_rank = cur_rank;
+        st->npicks = s_npicks;
+        st->iters = s_iters;
+        st->n_wrows = s_nwrows; st->n_recount = s_nrecount; st->n_words = s_nwords;
     }
 }
 
@@ -698,49 +845,49 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     int rc = 0;
     if (!distributed) {
         // ---- persistent single-workgroup solver ---------------------------
-        DevBuf<u32> rowcnt, segcnt, segcontrib, gain, segmax, ubind, blockdirty, dirty, pos_row, pos_row_alt, useg,
-            useg_alt, useg_ptr;
+        DevBuf<u32> prowcnt, segcnt, segcontrib, gain, dirty, pos_row, pos_row_alt, useg, useg_alt, useg_ptr,
+            bucket;
         DevBuf<u64> pos_key, pos_key_alt, ukeys, ukeys_alt;
-        DevBuf<unsigned long long> blockmax;
-        const u32 nblocks = (u32)div_up(nsets, GAIN_BLOCK);
-        TRY(rowcnt.alloc(nrows));
+        DevBuf<uint4> pent, wrow;
+        const u32 nbuckets = (u32)(R->total >> BUCKET_SHIFT) + 2;
+        TRY(prowcnt.alloc(nrows));
         TRY(segcnt.alloc(nseg));
         TRY(segcontrib.alloc(nseg));
         TRY(gain.alloc(nsets));
-        TRY(segmax.alloc(nuniv));
-        TRY(ubind.alloc(nuniv));
-        TRY(blockdirty.alloc(nblocks));
         TRY(dirty.alloc(nrows));
-        TRY(blockmax.alloc(nblocks));
         TRY(pos_key.alloc(nrows));
         TRY(pos_row.alloc(nrows));
+        TRY(pent.alloc(nrows));
+        TRY(wrow.alloc(nrows));
+        TRY(bucket.alloc(nbuckets));
         TRY(ukeys.alloc(nseg));
         TRY(useg.alloc(nseg));
         TRY(useg_ptr.alloc(nuniv + 1));
         HIP_TRY(hipMemsetAsync(segcnt.p, 0, sizeof(u32) * nseg, s));
-        HIP_TRY(hipMemsetAsync(gain.p, 0, sizeof(u32) * nsets, s));
-        HIP_TRY(hipMemsetAsync(segmax.p, 0, sizeof(u32) * nuniv, s));
-        HIP_TRY(hipMemsetAsync(ubind.p, 0, sizeof(u32) * nuniv, s));
-        HIP_TRY(hipMemsetAsync(blockdirty.p, 0, sizeof(u32) * nblocks, s));
-        hipLaunchKernelGGL(rowcnt_init_kernel, dim3(rb), dim3(256), 0, s, R->gs.p, R->ge.p, row_seg.p, nrows,
-                           rowcnt.p, segcnt.p);
+        hipLaunchKernelGGL(rowcnt_init_kernel, dim3(rb), dim3(256), 0, s, R->gs.p, R->ge.p, row_seg.p, nrows, segcnt.p);
         hipLaunchKernelGGL(seg_init_kernel, dim3((unsigned)div_up(nseg, 256)), dim3(256), 0, s, segcnt.p, seg_univ.p,
-                           seg_set.p, left.p, nseg, segcontrib.p, gain.p, segmax.p, ukeys.p, useg.p);
+                           seg_set.p, left.p, nseg, segcontrib.p, st.p, ukeys.p, useg.p);
+        hipLaunchKernelGGL(gain_init_kernel, dim3(sb), dim3(256), 0, s, segcontrib.p, set_seg_ptr.p, nsets, gain.p);
+        hipLaunchKernelGGL(wrow_fill_kernel, dim3(rb), dim3(256), 0, s, R->gs.p, R->ge.p, R->set_id.p, R->univ.p,
+                           row_seg.p, can.p, nrows, wrow.p);
         hipLaunchKernelGGL(pos_key_kernel, dim3(rb), dim3(256), 0, s, R->gs.p, nrows, pos_key.p, pos_row.p);
         TRY(chip_radix_sort_pairs(ctx, pos_key, pos_key_alt, pos_row, pos_row_alt, nrows,
                                   std::max(1, ceil_log2_u64((u64)R->total + 1))));
+        hipLaunchKernelGGL(pent_fill_kernel, dim3(rb), dim3(256), 0, s, pos_row.p, R->gs.p, R->ge.p, R->set_id.p,
+                           row_seg.p, nrows, pent.p, prowcnt.p);
+        hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)div_up(nbuckets, 256)), dim3(256), 0, s, pos_key.p, nrows,
+                           nbuckets, BUCKET_SHIFT, bucket.p);
         TRY(chip_radix_sort_pairs(ctx, ukeys, ukeys_alt, useg, useg_alt, nseg,
                                   std::max(1, ceil_log2_u64((u64)nuniv + 1))));
         hipLaunchKernelGGL(useg_ptr_kernel, dim3((unsigned)div_up(nuniv + 1, 256)), dim3(256), 0, s, ukeys.p, nseg,
                            nuniv, useg_ptr.p);
         GreedyArgs a;
-        a.bm = bm.p; a.gs = R->gs.p; a.ge = R->ge.p; a.row_set = R->set_id.p; a.row_univ = R->univ.p;
-        a.row_seg = row_seg.p; a.set_ptr = set_ptr.p; a.set_seg_ptr = set_seg_ptr.p; a.seg_univ = seg_univ.p;
-        a.seg_set = seg_set.p; a.pos_key = pos_key.p; a.pos_row = pos_row.p; a.useg_ptr = useg_ptr.p;
-        a.useg = useg.p; a.can = can.p; a.segmax = segmax.p; a.rank = rank.p; a.usize = usize.p; a.left = left.p;
-        a.rowcnt = rowcnt.p; a.segcnt = segcnt.p; a.segcontrib = segcontrib.p; a.gain = gain.p; a.picked = picked.p;
-        a.picks = picks.p; a.ubind = ubind.p; a.blockdirty = blockdirty.p; a.dirty = dirty.p; a.blockmax = blockmax.p; a.st = st.p;
-        a.nrows = nrows; a.nsets = nsets; a.nuniv = nuniv; a.nblocks = nblocks;
+        a.bm = bm.p; a.wrow = wrow.p; a.set_ptr = set_ptr.p; a.set_seg_ptr = set_seg_ptr.p;
+        a.seg_univ = seg_univ.p; a.seg_set = seg_set.p; a.pent = pent.p; a.prowcnt = prowcnt.p;
+        a.bucket = bucket.p; a.useg_ptr = useg_ptr.p; a.useg = useg.p; a.can = can.p;
+        a.rank = rank.p; a.usize = usize.p; a.left = left.p; a.segcnt = segcnt.p; a.segcontrib = segcontrib.p;
+        a.gain = gain.p; a.picked = picked.p; a.picks = picks.p; a.dirty = dirty.p; a.st = st.p;
+        a.nrows = nrows; a.nsets = nsets; a.nuniv = nuniv; a.chunk = (u32)div_up(nsets, GW_THREADS);
         hipLaunchKernelGGL(greedy_wg_kernel, dim3(1), dim3(GW_THREADS), 0, s, a);
         tm.launch(6);
         tm.stop();
@@ -749,12 +896,16 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         HIP_TRY(hipStreamSynchronize(s));
         tm.finish();
         ctx->phase_launches[PHASE_GREEDY] = h_st.iters;  // greedy iterations inside the persistent launch
+        ctx->counters[2] = h_st.iters; ctx->counters[3] = h_st.npicks; ctx->counters[4] = (i64)h_st.n_wrows;
+        ctx->counters[5] = (i64)h_st.n_recount; ctx->counters[6] = (i64)h_st.n_words;
+#ifdef CATCHHIP_PROFILE
         if (getenv("CATCHHIP_PROF")) {
             fprintf(stderr, "[catchhip] greedy wg: iters=%u picks=%u ms=%.3f ticks/iter:", h_st.iters, h_st.npicks,
                     ctx->phase_ms[PHASE_GREEDY]);
-            for (int i = 0; i < 7; ++i) fprintf(stderr, " p%d=%.0f", i, (double)h_st.prof[i] / (h_st.iters ? h_st.iters : 1));
+            for (int i = 0; i < 4; ++i) fprintf(stderr, " p%d=%.0f", i, (double)h_st.prof[i] / (h_st.iters ? h_st.iters : 1));
             fprintf(stderr, "\n");
         }
+#endif
     } else {
         const u32 nranks = (u32)ctx->nranks, myrank = (u32)ctx->rank;
         const u32 my_sets = (u32)div_up((i64)nsets, nranks);

@@ -65,6 +65,14 @@ class Context:
                                                   ctypes.byref(n)))
         return ms.value, n.value
 
+    def counters(self):
+        """catchhip_ctx_last_counters -> dict of work counters."""
+        out = np.zeros(8, dtype=np.int64)
+        check(self._L.catchhip_ctx_last_counters(self._h, _ptr(out, c_i64p)))
+        names = ["raw_hits", "seed_hits", "greedy_iters", "picks",
+                 "winner_rows", "rows_recounted", "bitmap_words_read", "_"]
+        return dict(zip(names, (int(x) for x in out)))
+
     # -- RCCL -----------------------------------------------------------
     @staticmethod
     def comm_unique_id():

@@ -57,6 +57,12 @@ int catchhip_ctx_sync(catchhip_ctx *ctx);
  * timed. */
 int catchhip_ctx_last_kernel_ms(catchhip_ctx *ctx, int phase, double *ms,
                                 int64_t *launches);
+/* Work counters of the most recent calls (for roofline accounting), 8 values:
+ * [0] raw hits found by the last cover scan, [1] seed hits (general path),
+ * [2] greedy iterations, [3] picks, [4] winner rows applied,
+ * [5] rows re-counted by the greedy solver, [6] bitmap words read while
+ * re-counting, [7] reserved. */
+int catchhip_ctx_last_counters(catchhip_ctx *ctx, int64_t *out8);
 
 /* ---- inputs ------------------------------------------------------------ */
 /* Target sequences (catch/genome.py Genome.seqs of every genome of a group).
