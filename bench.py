@@ -136,12 +136,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    ctx = engine.Context(local_rank)
+    ndev = max(1, engine.device_count())
+    ctx = engine.Context(local_rank % ndev)   # one rank per GPU on a real node
     seed = 2 + (rank if args.shard == "groups" else 0)
     groups, cands = make_workload(args.workload, seed, args.scale)
-    if world > 1 and args.shard == "probes":
+    if args.shard == "probes":
         ids = [engine.Context.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
+        if dist is not None:
+            dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(ids[0], world, rank)
 
     t_up0 = time.perf_counter()

@@ -310,6 +310,7 @@ useg_ptr_kernel(const u64 *__restrict__ ukeys, u32 nseg, u32 nuniv, u32 *__restr
 // ------------------------------------------------------------------------
 struct GreedyArgs {
     unsigned long long *bm;
+    unsigned long long *owner;   // per bitmap word: largest candidate key claiming it (batched solver)
     const uint4 *wrow;    // rows in set order: {gs, ge, prev_ge (same universe, else 0), segment}
     const u32 *set_ptr, *set_seg_ptr;
     const u32 *seg_univ, *seg_set;
@@ -625,6 +626,8 @@ greedy_wg_kernel(GreedyArgs a) {
     }
 }
 
+#include "setcover_batched.inc"
+
 // ------------------------------------------------------------------------
 // multi-launch solver (one gain launch + one apply launch per pick); used when
 // the candidate sets are sharded over several GPUs
@@ -765,7 +768,8 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     HIP_TRY(hipSetDevice(ctx->device));
     const u32 nrows = (u32)R->n, nsets = (u32)num_sets, nuniv = (u32)R->ngenomes;
     hipStream_t s = ctx->stream;
-    const bool distributed = ctx->comm != nullptr && ctx->nranks > 1;
+    // a communicator (even of one rank) selects the sharded multi-launch solver
+    const bool distributed = ctx->comm != nullptr;
 
     // dense ranks: index into sorted(set(ranks.values())) (set_cover.py:353-354)
     std::vector<u32> h_rank(nsets, 0);
@@ -824,8 +828,10 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     TRY(chip_exclusive_scan_u32(ctx, flag.p, idx.p, nrows, tmp));
     HIP_TRY(hipMemcpyAsync(ctx->h_pin, idx.p + (nrows - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync((u32 *)ctx->h_pin + 1, flag.p + (nrows - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync((u32 *)ctx->h_pin + 2, &st.p->lmax, sizeof(u32), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const u32 nseg = ((volatile u32 *)ctx->h_pin)[0] + ((volatile u32 *)ctx->h_pin)[1];
+    const u32 h_lmax = ((volatile u32 *)ctx->h_pin)[2];
     TRY(seg_row.alloc(nseg + 1));
     TRY(seg_univ.alloc(nseg + 1));
     TRY(seg_set.alloc(nseg + 1));
@@ -849,6 +855,9 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
             bucket;
         DevBuf<u64> pos_key, pos_key_alt, ukeys, ukeys_alt;
         DevBuf<uint4> pent, wrow;
+        DevBuf<unsigned long long> owner;
+        TRY(owner.alloc(nwords + 8));
+        HIP_TRY(hipMemsetAsync(owner.p, 0, sizeof(unsigned long long) * (nwords + 8), s));
         const u32 nbuckets = (u32)(R->total >> BUCKET_SHIFT) + 2;
         TRY(prowcnt.alloc(nrows));
         TRY(segcnt.alloc(nseg));
@@ -882,13 +891,19 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         hipLaunchKernelGGL(useg_ptr_kernel, dim3((unsigned)div_up(nuniv + 1, 256)), dim3(256), 0, s, ukeys.p, nseg,
                            nuniv, useg_ptr.p);
         GreedyArgs a;
-        a.bm = bm.p; a.wrow = wrow.p; a.set_ptr = set_ptr.p; a.set_seg_ptr = set_seg_ptr.p;
+        a.bm = bm.p; a.owner = owner.p; a.wrow = wrow.p; a.set_ptr = set_ptr.p; a.set_seg_ptr = set_seg_ptr.p;
         a.seg_univ = seg_univ.p; a.seg_set = seg_set.p; a.pent = pent.p; a.prowcnt = prowcnt.p;
         a.bucket = bucket.p; a.useg_ptr = useg_ptr.p; a.useg = useg.p; a.can = can.p;
         a.rank = rank.p; a.usize = usize.p; a.left = left.p; a.segcnt = segcnt.p; a.segcontrib = segcontrib.p;
         a.gain = gain.p; a.picked = picked.p; a.picks = picks.p; a.dirty = dirty.p; a.st = st.p;
         a.nrows = nrows; a.nsets = nsets; a.nuniv = nuniv; a.chunk = (u32)div_up(nsets, GW_THREADS);
-        hipLaunchKernelGGL(greedy_wg_kernel, dim3(1), dim3(GW_THREADS), 0, s, a);
+        // every universe fully covered and rows <= 257 bases: batched rounds
+        // (many independent picks per round); otherwise one pick per round
+        bool batched = h_lmax <= 257 && !getenv("CATCHHIP_GREEDY_SEQUENTIAL");
+        if (universe_p)
+            for (u32 u = 0; u < nuniv && batched; ++u) batched = universe_p[u] == 1.0;
+        if (batched) hipLaunchKernelGGL(greedy_wg_batched_kernel, dim3(1), dim3(GW_THREADS), 0, s, a);
+        else hipLaunchKernelGGL(greedy_wg_kernel, dim3(1), dim3(GW_THREADS), 0, s, a);
         tm.launch(6);
         tm.stop();
         HIP_TRY(hipGetLastError());

@@ -81,9 +81,22 @@ class Context:
         return buf.tobytes()
 
     def comm_init(self, unique_id, nranks, rank):
+        import os
+        import sys
         buf = np.frombuffer(unique_id, dtype=np.uint8).copy()
-        check(self._L.catchhip_comm_init(self._h, _ptr(buf, c_u8p), nranks,
-                                         rank))
+        # RCCL prints a version banner on stdout at first use; keep stdout
+        # clean for callers that emit machine-readable output
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            rc = self._L.catchhip_comm_init(self._h, _ptr(buf, c_u8p), nranks,
+                                            rank)
+            ctypes.CDLL(None).fflush(None)   # the banner sits in C stdio's buffer
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        check(rc)
 
     # -- near-duplicate filter --------------------------------------------
     def ndf_hamming(self, probe_strs, L, positions, dist_thres):

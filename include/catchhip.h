@@ -138,8 +138,12 @@ int catchhip_tolerant_bp(catchhip_ctx *ctx, const catchhip_probes *probes,
  * by catch/filter/set_cover_filter.py:113-144.  num_sets = number of
  * candidate probes (set ids 0..num_sets-1); ranks[num_sets] (NULL = all
  * equal); universe_p[ngenomes] float64 coverage fraction per universe
- * (NULL = 1.0).  out_ids (capacity num_sets) receives the chosen set ids in
- * pick order; *n_out their number. */
+ * (NULL = 1.0).  out_ids (capacity num_sets) receives the chosen set ids,
+ * *n_out their number.  The SET of ids equals the reference's (which returns
+ * a Python set).  Order: when some universe_p < 1, or rows exceed 257
+ * elements, or a communicator is attached, ids are in the sequential pick
+ * order; otherwise the solver takes all locally-maximal sets per round
+ * (setcover_batched.inc) and ids are ordered by round. */
 int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *rows,
                              int64_t num_sets, const int64_t *ranks,
                              const double *universe_p, int64_t *out_ids,
