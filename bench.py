@@ -34,6 +34,7 @@ from catch_amd.filter import candidate_probes  # noqa: E402
 from catch_amd.utils import synthetic  # noqa: E402
 
 PROBE_LEN, STRIDE, MISMATCHES, EXT = 100, 50, 2, 50
+SCAN_MODE = int(os.environ.get("CATCHHIP_SCAN_MODE", "0"))   # 0 auto, 1 general, 2 fast
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TOPS = 78.6     # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, 32-bit int ops
 
@@ -69,7 +70,7 @@ def one_step(ctx, groups, stats=None):
     picks = []
     for g in groups:
         rows = engine.Rows.scan(ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN,
-                                0, EXT, engine.SCAN_AUTO)
+                                0, EXT, SCAN_MODE)
         if stats is not None:
             ms, nl = ctx.kernel_ms(engine.PHASE_SCAN)
             stats["scan_ms"] += ms

@@ -202,6 +202,16 @@ pack_probes_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_o
     }
 }
 
+// word 0 of planes 0/1 per probe, contiguous: the hot loop of the scan reads
+// it through the scalar cache (one s_load per probe, operands in SGPRs)
+__global__ void __launch_bounds__(256)
+probe_w0_kernel(const u32 *__restrict__ planes, i64 nprobes, int pwords, u32 mask0, uint2 *__restrict__ w0) {
+    i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nprobes) return;
+    const u32 *q = planes + (size_t)p * pwords * 4;
+    w0[p] = make_uint2(q[0] & mask0, q[1] & mask0);
+}
+
 static void alphabet_scan(const u8 *b, i64 n, bool *dna5, bool *has_n) {
     bool present[256] = {false};
     for (i64 i = 0; i < n; ++i) present[b[i]] = true;
@@ -381,6 +391,11 @@ extern "C" int catchhip_probes_create(catchhip_ctx *ctx, const u8 *bytes, const 
             unsigned blocks = (unsigned)div_up(nprobes, 4);
             hipLaunchKernelGGL(pack_probes_kernel, dim3(blocks), dim3(256), 0, s, p->bytes.p, p->probe_off.p,
                                nprobes, p->pwords, p->planes.p);
+            if ((rc = p->w0.alloc((size_t)nprobes + 64))) break;
+            if (hipMemsetAsync(p->w0.p, 0, sizeof(uint2) * (nprobes + 64), s) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
+            const u32 mask0 = (p->pwords == 1 && (p->L & 31)) ? ((1u << (p->L & 31)) - 1u) : 0xffffffffu;
+            hipLaunchKernelGGL(probe_w0_kernel, dim3((unsigned)div_up(nprobes, 256)), dim3(256), 0, s, p->planes.p,
+                               nprobes, p->pwords, mask0, p->w0.p);
         }
         if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
             chip_set_error("probes pack failed");

@@ -140,7 +140,8 @@ struct catchhip_probes {
     DevBuf<i32> set_id;      // nprobes
     DevBuf<i32> ent_probe, ent_pos;
     i32 pwords = 0;          // 32-base words per probe (ceil(L/32))
-    DevBuf<u32> planes;      // [probe][plane(3)][pwords]
+    DevBuf<u32> planes;      // [probe][word][4] = planes 0,1,2 + pad per 32-base word
+    DevBuf<uint2> w0;        // [probe] word 0 of planes 0/1 (the scan's 32-base filter), masked to L
 };
 
 // rows: cover intervals in GLOBAL coordinates of a targets object

@@ -144,6 +144,149 @@ template <bool USE_N> static scan_fast_fn pick_fast(int nw) {
 }
 
 // ------------------------------------------------------------------------
+// fast kernel, second form: filter on the first 32 bases, verify the rest.
+//
+// The hot loop only needs a LOWER bound of the mismatch count to reject a
+// (probe, offset) pair: the XOR/OR of planes 0 and 1 over the first 32 bases
+// never over-counts (plane 2 -- "is not A/C/G/T" -- and the remaining words can
+// only add mismatches).  So each lane keeps just word 0 of planes 0/1 for
+// SF2_OPL = 16 offsets (32 VGPRs), a probe costs one 8-byte LDS broadcast,
+// and per pair the loop issues  v_xor, v_bitop3/(xor+or), v_bcnt, 1/2 v_min3.
+// When some lane of the wave stays within the budget (rare: only near true
+// homology) the wave verifies those offsets exactly, reading the target
+// windows and the probe's full bit-planes from global memory (L2-resident).
+// ------------------------------------------------------------------------
+#define SF2_THREADS 256
+#define SF2_OPL 16
+#define SF2_TILE (SF2_THREADS * SF2_OPL)
+#define SF2_PT 2048   // probes (word 0, planes 0/1) per LDS stage = 16 KB
+
+__device__ __forceinline__ u32 full_mismatches(const u32 *__restrict__ tplanes, i64 nwords, u32 o,
+                                               const uint4 *__restrict__ pq, int NW, bool use_n, u32 tailmask,
+                                               u32 budget) {
+    const u32 wi = o >> 5, sh = o & 31;
+    const u32 *p0 = tplanes + wi, *p1 = tplanes + nwords + wi, *p2 = tplanes + 2 * nwords + wi;
+    u32 cnt = 0;
+    for (int j = 0; j < NW; ++j) {
+        const uint4 q = pq[j];
+        u32 x = (__builtin_amdgcn_alignbit(p0[j + 1], p0[j], sh) ^ q.x) |
+                (__builtin_amdgcn_alignbit(p1[j + 1], p1[j], sh) ^ q.y);
+        if (use_n) x |= (__builtin_amdgcn_alignbit(p2[j + 1], p2[j], sh) ^ q.z);
+        if (j == NW - 1) x &= tailmask;
+        cnt += __popc(x);
+        if (cnt > budget) break;
+    }
+    return cnt;
+}
+
+__global__ void __launch_bounds__(SF2_THREADS)
+scan_fast2_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const u32 *__restrict__ seq_off,
+                  u32 nseq, const uint4 *__restrict__ pplanes, u32 nprobes, u32 probes_per_block, int L,
+                  int NW, int mm, u32 tailmask, int use_n, HitBuf hb) {
+    __shared__ uint2 lds[SF2_PT];
+    const int tid = threadIdx.x;
+    const u32 tile0 = blockIdx.x * SF2_TILE;
+    const u32 p_begin = blockIdx.y * probes_per_block;
+    const u32 p_end = min(nprobes, p_begin + probes_per_block);
+    const u32 mask0 = NW == 1 ? tailmask : 0xffffffffu;   // probes shorter than 32 bases
+
+    u32 T0[SF2_OPL], T1[SF2_OPL];
+#pragma unroll
+    for (int w = 0; w < SF2_OPL; ++w) {
+        const u32 o = tile0 + w * SF2_THREADS + tid;
+        const u32 wi = o >> 5, sh = o & 31;
+        const u32 *p0 = tplanes + wi, *p1 = tplanes + nwords + wi;
+        T0[w] = __builtin_amdgcn_alignbit(p0[1], p0[0], sh) & mask0;
+        T1[w] = __builtin_amdgcn_alignbit(p1[1], p1[0], sh) & mask0;
+    }
+
+    for (u32 ps = p_begin; ps < p_end; ps += SF2_PT) {
+        const u32 cnt = min((u32)SF2_PT, p_end - ps);
+        __syncthreads();
+        for (u32 i = tid; i < cnt; i += SF2_THREADS) {
+            const uint4 q = pplanes[(size_t)(ps + i) * NW];
+            lds[i] = make_uint2(q.x & mask0, q.y & mask0);
+        }
+        __syncthreads();
+        for (u32 q = 0; q < cnt; ++q) {
+            const uint2 qq = lds[q];
+            u32 mn = 64;
+#pragma unroll
+            for (int w = 0; w < SF2_OPL; ++w) {
+                // (T1 ^ q1) | (T0 ^ q0) as v_xor + v_bitop3 (truth table 0xde = (a ^ c) | b)
+                const u32 x = __builtin_amdgcn_bitop3_b32(T1[w], T0[w] ^ qq.x, qq.y, 0xde);
+                mn = min(mn, (u32)__popc(x));
+            }
+            if (__ballot(mn <= (u32)mm) == 0ull) continue;   // wave-uniform: nothing can match
+            if (mn > (u32)mm) continue;
+            // verify this lane's surviving offsets exactly
+            const uint4 *pq = pplanes + (size_t)(ps + q) * NW;
+#pragma unroll 1
+            for (int w = 0; w < SF2_OPL; ++w) {
+                if ((u32)__popc((T0[w] ^ qq.x) | (T1[w] ^ qq.y)) > (u32)mm) continue;
+                const u32 o = tile0 + w * SF2_THREADS + tid;
+                if (o >= total || o + (u32)L > total) continue;
+                if (full_mismatches(tplanes, nwords, o, pq, NW, use_n != 0, tailmask, (u32)mm) > (u32)mm) continue;
+                const u32 s = find_segment(seq_off, nseq, o);
+                if (o + (u32)L > seq_off[s + 1]) continue;   // window must lie inside one sequence
+                const u32 slot = atomicAdd(hb.count, 1u);
+                if (slot < hb.cap) { hb.a[slot] = ps + q; hb.b[slot] = o; }
+            }
+        }
+    }
+}
+
+// Third form: same filter, but the probe's word 0 comes through the scalar
+// cache (wave-uniform address -> s_load into SGPRs, used directly as the
+// scalar operand of v_xor / v_bitop3): no LDS, no staging barriers.
+__global__ void __launch_bounds__(SF2_THREADS)
+scan_fast3_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const u32 *__restrict__ seq_off,
+                  u32 nseq, const uint2 *__restrict__ pw0, const uint4 *__restrict__ pplanes, u32 nprobes,
+                  u32 probes_per_block, int L, int NW, int mm, u32 tailmask, int use_n,
+                  u32 *__restrict__ hit_probe, u32 *__restrict__ hit_pos, u32 *__restrict__ hit_count,
+                  u32 hit_cap) {
+    const int tid = threadIdx.x;
+    const u32 tile0 = blockIdx.x * SF2_TILE;
+    const u32 p_begin = blockIdx.y * probes_per_block;
+    const u32 p_end = min(nprobes, p_begin + probes_per_block);
+    const u32 mask0 = NW == 1 ? tailmask : 0xffffffffu;
+
+    u32 T0[SF2_OPL], T1[SF2_OPL];
+#pragma unroll
+    for (int w = 0; w < SF2_OPL; ++w) {
+        const u32 o = tile0 + w * SF2_THREADS + tid;
+        const u32 wi = o >> 5, sh = o & 31;
+        const u32 *p0 = tplanes + wi, *p1 = tplanes + nwords + wi;
+        T0[w] = __builtin_amdgcn_alignbit(p0[1], p0[0], sh) & mask0;
+        T1[w] = __builtin_amdgcn_alignbit(p1[1], p1[0], sh) & mask0;
+    }
+#pragma unroll 4
+    for (u32 q = p_begin; q < p_end; ++q) {
+        const uint2 qq = pw0[q];   // uniform
+        u32 mn = 64;
+#pragma unroll
+        for (int w = 0; w < SF2_OPL; ++w) {
+            const u32 x = __builtin_amdgcn_bitop3_b32(T1[w], T0[w] ^ qq.x, qq.y, 0xde);
+            mn = min(mn, (u32)__popc(x));
+        }
+        if (__ballot(mn <= (u32)mm) == 0ull) continue;
+        if (mn > (u32)mm) continue;
+        const uint4 *pq = pplanes + (size_t)q * NW;
+#pragma unroll 1
+        for (int w = 0; w < SF2_OPL; ++w) {
+            if ((u32)__popc((T0[w] ^ qq.x) | (T1[w] ^ qq.y)) > (u32)mm) continue;
+            const u32 o = tile0 + w * SF2_THREADS + tid;
+            if (o >= total || o + (u32)L > total) continue;
+            if (full_mismatches(tplanes, nwords, o, pq, NW, use_n != 0, tailmask, (u32)mm) > (u32)mm) continue;
+            const u32 s = find_segment(seq_off, nseq, o);
+            if (o + (u32)L > seq_off[s + 1]) continue;
+            const u32 slot = atomicAdd(hit_count, 1u);
+            if (slot < hit_cap) { hit_probe[slot] = q; hit_pos[slot] = o; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
 // general path
 // ------------------------------------------------------------------------
 __device__ __forceinline__ u64 kmer_hash(const u8 *__restrict__ p, int k) {
@@ -368,12 +511,31 @@ static int run_fast(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
     const u32 tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
     u32 cap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(P->nprobes * 64, (i64)1 << 28));
     TRY(H.count.alloc(1));
+    // second form (32-base filter + verification) unless CATCHHIP_SCAN_V1 is set
+    const bool v2 = getenv("CATCHHIP_SCAN_V1") == nullptr;
+    const u32 ntiles2 = (u32)div_up(T->total, SF2_TILE);
+    u32 want2 = (u32)div_up((i64)ctx->num_cus * 16, ntiles2);
+    u32 ppb2 = (u32)div_up(P->nprobes, want2 ? want2 : 1);
+    ppb2 = std::max<u32>(ppb2, 64u);
+    u32 nchunks2 = (u32)div_up(P->nprobes, ppb2);
+    if (nchunks2 > 65535) { ppb2 = (u32)div_up(P->nprobes, 65535); nchunks2 = (u32)div_up(P->nprobes, ppb2); }
     for (int attempt = 0; attempt < 3; ++attempt) {
         TRY(H.a.reserve(cap));
         TRY(H.b.reserve(cap));
         HIP_TRY(hipMemsetAsync(H.count.p, 0, sizeof(u32), ctx->stream));
         HitBuf hb = {H.a.p, H.b.p, nullptr, H.count.p, cap};
         tm.restart();  // time exactly the scan kernel (HIP events on this stream)
+        if (v2 && getenv("CATCHHIP_SCAN_V2") == nullptr)
+            hipLaunchKernelGGL(scan_fast3_kernel, dim3(ntiles2, nchunks2), dim3(SF2_THREADS), 0, ctx->stream,
+                               T->planes.p, T->nwords, (u32)T->total, T->seq_off.p, (u32)T->nseq, P->w0.p,
+                               (const uint4 *)P->planes.p, (u32)P->nprobes, ppb2, (int)P->L, (int)P->pwords, mm,
+                               tailmask, use_n ? 1 : 0, H.a.p, H.b.p, H.count.p, cap);
+        else if (v2)
+            hipLaunchKernelGGL(scan_fast2_kernel, dim3(ntiles2, nchunks2), dim3(SF2_THREADS), 0, ctx->stream,
+                               T->planes.p, T->nwords, (u32)T->total, T->seq_off.p, (u32)T->nseq,
+                               (const uint4 *)P->planes.p, (u32)P->nprobes, ppb2, (int)P->L, (int)P->pwords, mm,
+                               tailmask, use_n ? 1 : 0, hb);
+        else
         hipLaunchKernelGGL(fn, dim3(ntiles, nchunks), dim3(SF_THREADS), 0, ctx->stream, T->planes.p,
                            T->nwords, (u32)T->total, T->seq_off.p, (u32)T->nseq,
                            (const uint4 *)P->planes.p, (u32)P->nprobes, ppb, (int)P->L, mm, tailmask, hb);

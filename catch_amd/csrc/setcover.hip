@@ -41,6 +41,7 @@ struct GreedyState {
     u32 iters;
     u32 lmax;      // longest row
     u32 smax;      // largest (set, universe) element count
+    u32 narow, npairs;   // batched solver: accepted rows / (row, slot) pairs of the current round
     unsigned long long prof[8];  // shader-clock ticks per phase (thread 0)
     unsigned long long n_wrows, n_recount, n_words;  // work counters
 };
@@ -902,13 +903,41 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         bool batched = h_lmax <= 257 && !getenv("CATCHHIP_GREEDY_SEQUENTIAL");
         if (universe_p)
             for (u32 u = 0; u < nuniv && batched; ++u) batched = universe_p[u] == 1.0;
-        if (batched) hipLaunchKernelGGL(greedy_wg_batched_kernel, dim3(1), dim3(GW_THREADS), 0, s, a);
-        else hipLaunchKernelGGL(greedy_wg_kernel, dim3(1), dim3(GW_THREADS), 0, s, a);
-        tm.launch(6);
-        tm.stop();
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(&h_st, st.p, sizeof(h_st), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        DevBuf<uint4> arow;
+        DevBuf<u32> abase;
+        if (batched) {
+            // rounds of (select, re-count) launches; the host looks at the
+            // state every ROUNDS_PER_SYNC rounds (the kernels no-op once done)
+            TRY(arow.alloc(GB_MAXAROW));
+            TRY(abase.alloc(GB_MAXAROW + 1));
+            BatchArgs ba;
+            ba.g = a; ba.arow = arow.p; ba.abase = abase.p;
+            const unsigned rc_blocks = (unsigned)std::max(1, ctx->num_cus * 2);
+            const int ROUNDS_PER_SYNC = 16;
+            const i64 max_rounds = (i64)nsets + nrank + 2;
+            i64 rounds = 0;
+            for (;;) {
+                for (int r = 0; r < ROUNDS_PER_SYNC; ++r) {
+                    hipLaunchKernelGGL(gb_select_kernel, dim3(1), dim3(GW_THREADS), 0, s, ba);
+                    hipLaunchKernelGGL(gb_recount_kernel, dim3(rc_blocks), dim3(GB_RC_THREADS), 0, s, ba);
+                }
+                tm.launch(2 * ROUNDS_PER_SYNC);
+                rounds += ROUNDS_PER_SYNC;
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(&h_st, st.p, sizeof(h_st), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (h_st.done) break;
+                if (rounds > max_rounds) { chip_set_error("setcover: round cap exceeded"); return CATCHHIP_EINVAL; }
+            }
+            tm.stop();
+        } else {
+            hipLaunchKernelGGL(greedy_wg_kernel, dim3(1), dim3(GW_THREADS), 0, s, a);
+            tm.launch(6);
+            tm.stop();
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&h_st, st.p, sizeof(h_st), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
         tm.finish();
         ctx->phase_launches[PHASE_GREEDY] = h_st.iters;  // greedy iterations inside the persistent launch
         ctx->counters[2] = h_st.iters; ctx->counters[3] = h_st.npicks; ctx->counters[4] = (i64)h_st.n_wrows;
