@@ -36,7 +36,6 @@ from catch_amd.utils import synthetic  # noqa: E402
 PROBE_LEN, STRIDE, MISMATCHES, EXT = 100, 50, 2, 50
 SCAN_MODE = int(os.environ.get("CATCHHIP_SCAN_MODE", "0"))   # 0 auto, 1 general, 2 fast
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_PEAK_TOPS = 78.6     # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, 32-bit int ops
 
 
 def make_workload(name, seed, scale):
@@ -82,9 +81,12 @@ def one_step(ctx, groups, stats=None):
             ms, nl = ctx.kernel_ms(engine.PHASE_GREEDY)
             stats["greedy_ms"] += ms
             stats["greedy_launches"] += nl
+            rms, rnl = ctx.kernel_ms(engine.PHASE_GREEDY_ROUNDS)
+            stats["rounds_ms"] = stats.get("rounds_ms", 0.0) + rms
+            stats["rounds_launches"] = stats.get("rounds_launches", 0) + rnl
             stats["picks"] += len(ids)
             c = ctx.counters()
-            for k in ("winner_rows", "rows_recounted", "bitmap_words_read"):
+            for k in ("winner_rows", "rows_recounted", "bitmap_words_read", "greedy_iters"):
                 stats[k] = stats.get(k, 0) + c[k]
             if stats.get("want_rows"):
                 stats.setdefault("row_data", []).append(rows.fetch())
@@ -194,9 +196,6 @@ def main():
         k1_ms = stats["scan_ms"] / K
         k1_launch_ms = stats["scan_ms"] / max(stats["scan_launches"], 1)
         k1_gbs = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-        # VALU work of the brute-force form: 3*ceil(L/32) + 2*A 64-bit ops
-        # per probe x bp = 20 at L=100, A=4
-        k1_ops = 20.0 * sum(r.n_unique * r.G for r in resident)
         # K2 algorithmic bytes, per greedy solve:
         #   12 B per re-counted (dirty) row + 8 B per bitmap word read for
         #   them + 8 B per bitmap word of the winner's rows (read-modify-write)
@@ -206,21 +205,31 @@ def main():
         k2_bytes_step = (12.0 * stats.get("rows_recounted", 0)
                          + 8.0 * stats.get("bitmap_words_read", 0)
                          + 8.0 * words_per_row * stats.get("winner_rows", 0)) / K
-        k2_gbs = k2_bytes_step / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
-        dominant = "k2_greedy" if k2_ms >= k1_ms else "k1_scan"
+        k2_rounds_ms = stats.get("rounds_ms", 0.0) / K     # (select, re-count) launches only
+        k2_launches = stats.get("rounds_launches", 0)
+        k2_gbs = k2_bytes_step / (k2_rounds_ms * 1e-3) / 1e9 if k2_rounds_ms > 0 else 0.0
+        # dominant kernel = the one with the most device time per step; the
+        # solver rounds count as one unit (pairs of small launches)
+        dominant = "k2_greedy" if k2_rounds_ms >= k1_ms else "k1_scan"
         if dominant == "k1_scan":
-            roof = dict(bound="hbm", kernel="scan_fast_kernel",
+            # VALU-bound by construction (every target word is reused by all
+            # probes of a chunk); the HBM fraction is reported as the contract
+            # asks, the VALU figures say how busy the kernel really is
+            roof = dict(bound="hbm", kernel="scan_fast3_kernel",
                         achieved=k1_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=k1_gbs / HBM_PEAK_GBS, traffic=None,
-                        avg_launch_ms=k1_launch_ms)
+                        avg_launch_ms=k1_launch_ms,
+                        valu_inst_per_probe_bp=3.92,
+                        valu_lane_ops_per_s=(3.92 * sum(r.n_unique * r.G for r in resident)
+                                             / (k1_ms * 1e-3)) if k1_ms > 0 else None,
+                        valu_lane_ops_peak=78.6e12)
         else:
-            # one persistent launch per group and step (plus set-up kernels);
-            # latency-bound by design: the picks are sequential
-            roof = dict(bound="hbm", kernel="greedy_wg_kernel",
+            roof = dict(bound="hbm", kernel="gb_select_kernel+gb_recount_kernel",
                         achieved=k2_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=k2_gbs / HBM_PEAK_GBS, traffic=None,
-                        avg_launch_ms=k2_ms / max(len(resident), 1),
-                        us_per_pick=k2_ms * 1e3 / max(picks_per_step, 1),
+                        avg_launch_ms=(stats.get("rounds_ms", 0.0)
+                                       / max(k2_launches, 1)),
+                        us_per_pick=k2_rounds_ms * 1e3 / max(picks_per_step, 1),
                         rows_recounted_per_pick=(stats.get("rows_recounted", 0)
                                                  / max(stats["picks"], 1)))
         out = {
@@ -247,12 +256,10 @@ def main():
             "picks": picks_per_step, "rows": rows_per_step,
             "kernel_ms_per_step": {"k1_scan": k1_ms,
                                    "rows_build": stats["rows_ms"] / K,
-                                   "k2_greedy": k2_ms},
+                                   "k2_greedy": k2_ms,
+                                   "k2_greedy_rounds_only": k2_rounds_ms},
             "k1_probe_bp_per_s": (sum(r.n_unique * r.G for r in resident)
                                   / (k1_ms * 1e-3)) if k1_ms > 0 else None,
-            "k1_valu": {"achieved_Tops": k1_ops / (k1_ms * 1e-3) / 1e12
-                        if k1_ms > 0 else None, "peak_Tops": VALU_PEAK_TOPS,
-                        "note": "brute-force op count; early exit skips most"},
             "roofline": roof,
             "roofline_k1": dict(bound="hbm", achieved=k1_gbs,
                                 peak=HBM_PEAK_GBS, unit="GB/s",
@@ -261,7 +268,8 @@ def main():
             "roofline_k2": dict(bound="hbm", achieved=k2_gbs,
                                 peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=k2_gbs / HBM_PEAK_GBS,
-                                us_per_pick=k2_ms * 1e3 / max(picks_per_step, 1)),
+                                us_per_pick=k2_rounds_ms * 1e3 / max(picks_per_step, 1),
+                                rounds_per_step=stats.get("greedy_iters", 0) / K),
             "h2d_upload_s": upload_s,
             "value_incl_h2d": total_units / (elapsed / K + upload_s),
         }

@@ -88,7 +88,7 @@ template <typename T> struct DevBuf {
     }
 };
 
-enum { PHASE_SCAN = 0, PHASE_ROWS = 1, PHASE_GREEDY = 2, PHASE_NDF = 3, NPHASE = 4 };
+enum { PHASE_SCAN = 0, PHASE_ROWS = 1, PHASE_GREEDY = 2, PHASE_NDF = 3, PHASE_GREEDY_ROUNDS = 4, NPHASE = 5 };
 
 struct catchhip_ctx {
     int device = 0;

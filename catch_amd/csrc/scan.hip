@@ -662,7 +662,11 @@ extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, 
         chip_set_error("cover_scan: fast-path preconditions do not hold");
         return CATCHHIP_EINVAL;
     }
-    const bool use_fast = fast_ok && mode != CATCHHIP_SCAN_GENERAL;
+    // AUTO: both paths are exact; the tiled scan costs O(P*G), the seed join O(G log E + seeds).
+    // Measured crossover on MI355X is at a few 10^4 unique probes.
+    i64 fast_max = 32768;
+    if (const char *e = getenv("CATCHHIP_FAST_MAX_PROBES")) fast_max = atoll(e);
+    const bool use_fast = fast_ok && mode != CATCHHIP_SCAN_GENERAL && (mode == CATCHHIP_SCAN_FAST || P->nprobes <= fast_max);
 
     catchhip_rows *R = new catchhip_rows();
     R->ctx = ctx;

@@ -916,6 +916,7 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
             const int ROUNDS_PER_SYNC = 16;
             const i64 max_rounds = (i64)nsets + nrank + 2;
             i64 rounds = 0;
+            PhaseTimer tr(ctx, PHASE_GREEDY_ROUNDS);   // the (select, re-count) launches only
             for (;;) {
                 for (int r = 0; r < ROUNDS_PER_SYNC; ++r) {
                     hipLaunchKernelGGL(gb_select_kernel, dim3(1), dim3(GW_THREADS), 0, s, ba);
@@ -929,6 +930,8 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
                 if (h_st.done) break;
                 if (rounds > max_rounds) { chip_set_error("setcover: round cap exceeded"); return CATCHHIP_EINVAL; }
             }
+            tr.launch(2 * rounds);
+            tr.finish();
             tm.stop();
         } else {
             hipLaunchKernelGGL(greedy_wg_kernel, dim3(1), dim3(GW_THREADS), 0, s, a);

@@ -11,7 +11,7 @@ from catch_amd import _lib
 from catch_amd._lib import c_f64p, c_i32p, c_i64p, c_u8p, check
 
 SCAN_AUTO, SCAN_GENERAL, SCAN_FAST = 0, 1, 2
-PHASE_SCAN, PHASE_ROWS, PHASE_GREEDY, PHASE_NDF = 0, 1, 2, 3
+PHASE_SCAN, PHASE_ROWS, PHASE_GREEDY, PHASE_NDF, PHASE_GREEDY_ROUNDS = 0, 1, 2, 3, 4
 
 
 def _ptr(a, t):

@@ -53,8 +53,9 @@ int catchhip_ctx_sync(catchhip_ctx *ctx);
 /* Elapsed GPU milliseconds spent in the kernels of the most recent call of
  * the named phase (HIP events on the context's stream).  phase: 0 = cover
  * scan kernels (K1 hit search), 1 = row build (sort/merge), 2 = greedy
- * set-cover kernels, 3 = near-duplicate kernels. *launches = kernel launches
- * timed. */
+ * set-cover kernels (set-up + solver), 3 = near-duplicate kernels, 4 = only the
+ * (select, re-count) launch pairs of the batched greedy solver. *launches =
+ * kernel launches timed. */
 int catchhip_ctx_last_kernel_ms(catchhip_ctx *ctx, int phase, double *ms,
                                 int64_t *launches);
 /* Work counters of the most recent calls (for roofline accounting), 8 values:

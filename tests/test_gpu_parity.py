@@ -381,3 +381,46 @@ def test_greedy_rccl_solver_single_rank_matches(oracle):
         assert dev.greedy(P, ranks, up) == exp
         dev.close()
     c2.close()
+
+
+# ---------------------------------------------------------------- other configs
+@pytest.mark.parametrize("name,scale", [("S3", 0.02), ("S4", 0.01)])
+def test_scaled_baseline_configs_match_oracle(ctx, oracle, name, scale):
+    """BASELINE configs 3 and 4 at reduced scale: 800 single-segment genomes
+    in one group (S3) and 20 groups of very different sizes (S4); selected
+    probe sets identical to the oracle's."""
+    from catch_amd import genome, probe
+    from catch_amd.filter.set_cover_filter import SetCoverFilter
+    from catch_amd.utils import synthetic
+    groups = synthetic.dataset(name, scale=scale)
+    cands = [candidates(g, 100, 50) for g in groups]
+    exp = oracle.set_cover_filter(cands, groups, 2, 100, coverage=1.0,
+                                  cover_extension=50)
+    f = SetCoverFilter(mismatches=2, lcf_thres=100, coverage=1.0, cover_extension=50)
+    probes = [[probe.Probe.from_str(s) for s in c] for c in cands]
+    gen = [[genome.Genome.from_one_seq(g[0]) for g in grp] for grp in groups]
+    out = f.filter(probes, gen, input_is_grouped=True)
+    got = [sorted(p.seq_str for p in g) for g in out]
+    assert got == [sorted(cands[i][j] for j in ids) for i, ids in enumerate(exp)]
+
+
+def test_config3_pipeline_ndf_then_scf_matches_oracle(ctx, oracle):
+    """config 3 shape: --filter-with-lsh-hamming 2 before the set cover."""
+    from catch_amd import genome, probe
+    from catch_amd.filter.near_duplicate_filter import NearDuplicateFilterWithHammingDistance
+    from catch_amd.filter.set_cover_filter import SetCoverFilter
+    from catch_amd.utils import synthetic
+    groups = synthetic.dataset("S3", scale=0.01)
+    strs = candidates(groups[0], 100, 50, dedup=False)
+    random.seed(7)
+    pos = oracle.lsh_draw_positions(oracle.lsh_num_tables(2, 100, 20), 20, 100)
+    kept = oracle.ndf_hamming(strs, 2, pos)
+    exp = oracle.set_cover_filter([kept], groups, 2, 100, coverage=1.0, cover_extension=50)
+    random.seed(7)
+    ndf = NearDuplicateFilterWithHammingDistance(2, 100)
+    out1 = ndf.filter([probe.Probe.from_str(s) for s in strs])
+    assert [p.seq_str for p in out1] == kept
+    scf = SetCoverFilter(mismatches=2, lcf_thres=100, coverage=1.0, cover_extension=50)
+    gen = [[genome.Genome.from_one_seq(g[0]) for g in groups[0]]]
+    out2 = scf.filter([out1], gen, input_is_grouped=True)
+    assert sorted(p.seq_str for p in out2[0]) == sorted(kept[i] for i in exp[0])
