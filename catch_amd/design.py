@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Design probes on the GPU:  python -m catch_amd.design a.fasta [b.fasta ...] -o probes.fasta
+
+The hot-path subset of the reference CLI (bin/design.py:448-980), same option
+names and defaults ("basic" profile): every FASTA file is one dataset = one
+group of target genomes (bin/design.py:91-99), one Genome per record.  Filter
+list as bin/design.py:296-340 builds it: exact duplicate filter (or the
+Hamming near-duplicate filter with --filter-with-lsh-hamming), then the set
+cover filter.  Options outside the accelerated path (clustering, adapters,
+reverse complements, N expansion, custom hybridization functions, MinHash
+near-duplicate filter) are not offered.
+"""
+import argparse
+import logging
+import sys
+
+from catch_amd.filter import duplicate_filter, near_duplicate_filter
+from catch_amd.filter import probe_designer, set_cover_filter
+from catch_amd.utils import seq_io
+
+logger = logging.getLogger("catch_amd.design")
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    p.add_argument("dataset", nargs="+", help="FASTA file(s); one group each")
+    p.add_argument("-o", "--write-probe-fasta", help="output FASTA")
+    p.add_argument("-pl", "--probe-length", type=int, default=100)
+    p.add_argument("-ps", "--probe-stride", type=int, default=50)
+    p.add_argument("-m", "--mismatches", type=int, default=0)
+    p.add_argument("-l", "--lcf-thres", type=int, default=None,
+                   help="default: the probe length")
+    p.add_argument("--island-of-exact-match", type=int, default=0)
+    p.add_argument("-c", "--coverage", type=float, default=1.0,
+                   help="fraction (<= 1) or number of bp (> 1) per genome")
+    p.add_argument("-e", "--cover-extension", type=int, default=0)
+    p.add_argument("-i", "--identify", action="store_true")
+    p.add_argument("--avoid-genomes", nargs="+", default=[])
+    p.add_argument("-mt", "--mismatches-tolerant", type=int)
+    p.add_argument("-lt", "--lcf-thres-tolerant", type=int)
+    p.add_argument("--island-of-exact-match-tolerant", type=int, default=0)
+    p.add_argument("--filter-with-lsh-hamming", type=int,
+                   help="Hamming threshold of the near-duplicate filter")
+    p.add_argument("--small-seq-skip", type=int)
+    p.add_argument("--small-seq-min", type=int)
+    p.add_argument("--kmer-probe-map-k", type=int, default=20)
+    p.add_argument("--verbose", action="store_true")
+    return p.parse_args(argv)
+
+
+def main(args):
+    logging.basicConfig(
+        level=logging.INFO if args.verbose else logging.WARNING,
+        format="%(asctime)s - %(name)s [%(levelname)s] %(message)s")
+    lcf_thres = args.lcf_thres if args.lcf_thres is not None else args.probe_length
+    if args.coverage > 1:
+        args.coverage = int(args.coverage)
+    genomes_grouped = [seq_io.read_genomes_from_fasta(fn) for fn in args.dataset]
+
+    filters = []
+    if args.filter_with_lsh_hamming is not None:
+        if args.filter_with_lsh_hamming > args.mismatches:
+            logger.warning("Nearly duplicate probes are filtered by calling "
+                           "near-duplicates probes within a Hamming distance "
+                           "that exceeds --mismatches")
+        filters.append(near_duplicate_filter.NearDuplicateFilterWithHammingDistance(
+            args.filter_with_lsh_hamming, args.probe_length))
+    else:
+        filters.append(duplicate_filter.DuplicateFilter())
+    scf = set_cover_filter.SetCoverFilter(
+        mismatches=args.mismatches, lcf_thres=lcf_thres,
+        island_of_exact_match=args.island_of_exact_match,
+        mismatches_tolerant=args.mismatches_tolerant,
+        lcf_thres_tolerant=args.lcf_thres_tolerant,
+        island_of_exact_match_tolerant=args.island_of_exact_match_tolerant,
+        identify=args.identify, avoided_genomes=args.avoid_genomes,
+        coverage=args.coverage, cover_extension=args.cover_extension,
+        kmer_probe_map_k=args.kmer_probe_map_k)
+    filters.append(scf)
+
+    pb = probe_designer.ProbeDesigner(
+        genomes_grouped, filters, probe_length=args.probe_length,
+        probe_stride=args.probe_stride, allow_small_seqs=args.small_seq_min,
+        seq_length_to_skip=args.small_seq_skip)
+    pb.design()
+    if args.write_probe_fasta:
+        seq_io.write_probe_fasta(pb.final_probes, args.write_probe_fasta)
+    print(len(pb.final_probes))          # bin/design.py:445
+    return pb
+
+
+if __name__ == "__main__":
+    main(parse_args(sys.argv[1:]))

@@ -424,3 +424,29 @@ def test_config3_pipeline_ndf_then_scf_matches_oracle(ctx, oracle):
     gen = [[genome.Genome.from_one_seq(g[0]) for g in groups[0]]]
     out2 = scf.filter([out1], gen, input_is_grouped=True)
     assert sorted(p.seq_str for p in out2[0]) == sorted(kept[i] for i in exp[0])
+
+
+# ---------------------------------------------------------------- front end
+def test_design_cli_end_to_end(ctx, oracle, tmp_path, capsys):
+    """python -m catch_amd.design on two FASTA datasets: the written probe set
+    equals candidates -> dedup -> oracle set cover on the same files."""
+    from catch_amd import design
+    from catch_amd.utils import synthetic, seq_io
+    rng = np.random.Generator(np.random.PCG64(44))
+    groups = [synthetic.make_species(rng, [2500], 5, 2, 0.05, 0.01),
+              synthetic.make_species(rng, [1800], 4, 2, 0.04, 0.02)]
+    files = []
+    for i, grp in enumerate(groups):
+        fn = tmp_path / ("d%d.fasta" % i)
+        fn.write_text("".join(">g%d\n%s\n" % (j, g[0].lower() if j == 0 else g[0])
+                              for j, g in enumerate(grp)))
+        files.append(str(fn))
+    out = tmp_path / "probes.fasta"
+    pb = design.main(design.parse_args(files + ["-pl", "75", "-ps", "25", "-m", "2",
+                                                "-e", "30", "-o", str(out)]))
+    printed = int(capsys.readouterr().out.strip().splitlines()[-1])
+    cands = [candidates(g, 75, 25) for g in groups]
+    exp = oracle.set_cover_filter(cands, groups, 2, 75, coverage=1.0, cover_extension=30)
+    want = set(cands[i][j] for i, ids in enumerate(exp) for j in ids)
+    got = set(seq_io.read_fasta(str(out)).values())
+    assert got == want and printed == len(want) == len(pb.final_probes)
