@@ -95,6 +95,24 @@ def one_step(ctx, groups, stats=None):
     return picks
 
 
+def pmc_traffic(kernel, workload, scale):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in
+    separate runs of this same command; FETCH_SIZE doubled for gfx950 as
+    MI355X_MICROARCH.md prescribes).  None when no matching record exists:
+    counters cannot be collected from inside the timed run."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get("workload") != workload or scale != 1.0:
+            return None
+        k = rec["kernels"][kernel]
+        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(groups, cands, budget_s=12.0):
     """The CPU oracle (oracle/, plain C, 1 thread) timed on the same
     workload; reported beside the GPU number, never part of it."""
@@ -217,7 +235,9 @@ def main():
             # asks, the VALU figures say how busy the kernel really is
             roof = dict(bound="hbm", kernel="scan_fast3_kernel",
                         achieved=k1_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=k1_gbs / HBM_PEAK_GBS, traffic=None,
+                        frac=k1_gbs / HBM_PEAK_GBS,
+                        traffic=pmc_traffic("scan_fast3_kernel", args.workload, args.scale),
+                        algorithmic_bytes_per_launch=k1_bytes / max(len(resident), 1),
                         avg_launch_ms=k1_launch_ms,
                         valu_inst_per_probe_bp=3.92,
                         valu_lane_ops_per_s=(3.92 * sum(r.n_unique * r.G for r in resident)

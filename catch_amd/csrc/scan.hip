@@ -236,6 +236,208 @@ scan_fast2_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const 
     }
 }
 
+// ------------------------------------------------------------------------
+// K1c: seed filter for the same conditions as the tiled scan (pigeonhole
+// anchors, lcf_thres == L, DNA alphabet).  Under those conditions a covered
+// (probe, offset) has at least one anchor k-mer that matches exactly
+// (SURVEY.md App. A.8), which is how the reference itself finds it
+// (catch/probe.py:1062-1069).  Instead of testing every probe at every offset
+// (O(P*G)) each target position looks its k-mer up in a hash table of the
+// anchor k-mers (O(G)) and only the seeded (probe, offset) pairs are verified
+// with the exact plane-wise Hamming test.  Keys are the first min(k,32) bases
+// of the k-mer on planes 0/1 (N reads as A): a superset filter, the
+// verification is exact.  A covered pair is usually seeded by several
+// anchors; it is emitted only from the lowest exact anchor.
+// ------------------------------------------------------------------------
+struct SeedTable {
+    unsigned long long *keys;   // open addressing, EMPTY = ~0
+    u32 *cnt;                   // per slot: entries with this key (build time)
+    uint2 *range;               // per slot: (first index into ents, count)
+    u32 *ents;                  // entry ids (probe * nanchor + anchor) grouped by key
+    u32 mask;                   // capacity - 1
+};
+#define SEED_EMPTY 0xffffffffffffffffull
+
+__device__ __forceinline__ u32 seed_hash(unsigned long long k) {
+    k ^= k >> 29; k *= 0xbf58476d1ce4e5b9ull; k ^= k >> 32;
+    return (u32)k;
+}
+
+// exclusive prefix sum over the 64 lanes of a wave; *total = wave sum
+__device__ __forceinline__ u32 wave_excl_scan(u32 v, u32 *total) {
+    const int lane = __lane_id();
+    u32 incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    *total = __shfl(incl, 63);
+    return incl - v;
+}
+
+// 2-plane key of kb bases starting at base offset `o` of a plane pair
+__device__ __forceinline__ unsigned long long plane_key(const u32 *__restrict__ p0, const u32 *__restrict__ p1,
+                                                        u32 o, int kb) {
+    const u32 wi = o >> 5, sh = o & 31;
+    const u32 m = kb >= 32 ? 0xffffffffu : ((1u << kb) - 1u);
+    const u32 a = __builtin_amdgcn_alignbit(p0[wi + 1], p0[wi], sh) & m;
+    const u32 b = __builtin_amdgcn_alignbit(p1[wi + 1], p1[wi], sh) & m;
+    return ((unsigned long long)b << 32) | a;
+}
+
+// table build 1/3: claim the key's slot, count the entries per slot
+__global__ void __launch_bounds__(256)
+seed_count_kernel(const uint4 *__restrict__ pplanes, u32 nent, int NW, int k, int nanchor, int kb, SeedTable t,
+                  u32 *__restrict__ slot_of) {
+    const u32 e = blockIdx.x * blockDim.x + threadIdx.x;   // entry = probe * nanchor + anchor
+    if (e >= nent) return;
+    const u32 p = e / nanchor, a = e % nanchor;
+    // the probe image is [word][4]: planes 0/1 of the two words the k-mer starts in
+    const u32 o = a * k, wi = o >> 5, sh = o & 31;
+    const uint4 w0 = pplanes[(size_t)p * NW + wi];
+    const uint4 w1 = (int)(wi + 1) < NW ? pplanes[(size_t)p * NW + wi + 1] : make_uint4(0, 0, 0, 0);
+    const u32 m = kb >= 32 ? 0xffffffffu : ((1u << kb) - 1u);
+    const unsigned long long key = ((unsigned long long)(__builtin_amdgcn_alignbit(w1.y, w0.y, sh) & m) << 32) |
+                                   (__builtin_amdgcn_alignbit(w1.x, w0.x, sh) & m);
+    u32 s = seed_hash(key) & t.mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&t.keys[s], SEED_EMPTY, key);
+        if (prev == SEED_EMPTY || prev == key) break;
+        s = (s + 1) & t.mask;
+    }
+    slot_of[e] = s;
+    atomicAdd(&t.cnt[s], 1u);
+}
+
+// table build 2/3: give every used slot a contiguous range of ents[]
+__global__ void __launch_bounds__(256)
+seed_alloc_kernel(SeedTable t, u32 *__restrict__ cursor) {
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 n = s <= t.mask ? t.cnt[s] : 0u;
+    u32 total;
+    const u32 ex = wave_excl_scan(n, &total);
+    u32 base = 0;
+    if (__lane_id() == 0 && total) base = atomicAdd(cursor, total);
+    base = __shfl(base, 0);
+    if (s <= t.mask) t.range[s] = make_uint2(base + ex, n);
+}
+
+// table build 3/3: drop the entries into their slot's range
+__global__ void __launch_bounds__(256)
+seed_fill_kernel(u32 nent, SeedTable t, const u32 *__restrict__ slot_of) {
+    const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nent) return;
+    const u32 s = slot_of[e];
+    const u32 j = atomicSub(&t.cnt[s], 1u) - 1u;
+    t.ents[t.range[s].x + j] = e;
+}
+
+// scan 1/2: one thread per target position looks its k-mer up and expands the
+// matching anchors into the seed work list (position, entry, sequence)
+__global__ void __launch_bounds__(256)
+seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const u32 *__restrict__ seq_off, u32 nseq,
+                   int k, int kb, SeedTable t, u32 *__restrict__ seed_pos, u32 *__restrict__ seed_ent,
+                   u32 *__restrict__ seed_seq, u32 *__restrict__ seed_count, u32 seed_cap) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint2 r = make_uint2(0, 0);
+    if (i < total && i + (u32)k <= total) {
+        const unsigned long long key = plane_key(tplanes, tplanes + nwords, i, kb);
+        u32 s = seed_hash(key) & t.mask;
+        for (;;) {
+            const unsigned long long ks = t.keys[s];
+            if (ks == key) { r = t.range[s]; break; }
+            if (ks == SEED_EMPTY) break;
+            s = (s + 1) & t.mask;
+        }
+    }
+    u32 wtotal;
+    const u32 ex = wave_excl_scan(r.y, &wtotal);
+    if (wtotal == 0) return;
+    u32 base = 0;
+    if (__lane_id() == 0) base = atomicAdd(seed_count, wtotal);
+    base = __shfl(base, 0) + ex;
+    if (r.y == 0) return;
+    const u32 sq = find_segment(seq_off, nseq, i);
+    for (u32 j = 0; j < r.y; ++j) {
+        const u32 d = base + j;
+        if (d < seed_cap) { seed_pos[d] = i; seed_ent[d] = t.ents[r.x + j]; seed_seq[d] = sq; }
+    }
+}
+
+// bits [pos, pos+len) of the NW-word mismatch mask are all zero
+template <int NW>
+__device__ __forceinline__ bool mask_range_zero(const u32 (&mw)[NW], int pos, int len) {
+    u32 acc = 0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int lo = max(pos - 32 * j, 0), hi = min(pos + len - 32 * j, 32);
+        if (hi > lo) {
+            const u32 m = (hi - lo >= 32 ? 0xffffffffu : ((1u << (hi - lo)) - 1u)) << lo;
+            acc |= mw[j] & m;
+        }
+    }
+    return acc == 0;
+}
+
+// scan 2/2: one thread per seed verifies the (probe, offset) pair exactly
+template <int NW>
+__global__ void __launch_bounds__(256)
+seed_verify_kernel(const u32 *__restrict__ tplanes, i64 nwords, const u32 *__restrict__ seq_off,
+                   const uint4 *__restrict__ pplanes, int L, int k, int nanchor, int mm, u32 tailmask, int use_n,
+                   const u32 *__restrict__ seed_pos, const u32 *__restrict__ seed_ent,
+                   const u32 *__restrict__ seed_seq, const u32 *__restrict__ seed_count, u32 seed_cap,
+                   u32 *__restrict__ hit_probe, u32 *__restrict__ hit_pos, u32 *__restrict__ hit_count,
+                   u32 hit_cap) {
+    const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= min(*seed_count, seed_cap)) return;
+    const u32 i = seed_pos[d], e = seed_ent[d], sq = seed_seq[d];
+    const u32 p = e / nanchor, a = e % nanchor;
+    const u32 lo = seq_off[sq], hi = seq_off[sq + 1];
+    if (i < lo + a * (u32)k) return;
+    const u32 o = i - a * (u32)k;               // where the probe would start
+    if (o + (u32)L > hi) return;                // window inside this sequence
+    const u32 wi = o >> 5, sh = o & 31;
+    const u32 *p0 = tplanes + wi, *p1 = tplanes + nwords + wi, *p2 = tplanes + 2 * nwords + wi;
+    const uint4 *pq = pplanes + (size_t)p * NW;
+    u32 mw[NW];
+    u32 cnt = 0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const uint4 q = pq[j];
+        u32 x = (__builtin_amdgcn_alignbit(p0[j + 1], p0[j], sh) ^ q.x) |
+                (__builtin_amdgcn_alignbit(p1[j + 1], p1[j], sh) ^ q.y);
+        if (use_n) x |= (__builtin_amdgcn_alignbit(p2[j + 1], p2[j], sh) ^ q.z);
+        if (j == NW - 1) x &= tailmask;
+        mw[j] = x;
+        cnt += __popc(x);
+    }
+    if (cnt > (u32)mm) return;
+    // the seeding anchor must be exact on all planes (the key ignores plane 2 and
+    // bases beyond 32), and the pair is reported from its lowest exact anchor only
+    if (!mask_range_zero<NW>(mw, (int)a * k, k)) return;
+    for (u32 b = 0; b < a; ++b)
+        if (mask_range_zero<NW>(mw, (int)b * k, k)) return;
+    const u32 slot = atomicAdd(hit_count, 1u);
+    if (slot < hit_cap) { hit_probe[slot] = p; hit_pos[slot] = o; }
+}
+
+typedef void (*seed_verify_fn)(const u32 *, i64, const u32 *, const uint4 *, int, int, int, int, u32, int,
+                               const u32 *, const u32 *, const u32 *, const u32 *, u32, u32 *, u32 *, u32 *, u32);
+static seed_verify_fn pick_seed_verify(int nw) {
+    switch (nw) {
+    case 1: return seed_verify_kernel<1>;
+    case 2: return seed_verify_kernel<2>;
+    case 3: return seed_verify_kernel<3>;
+    case 4: return seed_verify_kernel<4>;
+    case 5: return seed_verify_kernel<5>;
+    case 6: return seed_verify_kernel<6>;
+    case 7: return seed_verify_kernel<7>;
+    case 8: return seed_verify_kernel<8>;
+    }
+    return nullptr;
+}
+
 // Third form: same filter, but the probe's word 0 comes through the scalar
 // cache (wave-uniform address -> s_load into SGPRs, used directly as the
 // scalar operand of v_xor / v_bitop3): no LDS, no staging barriers.
@@ -551,6 +753,73 @@ static int run_fast(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
     return CATCHHIP_ENOMEM;
 }
 
+// K1c host side: hash table of the anchor k-mers, one lookup per target
+// position, one exact verification per seed
+static int run_seed(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm, RawHits &H,
+                    PhaseTimer &tm) {
+    const bool use_n = P->has_n || T->has_n;
+    const int k = P->k, nanchor = P->L / P->k, kb = std::min(k, 32);
+    const u64 nent64 = (u64)P->nprobes * nanchor;
+    if (nent64 >= ((u64)1 << 31)) { chip_set_error("seed scan: too many anchors"); return CATCHHIP_EINVAL; }
+    const u32 nent = (u32)nent64;
+    seed_verify_fn verify = pick_seed_verify((int)P->pwords);
+    if (!verify) { chip_set_error("seed scan: unsupported probe length"); return CATCHHIP_EINVAL; }
+    u32 capacity = 1024;
+    while ((u64)capacity < 2 * nent64) capacity <<= 1;
+    DevBuf<unsigned long long> keys;
+    DevBuf<u32> cnt, ents, slot_of, ctr, spos, sent, sseq;
+    DevBuf<uint2> range;
+    TRY(keys.alloc(capacity));
+    TRY(cnt.alloc(capacity));
+    TRY(range.alloc(capacity));
+    TRY(ents.alloc(nent));
+    TRY(slot_of.alloc(nent));
+    TRY(ctr.alloc(4));   // [0] ents cursor, [1] seeds, [2] hits
+    const u32 tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
+    u32 cap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(P->nprobes * 64, (i64)1 << 28));
+    u32 scap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(T->total * 4, (i64)1 << 30));
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        TRY(H.a.reserve(cap));
+        TRY(H.b.reserve(cap));
+        TRY(spos.reserve(scap));
+        TRY(sent.reserve(scap));
+        TRY(sseq.reserve(scap));
+        tm.restart();
+        HIP_TRY(hipMemsetAsync(ctr.p, 0, 4 * sizeof(u32), ctx->stream));
+        HIP_TRY(hipMemsetAsync(keys.p, 0xff, sizeof(unsigned long long) * capacity, ctx->stream));
+        HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(u32) * capacity, ctx->stream));
+        SeedTable t = {keys.p, cnt.p, range.p, ents.p, capacity - 1};
+        const dim3 eb((unsigned)div_up((i64)nent, 256)), tb(256);
+        hipLaunchKernelGGL(seed_count_kernel, eb, tb, 0, ctx->stream, (const uint4 *)P->planes.p, nent,
+                           (int)P->pwords, k, nanchor, kb, t, slot_of.p);
+        hipLaunchKernelGGL(seed_alloc_kernel, dim3(capacity / 256), tb, 0, ctx->stream, t, ctr.p);
+        hipLaunchKernelGGL(seed_fill_kernel, eb, tb, 0, ctx->stream, nent, t, (const u32 *)slot_of.p);
+        hipLaunchKernelGGL(seed_lookup_kernel, dim3((unsigned)div_up(T->total, 256)), tb, 0, ctx->stream,
+                           (const u32 *)T->planes.p, T->nwords, (u32)T->total, (const u32 *)T->seq_off.p,
+                           (u32)T->nseq, k, kb, t, spos.p, sent.p, sseq.p, ctr.p + 1, scap);
+        hipLaunchKernelGGL(verify, dim3((unsigned)div_up((i64)scap, 256)), tb, 0, ctx->stream,
+                           (const u32 *)T->planes.p, T->nwords, (const u32 *)T->seq_off.p,
+                           (const uint4 *)P->planes.p, (int)P->L, k, nanchor, mm, tailmask, use_n ? 1 : 0,
+                           (const u32 *)spos.p, (const u32 *)sent.p, (const u32 *)sseq.p,
+                           (const u32 *)(ctr.p + 1), scap, H.a.p, H.b.p, ctr.p + 2, cap);
+        tm.launch(5);
+        tm.stop();
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ctx->h_pin, ctr.p, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const u32 nseeds = ((volatile u32 *)ctx->h_pin)[1], n = ((volatile u32 *)ctx->h_pin)[2];
+        if (nseeds <= scap && n <= cap) {
+            H.n = n; H.has_end = false;
+            ctx->counters[0] = n; ctx->counters[1] = nseeds;
+            return 0;
+        }
+        if (nseeds > scap) scap = nseeds;
+        if (n > cap) cap = n;
+    }
+    chip_set_error("seed scan: work list overflow");
+    return CATCHHIP_ENOMEM;
+}
+
 static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm,
                        int lcf_thres, int island, RawHits &H, PhaseTimer &tm) {
     H.n = 0;
@@ -662,12 +931,16 @@ extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, 
         chip_set_error("cover_scan: fast-path preconditions do not hold");
         return CATCHHIP_EINVAL;
     }
-    // AUTO: both paths are exact; the tiled scan costs O(P*G), the seed join O(G log E + seeds).
-    // Measured crossover on MI355X is at a few 10^4 unique probes.
-    i64 fast_max = 32768;
-    if (const char *e = getenv("CATCHHIP_FAST_MAX_PROBES")) fast_max = atoll(e);
-    const bool use_fast = fast_ok && mode != CATCHHIP_SCAN_GENERAL && (mode == CATCHHIP_SCAN_FAST || P->nprobes <= fast_max);
-
+    if (mode == CATCHHIP_SCAN_SEED && !fast_ok) {
+        chip_set_error("cover_scan: seed-filter preconditions do not hold");
+        return CATCHHIP_EINVAL;
+    }
+    // AUTO: all paths are exact.  When the pigeonhole/full-length conditions
+    // hold the seed filter (O(G + seeds)) is used; CATCHHIP_SCAN_FAST forces the
+    // tiled O(P*G) scan, CATCHHIP_SCAN_GENERAL the byte-exact seed join.
+    const bool use_seed = fast_ok && (mode == CATCHHIP_SCAN_SEED ||
+                                      (mode == CATCHHIP_SCAN_AUTO && !getenv("CATCHHIP_SCAN_TILED")));
+    const bool use_fast = fast_ok && !use_seed && mode != CATCHHIP_SCAN_GENERAL;
     catchhip_rows *R = new catchhip_rows();
     R->ctx = ctx;
     R->total = T->total;
@@ -682,8 +955,9 @@ extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, 
         {
             PhaseTimer tm(ctx, PHASE_SCAN);
             if (P->nprobes > 0 && T->total > 0) {
-                rc = use_fast ? run_fast(ctx, P, T, mismatches, H, tm)
-                              : run_general(ctx, P, T, mismatches, lcf_thres, island, H, tm);
+                rc = use_seed ? run_seed(ctx, P, T, mismatches, H, tm)
+                     : use_fast ? run_fast(ctx, P, T, mismatches, H, tm)
+                                : run_general(ctx, P, T, mismatches, lcf_thres, island, H, tm);
             }
             tm.stop();
             if (rc) break;
@@ -724,11 +998,11 @@ extern "C" int catchhip_tolerant_bp(catchhip_ctx *ctx, const catchhip_probes *P,
     ARG_CHECK(ctx && P && T && bp_out);
     HIP_TRY(hipSetDevice(ctx->device));
     if (P->nprobes == 0 || T->total == 0) return 0;
-    const bool use_fast = fast_path_ok(P, T, mismatches, lcf_thres, island);
+    const bool use_seed = fast_path_ok(P, T, mismatches, lcf_thres, island);
     RawHits H;
     {
         PhaseTimer tm(ctx, PHASE_SCAN);
-        int rc = use_fast ? run_fast(ctx, P, T, mismatches, H, tm)
+        int rc = use_seed ? run_seed(ctx, P, T, mismatches, H, tm)
                           : run_general(ctx, P, T, mismatches, lcf_thres, island, H, tm);
         tm.stop();
         if (rc) return rc;

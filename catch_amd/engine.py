@@ -10,7 +10,7 @@ import numpy as np
 from catch_amd import _lib
 from catch_amd._lib import c_f64p, c_i32p, c_i64p, c_u8p, check
 
-SCAN_AUTO, SCAN_GENERAL, SCAN_FAST = 0, 1, 2
+SCAN_AUTO, SCAN_GENERAL, SCAN_FAST, SCAN_SEED = 0, 1, 2, 3
 PHASE_SCAN, PHASE_ROWS, PHASE_GREEDY, PHASE_NDF, PHASE_GREEDY_ROUNDS = 0, 1, 2, 3, 4
 
 

@@ -95,6 +95,8 @@ int catchhip_probes_destroy(catchhip_probes *p);
 #define CATCHHIP_SCAN_GENERAL 1  /* force the seed-join + extension path */
 #define CATCHHIP_SCAN_FAST 2     /* force the tiled Hamming kernel (EINVAL if
                                     preconditions do not hold) */
+#define CATCHHIP_SCAN_SEED 3     /* force the hash-seeded Hamming kernel (same
+                                    preconditions as the tiled kernel) */
 /* Replaces SetCoverFilter._make_sets (catch/filter/set_cover_filter.py
  * :359-470) = for every target sequence, probe.find_probe_covers_in_sequence
  * (catch/probe.py:1008-1271) under the default hybridization model

@@ -68,6 +68,9 @@ def test_scan_fast_matches_oracle(ctx, oracle, L, stride, m, ext):
     # the seed-join + extension path must agree with the tiled Hamming kernel
     got_g = _scan_rows(ctx, probes, genomes, m, L, 0, ext, engine.SCAN_GENERAL)
     assert got_g == exp
+    # ... and so must the hash-seeded Hamming kernel (K1c)
+    got_s = _scan_rows(ctx, probes, genomes, m, L, 0, ext, engine.SCAN_SEED)
+    assert got_s == exp
 
 
 def test_scan_fast_no_n_two_planes(ctx, oracle):
@@ -76,6 +79,7 @@ def test_scan_fast_no_n_two_planes(ctx, oracle):
     probes = candidates(genomes, 100, 50)
     exp = _oracle_rows(oracle, probes, genomes, 2, 100, 0, 50)
     assert _scan_rows(ctx, probes, genomes, 2, 100, 0, 50, engine.SCAN_FAST) == exp
+    assert _scan_rows(ctx, probes, genomes, 2, 100, 0, 50, engine.SCAN_SEED) == exp
 
 
 @pytest.mark.parametrize("L,stride,m,thres,island,ext,seed", [
@@ -295,6 +299,9 @@ def test_full_size_properties(ctx):
         rg = engine.Rows.scan(ctx, p, t, 2, 100, 0, 50, engine.SCAN_GENERAL)
         a, b = rf.fetch(), rg.fetch()
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        rs = engine.Rows.scan(ctx, p, t, 2, 100, 0, 50, engine.SCAN_SEED)
+        assert all(np.array_equal(x, y) for x, y in zip(a, rs.fetch()))
+        rs.close()
         picks = rf.greedy(len(cand))
         assert picks == rf.greedy(len(cand))
         assert len(set(picks)) == len(picks)
