@@ -150,6 +150,7 @@ struct catchhip_rows {
     i64 n = 0;
     i64 total = 0;       // size of the global coordinate space
     i32 ngenomes = 0;
+    u32 lmax = 0;        // longest row (bases)
     DevBuf<i32> set_id;
     DevBuf<i32> univ;
     DevBuf<u32> gs, ge;

@@ -653,14 +653,21 @@ __global__ void __launch_bounds__(256)
 rows_compact_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ head,
                     const u32 *__restrict__ mend, const u32 *__restrict__ seg,
                     const u32 *__restrict__ idx, u32 n, i32 *__restrict__ o_set,
-                    i32 *__restrict__ o_univ, u32 *__restrict__ o_gs, u32 *__restrict__ o_ge) {
+                    i32 *__restrict__ o_univ, u32 *__restrict__ o_gs, u32 *__restrict__ o_ge,
+                    u32 *__restrict__ lmax) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n || !head[t]) return;
-    u32 d = idx[t];
-    o_set[d] = (i32)(keys[t] >> 32);
-    o_univ[d] = (i32)seg[t];
-    o_gs[d] = (u32)keys[t];
-    o_ge[d] = mend[t];
+    u32 len = 0;
+    if (t < n && head[t]) {
+        u32 d = idx[t];
+        o_set[d] = (i32)(keys[t] >> 32);
+        o_univ[d] = (i32)seg[t];
+        o_gs[d] = (u32)keys[t];
+        o_ge[d] = mend[t];
+        len = mend[t] - (u32)keys[t];
+    }
+    // longest row of the table: one atomic per wavefront
+    for (int d = 32; d > 0; d >>= 1) { u32 o = __shfl_down(len, d, 64); len = o > len ? o : len; }
+    if ((threadIdx.x & 63) == 0 && len) atomicMax(lmax, len);
 }
 
 __global__ void __launch_bounds__(256)
@@ -974,10 +981,17 @@ extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, 
         if ((rc = R->gs.alloc(R->n))) break;
         if ((rc = R->ge.alloc(R->n))) break;
         if (M.n) {
+            DevBuf<u32> d_lmax;
+            if ((rc = d_lmax.alloc(1))) break;
+            if (hipMemsetAsync(d_lmax.p, 0, sizeof(u32), ctx->stream) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
             hipLaunchKernelGGL(rows_compact_kernel, dim3((unsigned)div_up(M.n, 256)), dim3(256), 0, ctx->stream,
                                M.keys.p, M.head.p, M.mend.p, M.seg.p, M.idx.p, M.n, R->set_id.p, R->univ.p,
-                               R->gs.p, R->ge.p);
+                               R->gs.p, R->ge.p, d_lmax.p);
             tm.launch();
+            tm.stop();
+            if (hipMemcpyAsync(ctx->h_pin, d_lmax.p, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
+            R->lmax = *(volatile u32 *)ctx->h_pin;
         }
         tm.stop();
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
@@ -1082,6 +1096,7 @@ extern "C" int catchhip_rows_from_host(catchhip_ctx *ctx, const i32 *set_id, con
         if (!ok) { delete R; chip_set_error("rows_from_host: row %lld is invalid or out of order", (long long)i); return CATCHHIP_EINVAL; }
         gs[i] = (u32)(R->h_genome_off[u] + start[i]);
         ge[i] = (u32)(R->h_genome_off[u] + end[i]);
+        R->lmax = std::max(R->lmax, ge[i] - gs[i]);
     }
     int rc = 0;
     do {

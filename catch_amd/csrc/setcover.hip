@@ -41,7 +41,7 @@ struct GreedyState {
     u32 iters;
     u32 lmax;      // longest row
     u32 smax;      // largest (set, universe) element count
-    u32 narow, npairs;   // batched solver: accepted rows / (row, slot) pairs of the current round
+    u32 fr_cnt[2], fr_nclaim[2];   // batched solver: live-list sizes / claiming sets, by round parity
     unsigned long long prof[8];  // shader-clock ticks per phase (thread 0)
     unsigned long long n_wrows, n_recount, n_words;  // work counters
 };
@@ -790,17 +790,19 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
                 return CATCHHIP_EINVAL;
             }
 
+    // every universe fully covered and rows <= 257 bases: batched rounds (many
+    // independent picks per round); otherwise one pick per iteration
+    bool batched = !distributed && R->lmax <= 257 && !getenv("CATCHHIP_GREEDY_SEQUENTIAL");
+    if (universe_p)
+        for (u32 u = 0; u < nuniv && batched; ++u) batched = universe_p[u] == 1.0;
+
     DevBuf<u32> set_ptr, flag, idx, tmp, seg_row, seg_univ, seg_set, row_seg, set_seg_ptr, usize, can, left, rank,
         picked, picks;
-    DevBuf<unsigned long long> bm;
+    DevBuf<unsigned long long> bm, pick_key;
     DevBuf<double> d_p;
     DevBuf<GreedyState> st;
     const size_t nwords = (size_t)(R->total / 64 + 2);
     TRY(set_ptr.alloc(nsets + 1));
-    TRY(flag.alloc(nrows));
-    TRY(idx.alloc(nrows));
-    TRY(row_seg.alloc(nrows));
-    TRY(set_seg_ptr.alloc(nsets + 1));
     TRY(usize.alloc(nuniv));
     TRY(can.alloc(nuniv));
     TRY(left.alloc(nuniv));
@@ -824,41 +826,100 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     PhaseTimer tm(ctx, PHASE_GREEDY);
     const unsigned rb = (unsigned)div_up(nrows, 256), sb = (unsigned)div_up(nsets + 1, 256);
     hipLaunchKernelGGL(set_ptr_kernel, dim3(sb), dim3(256), 0, s, R->set_id.p, nrows, nsets, set_ptr.p);
-    hipLaunchKernelGGL(seg_flag_kernel, dim3(rb), dim3(256), 0, s, R->set_id.p, R->univ.p, R->gs.p, R->ge.p, nrows,
-                       flag.p, st.p);
-    TRY(chip_exclusive_scan_u32(ctx, flag.p, idx.p, nrows, tmp));
-    HIP_TRY(hipMemcpyAsync(ctx->h_pin, idx.p + (nrows - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync((u32 *)ctx->h_pin + 1, flag.p + (nrows - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync((u32 *)ctx->h_pin + 2, &st.p->lmax, sizeof(u32), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const u32 nseg = ((volatile u32 *)ctx->h_pin)[0] + ((volatile u32 *)ctx->h_pin)[1];
-    const u32 h_lmax = ((volatile u32 *)ctx->h_pin)[2];
-    TRY(seg_row.alloc(nseg + 1));
-    TRY(seg_univ.alloc(nseg + 1));
-    TRY(seg_set.alloc(nseg + 1));
-    hipLaunchKernelGGL(seg_fill_kernel, dim3(rb), dim3(256), 0, s, flag.p, idx.p, R->set_id.p, R->univ.p, nrows, nseg,
-                       seg_row.p, seg_univ.p, seg_set.p, row_seg.p);
-    hipLaunchKernelGGL(set_seg_ptr_kernel, dim3(sb), dim3(256), 0, s, set_ptr.p, idx.p, nrows, nsets, nseg,
-                       set_seg_ptr.p);
     hipLaunchKernelGGL(bitmap_build_kernel, dim3(rb), dim3(256), 0, s, R->gs.p, R->ge.p, nrows, bm.p);
     hipLaunchKernelGGL(universe_size_kernel, dim3(nuniv), dim3(256), 0, s, (const u64 *)bm.p, R->genome_off.p,
                        nuniv, usize.p);
     hipLaunchKernelGGL(universe_need_kernel, dim3((unsigned)div_up(nuniv, 256)), dim3(256), 0, s, usize.p,
                        universe_p ? d_p.p : (const double *)nullptr, nuniv, can.p, left.p, st.p);
     hipLaunchKernelGGL(greedy_start_kernel, dim3(1), dim3(1), 0, s, st.p);
-    tm.launch(8);
+    tm.launch(5);
     HIP_TRY(hipGetLastError());
 
+    u32 nseg = 0;
+    if (!batched) {
+        // (set, universe) segments of the row table
+        TRY(flag.alloc(nrows));
+        TRY(idx.alloc(nrows));
+        TRY(row_seg.alloc(nrows));
+        TRY(set_seg_ptr.alloc(nsets + 1));
+        hipLaunchKernelGGL(seg_flag_kernel, dim3(rb), dim3(256), 0, s, R->set_id.p, R->univ.p, R->gs.p, R->ge.p, nrows,
+                           flag.p, st.p);
+        TRY(chip_exclusive_scan_u32(ctx, flag.p, idx.p, nrows, tmp));
+        HIP_TRY(hipMemcpyAsync(ctx->h_pin, idx.p + (nrows - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync((u32 *)ctx->h_pin + 1, flag.p + (nrows - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        nseg = ((volatile u32 *)ctx->h_pin)[0] + ((volatile u32 *)ctx->h_pin)[1];
+        TRY(seg_row.alloc(nseg + 1));
+        TRY(seg_univ.alloc(nseg + 1));
+        TRY(seg_set.alloc(nseg + 1));
+        hipLaunchKernelGGL(seg_fill_kernel, dim3(rb), dim3(256), 0, s, flag.p, idx.p, R->set_id.p, R->univ.p, nrows, nseg,
+                           seg_row.p, seg_univ.p, seg_set.p, row_seg.p);
+        hipLaunchKernelGGL(set_seg_ptr_kernel, dim3(sb), dim3(256), 0, s, set_ptr.p, idx.p, nrows, nsets, nseg,
+                           set_seg_ptr.p);
+        tm.launch(6);
+    }
     int rc = 0;
-    if (!distributed) {
+    bool sort_picks = false;
+    if (batched) {
+        // ---- frontier solver: rounds of (count+claim, check+apply) launches ----
+        DevBuf<uint4> frow;
+        DevBuf<unsigned long long> owner0, owner1;
+        DevBuf<u32> gain, claimed, list0, list1;
+        DevBuf<u8> rowflag;
+        TRY(frow.alloc(nrows));
+        TRY(owner0.alloc(nwords + 8));
+        TRY(owner1.alloc(nwords + 8));
+        TRY(gain.alloc(nsets));
+        TRY(claimed.alloc(nsets));
+        TRY(list0.alloc(nsets));
+        TRY(list1.alloc(nsets));
+        TRY(rowflag.alloc(nrows));
+        TRY(pick_key.alloc(nsets));
+        HIP_TRY(hipMemsetAsync(owner0.p, 0, sizeof(unsigned long long) * (nwords + 8), s));
+        HIP_TRY(hipMemsetAsync(owner1.p, 0, sizeof(unsigned long long) * (nwords + 8), s));
+        HIP_TRY(hipMemsetAsync(claimed.p, 0, sizeof(u32) * nsets, s));
+        hipLaunchKernelGGL(frow_fill_kernel, dim3(rb), dim3(256), 0, s, R->gs.p, R->ge.p, R->univ.p, nrows, frow.p);
+        tm.launch(1);
+        FrontArgs fa;
+        fa.bm = bm.p; fa.owner[0] = owner0.p; fa.owner[1] = owner1.p; fa.frow = frow.p; fa.set_ptr = set_ptr.p;
+        fa.rank = rank.p; fa.usize = usize.p; fa.gain = gain.p; fa.claimed = claimed.p; fa.picked = picked.p;
+        fa.picks = picks.p; fa.pick_key = pick_key.p; fa.rowflag = rowflag.p; fa.list[0] = list0.p;
+        fa.list[1] = list1.p; fa.st = st.p; fa.nsets = nsets; fa.nwords = (u32)nwords;
+        const unsigned gblocks = (unsigned)std::min<i64>(div_up(nsets, GF_SETS), (i64)ctx->num_cus * 16);
+        // the host looks at the state after a batch of rounds (the kernels
+        // no-op once everything is covered)
+        const i64 max_rounds = (i64)nsets + nrank + 2;
+        i64 rounds = 0;
+        int per_sync = 8;
+        PhaseTimer tr(ctx, PHASE_GREEDY_ROUNDS);   // the round launches only
+        for (;;) {
+            for (int r = 0; r < per_sync; ++r, ++rounds) {
+                hipLaunchKernelGGL(gf_count_claim_kernel, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
+                hipLaunchKernelGGL(gf_check_apply_kernel, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
+            }
+            tm.launch(2 * per_sync);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&h_st, st.p, sizeof(h_st), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (h_st.done || h_st.n_need == 0) break;
+            if (rounds > max_rounds) { chip_set_error("setcover: round cap exceeded"); return CATCHHIP_EINVAL; }
+            per_sync = 4;
+        }
+        if (!h_st.done) h_st.done = 1;
+        tr.launch(2 * rounds);
+        tr.finish();
+        tm.stop();
+        tm.finish();
+        sort_picks = true;
+        ctx->phase_launches[PHASE_GREEDY] = h_st.iters;
+        ctx->counters[2] = h_st.iters; ctx->counters[3] = h_st.npicks; ctx->counters[4] = (i64)h_st.n_wrows;
+        ctx->counters[5] = (i64)h_st.n_recount; ctx->counters[6] = (i64)h_st.n_words;
+    } else if (!distributed) {
         // ---- persistent single-workgroup solver ---------------------------
         DevBuf<u32> prowcnt, segcnt, segcontrib, gain, dirty, pos_row, pos_row_alt, useg, useg_alt, useg_ptr,
             bucket;
         DevBuf<u64> pos_key, pos_key_alt, ukeys, ukeys_alt;
         DevBuf<uint4> pent, wrow;
-        DevBuf<unsigned long long> owner;
-        TRY(owner.alloc(nwords + 8));
-        HIP_TRY(hipMemsetAsync(owner.p, 0, sizeof(unsigned long long) * (nwords + 8), s));
         const u32 nbuckets = (u32)(R->total >> BUCKET_SHIFT) + 2;
         TRY(prowcnt.alloc(nrows));
         TRY(segcnt.alloc(nseg));
@@ -892,55 +953,18 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         hipLaunchKernelGGL(useg_ptr_kernel, dim3((unsigned)div_up(nuniv + 1, 256)), dim3(256), 0, s, ukeys.p, nseg,
                            nuniv, useg_ptr.p);
         GreedyArgs a;
-        a.bm = bm.p; a.owner = owner.p; a.wrow = wrow.p; a.set_ptr = set_ptr.p; a.set_seg_ptr = set_seg_ptr.p;
+        a.bm = bm.p; a.wrow = wrow.p; a.set_ptr = set_ptr.p; a.set_seg_ptr = set_seg_ptr.p;
         a.seg_univ = seg_univ.p; a.seg_set = seg_set.p; a.pent = pent.p; a.prowcnt = prowcnt.p;
         a.bucket = bucket.p; a.useg_ptr = useg_ptr.p; a.useg = useg.p; a.can = can.p;
         a.rank = rank.p; a.usize = usize.p; a.left = left.p; a.segcnt = segcnt.p; a.segcontrib = segcontrib.p;
         a.gain = gain.p; a.picked = picked.p; a.picks = picks.p; a.dirty = dirty.p; a.st = st.p;
         a.nrows = nrows; a.nsets = nsets; a.nuniv = nuniv; a.chunk = (u32)div_up(nsets, GW_THREADS);
-        // every universe fully covered and rows <= 257 bases: batched rounds
-        // (many independent picks per round); otherwise one pick per round
-        bool batched = h_lmax <= 257 && !getenv("CATCHHIP_GREEDY_SEQUENTIAL");
-        if (universe_p)
-            for (u32 u = 0; u < nuniv && batched; ++u) batched = universe_p[u] == 1.0;
-        DevBuf<uint4> arow;
-        DevBuf<u32> abase;
-        if (batched) {
-            // rounds of (select, re-count) launches; the host looks at the
-            // state every ROUNDS_PER_SYNC rounds (the kernels no-op once done)
-            TRY(arow.alloc(GB_MAXAROW));
-            TRY(abase.alloc(GB_MAXAROW + 1));
-            BatchArgs ba;
-            ba.g = a; ba.arow = arow.p; ba.abase = abase.p;
-            const unsigned rc_blocks = (unsigned)std::max(1, ctx->num_cus * 2);
-            const int ROUNDS_PER_SYNC = 16;
-            const i64 max_rounds = (i64)nsets + nrank + 2;
-            i64 rounds = 0;
-            PhaseTimer tr(ctx, PHASE_GREEDY_ROUNDS);   // the (select, re-count) launches only
-            for (;;) {
-                for (int r = 0; r < ROUNDS_PER_SYNC; ++r) {
-                    hipLaunchKernelGGL(gb_select_kernel, dim3(1), dim3(GW_THREADS), 0, s, ba);
-                    hipLaunchKernelGGL(gb_recount_kernel, dim3(rc_blocks), dim3(GB_RC_THREADS), 0, s, ba);
-                }
-                tm.launch(2 * ROUNDS_PER_SYNC);
-                rounds += ROUNDS_PER_SYNC;
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(&h_st, st.p, sizeof(h_st), hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                if (h_st.done) break;
-                if (rounds > max_rounds) { chip_set_error("setcover: round cap exceeded"); return CATCHHIP_EINVAL; }
-            }
-            tr.launch(2 * rounds);
-            tr.finish();
-            tm.stop();
-        } else {
-            hipLaunchKernelGGL(greedy_wg_kernel, dim3(1), dim3(GW_THREADS), 0, s, a);
-            tm.launch(6);
-            tm.stop();
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(&h_st, st.p, sizeof(h_st), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-        }
+        hipLaunchKernelGGL(greedy_wg_kernel, dim3(1), dim3(GW_THREADS), 0, s, a);
+        tm.launch(6);
+        tm.stop();
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&h_st, st.p, sizeof(h_st), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
         tm.finish();
         ctx->phase_launches[PHASE_GREEDY] = h_st.iters;  // greedy iterations inside the persistent launch
         ctx->counters[2] = h_st.iters; ctx->counters[3] = h_st.npicks; ctx->counters[4] = (i64)h_st.n_wrows;
@@ -990,11 +1014,30 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     }
     if (h_st.done != 1) { chip_set_error("setcover: solver did not finish"); return CATCHHIP_EHIP; }
     std::vector<u32> h_picks(h_st.npicks);
+    std::vector<unsigned long long> h_keys;
     if (h_st.npicks) {
         HIP_TRY(hipMemcpyAsync(h_picks.data(), picks.p, sizeof(u32) * h_st.npicks, hipMemcpyDeviceToHost, s));
+        if (sort_picks) {
+            h_keys.resize(h_st.npicks);
+            HIP_TRY(hipMemcpyAsync(h_keys.data(), pick_key.p, sizeof(unsigned long long) * h_st.npicks,
+                                   hipMemcpyDeviceToHost, s));
+        }
         HIP_TRY(hipStreamSynchronize(s));
     }
-    for (u32 i = 0; i < h_st.npicks; ++i) out_ids[i] = h_picks[i];
+    if (sort_picks) {
+        // sequential pick order = by rank, then by descending accept-time key
+        // (see setcover_batched.inc)
+        std::vector<u32> ord(h_st.npicks);
+        for (u32 i = 0; i < h_st.npicks; ++i) ord[i] = i;
+        std::sort(ord.begin(), ord.end(), [&](u32 x, u32 y) {
+            const u32 rx = h_rank[h_picks[x]], ry = h_rank[h_picks[y]];
+            if (rx != ry) return rx < ry;
+            return h_keys[x] > h_keys[y];
+        });
+        for (u32 i = 0; i < h_st.npicks; ++i) out_ids[i] = h_picks[ord[i]];
+    } else {
+        for (u32 i = 0; i < h_st.npicks; ++i) out_ids[i] = h_picks[i];
+    }
     *n_out = h_st.npicks;
     return 0;
 }

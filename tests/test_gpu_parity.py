@@ -212,11 +212,48 @@ def test_greedy_random_instances_match_oracle(ctx, oracle):
         dev = engine.Rows.from_host(ctx, r[:, 0], r[:, 1], r[:, 2], r[:, 3], glen)
         got = dev.greedy(P, ranks, up)
         dev.close()
-        if up is not None and any(x < 1.0 for x in up):
-            assert got == exp, trial          # sequential solver: same order too
-        else:
-            assert sorted(got) == sorted(exp), trial   # batched rounds: same set
-            assert len(set(got)) == len(got)
+        # same picks in the same (sequential) order, whichever solver ran
+        assert got == exp, trial
+
+
+def test_greedy_batched_rounds_restore_sequential_order(ctx, oracle):
+    """Larger full-coverage instances (many locally maximal sets per round,
+    with and without ranks): the frontier solver must return the oracle's
+    sequential pick order, and so must the one-pick-per-iteration solver."""
+    import os
+    engine = _engine()
+    rng = np.random.Generator(np.random.PCG64(321))
+    for trial in range(6):
+        P = int(rng.integers(300, 2500))
+        U = int(rng.integers(1, 12))
+        glen = rng.integers(2000, 9000, size=U)
+        rows = []
+        for s in range(P):
+            for u in range(U):
+                if rng.random() < 0.5:
+                    pos = int(rng.integers(0, glen[u] - 300))
+                    for _ in range(int(rng.integers(1, 3))):
+                        ln = int(rng.integers(1, 257))
+                        if pos + ln > glen[u]:
+                            break
+                        rows.append((s, u, pos, pos + ln))
+                        pos += ln + int(rng.integers(1, 200))
+        r = np.array(sorted(rows), dtype=np.int64)
+        ranks = rng.integers(0, 4, size=P) if trial % 2 else None
+        exp = oracle.approx_multiuniverse(r[:, 0], r[:, 1], r[:, 2], r[:, 3], P,
+                                          U, None, None, ranks)
+        dev = engine.Rows.from_host(ctx, r[:, 0], r[:, 1], r[:, 2], r[:, 3], glen)
+        got = dev.greedy(P, ranks, None)
+        rounds = ctx.counters()["greedy_iters"]
+        os.environ["CATCHHIP_GREEDY_SEQUENTIAL"] = "1"
+        try:
+            got_seq = dev.greedy(P, ranks, None)
+        finally:
+            del os.environ["CATCHHIP_GREEDY_SEQUENTIAL"]
+        dev.close()
+        assert got == exp, trial
+        assert got_seq == exp, trial
+        assert rounds < len(exp)      # really batched
 
 
 # ---------------------------------------------------------------- SCF
