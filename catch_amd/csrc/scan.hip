@@ -345,7 +345,9 @@ seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const
         const unsigned long long key = plane_key(tplanes, tplanes + nwords, i, kb);
         u32 s = seed_hash(key) & t.mask;
         for (;;) {
-            const unsigned long long ks = t.keys[s];
+            // keys[] was written by atomicCAS: agent-scope load (plain loads of
+            // atomically written lines are slow, see setcover_batched.inc)
+            const unsigned long long ks = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (ks == key) { r = t.range[s]; break; }
             if (ks == SEED_EMPTY) break;
             s = (s + 1) & t.mask;

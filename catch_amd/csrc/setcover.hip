@@ -41,7 +41,7 @@ struct GreedyState {
     u32 iters;
     u32 lmax;      // longest row
     u32 smax;      // largest (set, universe) element count
-    u32 fr_cnt[2], fr_nclaim[2];   // batched solver: live-list sizes / claiming sets, by round parity
+    u32 fr_claim[2];   // batched solver: some set of the current rank claimed, by round parity
     unsigned long long prof[8];  // shader-clock ticks per phase (thread 0)
     unsigned long long n_wrows, n_recount, n_words;  // work counters
 };
@@ -864,15 +864,14 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         // ---- frontier solver: rounds of (count+claim, check+apply) launches ----
         DevBuf<uint4> frow;
         DevBuf<unsigned long long> owner0, owner1;
-        DevBuf<u32> gain, claimed, list0, list1;
+        DevBuf<u32> gain, claimed;
+        DevBuf<unsigned long long> blkcnt;
         DevBuf<u8> rowflag;
         TRY(frow.alloc(nrows));
         TRY(owner0.alloc(nwords + 8));
         TRY(owner1.alloc(nwords + 8));
         TRY(gain.alloc(nsets));
         TRY(claimed.alloc(nsets));
-        TRY(list0.alloc(nsets));
-        TRY(list1.alloc(nsets));
         TRY(rowflag.alloc(nrows));
         TRY(pick_key.alloc(nsets));
         HIP_TRY(hipMemsetAsync(owner0.p, 0, sizeof(unsigned long long) * (nwords + 8), s));
@@ -883,9 +882,11 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         FrontArgs fa;
         fa.bm = bm.p; fa.owner[0] = owner0.p; fa.owner[1] = owner1.p; fa.frow = frow.p; fa.set_ptr = set_ptr.p;
         fa.rank = rank.p; fa.usize = usize.p; fa.gain = gain.p; fa.claimed = claimed.p; fa.picked = picked.p;
-        fa.picks = picks.p; fa.pick_key = pick_key.p; fa.rowflag = rowflag.p; fa.list[0] = list0.p;
-        fa.list[1] = list1.p; fa.st = st.p; fa.nsets = nsets; fa.nwords = (u32)nwords;
+        fa.picks = picks.p; fa.pick_key = pick_key.p; fa.rowflag = rowflag.p; fa.st = st.p; fa.nsets = nsets; fa.nwords = (u32)nwords;
         const unsigned gblocks = (unsigned)std::min<i64>(div_up(nsets, GF_SETS), (i64)ctx->num_cus * 16);
+        TRY(blkcnt.alloc(2 * (size_t)gblocks));
+        HIP_TRY(hipMemsetAsync(blkcnt.p, 0, sizeof(unsigned long long) * 2 * gblocks, s));
+        fa.blkcnt = blkcnt.p;
         // the host looks at the state after a batch of rounds (the kernels
         // no-op once everything is covered)
         const i64 max_rounds = (i64)nsets + nrank + 2;
@@ -911,9 +912,14 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         tm.stop();
         tm.finish();
         sort_picks = true;
+        std::vector<unsigned long long> h_blk(2 * (size_t)gblocks);
+        HIP_TRY(hipMemcpyAsync(h_blk.data(), blkcnt.p, sizeof(unsigned long long) * h_blk.size(), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        i64 n_rec = 0, n_wrd = 0;
+        for (unsigned b = 0; b < gblocks; ++b) { n_rec += (i64)h_blk[2 * b]; n_wrd += (i64)h_blk[2 * b + 1]; }
         ctx->phase_launches[PHASE_GREEDY] = h_st.iters;
-        ctx->counters[2] = h_st.iters; ctx->counters[3] = h_st.npicks; ctx->counters[4] = (i64)h_st.n_wrows;
-        ctx->counters[5] = (i64)h_st.n_recount; ctx->counters[6] = (i64)h_st.n_words;
+        ctx->counters[2] = h_st.iters; ctx->counters[3] = h_st.npicks; ctx->counters[4] = 0;
+        ctx->counters[5] = n_rec; ctx->counters[6] = n_wrd;
     } else if (!distributed) {
         // ---- persistent single-workgroup solver ---------------------------
         DevBuf<u32> prowcnt, segcnt, segcontrib, gain, dirty, pos_row, pos_row_alt, useg, useg_alt, useg_ptr,
