@@ -1,6 +1,9 @@
 // Context, error handling, input upload and bit-plane packing.
 #include <stdarg.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "internal.h"
 
 static thread_local char g_err[1024] = "";
@@ -382,6 +385,24 @@ extern "C" int catchhip_probes_create(catchhip_ctx *ctx, const u8 *bytes, const 
             chip_set_error("probes upload failed");
             rc = CATCHHIP_EHIP;
             break;
+        }
+        {   // buckets of the row build: unique probes grouped by set id, in set-id order
+            std::vector<i32> ids(set_id, set_id + nprobes);
+            std::sort(ids.begin(), ids.end());
+            ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+            p->nbuckets = (i64)ids.size();
+            std::vector<u32> bo((size_t)nprobes);
+            for (i64 i = 0; i < nprobes; ++i)
+                bo[i] = (u32)(std::lower_bound(ids.begin(), ids.end(), set_id[i]) - ids.begin());
+            if ((rc = p->bucket_of.alloc((size_t)nprobes + 1))) break;
+            if ((rc = p->bucket_set.alloc(ids.size() + 1))) break;
+            if (nprobes && (hipMemcpyAsync(p->bucket_of.p, bo.data(), sizeof(u32) * nprobes, hipMemcpyHostToDevice, s) != hipSuccess ||
+                            hipMemcpyAsync(p->bucket_set.p, ids.data(), sizeof(i32) * ids.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
+                            hipStreamSynchronize(s) != hipSuccess)) {
+                chip_set_error("probes upload failed");
+                rc = CATCHHIP_EHIP;
+                break;
+            }
         }
         if (p->dna5 && p->L > 0 && p->L <= 256) {
             p->pwords = (p->L + 31) / 32;

@@ -138,6 +138,9 @@ struct catchhip_probes {
     DevBuf<u8> bytes;
     DevBuf<u32> probe_off;   // nprobes+1
     DevBuf<i32> set_id;      // nprobes
+    i64 nbuckets = 0;        // distinct set ids
+    DevBuf<u32> bucket_of;   // nprobes: dense rank of the probe's set id (row-table order)
+    DevBuf<i32> bucket_set;  // nbuckets: set id of each bucket, ascending
     DevBuf<i32> ent_probe, ent_pos;
     i32 pwords = 0;          // 32-base words per probe (ceil(L/32))
     DevBuf<u32> planes;      // [probe][word][4] = planes 0,1,2 + pad per 32-base word
@@ -163,7 +166,12 @@ struct PhaseTimer {
     catchhip_ctx *c;
     int phase;
     bool stopped = false;
-    PhaseTimer(catchhip_ctx *ctx, int ph) : c(ctx), phase(ph) { restart(); }
+    // keep = true continues a phase that was already timed once in this call:
+    // finish_add() then adds to its time instead of replacing it
+    PhaseTimer(catchhip_ctx *ctx, int ph, bool keep = false) : c(ctx), phase(ph) {
+        if (keep) (void)hipEventRecord(c->ev[2 * phase], c->stream);
+        else restart();
+    }
     void restart() {
         stopped = false;
         c->phase_launches[phase] = 0;
@@ -183,6 +191,11 @@ struct PhaseTimer {
         (void)hipEventSynchronize(c->ev[2 * phase + 1]);
         if (hipEventElapsedTime(&ms, c->ev[2 * phase], c->ev[2 * phase + 1]) == hipSuccess)
             c->phase_ms[phase] = ms;
+    }
+    void finish_add() {
+        const double before = c->phase_ms[phase];
+        finish();
+        c->phase_ms[phase] += before;
     }
 };
 

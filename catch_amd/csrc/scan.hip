@@ -249,6 +249,8 @@ scan_fast2_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const 
 // verification is exact.  A covered pair is usually seeded by several
 // anchors; it is emitted only from the lowest exact anchor.
 // ------------------------------------------------------------------------
+#include "rows_bucket.inc"
+
 struct SeedTable {
     unsigned long long *keys;   // open addressing, EMPTY = ~0
     u32 *cnt;                   // per slot: entries with this key (build time)
@@ -310,17 +312,32 @@ seed_count_kernel(const uint4 *__restrict__ pplanes, u32 nent, int NW, int k, in
     atomicAdd(&t.cnt[s], 1u);
 }
 
-// table build 2/3: give every used slot a contiguous range of ents[]
+// one launch instead of five memsets
 __global__ void __launch_bounds__(256)
+seed_init_kernel(unsigned long long *__restrict__ keys, u32 *__restrict__ cnt, u32 capacity, u32 *__restrict__ ctr,
+                 u32 *__restrict__ bcnt, u32 nb, u32 *__restrict__ res) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (u32 i = t; i < capacity; i += stride) { keys[i] = SEED_EMPTY; cnt[i] = 0; }
+    for (u32 i = t; i < nb; i += stride) bcnt[i] = 0;
+    if (t < 8) { ctr[t & 3] = 0; res[t] = 0; }
+}
+
+// table build 2/3: give every used slot a contiguous range of ents[]
+// (one cursor atomic per 1024-slot workgroup: same-address atomics cost ~10 ns each)
+__global__ void __launch_bounds__(1024)
 seed_alloc_kernel(SeedTable t, u32 *__restrict__ cursor) {
-    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 n = s <= t.mask ? t.cnt[s] : 0u;
+    __shared__ u32 s_part[16], s_base;
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 n = s <= t.mask ? __hip_atomic_load(&t.cnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     u32 total;
     const u32 ex = wave_excl_scan(n, &total);
-    u32 base = 0;
-    if (__lane_id() == 0 && total) base = atomicAdd(cursor, total);
-    base = __shfl(base, 0);
-    if (s <= t.mask) t.range[s] = make_uint2(base + ex, n);
+    if (lane == 0) s_part[wave] = total;
+    __syncthreads();
+    u32 woff = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) { if (w < (int)wave) woff += s_part[w]; tot += s_part[w]; }
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(cursor, tot) : 0u;
+    __syncthreads();
+    if (s <= t.mask) t.range[s] = make_uint2(s_base + woff + ex, n);
 }
 
 // table build 3/3: drop the entries into their slot's range
@@ -333,37 +350,66 @@ seed_fill_kernel(u32 nent, SeedTable t, const u32 *__restrict__ slot_of) {
     t.ents[t.range[s].x + j] = e;
 }
 
-// scan 1/2: one thread per target position looks its k-mer up and expands the
-// matching anchors into the seed work list (position, entry, sequence)
-__global__ void __launch_bounds__(256)
+// scan 1/2: every target position looks its k-mer up; the matching anchors
+// are expanded into the seed work list (position, entry, sequence).  A
+// workgroup owns SL_TILE positions: one cursor atomic per workgroup, and the
+// seeds (a few positions hold dozens, most none) are written by all threads
+// through a prefix-sum + binary search in LDS.
+#define SL_THREADS 512
+#define SL_PPT 4
+#define SL_TILE (SL_THREADS * SL_PPT)
+__global__ void __launch_bounds__(SL_THREADS)
 seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const u32 *__restrict__ seq_off, u32 nseq,
                    int k, int kb, SeedTable t, u32 *__restrict__ seed_pos, u32 *__restrict__ seed_ent,
                    u32 *__restrict__ seed_seq, u32 *__restrict__ seed_count, u32 seed_cap) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint2 r = make_uint2(0, 0);
-    if (i < total && i + (u32)k <= total) {
-        const unsigned long long key = plane_key(tplanes, tplanes + nwords, i, kb);
-        u32 s = seed_hash(key) & t.mask;
-        for (;;) {
-            // keys[] was written by atomicCAS: agent-scope load (plain loads of
-            // atomically written lines are slow, see setcover_batched.inc)
-            const unsigned long long ks = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ks == key) { r = t.range[s]; break; }
-            if (ks == SEED_EMPTY) break;
-            s = (s + 1) & t.mask;
+    __shared__ u32 s_off[SL_TILE + 1], s_rx[SL_TILE], s_sq[SL_TILE], s_part[SL_THREADS / 64], s_base;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 tile0 = blockIdx.x * SL_TILE;
+    u32 cnt[SL_PPT], mine = 0;
+#pragma unroll
+    for (int j = 0; j < SL_PPT; ++j) {
+        const u32 q = tid * SL_PPT + j, i = tile0 + q;
+        uint2 r = make_uint2(0, 0);
+        if (i < total && i + (u32)k <= total) {
+            const unsigned long long key = plane_key(tplanes, tplanes + nwords, i, kb);
+            u32 s = seed_hash(key) & t.mask;
+            for (;;) {
+                // keys[] was written by atomicCAS: agent-scope load (plain loads of
+                // atomically written lines are slow, see setcover_batched.inc)
+                const unsigned long long ks = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ks == key) { r = t.range[s]; break; }
+                if (ks == SEED_EMPTY) break;
+                s = (s + 1) & t.mask;
+            }
         }
+        s_rx[q] = r.x;
+        cnt[j] = r.y;
+        mine += r.y;
+        if (r.y) s_sq[q] = find_segment(seq_off, nseq, i);
     }
     u32 wtotal;
-    const u32 ex = wave_excl_scan(r.y, &wtotal);
-    if (wtotal == 0) return;
-    u32 base = 0;
-    if (__lane_id() == 0) base = atomicAdd(seed_count, wtotal);
-    base = __shfl(base, 0) + ex;
-    if (r.y == 0) return;
-    const u32 sq = find_segment(seq_off, nseq, i);
-    for (u32 j = 0; j < r.y; ++j) {
-        const u32 d = base + j;
-        if (d < seed_cap) { seed_pos[d] = i; seed_ent[d] = t.ents[r.x + j]; seed_seq[d] = sq; }
+    const u32 ex = wave_excl_scan(mine, &wtotal);
+    if (lane == 0) s_part[wave] = wtotal;
+    __syncthreads();
+    u32 woff = 0, tot = 0;
+    for (int w = 0; w < SL_THREADS / 64; ++w) { if (w < (int)wave) woff += s_part[w]; tot += s_part[w]; }
+    if (tot == 0) return;
+    u32 run = woff + ex;
+#pragma unroll
+    for (int j = 0; j < SL_PPT; ++j) { s_off[tid * SL_PPT + j] = run; run += cnt[j]; }
+    if (tid == 0) { s_off[SL_TILE] = tot; s_base = atomicAdd(seed_count, tot); }
+    __syncthreads();
+    const u32 base = s_base;
+    for (u32 d = tid; d < tot; d += SL_THREADS) {
+        // last position q with s_off[q] <= d (positions without seeds share the next one's offset)
+        u32 lo = 0, hi = SL_TILE;
+        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_off[mid] <= d) lo = mid; else hi = mid; }
+        const u32 o = base + d;
+        if (o < seed_cap) {
+            seed_pos[o] = tile0 + lo;
+            seed_ent[o] = t.ents[s_rx[lo] + (d - s_off[lo])];
+            seed_seq[o] = s_sq[lo];
+        }
     }
 }
 
@@ -382,50 +428,52 @@ __device__ __forceinline__ bool mask_range_zero(const u32 (&mw)[NW], int pos, in
     return acc == 0;
 }
 
-// scan 2/2: one thread per seed verifies the (probe, offset) pair exactly
+// scan 2/2: one thread per seed verifies the (probe, offset) pair exactly and
+// files the hit with its bucket (rows_bucket.inc)
 template <int NW>
 __global__ void __launch_bounds__(256)
 seed_verify_kernel(const u32 *__restrict__ tplanes, i64 nwords, const u32 *__restrict__ seq_off,
                    const uint4 *__restrict__ pplanes, int L, int k, int nanchor, int mm, u32 tailmask, int use_n,
                    const u32 *__restrict__ seed_pos, const u32 *__restrict__ seed_ent,
                    const u32 *__restrict__ seed_seq, const u32 *__restrict__ seed_count, u32 seed_cap,
-                   u32 *__restrict__ hit_probe, u32 *__restrict__ hit_pos, u32 *__restrict__ hit_count,
-                   u32 hit_cap) {
+                   HitSink sink) {
     const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= min(*seed_count, seed_cap)) return;
     const u32 i = seed_pos[d], e = seed_ent[d], sq = seed_seq[d];
     const u32 p = e / nanchor, a = e % nanchor;
     const u32 lo = seq_off[sq], hi = seq_off[sq + 1];
-    if (i < lo + a * (u32)k) return;
+    bool ok = i >= lo + a * (u32)k;
     const u32 o = i - a * (u32)k;               // where the probe would start
-    if (o + (u32)L > hi) return;                // window inside this sequence
-    const u32 wi = o >> 5, sh = o & 31;
-    const u32 *p0 = tplanes + wi, *p1 = tplanes + nwords + wi, *p2 = tplanes + 2 * nwords + wi;
-    const uint4 *pq = pplanes + (size_t)p * NW;
-    u32 mw[NW];
-    u32 cnt = 0;
+    ok = ok && o + (u32)L <= hi;                // window inside this sequence
+    if (ok) {
+        const u32 wi = o >> 5, sh = o & 31;
+        const u32 *p0 = tplanes + wi, *p1 = tplanes + nwords + wi, *p2 = tplanes + 2 * nwords + wi;
+        const uint4 *pq = pplanes + (size_t)p * NW;
+        u32 mw[NW];
+        u32 cnt = 0;
 #pragma unroll
-    for (int j = 0; j < NW; ++j) {
-        const uint4 q = pq[j];
-        u32 x = (__builtin_amdgcn_alignbit(p0[j + 1], p0[j], sh) ^ q.x) |
-                (__builtin_amdgcn_alignbit(p1[j + 1], p1[j], sh) ^ q.y);
-        if (use_n) x |= (__builtin_amdgcn_alignbit(p2[j + 1], p2[j], sh) ^ q.z);
-        if (j == NW - 1) x &= tailmask;
-        mw[j] = x;
-        cnt += __popc(x);
+        for (int j = 0; j < NW; ++j) {
+            const uint4 q = pq[j];
+            u32 x = (__builtin_amdgcn_alignbit(p0[j + 1], p0[j], sh) ^ q.x) |
+                    (__builtin_amdgcn_alignbit(p1[j + 1], p1[j], sh) ^ q.y);
+            if (use_n) x |= (__builtin_amdgcn_alignbit(p2[j + 1], p2[j], sh) ^ q.z);
+            if (j == NW - 1) x &= tailmask;
+            mw[j] = x;
+            cnt += __popc(x);
+        }
+        ok = cnt <= (u32)mm;
+        // the seeding anchor must be exact on all planes (the key ignores plane 2 and
+        // bases beyond 32), and the pair is reported from its lowest exact anchor only
+        ok = ok && mask_range_zero<NW>(mw, (int)a * k, k);
+        for (u32 b = 0; ok && b < a; ++b)
+            if (mask_range_zero<NW>(mw, (int)b * k, k)) ok = false;
     }
-    if (cnt > (u32)mm) return;
-    // the seeding anchor must be exact on all planes (the key ignores plane 2 and
-    // bases beyond 32), and the pair is reported from its lowest exact anchor only
-    if (!mask_range_zero<NW>(mw, (int)a * k, k)) return;
-    for (u32 b = 0; b < a; ++b)
-        if (mask_range_zero<NW>(mw, (int)b * k, k)) return;
-    const u32 slot = atomicAdd(hit_count, 1u);
-    if (slot < hit_cap) { hit_probe[slot] = p; hit_pos[slot] = o; }
+    if (ok) hit_record(sink, d, p, o, o + (u32)L, sq, lo, hi);
+    else sink.rank[d] = BK_NONE;
 }
 
 typedef void (*seed_verify_fn)(const u32 *, i64, const u32 *, const uint4 *, int, int, int, int, u32, int,
-                               const u32 *, const u32 *, const u32 *, const u32 *, u32, u32 *, u32 *, u32 *, u32);
+                               const u32 *, const u32 *, const u32 *, const u32 *, u32, HitSink);
 static seed_verify_fn pick_seed_verify(int nw) {
     switch (nw) {
     case 1: return seed_verify_kernel<1>;
@@ -596,24 +644,6 @@ extend_kernel(const u8 *__restrict__ tbytes, const u32 *__restrict__ seq_off, u3
 // key = (owner set id << 32) | clipped start, val = clipped end
 // (catch/filter/set_cover_filter.py:424-439; the genome offset is implicit in
 // the global coordinate)
-__global__ void __launch_bounds__(256)
-rows_key_kernel(const u32 *__restrict__ hp, const u32 *__restrict__ hs, const u32 *__restrict__ he,
-                u32 fixed_len, u32 n, const u32 *__restrict__ seq_off, u32 nseq,
-                const i32 *__restrict__ set_id, u32 ext, u64 *__restrict__ keys,
-                u32 *__restrict__ vals) {
-    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    u32 gs = hs[t];
-    u32 ge = he ? he[t] : gs + fixed_len;
-    u32 s = find_segment(seq_off, nseq, gs);
-    u32 lo = seq_off[s], hi = seq_off[s + 1];
-    u32 es = (gs - lo > ext) ? gs - ext : lo;
-    u32 ee = (hi - ge > ext) ? ge + ext : hi;
-    u32 sid = set_id ? (u32)set_id[hp[t]] : hp[t];
-    keys[t] = ((u64)sid << 32) | es;
-    vals[t] = ee;
-}
-
 // After the sort: rows of one (set, segment) group are adjacent and ordered by
 // start.  The thread standing on the first row of a group walks it, merging
 // overlapping and touching intervals (catch/utils/interval.py:288-316);
@@ -763,9 +793,18 @@ static int run_fast(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
 }
 
 // K1c host side: hash table of the anchor k-mers, one lookup per target
-// position, one exact verification per seed
-static int run_seed(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm, RawHits &H,
-                    PhaseTimer &tm) {
+// position, one exact verification per seed.  Everything is stream-ordered;
+// the number of seeds stays on the device (S.ctr[1]) and the hits go straight
+// into the bucketed row build as records indexed like the seeds.
+struct SeedRun {
+    DevBuf<unsigned long long> keys;
+    DevBuf<u32> cnt, ents, slot_of, ctr, spos, sent, sseq;
+    DevBuf<uint2> range;
+    u32 scap = 0;
+};
+
+static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm, SeedRun &S,
+                          const HitSink &sink, u32 nb, u32 *res, PhaseTimer &tm) {
     const bool use_n = P->has_n || T->has_n;
     const int k = P->k, nanchor = P->L / P->k, kb = std::min(k, 32);
     const u64 nent64 = (u64)P->nprobes * nanchor;
@@ -775,58 +814,35 @@ static int run_seed(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
     if (!verify) { chip_set_error("seed scan: unsupported probe length"); return CATCHHIP_EINVAL; }
     u32 capacity = 1024;
     while ((u64)capacity < 2 * nent64) capacity <<= 1;
-    DevBuf<unsigned long long> keys;
-    DevBuf<u32> cnt, ents, slot_of, ctr, spos, sent, sseq;
-    DevBuf<uint2> range;
-    TRY(keys.alloc(capacity));
-    TRY(cnt.alloc(capacity));
-    TRY(range.alloc(capacity));
-    TRY(ents.alloc(nent));
-    TRY(slot_of.alloc(nent));
-    TRY(ctr.alloc(4));   // [0] ents cursor, [1] seeds, [2] hits
+    TRY(S.keys.reserve(capacity));
+    TRY(S.cnt.reserve(capacity));
+    TRY(S.range.reserve(capacity));
+    TRY(S.ents.reserve(nent));
+    TRY(S.slot_of.reserve(nent));
+    TRY(S.ctr.reserve(4));   // [0] ents cursor, [1] seeds
+    TRY(S.spos.reserve(S.scap));
+    TRY(S.sent.reserve(S.scap));
+    TRY(S.sseq.reserve(S.scap));
     const u32 tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
-    u32 cap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(P->nprobes * 64, (i64)1 << 28));
-    u32 scap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(T->total * 4, (i64)1 << 30));
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        TRY(H.a.reserve(cap));
-        TRY(H.b.reserve(cap));
-        TRY(spos.reserve(scap));
-        TRY(sent.reserve(scap));
-        TRY(sseq.reserve(scap));
-        tm.restart();
-        HIP_TRY(hipMemsetAsync(ctr.p, 0, 4 * sizeof(u32), ctx->stream));
-        HIP_TRY(hipMemsetAsync(keys.p, 0xff, sizeof(unsigned long long) * capacity, ctx->stream));
-        HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(u32) * capacity, ctx->stream));
-        SeedTable t = {keys.p, cnt.p, range.p, ents.p, capacity - 1};
-        const dim3 eb((unsigned)div_up((i64)nent, 256)), tb(256);
-        hipLaunchKernelGGL(seed_count_kernel, eb, tb, 0, ctx->stream, (const uint4 *)P->planes.p, nent,
-                           (int)P->pwords, k, nanchor, kb, t, slot_of.p);
-        hipLaunchKernelGGL(seed_alloc_kernel, dim3(capacity / 256), tb, 0, ctx->stream, t, ctr.p);
-        hipLaunchKernelGGL(seed_fill_kernel, eb, tb, 0, ctx->stream, nent, t, (const u32 *)slot_of.p);
-        hipLaunchKernelGGL(seed_lookup_kernel, dim3((unsigned)div_up(T->total, 256)), tb, 0, ctx->stream,
-                           (const u32 *)T->planes.p, T->nwords, (u32)T->total, (const u32 *)T->seq_off.p,
-                           (u32)T->nseq, k, kb, t, spos.p, sent.p, sseq.p, ctr.p + 1, scap);
-        hipLaunchKernelGGL(verify, dim3((unsigned)div_up((i64)scap, 256)), tb, 0, ctx->stream,
-                           (const u32 *)T->planes.p, T->nwords, (const u32 *)T->seq_off.p,
-                           (const uint4 *)P->planes.p, (int)P->L, k, nanchor, mm, tailmask, use_n ? 1 : 0,
-                           (const u32 *)spos.p, (const u32 *)sent.p, (const u32 *)sseq.p,
-                           (const u32 *)(ctr.p + 1), scap, H.a.p, H.b.p, ctr.p + 2, cap);
-        tm.launch(5);
-        tm.stop();
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(ctx->h_pin, ctr.p, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        const u32 nseeds = ((volatile u32 *)ctx->h_pin)[1], n = ((volatile u32 *)ctx->h_pin)[2];
-        if (nseeds <= scap && n <= cap) {
-            H.n = n; H.has_end = false;
-            ctx->counters[0] = n; ctx->counters[1] = nseeds;
-            return 0;
-        }
-        if (nseeds > scap) scap = nseeds;
-        if (n > cap) cap = n;
-    }
-    chip_set_error("seed scan: work list overflow");
-    return CATCHHIP_ENOMEM;
+    SeedTable t = {S.keys.p, S.cnt.p, S.range.p, S.ents.p, capacity - 1};
+    const dim3 eb((unsigned)div_up((i64)nent, 256)), tb(256);
+    hipLaunchKernelGGL(seed_init_kernel, dim3((unsigned)std::min<i64>(div_up((i64)capacity, 256), 2048)), tb, 0,
+                       ctx->stream, S.keys.p, S.cnt.p, capacity, S.ctr.p, sink.bcnt, nb, res);
+    hipLaunchKernelGGL(seed_count_kernel, eb, tb, 0, ctx->stream, (const uint4 *)P->planes.p, nent,
+                       (int)P->pwords, k, nanchor, kb, t, S.slot_of.p);
+    hipLaunchKernelGGL(seed_alloc_kernel, dim3(capacity / 1024), dim3(1024), 0, ctx->stream, t, S.ctr.p);
+    hipLaunchKernelGGL(seed_fill_kernel, eb, tb, 0, ctx->stream, nent, t, (const u32 *)S.slot_of.p);
+    hipLaunchKernelGGL(seed_lookup_kernel, dim3((unsigned)div_up(T->total, SL_TILE)), dim3(SL_THREADS), 0, ctx->stream,
+                       (const u32 *)T->planes.p, T->nwords, (u32)T->total, (const u32 *)T->seq_off.p,
+                       (u32)T->nseq, k, kb, t, S.spos.p, S.sent.p, S.sseq.p, S.ctr.p + 1, S.scap);
+    hipLaunchKernelGGL(verify, dim3((unsigned)div_up((i64)S.scap, 256)), tb, 0, ctx->stream,
+                       (const u32 *)T->planes.p, T->nwords, (const u32 *)T->seq_off.p,
+                       (const uint4 *)P->planes.p, (int)P->L, k, nanchor, mm, tailmask, use_n ? 1 : 0,
+                       (const u32 *)S.spos.p, (const u32 *)S.sent.p, (const u32 *)S.sseq.p,
+                       (const u32 *)(S.ctr.p + 1), S.scap, sink);
+    tm.launch(6);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm,
@@ -884,27 +900,97 @@ static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchh
     return 0;
 }
 
-// Sorted + merged rows from raw hits.  bounds = genome offsets (sets) or
-// sequence offsets (tolerant bp).
+// ------------------------------------------------------------------------
+// row build, host side
+// ------------------------------------------------------------------------
+struct BucketBuild {
+    DevBuf<uint4> rec;
+    DevBuf<u32> rank, bcnt, bstart, S_es, S_ee, S_seg, mcnt, blmax, rstart, biglist, res;
+    DevBuf<unsigned long long> bsum;
+    u32 nb = 0, cap = 0;
+};
+// res words: [0] large buckets listed, [1] overflow flag, [2] hits, [3] largest bucket,
+//            [4] merged rows, [5] longest row
+#define BK_MAX_BUCKETS ((i64)1 << 20)   // one-workgroup scans
+
+static int bucket_prepare(BucketBuild &B, u32 nb, u32 cap, bool want_sum) {
+    B.nb = nb; B.cap = cap;
+    TRY(B.rec.reserve(cap));
+    TRY(B.rank.reserve(cap));
+    TRY(B.S_es.reserve(cap));
+    TRY(B.S_ee.reserve(cap));
+    TRY(B.S_seg.reserve(cap));
+    TRY(B.bcnt.reserve((size_t)nb + 1));
+    TRY(B.bstart.reserve((size_t)nb + 2));
+    TRY(B.mcnt.reserve((size_t)nb + 1));
+    TRY(B.blmax.reserve((size_t)nb + 1));
+    TRY(B.rstart.reserve((size_t)nb + 2));
+    TRY(B.biglist.reserve(BK_BIGLIST));
+    TRY(B.res.reserve(8));
+    if (want_sum) TRY(B.bsum.reserve((size_t)nb + 1));
+    return 0;
+}
+
+// scan of the bucket sizes, scatter, per-bucket sort + merge, scan of the
+// merged counts.  nrec = hit records to look at (a device count, bounded by
+// B.cap, when nrec_dev is given).
+static void bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, const u32 *nrec_dev, bool want_sum,
+                                PhaseTimer &tm) {
+    hipStream_t s = ctx->stream;
+    hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, s, (const u32 *)B.bcnt.p, B.bstart.p, B.nb,
+                       B.res.p + 2, B.res.p + 3, (const u32 *)nullptr, (u32 *)nullptr);
+    if (nrec)
+        hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)div_up((i64)nrec, 256)), dim3(256), 0, s,
+                       (const uint4 *)B.rec.p, (const u32 *)B.rank.p, nrec, nrec_dev, (const u32 *)B.bstart.p,
+                       B.S_es.p, B.S_ee.p, B.S_seg.p);
+    unsigned long long *bsum = want_sum ? B.bsum.p : nullptr;
+    hipLaunchKernelGGL((bucket_merge_kernel<64, BK_SMALL>), dim3((unsigned)std::min<i64>(B.nb, (i64)1 << 20)), dim3(64),
+                       0, s, (const u32 *)B.bstart.p, B.nb, B.S_es.p, B.S_ee.p, B.S_seg.p, B.mcnt.p, B.blmax.p, bsum,
+                       (const u32 *)nullptr, (const u32 *)nullptr, B.biglist.p, B.res.p, B.res.p + 1);
+    hipLaunchKernelGGL((bucket_merge_kernel<1024, BK_BIG>), dim3(64), dim3(1024), 0, s, (const u32 *)B.bstart.p,
+                       B.nb, B.S_es.p, B.S_ee.p, B.S_seg.p, B.mcnt.p, B.blmax.p, bsum, (const u32 *)B.biglist.p,
+                       (const u32 *)B.res.p, (u32 *)nullptr, (u32 *)nullptr, B.res.p + 1);
+    hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, s, (const u32 *)B.mcnt.p, B.rstart.p, B.nb,
+                       B.res.p + 4, (u32 *)nullptr, (const u32 *)B.blmax.p, B.res.p + 5);
+    tm.launch(5);
+}
+
+// radix-sort build (fallback for buckets beyond BK_BIG / very many buckets):
+// keys (set id << 32 | start) + ends from the hit records
+__global__ void __launch_bounds__(256)
+rec_keys_kernel(const uint4 *__restrict__ rec, const u32 *__restrict__ rank, u32 nrec_cap,
+                const u32 *__restrict__ nrec_dev, const i32 *__restrict__ bucket_set, u64 *__restrict__ keys,
+                u32 *__restrict__ vals, u32 *__restrict__ count) {
+    const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 n = nrec_dev ? min(*nrec_dev, nrec_cap) : nrec_cap;
+    if (d >= n || rank[d] == BK_NONE) return;
+    const uint4 r = rec[d];
+    const u32 slot = atomicAdd(count, 1u);
+    keys[slot] = ((u64)(bucket_set ? (u32)bucket_set[r.w] : r.w) << 32) | r.x;
+    vals[slot] = r.y;
+}
+
 struct MergedRows {
     DevBuf<u64> keys, keys_alt;
-    DevBuf<u32> vals, vals_alt, head, mend, seg, idx, tmp;
+    DevBuf<u32> vals, vals_alt, head, mend, seg, idx, tmp, count;
     u32 n = 0;       // sorted raw rows
     u32 nmerged = 0; // merged rows
 };
 
-static int build_rows(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,
-                      const RawHits &H, u32 ext, bool use_set_id, const u32 *bounds, u32 nbounds,
-                      i64 max_set_id, MergedRows &M, PhaseTimer &tm) {
-    M.n = H.n;
+static int build_rows_radix(catchhip_ctx *ctx, const BucketBuild &B, u32 nrec, const u32 *nrec_dev, u32 nhits,
+                            const i32 *bucket_set, const u32 *bounds, u32 nbounds, i64 max_set_id, MergedRows &M,
+                            PhaseTimer &tm) {
+    M.n = nhits;
     M.nmerged = 0;
-    if (H.n == 0) return 0;
-    const u32 n = H.n;
+    if (nhits == 0) return 0;
+    const u32 n = nhits;
     TRY(M.keys.alloc(n));
     TRY(M.vals.alloc(n));
-    hipLaunchKernelGGL(rows_key_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, ctx->stream, H.a.p, H.b.p,
-                       H.has_end ? H.c.p : (const u32 *)nullptr, (u32)(P->L > 0 ? P->L : 0), n, T->seq_off.p,
-                       (u32)T->nseq, use_set_id ? P->set_id.p : (const i32 *)nullptr, ext, M.keys.p, M.vals.p);
+    TRY(M.count.alloc(1));
+    HIP_TRY(hipMemsetAsync(M.count.p, 0, sizeof(u32), ctx->stream));
+    hipLaunchKernelGGL(rec_keys_kernel, dim3((unsigned)div_up((i64)nrec, 256)), dim3(256), 0, ctx->stream,
+                       (const uint4 *)B.rec.p, (const u32 *)B.rank.p, nrec, nrec_dev, bucket_set, M.keys.p, M.vals.p,
+                       M.count.p);
     tm.launch();
     int bits = 32 + ceil_log2_u64((u64)max_set_id + 1);
     if (bits > 64) bits = 64;
@@ -924,6 +1010,97 @@ static int build_rows(catchhip_ctx *ctx, const catchhip_probes *P, const catchhi
     HIP_TRY(hipMemcpyAsync((u32 *)ctx->h_pin + 1, M.head.p + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     M.nmerged = ((volatile u32 *)ctx->h_pin)[0] + ((volatile u32 *)ctx->h_pin)[1];
+    return 0;
+}
+
+// Scan + grouped hit records for either consumer.  by_sequence: merge per
+// (probe, sequence) with buckets = probes (tolerant bp); otherwise per (set,
+// genome) with buckets = set ids and the cover extension applied.
+struct ScanOut {
+    BucketBuild B;
+    SeedRun S;
+    u32 nrec = 0;              // records to look at (grid size)
+    const u32 *nrec_dev = nullptr;
+    u32 nhits = 0, nrows = 0, lmax = 0, maxbucket = 0;
+    bool overflow = false;     // a bucket beyond BK_BIG: use the radix build
+};
+
+static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mismatches,
+                          int lcf_thres, int island, u32 ext, bool by_sequence, int mode, ScanOut &O) {
+    const bool fast_ok = fast_path_ok(P, T, mismatches, lcf_thres, island);
+    const bool use_seed = fast_ok && (mode == CATCHHIP_SCAN_SEED ||
+                                      (mode == CATCHHIP_SCAN_AUTO && !getenv("CATCHHIP_SCAN_TILED")));
+    const bool use_fast = fast_ok && !use_seed && mode != CATCHHIP_SCAN_GENERAL;
+    const u32 nb = by_sequence ? (u32)P->nprobes : (u32)P->nbuckets;
+    const bool force_radix = (i64)nb > BK_MAX_BUCKETS || getenv("CATCHHIP_ROWS_RADIX");
+    HitSink sink;
+    sink.bucket_of = by_sequence ? nullptr : P->bucket_of.p;
+    sink.seq_genome = by_sequence ? nullptr : T->seq_genome.p;
+    sink.ext = ext;
+    PhaseTimer ts(ctx, PHASE_SCAN), tr(ctx, PHASE_ROWS);
+    if (use_seed) {
+        O.S.scap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(T->total * 4, (i64)1 << 30));
+        for (int attempt = 0;; ++attempt) {
+            TRY(bucket_prepare(O.B, nb, O.S.scap, by_sequence));
+            sink.rec = O.B.rec.p; sink.rank = O.B.rank.p; sink.bcnt = O.B.bcnt.p;
+            ts.restart();
+            TRY(run_seed_async(ctx, P, T, mismatches, O.S, sink, nb, O.B.res.p, ts));
+            ts.stop();
+            O.nrec = O.S.scap; O.nrec_dev = O.S.ctr.p + 1;
+            tr.restart();
+            if (!force_radix) bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, by_sequence, tr);
+            else hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)O.B.bcnt.p,
+                                    O.B.bstart.p, nb, O.B.res.p + 2, O.B.res.p + 3, (const u32 *)nullptr,
+                                    (u32 *)nullptr);
+            tr.stop();
+            HIP_TRY(hipGetLastError());
+            u32 *h = (u32 *)ctx->h_pin;
+            HIP_TRY(hipMemcpyAsync(h, O.B.res.p, 8 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(h + 8, O.S.ctr.p, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            const u32 nseeds = ((volatile u32 *)h)[9];
+            if (nseeds > O.S.scap) {
+                if (attempt >= 2) { chip_set_error("seed scan: work list overflow"); return CATCHHIP_ENOMEM; }
+                O.S.scap = nseeds;
+                continue;
+            }
+            ctx->counters[1] = nseeds;
+            break;
+        }
+    } else {
+        RawHits H;
+        int rc = 0;
+        if (P->nprobes > 0 && T->total > 0)
+            rc = use_fast ? run_fast(ctx, P, T, mismatches, H, ts)
+                          : run_general(ctx, P, T, mismatches, lcf_thres, island, H, ts);
+        ts.stop();
+        if (rc) return rc;
+        TRY(bucket_prepare(O.B, nb, std::max(H.n, 1u), by_sequence));
+        sink.rec = O.B.rec.p; sink.rank = O.B.rank.p; sink.bcnt = O.B.bcnt.p;
+        HIP_TRY(hipMemsetAsync(O.B.bcnt.p, 0, sizeof(u32) * ((size_t)nb + 1), ctx->stream));
+        HIP_TRY(hipMemsetAsync(O.B.res.p, 0, sizeof(u32) * 8, ctx->stream));
+        O.nrec = H.n; O.nrec_dev = nullptr;
+        tr.restart();
+        if (H.n) {
+            hipLaunchKernelGGL(hit_record_kernel, dim3((unsigned)div_up((i64)H.n, 256)), dim3(256), 0, ctx->stream,
+                               (const u32 *)H.a.p, (const u32 *)H.b.p, H.has_end ? (const u32 *)H.c.p : (const u32 *)nullptr,
+                               (u32)(P->L > 0 ? P->L : 0), H.n, (const u32 *)T->seq_off.p, (u32)T->nseq, sink);
+            tr.launch();
+        }
+        if (!force_radix) bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, by_sequence, tr);
+        else hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)O.B.bcnt.p,
+                                O.B.bstart.p, nb, O.B.res.p + 2, O.B.res.p + 3, (const u32 *)nullptr, (u32 *)nullptr);
+        tr.stop();
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ctx->h_pin, O.B.res.p, 8 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));   // H's buffers are released after this
+    }
+    ts.finish();
+    const volatile u32 *h = (const volatile u32 *)ctx->h_pin;
+    O.overflow = h[1] != 0 || force_radix;
+    O.nhits = h[2]; O.maxbucket = h[3]; O.nrows = h[4]; O.lmax = h[5];
+    ctx->counters[0] = O.nhits;
+    tr.finish();
     return 0;
 }
 
@@ -947,9 +1124,6 @@ extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, 
     // AUTO: all paths are exact.  When the pigeonhole/full-length conditions
     // hold the seed filter (O(G + seeds)) is used; CATCHHIP_SCAN_FAST forces the
     // tiled O(P*G) scan, CATCHHIP_SCAN_GENERAL the byte-exact seed join.
-    const bool use_seed = fast_ok && (mode == CATCHHIP_SCAN_SEED ||
-                                      (mode == CATCHHIP_SCAN_AUTO && !getenv("CATCHHIP_SCAN_TILED")));
-    const bool use_fast = fast_ok && !use_seed && mode != CATCHHIP_SCAN_GENERAL;
     catchhip_rows *R = new catchhip_rows();
     R->ctx = ctx;
     R->total = T->total;
@@ -960,48 +1134,54 @@ extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, 
         if ((rc = R->genome_off.alloc((size_t)T->ngenomes + 1))) break;
         if (hipMemcpyAsync(R->genome_off.p, T->genome_off.p, sizeof(u32) * (T->ngenomes + 1),
                            hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
-        RawHits H;
-        {
-            PhaseTimer tm(ctx, PHASE_SCAN);
-            if (P->nprobes > 0 && T->total > 0) {
-                rc = use_seed ? run_seed(ctx, P, T, mismatches, H, tm)
-                     : use_fast ? run_fast(ctx, P, T, mismatches, H, tm)
-                                : run_general(ctx, P, T, mismatches, lcf_thres, island, H, tm);
+        if (P->nprobes == 0 || T->total == 0) break;   // no rows
+        ScanOut O;
+        if ((rc = scan_and_group(ctx, P, T, mismatches, lcf_thres, island, (u32)cover_extension, false, mode, O))) break;
+        PhaseTimer tm(ctx, PHASE_ROWS, true);   // continues the row-build phase (adds to its time)
+        if (!O.overflow) {
+            R->n = O.nrows;
+            R->lmax = O.lmax;
+            if ((rc = R->set_id.alloc(R->n))) break;
+            if ((rc = R->univ.alloc(R->n))) break;
+            if ((rc = R->gs.alloc(R->n))) break;
+            if ((rc = R->ge.alloc(R->n))) break;
+            if (R->n) {
+                hipLaunchKernelGGL(rows_emit_kernel, dim3((unsigned)div_up(R->n, 256)), dim3(256), 0, ctx->stream,
+                                   (const u32 *)O.B.rstart.p, O.B.nb, (const u32 *)O.B.bstart.p,
+                                   (const i32 *)P->bucket_set.p, (const u32 *)O.B.S_es.p, (const u32 *)O.B.S_ee.p,
+                                   (const u32 *)O.B.S_seg.p, (u32)R->n, R->set_id.p, R->univ.p, R->gs.p, R->ge.p);
+                tm.launch();
             }
-            tm.stop();
-            if (rc) break;
-            tm.finish();
-        }
-        MergedRows M;
-        PhaseTimer tm(ctx, PHASE_ROWS);
-        const i64 max_sid = P->max_set_id;
-        if ((rc = build_rows(ctx, P, T, H, (u32)cover_extension, true, T->genome_off.p, (u32)T->ngenomes,
-                             max_sid, M, tm))) break;
-        R->n = M.nmerged;
-        if ((rc = R->set_id.alloc(R->n))) break;
-        if ((rc = R->univ.alloc(R->n))) break;
-        if ((rc = R->gs.alloc(R->n))) break;
-        if ((rc = R->ge.alloc(R->n))) break;
-        if (M.n) {
-            DevBuf<u32> d_lmax;
-            if ((rc = d_lmax.alloc(1))) break;
-            if (hipMemsetAsync(d_lmax.p, 0, sizeof(u32), ctx->stream) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
-            hipLaunchKernelGGL(rows_compact_kernel, dim3((unsigned)div_up(M.n, 256)), dim3(256), 0, ctx->stream,
-                               M.keys.p, M.head.p, M.mend.p, M.seg.p, M.idx.p, M.n, R->set_id.p, R->univ.p,
-                               R->gs.p, R->ge.p, d_lmax.p);
-            tm.launch();
-            tm.stop();
-            if (hipMemcpyAsync(ctx->h_pin, d_lmax.p, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
-            R->lmax = *(volatile u32 *)ctx->h_pin;
+        } else {
+            MergedRows M;
+            if ((rc = build_rows_radix(ctx, O.B, O.nrec, O.nrec_dev, O.nhits, P->bucket_set.p, T->genome_off.p,
+                                       (u32)T->ngenomes, P->max_set_id, M, tm))) break;
+            R->n = M.nmerged;
+            if ((rc = R->set_id.alloc(R->n))) break;
+            if ((rc = R->univ.alloc(R->n))) break;
+            if ((rc = R->gs.alloc(R->n))) break;
+            if ((rc = R->ge.alloc(R->n))) break;
+            if (M.n) {
+                DevBuf<u32> d_lmax;
+                if ((rc = d_lmax.alloc(1))) break;
+                if (hipMemsetAsync(d_lmax.p, 0, sizeof(u32), ctx->stream) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
+                hipLaunchKernelGGL(rows_compact_kernel, dim3((unsigned)div_up(M.n, 256)), dim3(256), 0, ctx->stream,
+                                   M.keys.p, M.head.p, M.mend.p, M.seg.p, M.idx.p, M.n, R->set_id.p, R->univ.p,
+                                   R->gs.p, R->ge.p, d_lmax.p);
+                tm.launch();
+                if (hipMemcpyAsync(ctx->h_pin, d_lmax.p, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                    hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
+                R->lmax = *(volatile u32 *)ctx->h_pin;
+            }
         }
         tm.stop();
+        // the scratch buffers of the build are released when O goes out of scope
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
             chip_set_error("cover_scan: row build failed: %s", hipGetErrorString(hipGetLastError()));
             rc = CATCHHIP_EHIP;
             break;
         }
-        tm.finish();
+        tm.finish_add();
     } while (0);
     if (rc) { delete R; return rc; }
     *out = R;
@@ -1014,33 +1194,32 @@ extern "C" int catchhip_tolerant_bp(catchhip_ctx *ctx, const catchhip_probes *P,
     ARG_CHECK(ctx && P && T && bp_out);
     HIP_TRY(hipSetDevice(ctx->device));
     if (P->nprobes == 0 || T->total == 0) return 0;
-    const bool use_seed = fast_path_ok(P, T, mismatches, lcf_thres, island);
-    RawHits H;
-    {
-        PhaseTimer tm(ctx, PHASE_SCAN);
-        int rc = use_seed ? run_seed(ctx, P, T, mismatches, H, tm)
-                          : run_general(ctx, P, T, mismatches, lcf_thres, island, H, tm);
-        tm.stop();
-        if (rc) return rc;
-        tm.finish();
-    }
-    if (H.n == 0) return 0;
-    MergedRows M;
-    PhaseTimer tm(ctx, PHASE_ROWS);
     // merge per (probe, sequence): probe.find_probe_covers_in_sequence merges per sequence
-    TRY(build_rows(ctx, P, T, H, 0u, false, T->seq_off.p, (u32)T->nseq, P->nprobes, M, tm));
-    DevBuf<unsigned long long> bp;
-    TRY(bp.alloc((size_t)P->nprobes));
-    HIP_TRY(hipMemsetAsync(bp.p, 0, sizeof(unsigned long long) * P->nprobes, ctx->stream));
-    hipLaunchKernelGGL(rows_bp_kernel, dim3((unsigned)div_up(M.n, 256)), dim3(256), 0, ctx->stream, M.keys.p,
-                       M.head.p, M.mend.p, M.n, bp.p);
-    tm.launch();
-    tm.stop();
+    ScanOut O;
+    TRY(scan_and_group(ctx, P, T, mismatches, lcf_thres, island, 0u, true, CATCHHIP_SCAN_AUTO, O));
+    if (O.nhits == 0) return 0;
     std::vector<unsigned long long> h((size_t)P->nprobes);
-    HIP_TRY(hipMemcpyAsync(h.data(), bp.p, sizeof(unsigned long long) * P->nprobes, hipMemcpyDeviceToHost,
-                           ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    tm.finish();
+    if (!O.overflow) {
+        HIP_TRY(hipMemcpyAsync(h.data(), O.B.bsum.p, sizeof(unsigned long long) * P->nprobes, hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    } else {
+        MergedRows M;
+        PhaseTimer tm(ctx, PHASE_ROWS, true);
+        TRY(build_rows_radix(ctx, O.B, O.nrec, O.nrec_dev, O.nhits, nullptr, T->seq_off.p, (u32)T->nseq, P->nprobes,
+                             M, tm));
+        DevBuf<unsigned long long> bp;
+        TRY(bp.alloc((size_t)P->nprobes));
+        HIP_TRY(hipMemsetAsync(bp.p, 0, sizeof(unsigned long long) * P->nprobes, ctx->stream));
+        hipLaunchKernelGGL(rows_bp_kernel, dim3((unsigned)div_up(M.n, 256)), dim3(256), 0, ctx->stream, M.keys.p,
+                           M.head.p, M.mend.p, M.n, bp.p);
+        tm.launch();
+        tm.stop();
+        HIP_TRY(hipMemcpyAsync(h.data(), bp.p, sizeof(unsigned long long) * P->nprobes, hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        tm.finish_add();
+    }
     for (i64 i = 0; i < P->nprobes; ++i) bp_out[i] += (i64)h[i];
     return 0;
 }

@@ -102,6 +102,41 @@ def test_scan_general_matches_oracle(ctx, oracle, L, stride, m, thres, island,
     assert got == exp
 
 
+@pytest.mark.parametrize("copies", [40, 700, 4500])
+def test_scan_repeats_fill_large_buckets(ctx, oracle, copies):
+    """A unit repeated `copies` times: the probes inside the unit hit every
+    copy, so their row-build buckets exceed what one wavefront (512 hits) and
+    one workgroup (4096) sort -- the wave, workgroup and radix-sort builds must
+    all give the reference's rows, in every scan mode."""
+    engine = _engine()
+    rng = random.Random(copies)
+    def rs(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+    unit = rs(150)
+    g0 = "".join(unit + rs(30) for _ in range(copies))
+    genomes = [[g0], [rs(400) + unit + rs(300)]]
+    probes = candidates([[unit + rs(50)], [g0[:2000]]], 100, 25)
+    exp = _oracle_rows(oracle, probes, genomes, 2, 100, 0, 20)
+    assert max(np.bincount([r[0] for r in exp])) >= min(copies, 2)
+    for mode in (engine.SCAN_SEED, engine.SCAN_GENERAL, engine.SCAN_FAST):
+        assert _scan_rows(ctx, probes, genomes, 2, 100, 0, 20, mode) == exp
+    if copies == 700:
+        # tolerant-bp accounting goes through the same bucket build
+        p_mod = _probe_mod()
+        k, uniq, owner, ep, eo = p_mod.anchor_table(probes, 2, 100)
+        t = engine.Targets(ctx, genomes)
+        p = engine.Probes(ctx, uniq, owner, ep, eo, k)
+        out = np.zeros(len(uniq), dtype=np.int64)
+        engine.tolerant_bp(ctx, p, t, 2, 100, 0, out)
+        rows = _scan_rows(ctx, probes, [[s] for g in genomes for s in g], 2, 100, 0, 0)
+        want = np.zeros(len(probes), dtype=np.int64)
+        for sid, _, a, b in rows:
+            want[sid] += b - a
+        own = np.array(owner)
+        assert np.array_equal(out, want[own])
+        p.close(); t.close()
+
+
 def test_scan_multi_chromosome_and_short_sequences(ctx, oracle):
     """Genome coordinates across chromosomes (set_cover_filter.py:429-453),
     sequences shorter than the probe and than k, empty sequences."""
