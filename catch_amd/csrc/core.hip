@@ -120,6 +120,19 @@ extern "C" int catchhip_ctx_create(int device, catchhip_ctx **out) {
     return 0;
 }
 
+int chip_pinned_reserve(catchhip_ctx *c, size_t bytes) {
+    if (bytes <= c->h_big_bytes) return 0;
+    size_t want = std::max<size_t>(bytes, (size_t)1 << 20);
+    want = (want + 4095) & ~(size_t)4095;
+    if (c->h_big) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->h_big); c->h_big = nullptr; c->h_big_bytes = 0; }
+    if (hipHostMalloc(&c->h_big, want, hipHostMallocDefault) != hipSuccess) {
+        chip_set_error("hipHostMalloc(%zu) failed", want);
+        return CATCHHIP_ENOMEM;
+    }
+    c->h_big_bytes = want;
+    return 0;
+}
+
 extern "C" int catchhip_ctx_destroy(catchhip_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
@@ -128,6 +141,7 @@ extern "C" int catchhip_ctx_destroy(catchhip_ctx *c) {
     for (int i = 0; i < 2 * NPHASE; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_big) (void)hipHostFree(c->h_big);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;

@@ -99,11 +99,18 @@ struct catchhip_ctx {
     i64 counters[8] = {};
     // pinned staging word(s) for small device->host reads
     u64 *h_pin = nullptr;
+    // larger pinned staging area (grown on demand) so that result read-backs are
+    // truly asynchronous and one synchronisation collects all of them
+    void *h_big = nullptr;
+    size_t h_big_bytes = 0;
     // RCCL (optional)
     void *comm = nullptr;
     int nranks = 1, rank = 0;
     int num_cus = 256;
 };
+
+// pinned host scratch of at least `bytes` (contents not preserved on growth)
+int chip_pinned_reserve(catchhip_ctx *ctx, size_t bytes);
 
 struct catchhip_targets {
     catchhip_ctx *ctx = nullptr;

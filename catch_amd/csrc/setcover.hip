@@ -758,6 +758,113 @@ extern "C" int catchhip_comm_destroy(catchhip_ctx *ctx) {
     return 0;
 }
 
+// Host side of the frontier solver (setcover_batched.inc).  One zeroed arena,
+// two set-up launches, rounds in batches, ONE synchronisation per batch that
+// brings back the state, the picks and their keys through pinned memory.
+static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets, const u32 *h_rank, u32 nrank,
+                           i64 *out_ids, i64 *n_out) {
+    hipStream_t s = ctx->stream;
+    const u32 nrows = (u32)R->n, nuniv = (u32)R->ngenomes;
+    const size_t nwords = (size_t)(R->total / 64 + 2);
+    const unsigned gblocks = (unsigned)std::min<i64>(div_up(nsets, GF_SETS), (i64)ctx->num_cus * 16);
+    // arena: the zero-initialised part first
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_bm = take(8 * nwords), o_ow0 = take(8 * (nwords + 8)), o_ow1 = take(8 * (nwords + 8)),
+                 o_blk = take(16 * (size_t)gblocks), o_st = take(sizeof(GreedyState)),
+                 o_picked = take(4 * (size_t)nsets), o_claimed = take(4 * (size_t)nsets),
+                 o_rank = take(4 * (size_t)nsets);
+    const size_t zero_bytes = off;
+    const size_t o_usize = take(4 * (size_t)nuniv), o_gain = take(4 * (size_t)nsets),
+                 o_setptr = take(4 * ((size_t)nsets + 1)), o_frow = take(16 * (size_t)nrows),
+                 o_flag = take(nrows), o_picks = take(4 * (size_t)nsets), o_keys = take(8 * (size_t)nsets);
+    DevBuf<u8> arena;
+    TRY(arena.alloc(off));
+    u8 *A = arena.p;
+    // pinned staging: ranks up, {state, counters, picks, keys} down
+    const size_t pin_bytes = sizeof(GreedyState) + 16 * (size_t)gblocks + 12 * (size_t)nsets + 64;
+    TRY(chip_pinned_reserve(ctx, std::max(pin_bytes, 4 * (size_t)nsets)));
+    HIP_TRY(hipMemsetAsync(A, 0, zero_bytes, s));
+    if (h_rank) {
+        memcpy(ctx->h_big, h_rank, 4 * (size_t)nsets);
+        HIP_TRY(hipMemcpyAsync(A + o_rank, ctx->h_big, 4 * (size_t)nsets, hipMemcpyHostToDevice, s));
+    }
+    FrontArgs fa;
+    fa.bm = (unsigned long long *)(A + o_bm);
+    fa.owner[0] = (unsigned long long *)(A + o_ow0); fa.owner[1] = (unsigned long long *)(A + o_ow1);
+    fa.frow = (const uint4 *)(A + o_frow); fa.set_ptr = (const u32 *)(A + o_setptr); fa.rank = (const u32 *)(A + o_rank);
+    fa.usize = (u32 *)(A + o_usize); fa.gain = (u32 *)(A + o_gain); fa.claimed = (u32 *)(A + o_claimed);
+    fa.picked = (u32 *)(A + o_picked); fa.picks = (u32 *)(A + o_picks);
+    fa.pick_key = (unsigned long long *)(A + o_keys); fa.rowflag = A + o_flag;
+    fa.blkcnt = (unsigned long long *)(A + o_blk); fa.st = (GreedyState *)(A + o_st);
+    fa.nsets = nsets; fa.nwords = (u32)nwords;
+
+    PhaseTimer tm(ctx, PHASE_GREEDY);
+    hipLaunchKernelGGL(gf_build_kernel, dim3((unsigned)div_up(std::max(nrows, nsets + 1), 256)), dim3(256), 0, s,
+                       (const i32 *)R->set_id.p, (const i32 *)R->univ.p, (const u32 *)R->gs.p, (const u32 *)R->ge.p,
+                       nrows, nsets, nrank, (uint4 *)(A + o_frow), fa.bm, (u32 *)(A + o_setptr), fa.st);
+    hipLaunchKernelGGL(gf_universe_kernel, dim3(nuniv), dim3(256), 0, s, (const unsigned long long *)fa.bm,
+                       (const u32 *)R->genome_off.p, fa.usize, fa.st);
+    tm.launch(2);
+    // the host looks at the state after a batch of rounds (the kernels no-op
+    // once everything is covered)
+    const i64 max_rounds = (i64)nsets + nrank + 2;
+    i64 rounds = 0;
+    int per_sync = 10;
+    u8 *H = (u8 *)ctx->h_big;
+    GreedyState *h_st = (GreedyState *)H;
+    unsigned long long *h_blk = (unsigned long long *)(H + sizeof(GreedyState));
+    u32 *h_picks = (u32 *)(H + sizeof(GreedyState) + 16 * (size_t)gblocks);
+    unsigned long long *h_keys = (unsigned long long *)(H + sizeof(GreedyState) + 16 * (size_t)gblocks +
+                                                         ((4 * (size_t)nsets + 7) & ~(size_t)7));
+    PhaseTimer tr(ctx, PHASE_GREEDY_ROUNDS);   // the round launches only
+    for (;;) {
+        for (int r = 0; r < per_sync; ++r, ++rounds) {
+            hipLaunchKernelGGL(gf_count_claim_kernel, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
+            hipLaunchKernelGGL(gf_check_apply_kernel, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
+        }
+        tm.launch(2 * per_sync);
+        tr.stop();
+        tm.stop();
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_st, fa.st, sizeof(GreedyState), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h_blk, fa.blkcnt, 16 * (size_t)gblocks, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h_picks, fa.picks, 4 * (size_t)nsets, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h_keys, fa.pick_key, 8 * (size_t)nsets, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (h_st->done || h_st->n_need == 0) break;
+        if (rounds > max_rounds) { chip_set_error("setcover: round cap exceeded"); return CATCHHIP_EINVAL; }
+        per_sync = 6;
+        tr.stopped = false;   // further rounds extend both phases
+        tm.stopped = false;
+    }
+    tr.launch(2 * rounds);
+    tr.finish();
+    tm.finish();
+    i64 n_rec = 0, n_wrd = 0;
+    for (unsigned b = 0; b < gblocks; ++b) { n_rec += (i64)h_blk[2 * b]; n_wrd += (i64)h_blk[2 * b + 1]; }
+    ctx->phase_launches[PHASE_GREEDY] = h_st->iters;
+    ctx->counters[2] = h_st->iters; ctx->counters[3] = h_st->npicks; ctx->counters[4] = 0;
+    ctx->counters[5] = n_rec; ctx->counters[6] = n_wrd;
+    if (h_st->done == 2) {
+        chip_set_error("setcover: ranks exhausted while coverage is still required");
+        return CATCHHIP_ERANK;
+    }
+    // sequential pick order = by rank, then by descending accept-time key
+    // (see setcover_batched.inc)
+    const u32 np = h_st->npicks;
+    std::vector<u32> ord(np);
+    for (u32 i = 0; i < np; ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](u32 x, u32 y) {
+        const u32 rx = h_rank ? h_rank[h_picks[x]] : 0u, ry = h_rank ? h_rank[h_picks[y]] : 0u;
+        if (rx != ry) return rx < ry;
+        return h_keys[x] > h_keys[y];
+    });
+    for (u32 i = 0; i < np; ++i) out_ids[i] = h_picks[ord[i]];
+    *n_out = np;
+    return 0;
+}
+
 extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *R, i64 num_sets, const i64 *ranks,
                                         const double *universe_p, i64 *out_ids, i64 *n_out) {
     ARG_CHECK(ctx && R && n_out && num_sets >= 0 && R->ctx == ctx);
@@ -796,9 +903,11 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     if (universe_p)
         for (u32 u = 0; u < nuniv && batched; ++u) batched = universe_p[u] == 1.0;
 
+    if (batched) return greedy_frontier(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out);
+
     DevBuf<u32> set_ptr, flag, idx, tmp, seg_row, seg_univ, seg_set, row_seg, set_seg_ptr, usize, can, left, rank,
         picked, picks;
-    DevBuf<unsigned long long> bm, pick_key;
+    DevBuf<unsigned long long> bm;
     DevBuf<double> d_p;
     DevBuf<GreedyState> st;
     const size_t nwords = (size_t)(R->total / 64 + 2);
@@ -859,68 +968,7 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         tm.launch(6);
     }
     int rc = 0;
-    bool sort_picks = false;
-    if (batched) {
-        // ---- frontier solver: rounds of (count+claim, check+apply) launches ----
-        DevBuf<uint4> frow;
-        DevBuf<unsigned long long> owner0, owner1;
-        DevBuf<u32> gain, claimed;
-        DevBuf<unsigned long long> blkcnt;
-        DevBuf<u8> rowflag;
-        TRY(frow.alloc(nrows));
-        TRY(owner0.alloc(nwords + 8));
-        TRY(owner1.alloc(nwords + 8));
-        TRY(gain.alloc(nsets));
-        TRY(claimed.alloc(nsets));
-        TRY(rowflag.alloc(nrows));
-        TRY(pick_key.alloc(nsets));
-        HIP_TRY(hipMemsetAsync(owner0.p, 0, sizeof(unsigned long long) * (nwords + 8), s));
-        HIP_TRY(hipMemsetAsync(owner1.p, 0, sizeof(unsigned long long) * (nwords + 8), s));
-        HIP_TRY(hipMemsetAsync(claimed.p, 0, sizeof(u32) * nsets, s));
-        hipLaunchKernelGGL(frow_fill_kernel, dim3(rb), dim3(256), 0, s, R->gs.p, R->ge.p, R->univ.p, nrows, frow.p);
-        tm.launch(1);
-        FrontArgs fa;
-        fa.bm = bm.p; fa.owner[0] = owner0.p; fa.owner[1] = owner1.p; fa.frow = frow.p; fa.set_ptr = set_ptr.p;
-        fa.rank = rank.p; fa.usize = usize.p; fa.gain = gain.p; fa.claimed = claimed.p; fa.picked = picked.p;
-        fa.picks = picks.p; fa.pick_key = pick_key.p; fa.rowflag = rowflag.p; fa.st = st.p; fa.nsets = nsets; fa.nwords = (u32)nwords;
-        const unsigned gblocks = (unsigned)std::min<i64>(div_up(nsets, GF_SETS), (i64)ctx->num_cus * 16);
-        TRY(blkcnt.alloc(2 * (size_t)gblocks));
-        HIP_TRY(hipMemsetAsync(blkcnt.p, 0, sizeof(unsigned long long) * 2 * gblocks, s));
-        fa.blkcnt = blkcnt.p;
-        // the host looks at the state after a batch of rounds (the kernels
-        // no-op once everything is covered)
-        const i64 max_rounds = (i64)nsets + nrank + 2;
-        i64 rounds = 0;
-        int per_sync = 8;
-        PhaseTimer tr(ctx, PHASE_GREEDY_ROUNDS);   // the round launches only
-        for (;;) {
-            for (int r = 0; r < per_sync; ++r, ++rounds) {
-                hipLaunchKernelGGL(gf_count_claim_kernel, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
-                hipLaunchKernelGGL(gf_check_apply_kernel, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
-            }
-            tm.launch(2 * per_sync);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(&h_st, st.p, sizeof(h_st), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (h_st.done || h_st.n_need == 0) break;
-            if (rounds > max_rounds) { chip_set_error("setcover: round cap exceeded"); return CATCHHIP_EINVAL; }
-            per_sync = 4;
-        }
-        if (!h_st.done) h_st.done = 1;
-        tr.launch(2 * rounds);
-        tr.finish();
-        tm.stop();
-        tm.finish();
-        sort_picks = true;
-        std::vector<unsigned long long> h_blk(2 * (size_t)gblocks);
-        HIP_TRY(hipMemcpyAsync(h_blk.data(), blkcnt.p, sizeof(unsigned long long) * h_blk.size(), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        i64 n_rec = 0, n_wrd = 0;
-        for (unsigned b = 0; b < gblocks; ++b) { n_rec += (i64)h_blk[2 * b]; n_wrd += (i64)h_blk[2 * b + 1]; }
-        ctx->phase_launches[PHASE_GREEDY] = h_st.iters;
-        ctx->counters[2] = h_st.iters; ctx->counters[3] = h_st.npicks; ctx->counters[4] = 0;
-        ctx->counters[5] = n_rec; ctx->counters[6] = n_wrd;
-    } else if (!distributed) {
+    if (!distributed) {
         // ---- persistent single-workgroup solver ---------------------------
         DevBuf<u32> prowcnt, segcnt, segcontrib, gain, dirty, pos_row, pos_row_alt, useg, useg_alt, useg_ptr,
             bucket;
@@ -1020,30 +1068,11 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     }
     if (h_st.done != 1) { chip_set_error("setcover: solver did not finish"); return CATCHHIP_EHIP; }
     std::vector<u32> h_picks(h_st.npicks);
-    std::vector<unsigned long long> h_keys;
     if (h_st.npicks) {
         HIP_TRY(hipMemcpyAsync(h_picks.data(), picks.p, sizeof(u32) * h_st.npicks, hipMemcpyDeviceToHost, s));
-        if (sort_picks) {
-            h_keys.resize(h_st.npicks);
-            HIP_TRY(hipMemcpyAsync(h_keys.data(), pick_key.p, sizeof(unsigned long long) * h_st.npicks,
-                                   hipMemcpyDeviceToHost, s));
-        }
         HIP_TRY(hipStreamSynchronize(s));
     }
-    if (sort_picks) {
-        // sequential pick order = by rank, then by descending accept-time key
-        // (see setcover_batched.inc)
-        std::vector<u32> ord(h_st.npicks);
-        for (u32 i = 0; i < h_st.npicks; ++i) ord[i] = i;
-        std::sort(ord.begin(), ord.end(), [&](u32 x, u32 y) {
-            const u32 rx = h_rank[h_picks[x]], ry = h_rank[h_picks[y]];
-            if (rx != ry) return rx < ry;
-            return h_keys[x] > h_keys[y];
-        });
-        for (u32 i = 0; i < h_st.npicks; ++i) out_ids[i] = h_picks[ord[i]];
-    } else {
-        for (u32 i = 0; i < h_st.npicks; ++i) out_ids[i] = h_picks[i];
-    }
+    for (u32 i = 0; i < h_st.npicks; ++i) out_ids[i] = h_picks[i];
     *n_out = h_st.npicks;
     return 0;
 }
