@@ -76,6 +76,9 @@ def one_step(ctx, groups, stats=None):
             stats["scan_launches"] += nl
             stats["rows_ms"] += ctx.kernel_ms(engine.PHASE_ROWS)[0]
             stats["rows"] += rows.n
+            c = ctx.counters()
+            for k in ("raw_hits", "seed_hits"):
+                stats[k] = stats.get(k, 0) + c[k]
         ids = rows.greedy(g.n_sets)
         if stats is not None:
             ms, nl = ctx.kernel_ms(engine.PHASE_GREEDY)
@@ -95,8 +98,9 @@ def one_step(ctx, groups, stats=None):
     return picks
 
 
-def pmc_traffic(kernel, workload, scale):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+def pmc_traffic(unit, workload, scale):
+    """HBM bytes per launch of `unit` (a kernel, or the pair of kernels of a
+    solver round) from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in
     separate runs of this same command; FETCH_SIZE doubled for gfx950 as
     MI355X_MICROARCH.md prescribes).  None when no matching record exists:
@@ -107,8 +111,9 @@ def pmc_traffic(kernel, workload, scale):
             rec = json.load(f)
         if rec.get("workload") != workload or scale != 1.0:
             return None
-        k = rec["kernels"][kernel]
-        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+        k = rec["units"][unit]
+        return (2.0 * k["FETCH_SIZE_KB_per_launch"]
+                + k["WRITE_SIZE_KB_per_launch"]) * 1024.0
     except (OSError, KeyError, ValueError):
         return None
 
@@ -207,51 +212,67 @@ def main():
         P = sum(r.n_sets for r in resident)
         G = sum(r.G for r in resident)
         rows_per_step = stats["rows"] / K
-        # K1 algorithmic bytes: 0.375 B/base, T_p = 1024
-        k1_bytes = sum(0.375 * r.G * -(-r.n_unique // 1024)
-                       + 0.375 * PROBE_LEN * r.n_unique for r in resident) \
-            + 16.0 * rows_per_step
+        # Algorithmic bytes per step (DESIGN.md "Roofline accounting"):
+        #  K1 seed scan: 2 planes of the targets (0.25 B/base) + one hash-table
+        #    probe per position (8 B key + 8 B range) + per seed: work-list
+        #    write+read (24 B), the target window (3 planes x 5 words = 60 B),
+        #    the probe image (64 B) and the hit record (20 B)
+        #  rows: per hit 20 B record read + 12 B scatter + 12 B sort read; per
+        #    merged row 12 B write + 12 B read + 16 B final row
+        #  K2 round: per re-counted row 16 B record + 1 B flag, per bitmap word
+        #    8 B read + 8 B owner word, per set and round 12 B of state
+        seeds_step = stats.get("seed_hits", 0) / K
+        hits_step = stats.get("raw_hits", 0) / K
+        k1_bytes = 16.25 * G + 168.0 * seeds_step
+        rows_bytes = 44.0 * hits_step + 40.0 * rows_per_step
         k1_ms = stats["scan_ms"] / K
+        rows_ms = stats["rows_ms"] / K
         k1_launch_ms = stats["scan_ms"] / max(stats["scan_launches"], 1)
         k1_gbs = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-        # K2 algorithmic bytes, per greedy solve:
-        #   12 B per re-counted (dirty) row + 8 B per bitmap word read for
-        #   them + 8 B per bitmap word of the winner's rows (read-modify-write)
+        rows_gbs = rows_bytes / (rows_ms * 1e-3) / 1e9 if rows_ms > 0 else 0.0
         picks_per_step = stats["picks"] / K
         k2_ms = stats["greedy_ms"] / K
-        words_per_row = (PROBE_LEN + 2 * EXT + 63) // 64 + 1
-        k2_bytes_step = (12.0 * stats.get("rows_recounted", 0)
-                         + 8.0 * stats.get("bitmap_words_read", 0)
-                         + 8.0 * words_per_row * stats.get("winner_rows", 0)) / K
-        k2_rounds_ms = stats.get("rounds_ms", 0.0) / K     # (select, re-count) launches only
+        rounds_step = stats.get("greedy_iters", 0) / K
+        k2_bytes_step = (17.0 * stats.get("rows_recounted", 0)
+                         + 16.0 * stats.get("bitmap_words_read", 0)) / K \
+            + 12.0 * P * rounds_step
+        k2_rounds_ms = stats.get("rounds_ms", 0.0) / K     # the round launches only
         k2_launches = stats.get("rounds_launches", 0)
         k2_gbs = k2_bytes_step / (k2_rounds_ms * 1e-3) / 1e9 if k2_rounds_ms > 0 else 0.0
-        # dominant kernel = the one with the most device time per step; the
-        # solver rounds count as one unit (pairs of small launches)
-        dominant = "k2_greedy" if k2_rounds_ms >= k1_ms else "k1_scan"
-        if dominant == "k1_scan":
-            # VALU-bound by construction (every target word is reused by all
-            # probes of a chunk); the HBM fraction is reported as the contract
-            # asks, the VALU figures say how busy the kernel really is
-            roof = dict(bound="hbm", kernel="scan_fast3_kernel",
+        # dominant kernel = the unit with the most device time per step.  A
+        # solver round is one unit: gf_count_claim_kernel + gf_check_apply_kernel
+        # (two dependent launches; HIP events bracket the whole batch of rounds)
+        phases = {"k1_seed_scan": k1_ms, "rows_build": rows_ms,
+                  "k2_solver_rounds": k2_rounds_ms}
+        dominant = max(phases, key=phases.get)
+        if dominant == "k2_solver_rounds":
+            pair_ms = stats.get("rounds_ms", 0.0) / max(k2_launches // 2, 1)
+            roof = dict(bound="hbm",
+                        kernel="gf_count_claim_kernel+gf_check_apply_kernel",
+                        achieved=k2_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=k2_gbs / HBM_PEAK_GBS,
+                        traffic=pmc_traffic("solver_round", args.workload, args.scale),
+                        algorithmic_bytes_per_launch=(
+                            k2_bytes_step * K / max(k2_launches // 2, 1)),
+                        avg_launch_ms=pair_ms,
+                        launches_are="pairs (count+claim, check+apply), "
+                                     "including the no-op pairs after the last round",
+                        us_per_pick=k2_rounds_ms * 1e3 / max(picks_per_step, 1),
+                        rounds_per_step=rounds_step)
+        elif dominant == "k1_seed_scan":
+            roof = dict(bound="hbm", kernel="seed scan (6 launches)",
                         achieved=k1_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=k1_gbs / HBM_PEAK_GBS,
-                        traffic=pmc_traffic("scan_fast3_kernel", args.workload, args.scale),
-                        algorithmic_bytes_per_launch=k1_bytes / max(len(resident), 1),
-                        avg_launch_ms=k1_launch_ms,
-                        valu_inst_per_probe_bp=3.92,
-                        valu_lane_ops_per_s=(3.92 * sum(r.n_unique * r.G for r in resident)
-                                             / (k1_ms * 1e-3)) if k1_ms > 0 else None,
-                        valu_lane_ops_peak=78.6e12)
+                        traffic=pmc_traffic("seed_scan", args.workload, args.scale),
+                        algorithmic_bytes_per_launch=k1_bytes * K / max(stats["scan_launches"], 1),
+                        avg_launch_ms=k1_launch_ms)
         else:
-            roof = dict(bound="hbm", kernel="gb_select_kernel+gb_recount_kernel",
-                        achieved=k2_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=k2_gbs / HBM_PEAK_GBS, traffic=None,
-                        avg_launch_ms=(stats.get("rounds_ms", 0.0)
-                                       / max(k2_launches, 1)),
-                        us_per_pick=k2_rounds_ms * 1e3 / max(picks_per_step, 1),
-                        rows_recounted_per_pick=(stats.get("rows_recounted", 0)
-                                                 / max(stats["picks"], 1)))
+            roof = dict(bound="hbm", kernel="bucketed row build",
+                        achieved=rows_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=rows_gbs / HBM_PEAK_GBS,
+                        traffic=pmc_traffic("rows_build", args.workload, args.scale),
+                        algorithmic_bytes_per_launch=rows_bytes / 6.0,
+                        avg_launch_ms=rows_ms / 6.0)
         out = {
             "metric": "candidate-probe x target-bp / s through SetCoverFilter "
                       "(K1 scan + K2 greedy)",
@@ -264,10 +285,12 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 bit-planes / u64 bitmap (integer)",
             "data": "synthetic",
-            "config": {"workload": "%s (BASELINE configs[1]): %d genomes in "
+            "config": {"workload": "%s (BASELINE configs[%d]%s): %d genomes in "
                                    "%d groups, G=%d bp, P=%d candidates, "
                                    "-pl 100 -ps 50 -m 2 -e 50 -c 1.0"
                                    % (args.workload,
+                                      {"S1": 0, "S2": 1, "S3": 2, "S4": 3}.get(args.workload, 1),
+                                      "" if args.scale == 1.0 else " scaled x%g" % args.scale,
                                       sum(len(g) for g in groups),
                                       len(groups), G, P),
                        "per_rank": True, "shard": args.shard,
@@ -275,7 +298,7 @@ def main():
             "setcoverfilter_ms": elapsed / K * 1e3,
             "picks": picks_per_step, "rows": rows_per_step,
             "kernel_ms_per_step": {"k1_scan": k1_ms,
-                                   "rows_build": stats["rows_ms"] / K,
+                                   "rows_build": rows_ms,
                                    "k2_greedy": k2_ms,
                                    "k2_greedy_rounds_only": k2_rounds_ms},
             "k1_probe_bp_per_s": (sum(r.n_unique * r.G for r in resident)
@@ -285,11 +308,18 @@ def main():
                                 peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=k1_gbs / HBM_PEAK_GBS,
                                 avg_launch_ms=k1_launch_ms),
+            "roofline_rows": dict(bound="hbm", achieved=rows_gbs,
+                                  peak=HBM_PEAK_GBS, unit="GB/s",
+                                  frac=rows_gbs / HBM_PEAK_GBS),
             "roofline_k2": dict(bound="hbm", achieved=k2_gbs,
                                 peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=k2_gbs / HBM_PEAK_GBS,
                                 us_per_pick=k2_rounds_ms * 1e3 / max(picks_per_step, 1),
-                                rounds_per_step=stats.get("greedy_iters", 0) / K),
+                                rounds_per_step=rounds_step),
+            "work_per_step": {"seeds": seeds_step, "hits": hits_step,
+                              "rows": rows_per_step,
+                              "rows_recounted": stats.get("rows_recounted", 0) / K,
+                              "bitmap_words_read": stats.get("bitmap_words_read", 0) / K},
             "h2d_upload_s": upload_s,
             "value_incl_h2d": total_units / (elapsed / K + upload_s),
         }

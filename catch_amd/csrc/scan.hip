@@ -905,13 +905,12 @@ static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchh
 // ------------------------------------------------------------------------
 struct BucketBuild {
     DevBuf<uint4> rec;
-    DevBuf<u32> rank, bcnt, bstart, S_es, S_ee, S_seg, mcnt, blmax, rstart, biglist, res;
+    DevBuf<u32> rank, bcnt, bstart, S_es, S_ee, S_seg, mcnt, blmax, rstart, res, tsum, tamax;
     DevBuf<unsigned long long> bsum;
     u32 nb = 0, cap = 0;
 };
-// res words: [0] large buckets listed, [1] overflow flag, [2] hits, [3] largest bucket,
-//            [4] merged rows, [5] longest row
-#define BK_MAX_BUCKETS ((i64)1 << 20)   // one-workgroup scans
+// res words: [0] unused, [1] overflow flag (a bucket beyond BK_BIG), [2] hits, [3] largest bucket,
+//            [4] merged rows, [5] longest row   ([3] is no longer filled)
 
 static int bucket_prepare(BucketBuild &B, u32 nb, u32 cap, bool want_sum) {
     B.nb = nb; B.cap = cap;
@@ -925,54 +924,82 @@ static int bucket_prepare(BucketBuild &B, u32 nb, u32 cap, bool want_sum) {
     TRY(B.mcnt.reserve((size_t)nb + 1));
     TRY(B.blmax.reserve((size_t)nb + 1));
     TRY(B.rstart.reserve((size_t)nb + 2));
-    TRY(B.biglist.reserve(BK_BIGLIST));
     TRY(B.res.reserve(8));
     if (want_sum) TRY(B.bsum.reserve((size_t)nb + 1));
+    return 0;
+}
+
+// exclusive scan of n counts (device-resident results): one workgroup for
+// small inputs, tiles otherwise
+static int bucket_scan(catchhip_ctx *ctx, BucketBuild &B, const u32 *in, u32 *out, u32 n, u32 *total_out,
+                       const u32 *aux, u32 *auxmax_out, PhaseTimer &tm) {
+    hipStream_t s = ctx->stream;
+    if (n <= 16384) {
+        hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, s, in, out, n, total_out, (u32 *)nullptr, aux,
+                           auxmax_out);
+        tm.launch(1);
+        return 0;
+    }
+    const u32 ntiles = (u32)div_up((i64)n, SCT_TILE);
+    TRY(B.tsum.reserve(ntiles));
+    TRY(B.tamax.reserve(ntiles));
+    hipLaunchKernelGGL(scan_tiles_reduce_kernel, dim3(ntiles), dim3(SCT_THREADS), 0, s, in, n, aux, B.tsum.p,
+                       B.tamax.p);
+    hipLaunchKernelGGL(scan_tiles_apply_kernel, dim3(ntiles), dim3(SCT_THREADS), 0, s, in, out, n,
+                       (const u32 *)B.tsum.p, (const u32 *)B.tamax.p, ntiles, total_out, auxmax_out);
+    tm.launch(2);
     return 0;
 }
 
 // scan of the bucket sizes, scatter, per-bucket sort + merge, scan of the
 // merged counts.  nrec = hit records to look at (a device count, bounded by
 // B.cap, when nrec_dev is given).
-static void bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, const u32 *nrec_dev, bool want_sum,
-                                PhaseTimer &tm) {
+static int bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, const u32 *nrec_dev, bool want_sum,
+                               bool merge, PhaseTimer &tm) {
     hipStream_t s = ctx->stream;
-    hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, s, (const u32 *)B.bcnt.p, B.bstart.p, B.nb,
-                       B.res.p + 2, B.res.p + 3, (const u32 *)nullptr, (u32 *)nullptr);
+    TRY(bucket_scan(ctx, B, B.bcnt.p, B.bstart.p, B.nb, B.res.p + 2, nullptr, nullptr, tm));
+    if (!merge) return 0;   // radix build: only the bucket offsets are needed
     if (nrec)
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)div_up((i64)nrec, 256)), dim3(256), 0, s,
-                       (const uint4 *)B.rec.p, (const u32 *)B.rank.p, nrec, nrec_dev, (const u32 *)B.bstart.p,
-                       B.S_es.p, B.S_ee.p, B.S_seg.p);
+                           (const uint4 *)B.rec.p, (const u32 *)B.rank.p, nrec, nrec_dev, (const u32 *)B.bstart.p,
+                           B.S_es.p, B.S_ee.p, B.S_seg.p);
     unsigned long long *bsum = want_sum ? B.bsum.p : nullptr;
     hipLaunchKernelGGL((bucket_merge_kernel<64, BK_SMALL>), dim3((unsigned)std::min<i64>(B.nb, (i64)1 << 20)), dim3(64),
-                       0, s, (const u32 *)B.bstart.p, B.nb, B.S_es.p, B.S_ee.p, B.S_seg.p, B.mcnt.p, B.blmax.p, bsum,
-                       (const u32 *)nullptr, (const u32 *)nullptr, B.biglist.p, B.res.p, B.res.p + 1);
-    hipLaunchKernelGGL((bucket_merge_kernel<1024, BK_BIG>), dim3(64), dim3(1024), 0, s, (const u32 *)B.bstart.p,
-                       B.nb, B.S_es.p, B.S_ee.p, B.S_seg.p, B.mcnt.p, B.blmax.p, bsum, (const u32 *)B.biglist.p,
-                       (const u32 *)B.res.p, (u32 *)nullptr, (u32 *)nullptr, B.res.p + 1);
-    hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, s, (const u32 *)B.mcnt.p, B.rstart.p, B.nb,
-                       B.res.p + 4, (u32 *)nullptr, (const u32 *)B.blmax.p, B.res.p + 5);
-    tm.launch(5);
+                       0, s, (const u32 *)B.bstart.p, B.nb, B.S_es.p, B.S_ee.p, B.S_seg.p, B.mcnt.p, B.blmax.p, bsum);
+    static bool big_attr_set = false;
+    if (!big_attr_set) {
+        (void)hipFuncSetAttribute((const void *)bucket_merge_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  3 * BK_BIG * (int)sizeof(u32));
+        big_attr_set = true;
+    }
+    hipLaunchKernelGGL(bucket_merge_big_kernel, dim3((unsigned)ctx->num_cus), dim3(1024), 3 * BK_BIG * sizeof(u32), s,
+                       (const u32 *)B.bstart.p, B.nb, B.S_es.p, B.S_ee.p, B.S_seg.p, B.mcnt.p, B.blmax.p, bsum,
+                       B.res.p + 1);
+    tm.launch(3);
+    TRY(bucket_scan(ctx, B, B.mcnt.p, B.rstart.p, B.nb, B.res.p + 4, B.blmax.p, B.res.p + 5, tm));
+    return 0;
 }
 
 // radix-sort build (fallback for buckets beyond BK_BIG / very many buckets):
 // keys (set id << 32 | start) + ends from the hit records
 __global__ void __launch_bounds__(256)
 rec_keys_kernel(const uint4 *__restrict__ rec, const u32 *__restrict__ rank, u32 nrec_cap,
-                const u32 *__restrict__ nrec_dev, const i32 *__restrict__ bucket_set, u64 *__restrict__ keys,
-                u32 *__restrict__ vals, u32 *__restrict__ count) {
+                const u32 *__restrict__ nrec_dev, const u32 *__restrict__ bstart,
+                const i32 *__restrict__ bucket_set, u64 *__restrict__ keys, u32 *__restrict__ vals) {
     const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 n = nrec_dev ? min(*nrec_dev, nrec_cap) : nrec_cap;
-    if (d >= n || rank[d] == BK_NONE) return;
+    if (d >= n) return;
+    const u32 rk = rank[d];
+    if (rk == BK_NONE) return;
     const uint4 r = rec[d];
-    const u32 slot = atomicAdd(count, 1u);
+    const u32 slot = bstart[r.w] + rk;   // the bucket offsets give every hit its own slot
     keys[slot] = ((u64)(bucket_set ? (u32)bucket_set[r.w] : r.w) << 32) | r.x;
     vals[slot] = r.y;
 }
 
 struct MergedRows {
     DevBuf<u64> keys, keys_alt;
-    DevBuf<u32> vals, vals_alt, head, mend, seg, idx, tmp, count;
+    DevBuf<u32> vals, vals_alt, head, mend, seg, idx, tmp;
     u32 n = 0;       // sorted raw rows
     u32 nmerged = 0; // merged rows
 };
@@ -986,11 +1013,9 @@ static int build_rows_radix(catchhip_ctx *ctx, const BucketBuild &B, u32 nrec, c
     const u32 n = nhits;
     TRY(M.keys.alloc(n));
     TRY(M.vals.alloc(n));
-    TRY(M.count.alloc(1));
-    HIP_TRY(hipMemsetAsync(M.count.p, 0, sizeof(u32), ctx->stream));
     hipLaunchKernelGGL(rec_keys_kernel, dim3((unsigned)div_up((i64)nrec, 256)), dim3(256), 0, ctx->stream,
-                       (const uint4 *)B.rec.p, (const u32 *)B.rank.p, nrec, nrec_dev, bucket_set, M.keys.p, M.vals.p,
-                       M.count.p);
+                       (const uint4 *)B.rec.p, (const u32 *)B.rank.p, nrec, nrec_dev, (const u32 *)B.bstart.p,
+                       bucket_set, M.keys.p, M.vals.p);
     tm.launch();
     int bits = 32 + ceil_log2_u64((u64)max_set_id + 1);
     if (bits > 64) bits = 64;
@@ -1032,7 +1057,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
                                       (mode == CATCHHIP_SCAN_AUTO && !getenv("CATCHHIP_SCAN_TILED")));
     const bool use_fast = fast_ok && !use_seed && mode != CATCHHIP_SCAN_GENERAL;
     const u32 nb = by_sequence ? (u32)P->nprobes : (u32)P->nbuckets;
-    const bool force_radix = (i64)nb > BK_MAX_BUCKETS || getenv("CATCHHIP_ROWS_RADIX");
+    const bool force_radix = getenv("CATCHHIP_ROWS_RADIX") != nullptr;
     HitSink sink;
     sink.bucket_of = by_sequence ? nullptr : P->bucket_of.p;
     sink.seq_genome = by_sequence ? nullptr : T->seq_genome.p;
@@ -1048,10 +1073,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
             ts.stop();
             O.nrec = O.S.scap; O.nrec_dev = O.S.ctr.p + 1;
             tr.restart();
-            if (!force_radix) bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, by_sequence, tr);
-            else hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)O.B.bcnt.p,
-                                    O.B.bstart.p, nb, O.B.res.p + 2, O.B.res.p + 3, (const u32 *)nullptr,
-                                    (u32 *)nullptr);
+            TRY(bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, by_sequence, !force_radix, tr));
             tr.stop();
             HIP_TRY(hipGetLastError());
             u32 *h = (u32 *)ctx->h_pin;
@@ -1087,9 +1109,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
                                (u32)(P->L > 0 ? P->L : 0), H.n, (const u32 *)T->seq_off.p, (u32)T->nseq, sink);
             tr.launch();
         }
-        if (!force_radix) bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, by_sequence, tr);
-        else hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)O.B.bcnt.p,
-                                O.B.bstart.p, nb, O.B.res.p + 2, O.B.res.p + 3, (const u32 *)nullptr, (u32 *)nullptr);
+        TRY(bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, by_sequence, !force_radix, tr));
         tr.stop();
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(ctx->h_pin, O.B.res.p, 8 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));

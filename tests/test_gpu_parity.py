@@ -102,11 +102,11 @@ def test_scan_general_matches_oracle(ctx, oracle, L, stride, m, thres, island,
     assert got == exp
 
 
-@pytest.mark.parametrize("copies", [40, 700, 4500])
+@pytest.mark.parametrize("copies", [40, 700, 9000])
 def test_scan_repeats_fill_large_buckets(ctx, oracle, copies):
     """A unit repeated `copies` times: the probes inside the unit hit every
     copy, so their row-build buckets exceed what one wavefront (512 hits) and
-    one workgroup (4096) sort -- the wave, workgroup and radix-sort builds must
+    one workgroup (8192) sort -- the wave, workgroup and radix-sort builds must
     all give the reference's rows, in every scan mode."""
     engine = _engine()
     rng = random.Random(copies)
