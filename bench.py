@@ -53,6 +53,7 @@ def make_workload(name, seed, scale):
 
 class ResidentGroup:
     def __init__(self, ctx, genomes, cand):
+        self.ctx = ctx
         self.n_sets = len(cand)
         self.G = sum(len(s) for g in genomes for s in g)
         k, uniq, owner, ep, eo = probe.anchor_table(cand, MISMATCHES, PROBE_LEN)
@@ -65,37 +66,47 @@ class ResidentGroup:
         self.targets.close()
 
 
-def one_step(ctx, groups, stats=None):
-    picks = []
-    for g in groups:
-        rows = engine.Rows.scan(ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN,
-                                0, EXT, SCAN_MODE)
-        if stats is not None:
-            ms, nl = ctx.kernel_ms(engine.PHASE_SCAN)
+def one_step(ctx, groups, stats=None, in_flight=0):
+    """One pass of the hot path over every group.  in_flight = 0: all groups
+    at once (catchhip_setcover_filter_many: one stream + host thread per
+    group); 1: one group after the other (catchhip_setcover_filter)."""
+    if ctx.has_comm:
+        # probe-sharded RCCL solver: separate scan / solve calls on one context
+        res = []
+        for g in groups:
+            rows = engine.Rows.scan(ctx, g.probes, g.targets, MISMATCHES,
+                                    PROBE_LEN, 0, EXT, SCAN_MODE)
+            res.append((rows.greedy(g.n_sets), rows.n))
+            rows.close()
+    else:
+        specs = [(g.ctx, g.probes, g.targets, g.n_sets, None, None)
+                 for g in groups]
+        if in_flight == 1:
+            res = [engine.setcover_filter(*sp[:3], MISMATCHES, PROBE_LEN, 0, EXT,
+                                          sp[3], mode=SCAN_MODE) for sp in specs]
+        else:
+            res = engine.setcover_filter_many(specs, MISMATCHES, PROBE_LEN, 0,
+                                              EXT, SCAN_MODE)
+    if stats is not None:
+        for g, (ids, nrows) in zip(groups, res):
+            c = g.ctx
+            ms, nl = c.kernel_ms(engine.PHASE_SCAN)
             stats["scan_ms"] += ms
             stats["scan_launches"] += nl
-            stats["rows_ms"] += ctx.kernel_ms(engine.PHASE_ROWS)[0]
-            stats["rows"] += rows.n
-            c = ctx.counters()
-            for k in ("raw_hits", "seed_hits"):
-                stats[k] = stats.get(k, 0) + c[k]
-        ids = rows.greedy(g.n_sets)
-        if stats is not None:
-            ms, nl = ctx.kernel_ms(engine.PHASE_GREEDY)
+            stats["rows_ms"] += c.kernel_ms(engine.PHASE_ROWS)[0]
+            stats["rows"] += nrows
+            ms, nl = c.kernel_ms(engine.PHASE_GREEDY)
             stats["greedy_ms"] += ms
             stats["greedy_launches"] += nl
-            rms, rnl = ctx.kernel_ms(engine.PHASE_GREEDY_ROUNDS)
+            rms, rnl = c.kernel_ms(engine.PHASE_GREEDY_ROUNDS)
             stats["rounds_ms"] = stats.get("rounds_ms", 0.0) + rms
             stats["rounds_launches"] = stats.get("rounds_launches", 0) + rnl
             stats["picks"] += len(ids)
-            c = ctx.counters()
-            for k in ("winner_rows", "rows_recounted", "bitmap_words_read", "greedy_iters"):
-                stats[k] = stats.get(k, 0) + c[k]
-            if stats.get("want_rows"):
-                stats.setdefault("row_data", []).append(rows.fetch())
-        rows.close()
-        picks.append(ids)
-    return picks
+            cn = c.counters()
+            for k in ("raw_hits", "seed_hits", "winner_rows", "rows_recounted",
+                      "bitmap_words_read", "greedy_iters"):
+                stats[k] = stats.get(k, 0) + cn[k]
+    return [ids for ids, _ in res]
 
 
 def pmc_traffic(unit, workload, scale):
@@ -151,6 +162,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--shard", choices=["groups", "probes"], default="groups")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--groups-in-flight", type=int, default=0,
+                    help="0 = all groups of the batch at once (one stream "
+                         "each), 1 = one after the other")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,26 +187,34 @@ def main():
         ctx.comm_init(ids[0], world, rank)
 
     t_up0 = time.perf_counter()
-    resident = [ResidentGroup(ctx, g, c) for g, c in zip(groups, cands)]
-    ctx.sync()
+    # one context (= one HIP stream) per group, so that independent groups can
+    # be in flight together; the probe-sharded mode keeps everything on ctx
+    ctx.has_comm = args.shard == "probes"
+    gctx = [ctx if (i == 0 or ctx.has_comm) else engine.Context(ctx.device)
+            for i in range(len(groups))]
+    resident = [ResidentGroup(c, g, cd) for c, g, cd in zip(gctx, groups, cands)]
+    for c in gctx:
+        c.sync()
     upload_s = time.perf_counter() - t_up0
     units = sum(r.n_sets * r.G for r in resident)
 
     def barrier():
-        ctx.sync()
+        for c in gctx:
+            c.sync()
         if dist is not None:
             dist.barrier()
 
     for _ in range(args.warmup):
-        one_step(ctx, resident)
+        one_step(ctx, resident, None, args.groups_in_flight)
     stats = dict(scan_ms=0.0, rows_ms=0.0, greedy_ms=0.0, scan_launches=0,
                  greedy_launches=0, picks=0, rows=0)
     barrier()
     t0 = time.perf_counter()
     picks = None
     for _ in range(args.steps):
-        picks = one_step(ctx, resident, stats)
-    ctx.sync()
+        picks = one_step(ctx, resident, stats, args.groups_in_flight)
+    for c in gctx:
+        c.sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
@@ -294,6 +316,8 @@ def main():
                                       sum(len(g) for g in groups),
                                       len(groups), G, P),
                        "per_rank": True, "shard": args.shard,
+                       "groups_in_flight": (len(groups) if args.groups_in_flight == 0
+                                            else args.groups_in_flight),
                        "scale": args.scale},
             "setcoverfilter_ms": elapsed / K * 1e3,
             "picks": picks_per_step, "rows": rows_per_step,

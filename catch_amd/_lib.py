@@ -48,6 +48,15 @@ PROTOTYPES = {
         c_i64p]),
     "catchhip_setcover_greedy": (ctypes.c_int, [
         c_vp, c_vp, ctypes.c_int64, c_i64p, c_f64p, c_i64p, c_i64p]),
+    "catchhip_setcover_filter": (ctypes.c_int, [
+        c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, c_i64p, c_f64p,
+        c_i64p, c_i64p, c_i64p]),
+    "catchhip_setcover_filter_many": (ctypes.c_int, [
+        ctypes.c_int32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+        ctypes.POINTER(c_vp), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_int32, c_i64p, ctypes.POINTER(c_i64p),
+        ctypes.POINTER(c_f64p), ctypes.POINTER(c_i64p), c_i64p, c_i64p]),
     "catchhip_comm_unique_id": (ctypes.c_int, [c_u8p]),
     "catchhip_comm_init": (ctypes.c_int, [
         c_vp, c_u8p, ctypes.c_int32, ctypes.c_int32]),

@@ -21,10 +21,14 @@ void chip_set_error(const char *fmt, ...) {
 #include <unordered_map>
 
 namespace {
-struct PoolBlock { int dev; size_t cls; };
 std::mutex g_pool_mu;
-std::multimap<std::pair<int, size_t>, void *> g_pool_free;
-std::unordered_map<void *, PoolBlock> g_pool_live;
+// free blocks are cached per (owner, size class): the owner is the context the
+// calling entry point works for (PoolScope), so a block never moves between
+// streams -- reuse inside one context is ordered by its stream
+std::multimap<std::pair<const void *, size_t>, void *> g_pool_free;
+struct PoolLive { const void *owner; size_t cls; };
+std::unordered_map<void *, PoolLive> g_pool_live;
+thread_local const void *g_pool_owner = nullptr;
 
 size_t pool_class(size_t b) {
     if (b < 512) return 512;
@@ -38,29 +42,37 @@ size_t pool_class(size_t b) {
 }
 }  // namespace
 
+const void *chip_pool_set_owner(const void *owner) {
+    const void *prev = g_pool_owner;
+    g_pool_owner = owner;
+    return prev;
+}
+
 void *chip_pool_alloc(size_t bytes) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+    const void *owner = g_pool_owner;
     const size_t cls = pool_class(bytes);
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        auto it = g_pool_free.find(std::make_pair(dev, cls));
+        auto it = g_pool_free.find(std::make_pair(owner, cls));
         if (it != g_pool_free.end()) {
             void *p = it->second;
             g_pool_free.erase(it);
-            g_pool_live[p] = PoolBlock{dev, cls};
+            g_pool_live[p] = PoolLive{owner, cls};
             return p;
         }
     }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, cls);
     if (e != hipSuccess) {
-        // give cached blocks back to the driver and retry once
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        for (auto &kv : g_pool_free)
-            if (kv.first.first == dev) (void)hipFree(kv.second);
-        for (auto it = g_pool_free.begin(); it != g_pool_free.end();)
-            it = (it->first.first == dev) ? g_pool_free.erase(it) : std::next(it);
+        // give this owner's cached blocks back to the driver and retry once
+        // (other owners' blocks may still be referenced by queued work)
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            for (auto it = g_pool_free.begin(); it != g_pool_free.end();) {
+                if (it->first.first == owner) { (void)hipFree(it->second); it = g_pool_free.erase(it); }
+                else ++it;
+            }
+        }
         e = hipMalloc(&p, cls);
         if (e != hipSuccess) {
             chip_set_error("hipMalloc(%zu bytes) failed: %s", cls, hipGetErrorString(e));
@@ -68,7 +80,7 @@ void *chip_pool_alloc(size_t bytes) {
         }
     }
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_pool_live[p] = PoolBlock{dev, cls};
+    g_pool_live[p] = PoolLive{owner, cls};
     return p;
 }
 
@@ -77,8 +89,17 @@ void chip_pool_free(void *p) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     auto it = g_pool_live.find(p);
     if (it == g_pool_live.end()) return;
-    g_pool_free.insert(std::make_pair(std::make_pair(it->second.dev, it->second.cls), p));
+    g_pool_free.insert(std::make_pair(std::make_pair(it->second.owner, it->second.cls), p));
     g_pool_live.erase(it);
+}
+
+// a context is going away: its cached blocks go back to the driver
+void chip_pool_release_owner(const void *owner) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto it = g_pool_free.begin(); it != g_pool_free.end();) {
+        if (it->first.first == owner) { (void)hipFree(it->second); it = g_pool_free.erase(it); }
+        else ++it;
+    }
 }
 
 extern "C" const char *catchhip_last_error(void) { return g_err; }
@@ -138,6 +159,7 @@ extern "C" int catchhip_ctx_destroy(catchhip_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)catchhip_comm_destroy(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    chip_pool_release_owner(c);
     for (int i = 0; i < 2 * NPHASE; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -246,6 +268,7 @@ extern "C" int catchhip_targets_create(catchhip_ctx *ctx, const u8 *bytes, const
                                        const i32 *seq_genome, i64 nseq, i32 ngenomes,
                                        catchhip_targets **out) {
     ARG_CHECK(ctx && out && seq_off && nseq >= 0 && ngenomes >= 0);
+    PoolScope pool_scope(ctx);
     ARG_CHECK(nseq == 0 || (bytes != nullptr && seq_genome != nullptr) || seq_off[nseq] == 0);
     *out = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -335,6 +358,7 @@ extern "C" int catchhip_probes_create(catchhip_ctx *ctx, const u8 *bytes, const 
                                       i64 nprobes, const i32 *set_id, const i32 *ent_probe,
                                       const i32 *ent_pos, i64 nent, i32 k, catchhip_probes **out) {
     ARG_CHECK(ctx && out && probe_off && nprobes >= 0 && nent >= 0);
+    PoolScope pool_scope(ctx);
     ARG_CHECK(nprobes == 0 || (bytes && set_id));
     ARG_CHECK(nent == 0 || (ent_probe && ent_pos && k > 0));
     *out = nullptr;

@@ -1,0 +1,50 @@
+// Fused entry points: cover scan + greedy solve per group, and several
+// independent groups at once on their own streams
+// (catch/filter/set_cover_filter.py:816-846 per group).
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "internal.h"
+
+extern "C" int catchhip_setcover_filter(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,
+                                        i32 mismatches, i32 lcf_thres, i32 island, i32 cover_extension, i32 mode,
+                                        i64 num_sets, const i64 *ranks, const double *universe_p, i64 *out_ids,
+                                        i64 *n_out, i64 *nrows) {
+    ARG_CHECK(ctx && P && T && n_out);
+    catchhip_rows *R = nullptr;
+    i64 nr = 0;
+    int rc = catchhip_cover_scan(ctx, P, T, mismatches, lcf_thres, island, cover_extension, mode, &R, &nr);
+    if (rc) return rc;
+    if (nrows) *nrows = nr;
+    rc = catchhip_setcover_greedy(ctx, R, num_sets, ranks, universe_p, out_ids, n_out);
+    (void)catchhip_rows_destroy(R);
+    return rc;
+}
+
+extern "C" int catchhip_setcover_filter_many(i32 n, catchhip_ctx *const *ctxs, const catchhip_probes *const *probes,
+                                             const catchhip_targets *const *targets, i32 mismatches, i32 lcf_thres,
+                                             i32 island, i32 cover_extension, i32 mode, const i64 *num_sets,
+                                             const i64 *const *ranks, const double *const *universe_p,
+                                             i64 *const *out_ids, i64 *n_out, i64 *nrows) {
+    ARG_CHECK(n >= 0 && (n == 0 || (ctxs && probes && targets && num_sets && out_ids && n_out)));
+    for (i32 g = 0; g < n; ++g)
+        for (i32 h = 0; h < g; ++h)
+            if (ctxs[g] == ctxs[h]) { chip_set_error("setcover_filter_many: contexts must be distinct"); return CATCHHIP_EINVAL; }
+    std::vector<int> rcs((size_t)n, 0);
+    std::vector<std::string> msgs((size_t)n);
+    auto work = [&](i32 g) {
+        rcs[g] = catchhip_setcover_filter(ctxs[g], probes[g], targets[g], mismatches, lcf_thres, island,
+                                          cover_extension, mode, num_sets[g], ranks ? ranks[g] : nullptr,
+                                          universe_p ? universe_p[g] : nullptr, out_ids[g], &n_out[g],
+                                          nrows ? &nrows[g] : nullptr);
+        if (rcs[g]) msgs[g] = catchhip_last_error();   // thread-local: carry it to the caller
+    };
+    std::vector<std::thread> th;
+    for (i32 g = 1; g < n; ++g) th.emplace_back(work, g);
+    if (n > 0) work(0);
+    for (auto &t : th) t.join();
+    for (i32 g = 0; g < n; ++g)
+        if (rcs[g]) { chip_set_error("%s", msgs[g].c_str()); return rcs[g]; }
+    return 0;
+}

@@ -54,6 +54,15 @@ void chip_set_error(const char *fmt, ...);
 // only reused by work enqueued later on the context's single stream, after
 // the host has observed the previous user's results.
 void *chip_pool_alloc(size_t bytes);
+// The cache is partitioned by owner (a context): entry points open a PoolScope
+// so that blocks are only ever reused on the stream they were used on.
+const void *chip_pool_set_owner(const void *owner);
+void chip_pool_release_owner(const void *owner);
+struct PoolScope {
+    const void *prev;
+    explicit PoolScope(const void *owner) : prev(chip_pool_set_owner(owner)) {}
+    ~PoolScope() { chip_pool_set_owner(prev); }
+};
 void chip_pool_free(void *p);
 
 // Device buffer owning a pooled region (returned to the pool in the destructor).

@@ -94,6 +94,7 @@ ndf_node_round_kernel(u32 *__restrict__ status, u32 *__restrict__ flags, u32 n, 
 extern "C" int catchhip_ndf_hamming(catchhip_ctx *ctx, const u8 *bytes, i64 n, i32 L, const i32 *positions,
                                     i32 ntables, i32 k, i32 dist_thres, u8 *keep) {
     ARG_CHECK(ctx && n >= 0 && L > 0 && ntables >= 1 && k >= 1 && positions);
+    PoolScope pool_scope(ctx);
     if (n == 0) return 0;
     ARG_CHECK(bytes && keep);
     ARG_CHECK(n < ((i64)1 << 31) && n * (i64)L < ((i64)1 << 40));

@@ -1128,6 +1128,7 @@ extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, 
                                    i32 mismatches, i32 lcf_thres, i32 island, i32 cover_extension, i32 mode,
                                    catchhip_rows **out, i64 *nrows) {
     ARG_CHECK(ctx && P && T && out && cover_extension >= 0);
+    PoolScope pool_scope(ctx);
     ARG_CHECK(P->ctx == ctx && T->ctx == ctx);
     *out = nullptr;
     if (nrows) *nrows = 0;
@@ -1212,6 +1213,7 @@ extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, 
 extern "C" int catchhip_tolerant_bp(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,
                                     i32 mismatches, i32 lcf_thres, i32 island, i64 *bp_out) {
     ARG_CHECK(ctx && P && T && bp_out);
+    PoolScope pool_scope(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     if (P->nprobes == 0 || T->total == 0) return 0;
     // merge per (probe, sequence): probe.find_probe_covers_in_sequence merges per sequence
@@ -1268,6 +1270,7 @@ extern "C" int catchhip_rows_from_host(catchhip_ctx *ctx, const i32 *set_id, con
                                        const i64 *start, const i64 *end, i64 nrows, const i64 *genome_len,
                                        i32 ngenomes, catchhip_rows **out) {
     ARG_CHECK(ctx && out && nrows >= 0 && ngenomes >= 0 && (ngenomes == 0 || genome_len));
+    PoolScope pool_scope(ctx);
     ARG_CHECK(nrows == 0 || (set_id && universe && start && end));
     *out = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));

@@ -868,6 +868,7 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
 extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *R, i64 num_sets, const i64 *ranks,
                                         const double *universe_p, i64 *out_ids, i64 *n_out) {
     ARG_CHECK(ctx && R && n_out && num_sets >= 0 && R->ctx == ctx);
+    PoolScope pool_scope(ctx);
     *n_out = 0;
     if (num_sets == 0 || R->n == 0) return 0;  // no universe has anything to cover
     ARG_CHECK(out_ids != nullptr);

@@ -262,6 +262,55 @@ def tolerant_bp(ctx, probes, targets, mismatches, lcf_thres, island, out):
                                       int(island), _ptr(out, c_i64p)))
 
 
+def setcover_filter(ctx, probes, targets, mismatches, lcf_thres, island,
+                    cover_extension, num_sets, ranks=None, universe_p=None,
+                    mode=SCAN_AUTO):
+    """catchhip_setcover_filter: scan + greedy in one call.
+    Returns (picked set ids in pick order, number of cover rows)."""
+    return setcover_filter_many([(ctx, probes, targets, num_sets, ranks,
+                                  universe_p)], mismatches, lcf_thres, island,
+                                cover_extension, mode)[0]
+
+
+def setcover_filter_many(groups, mismatches, lcf_thres, island,
+                         cover_extension, mode=SCAN_AUTO):
+    """catchhip_setcover_filter_many over independent groups, each a tuple
+    (ctx, probes, targets, num_sets, ranks or None, universe_p or None) with
+    its own Context.  Returns [(ids, nrows)] per group."""
+    n = len(groups)
+    if n == 0:
+        return []
+    L = groups[0][0]._L
+    VP = ctypes.c_void_p
+    ctxs = (VP * n)(*[g[0]._h for g in groups])
+    prs = (VP * n)(*[g[1]._h for g in groups])
+    tgs = (VP * n)(*[g[2]._h for g in groups])
+    nsets = np.array([int(g[3]) for g in groups], dtype=np.int64)
+    outs = [np.zeros(max(int(g[3]), 1), dtype=np.int64) for g in groups]
+    rks = [None if g[4] is None else np.ascontiguousarray(g[4], np.int64)
+           for g in groups]
+    ups = [None if g[5] is None else np.ascontiguousarray(g[5], np.float64)
+           for g in groups]
+    out_p = (c_i64p * n)(*[_ptr(o, c_i64p) for o in outs])
+    rk_p = (c_i64p * n)(*[None if r is None else _ptr(r, c_i64p) for r in rks])
+    up_p = (c_f64p * n)(*[None if u is None else _ptr(u, c_f64p) for u in ups])
+    n_out = np.zeros(n, dtype=np.int64)
+    nrows = np.zeros(n, dtype=np.int64)
+    if n == 1:
+        check(L.catchhip_setcover_filter(
+            ctxs[0], prs[0], tgs[0], int(mismatches), int(lcf_thres),
+            int(island), int(cover_extension), int(mode), int(nsets[0]),
+            rk_p[0], up_p[0], out_p[0], _ptr(n_out, c_i64p),
+            _ptr(nrows, c_i64p)))
+    else:
+        check(L.catchhip_setcover_filter_many(
+            n, ctxs, prs, tgs, int(mismatches), int(lcf_thres), int(island),
+            int(cover_extension), int(mode), _ptr(nsets, c_i64p), rk_p, up_p,
+            out_p, _ptr(n_out, c_i64p), _ptr(nrows, c_i64p)))
+    return [([int(x) for x in outs[g][:n_out[g]]], int(nrows[g]))
+            for g in range(n)]
+
+
 _default_ctx = None
 
 

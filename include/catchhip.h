@@ -152,6 +152,37 @@ int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *rows,
                              const double *universe_p, int64_t *out_ids,
                              int64_t *n_out);
 
+/* Replaces SetCoverFilter._filter's device work for one group in ONE call
+ * (catch/filter/set_cover_filter.py:816-846 = _make_sets then
+ * set_cover.approx_multiuniverse): catchhip_cover_scan + catchhip_setcover_
+ * greedy with the rows never leaving the device.  Arguments as for those two
+ * functions; *nrows (may be NULL) receives the number of cover rows. */
+int catchhip_setcover_filter(catchhip_ctx *ctx, const catchhip_probes *probes,
+                             const catchhip_targets *targets,
+                             int32_t mismatches, int32_t lcf_thres,
+                             int32_t island, int32_t cover_extension,
+                             int32_t mode, int64_t num_sets,
+                             const int64_t *ranks, const double *universe_p,
+                             int64_t *out_ids, int64_t *n_out, int64_t *nrows);
+/* The same for n independent groups at once (the reference handles the groups
+ * of a design one after the other, set_cover_filter.py:816-846 per group):
+ * group g runs on ctxs[g] -- its own HIP stream -- driven by its own host
+ * thread, so the groups' kernels overlap on the device.  All arrays have n
+ * entries; ranks[g] / universe_p[g] may be NULL, as may the two arrays
+ * themselves; out_ids[g] has room for num_sets[g] ids.  Contexts must be
+ * distinct.  Returns the first failing group's error code (its message through
+ * catchhip_last_error of the calling thread). */
+int catchhip_setcover_filter_many(int32_t n, catchhip_ctx *const *ctxs,
+                                  const catchhip_probes *const *probes,
+                                  const catchhip_targets *const *targets,
+                                  int32_t mismatches, int32_t lcf_thres,
+                                  int32_t island, int32_t cover_extension,
+                                  int32_t mode, const int64_t *num_sets,
+                                  const int64_t *const *ranks,
+                                  const double *const *universe_p,
+                                  int64_t *const *out_ids, int64_t *n_out,
+                                  int64_t *nrows);
+
 /* Multi-GPU form: every rank holds the full rows; rank r evaluates the gains
  * of sets s with s % nranks == r and the per-pick winner is agreed with one
  * RCCL all-reduce(MAX) of a 64-bit key.  Requires catchhip_comm_init. */

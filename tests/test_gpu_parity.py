@@ -529,3 +529,39 @@ def test_design_cli_end_to_end(ctx, oracle, tmp_path, capsys):
     want = set(cands[i][j] for i, ids in enumerate(exp) for j in ids)
     got = set(seq_io.read_fasta(str(out)).values())
     assert got == want and printed == len(want) == len(pb.final_probes)
+
+
+def test_fused_filter_many_groups_matches_separate_calls(ctx, oracle):
+    """catchhip_setcover_filter / _many (scan + solve in one call, independent
+    groups on their own streams) give the picks of the two-call path and of the
+    oracle, with and without ranks / partial coverage."""
+    engine, probe = _engine(), _probe_mod()
+    ctxs = [ctx, engine.Context(ctx.device), engine.Context(ctx.device)]
+    specs, want = [], []
+    keep = []
+    for gi, c in enumerate(ctxs):
+        genomes = small_species(seed=40 + gi, n=4 + gi, length=2500 + 500 * gi)
+        cand = candidates(genomes, 100, 50)
+        k, uniq, owner, ep, eo = probe.anchor_table(cand, 2, 100)
+        t = engine.Targets(c, genomes)
+        p = engine.Probes(c, uniq, owner, ep, eo, k)
+        ranks = None if gi != 1 else [i % 3 for i in range(len(cand))]
+        up = None if gi != 2 else [0.9] * len(genomes)
+        specs.append((c, p, t, len(cand), ranks, up))
+        rows = engine.Rows.scan(c, p, t, 2, 100, 0, 30)
+        want.append((rows.greedy(len(cand), ranks, up), rows.n))
+        rows.close()
+        keep.append((p, t))
+    got = engine.setcover_filter_many(specs, 2, 100, 0, 30)
+    assert got == want
+    for _ in range(3):   # repeated use of the per-context caches
+        assert engine.setcover_filter_many(specs, 2, 100, 0, 30) == want
+    one = engine.setcover_filter(ctxs[1], specs[1][1], specs[1][2], 2, 100, 0, 30,
+                                 specs[1][3], specs[1][4], specs[1][5])
+    assert one == want[1]
+    with pytest.raises(ValueError):
+        engine.setcover_filter_many([specs[0], specs[0]], 2, 100, 0, 30)
+    for p, t in keep:
+        p.close(); t.close()
+    for c in ctxs[1:]:
+        c.close()
