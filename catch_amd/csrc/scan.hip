@@ -1065,6 +1065,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     PhaseTimer ts(ctx, PHASE_SCAN), tr(ctx, PHASE_ROWS);
     if (use_seed) {
         O.S.scap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(T->total * 4, (i64)1 << 30));
+        if (const char *e = getenv("CATCHHIP_SEED_CAP")) O.S.scap = (u32)std::max(1, atoi(e));   // tests: force the retry
         for (int attempt = 0;; ++attempt) {
             TRY(bucket_prepare(O.B, nb, O.S.scap, by_sequence));
             sink.rec = O.B.rec.p; sink.rank = O.B.rank.p; sink.bcnt = O.B.bcnt.p;

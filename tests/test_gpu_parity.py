@@ -565,3 +565,15 @@ def test_fused_filter_many_groups_matches_separate_calls(ctx, oracle):
         p.close(); t.close()
     for c in ctxs[1:]:
         c.close()
+
+
+def test_seed_work_list_overflow_retries(ctx, oracle, monkeypatch):
+    """A seed work list that is too small is detected on the device and the
+    scan re-runs with the exact size (same rows)."""
+    engine = _engine()
+    genomes = small_species(seed=8)
+    probes = candidates(genomes, 100, 50)
+    exp = _oracle_rows(oracle, probes, genomes, 2, 100, 0, 50)
+    monkeypatch.setenv("CATCHHIP_SEED_CAP", "100")
+    assert _scan_rows(ctx, probes, genomes, 2, 100, 0, 50, engine.SCAN_SEED) == exp
+    assert ctx.counters()["seed_hits"] > 100
