@@ -1,0 +1,58 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): collects the evidence that goes under
+# profiles/ for the current round: the bench JSON line, the rocprofv3
+# kernel-trace summary of the same command, and the HBM traffic counters
+# (FETCH_SIZE / WRITE_SIZE in separate passes, as MI355X_MICROARCH.md says).
+#   tools/collect_profiles.sh <tag>     -> gpurun_out/profiles_<tag>/
+tag=${1:-r01}
+out=/root/repo/gpurun_out/profiles_$tag
+mkdir -p $out
+cd /root/repo
+python bench.py > $out/bench.json 2> $out/bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python /root/repo/bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cd /root/repo
+OUT=$out python - <<'PY'
+import csv, glob, json, collections, shutil, os
+out = os.environ["OUT"]
+ks = glob.glob(out + "/trace/*/*kernel_stats.csv")[0]
+ds = glob.glob(out + "/trace/*/*domain_stats.csv")
+shutil.copy(ks, out + "/bench_kernel_stats.csv")
+if ds: shutil.copy(ds[0], out + "/bench_domain_stats.csv")
+def pmc(dirname, counter):
+    f = glob.glob(out + "/" + dirname + "/*/*counter_collection.csv")
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    if not f: return acc
+    for r in csv.DictReader(open(f[0])):
+        if r.get("Counter_Name") != counter: continue
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        a = acc[name]; a[0] += float(r["Counter_Value"]); a[1] += 1
+    return acc
+fe, wr = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+kern = {}
+for k in sorted(set(fe) | set(wr)):
+    kern[k] = {"FETCH_SIZE_KB_per_launch": fe[k][0] / max(fe[k][1], 1), "launches": fe[k][1] or wr[k][1],
+               "WRITE_SIZE_KB_per_launch": wr[k][0] / max(wr[k][1], 1)}
+def unit(names):
+    return {"kernels": names,
+            "FETCH_SIZE_KB_per_launch": sum(kern[n]["FETCH_SIZE_KB_per_launch"] for n in names if n in kern),
+            "WRITE_SIZE_KB_per_launch": sum(kern[n]["WRITE_SIZE_KB_per_launch"] for n in names if n in kern)}
+seed = [k for k in kern if k.startswith("seed_")]
+rows = [k for k in kern if k.startswith(("scan1_", "bucket_", "rows_emit", "scan_tiles"))]
+rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
+               "'python bench.py --steps 5 --warmup 1 --no-cpu-baseline' (S2); KB per launch averaged over "
+               "the launches of the run; a unit sums the per-launch averages of its kernels (one launch of "
+               "each); on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md), "
+               "bench.py doubles it; other widths and WRITE_SIZE are uncalibrated",
+       "workload": "S2",
+       "units": {"solver_round": unit(["gf_count_claim_kernel", "gf_check_apply_kernel"]),
+                 "seed_scan": unit(seed), "rows_build": unit(rows)},
+       "kernels": kern}
+json.dump(rec, open(out + "/pmc_traffic.json", "w"), indent=1)
+for i, r in enumerate(csv.DictReader(open(ks))):
+    if i < 14: print(r["Name"][:44].ljust(44), r["Calls"].rjust(5), r["TotalDurationNs"].rjust(11), r["AverageNs"][:10].rjust(11))
+print(open(out + "/bench.json").read()[:1500])
+print(json.dumps(rec["units"], indent=0)[:900])
+PY
