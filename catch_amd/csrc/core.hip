@@ -141,6 +141,12 @@ extern "C" int catchhip_ctx_create(int device, catchhip_ctx **out) {
     return 0;
 }
 
+void chip_phase_collect(catchhip_ctx *c, int phase) {
+    float ms = 0.f;
+    (void)hipEventSynchronize(c->ev[2 * phase + 1]);
+    if (hipEventElapsedTime(&ms, c->ev[2 * phase], c->ev[2 * phase + 1]) == hipSuccess) c->phase_ms[phase] = ms;
+}
+
 int chip_pinned_reserve(catchhip_ctx *c, size_t bytes) {
     if (bytes <= c->h_big_bytes) return 0;
     size_t want = std::max<size_t>(bytes, (size_t)1 << 20);

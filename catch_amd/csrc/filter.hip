@@ -12,9 +12,34 @@ extern "C" int catchhip_setcover_filter(catchhip_ctx *ctx, const catchhip_probes
                                         i64 num_sets, const i64 *ranks, const double *universe_p, i64 *out_ids,
                                         i64 *n_out, i64 *nrows) {
     ARG_CHECK(ctx && P && T && n_out);
+    ARG_CHECK(P->ctx == ctx && T->ctx == ctx && cover_extension >= 0 && num_sets >= 0);
     catchhip_rows *R = nullptr;
     i64 nr = 0;
-    int rc = catchhip_cover_scan(ctx, P, T, mismatches, lcf_thres, island, cover_extension, mode, &R, &nr);
+    int rc;
+    // Full coverage of every universe (the default -c 1.0) on the seed path:
+    // scan, row build and the first batch of solver rounds are queued without a
+    // single host synchronisation; the solver checks on the device that the scan
+    // did not overflow and the rows fit its 5-word path, otherwise the group is
+    // redone through the two synchronous calls below.
+    bool full = ctx->comm == nullptr && !getenv("CATCHHIP_GREEDY_SEQUENTIAL") && num_sets > 0 && out_ids;
+    if (universe_p)
+        for (i32 u = 0; u < T->ngenomes && full; ++u) full = universe_p[u] == 1.0;
+    if (full) {
+        rc = chip_cover_scan_nosync(ctx, P, T, mismatches, lcf_thres, island, cover_extension, mode, &R);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            int retry = 0;
+            rc = chip_greedy_deferred(ctx, R, num_sets, ranks, out_ids, n_out, &retry);
+            (void)catchhip_rows_destroy(R);
+            R = nullptr;
+            if (rc) return rc;
+            if (!retry) {
+                if (nrows) *nrows = ctx->counters[7];
+                return 0;
+            }
+        }
+    }
+    rc = catchhip_cover_scan(ctx, P, T, mismatches, lcf_thres, island, cover_extension, mode, &R, &nr);
     if (rc) return rc;
     if (nrows) *nrows = nr;
     rc = catchhip_setcover_greedy(ctx, R, num_sets, ranks, universe_p, out_ids, n_out);

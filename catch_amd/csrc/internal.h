@@ -121,6 +121,17 @@ struct catchhip_ctx {
 // pinned host scratch of at least `bytes` (contents not preserved on growth)
 int chip_pinned_reserve(catchhip_ctx *ctx, size_t bytes);
 
+// elapsed time of a phase whose start/stop events were recorded earlier
+void chip_phase_collect(catchhip_ctx *ctx, int phase);
+// scan + row build with no host synchronisation (seed path only); returns 1
+// when the inputs do not qualify (the caller then uses catchhip_cover_scan)
+int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, i32 mismatches,
+                           i32 lcf_thres, i32 island, i32 cover_extension, i32 mode, catchhip_rows **out);
+// frontier solver on deferred rows; *retry = 1 when the device found the
+// deferred scan unusable (overflow, long rows): redo through the synchronous calls
+int chip_greedy_deferred(catchhip_ctx *ctx, catchhip_rows *R, i64 num_sets, const i64 *ranks, i64 *out_ids,
+                         i64 *n_out, int *retry);
+
 struct catchhip_targets {
     catchhip_ctx *ctx = nullptr;
     i64 total = 0;    // total bases (concatenated)
@@ -170,6 +181,13 @@ struct catchhip_rows {
     i64 total = 0;       // size of the global coordinate space
     i32 ngenomes = 0;
     u32 lmax = 0;        // longest row (bases)
+    // Deferred rows (fused scan + solve, never handed to the caller): the scan
+    // has not been synchronised, n is only the capacity of the arrays and the
+    // facts live on the device: info[0..7] = row-build results (scan.hip "res
+    // words": [1] overflow, [2] hits, [4] rows, [5] longest row), info[8..11] =
+    // seed counters ([9] seeds), info[12] = seed capacity
+    bool deferred = false;
+    DevBuf<u32> info;
     DevBuf<i32> set_id;
     DevBuf<i32> univ;
     DevBuf<u32> gs, ge;

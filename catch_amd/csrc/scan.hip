@@ -1125,6 +1125,74 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     return 0;
 }
 
+// gathers the facts of a deferred scan into the rows object (device side)
+__global__ void rows_info_kernel(const u32 *__restrict__ res, const u32 *__restrict__ ctr, u32 scap,
+                                 u32 *__restrict__ info) {
+    const u32 t = threadIdx.x;
+    if (t < 8) info[t] = res[t];
+    else if (t < 12) info[t] = ctr[t - 8];
+    else if (t == 12) info[t] = scap;
+}
+
+int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, i32 mismatches,
+                           i32 lcf_thres, i32 island, i32 cover_extension, i32 mode, catchhip_rows **out) {
+    *out = nullptr;
+    if (P->nprobes == 0 || T->total == 0) return 1;
+    if (!fast_path_ok(P, T, mismatches, lcf_thres, island)) return 1;
+    if (!(mode == CATCHHIP_SCAN_SEED || (mode == CATCHHIP_SCAN_AUTO && !getenv("CATCHHIP_SCAN_TILED")))) return 1;
+    if (getenv("CATCHHIP_ROWS_RADIX") || getenv("CATCHHIP_SEED_CAP") || getenv("CATCHHIP_FUSED_SYNC")) return 1;
+    const i64 scap64 = std::max<i64>((i64)1 << 20, T->total * 4);
+    if (scap64 > ((i64)1 << 26)) return 1;   // keep the capacity-sized row arrays small
+    HIP_TRY(hipSetDevice(ctx->device));
+    PoolScope pool_scope(ctx);
+    ScanOut O;
+    O.S.scap = (u32)scap64;
+    const u32 nb = (u32)P->nbuckets;
+    HitSink sink;
+    sink.bucket_of = P->bucket_of.p;
+    sink.seq_genome = T->seq_genome.p;
+    sink.ext = (u32)cover_extension;
+    TRY(bucket_prepare(O.B, nb, O.S.scap, false));
+    sink.rec = O.B.rec.p; sink.rank = O.B.rank.p; sink.bcnt = O.B.bcnt.p;
+    catchhip_rows *R = new catchhip_rows();
+    R->ctx = ctx;
+    R->total = T->total;
+    R->ngenomes = T->ngenomes;
+    R->h_genome_off = T->h_genome_off;
+    R->deferred = true;
+    R->n = O.S.scap;   // capacity; the row count is info[4]
+    int rc = 0;
+    do {
+        if ((rc = R->genome_off.alloc((size_t)T->ngenomes + 1))) break;
+        if ((rc = R->info.alloc(16))) break;
+        if ((rc = R->set_id.alloc(R->n))) break;
+        if ((rc = R->univ.alloc(R->n))) break;
+        if ((rc = R->gs.alloc(R->n))) break;
+        if ((rc = R->ge.alloc(R->n))) break;
+        if (hipMemcpyAsync(R->genome_off.p, T->genome_off.p, sizeof(u32) * (T->ngenomes + 1),
+                           hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
+        PhaseTimer ts(ctx, PHASE_SCAN);
+        if ((rc = run_seed_async(ctx, P, T, mismatches, O.S, sink, nb, O.B.res.p, ts))) break;
+        ts.stop();
+        PhaseTimer tr(ctx, PHASE_ROWS);
+        if ((rc = bucket_finish_async(ctx, O.B, O.S.scap, O.S.ctr.p + 1, false, true, tr))) break;
+        hipLaunchKernelGGL(rows_emit_kernel, dim3((unsigned)div_up(R->n, 256)), dim3(256), 0, ctx->stream,
+                           (const u32 *)O.B.rstart.p, O.B.nb, (const u32 *)O.B.bstart.p, (const i32 *)P->bucket_set.p,
+                           (const u32 *)O.B.S_es.p, (const u32 *)O.B.S_ee.p, (const u32 *)O.B.S_seg.p, (u32)R->n,
+                           (const u32 *)(O.B.res.p + 4), R->set_id.p, R->univ.p, R->gs.p, R->ge.p);
+        hipLaunchKernelGGL(rows_info_kernel, dim3(1), dim3(64), 0, ctx->stream, (const u32 *)O.B.res.p,
+                           (const u32 *)O.S.ctr.p, O.S.scap, R->info.p);
+        tr.launch(2);
+        tr.stop();
+        if (hipGetLastError() != hipSuccess) { chip_set_error("cover scan: launch failed"); rc = CATCHHIP_EHIP; break; }
+    } while (0);
+    if (rc) { delete R; return rc; }
+    // O's scratch goes back to this context's cache here; whatever reuses it is
+    // ordered behind the kernels above on the context's stream
+    *out = R;
+    return 0;
+}
+
 extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,
                                    i32 mismatches, i32 lcf_thres, i32 island, i32 cover_extension, i32 mode,
                                    catchhip_rows **out, i64 *nrows) {
@@ -1171,7 +1239,8 @@ extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, 
                 hipLaunchKernelGGL(rows_emit_kernel, dim3((unsigned)div_up(R->n, 256)), dim3(256), 0, ctx->stream,
                                    (const u32 *)O.B.rstart.p, O.B.nb, (const u32 *)O.B.bstart.p,
                                    (const i32 *)P->bucket_set.p, (const u32 *)O.B.S_es.p, (const u32 *)O.B.S_ee.p,
-                                   (const u32 *)O.B.S_seg.p, (u32)R->n, R->set_id.p, R->univ.p, R->gs.p, R->ge.p);
+                                   (const u32 *)O.B.S_seg.p, (u32)R->n, (const u32 *)nullptr, R->set_id.p, R->univ.p,
+                                   R->gs.p, R->ge.p);
                 tm.launch();
             }
         } else {

@@ -762,8 +762,10 @@ extern "C" int catchhip_comm_destroy(catchhip_ctx *ctx) {
 // two set-up launches, rounds in batches, ONE synchronisation per batch that
 // brings back the state, the picks and their keys through pinned memory.
 static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets, const u32 *h_rank, u32 nrank,
-                           i64 *out_ids, i64 *n_out) {
+                           i64 *out_ids, i64 *n_out, int *retry) {
     hipStream_t s = ctx->stream;
+    // deferred rows: R->n is the capacity of the table, its size is info[4]
+    const u32 *d_info = R->deferred ? R->info.p : nullptr;
     const u32 nrows = (u32)R->n, nuniv = (u32)R->ngenomes;
     const size_t nwords = (size_t)(R->total / 64 + 2);
     const unsigned gblocks = (unsigned)std::min<i64>(div_up(nsets, GF_SETS), (i64)ctx->num_cus * 16);
@@ -782,7 +784,7 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     TRY(arena.alloc(off));
     u8 *A = arena.p;
     // pinned staging: ranks up, {state, counters, picks, keys} down
-    const size_t pin_bytes = sizeof(GreedyState) + 16 * (size_t)gblocks + 12 * (size_t)nsets + 64;
+    const size_t pin_bytes = sizeof(GreedyState) + 16 * (size_t)gblocks + 12 * (size_t)nsets + 64 + 64;
     TRY(chip_pinned_reserve(ctx, std::max(pin_bytes, 4 * (size_t)nsets)));
     HIP_TRY(hipMemsetAsync(A, 0, zero_bytes, s));
     if (h_rank) {
@@ -802,9 +804,10 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     PhaseTimer tm(ctx, PHASE_GREEDY);
     hipLaunchKernelGGL(gf_build_kernel, dim3((unsigned)div_up(std::max(nrows, nsets + 1), 256)), dim3(256), 0, s,
                        (const i32 *)R->set_id.p, (const i32 *)R->univ.p, (const u32 *)R->gs.p, (const u32 *)R->ge.p,
-                       nrows, nsets, nrank, (uint4 *)(A + o_frow), fa.bm, (u32 *)(A + o_setptr), fa.st);
+                       nrows, d_info ? d_info + 4 : (const u32 *)nullptr, nsets, nrank, (uint4 *)(A + o_frow), fa.bm,
+                       (u32 *)(A + o_setptr), fa.st);
     hipLaunchKernelGGL(gf_universe_kernel, dim3(nuniv), dim3(256), 0, s, (const unsigned long long *)fa.bm,
-                       (const u32 *)R->genome_off.p, fa.usize, fa.st);
+                       (const u32 *)R->genome_off.p, fa.usize, fa.st, d_info);
     tm.launch(2);
     // the host looks at the state after a batch of rounds (the kernels no-op
     // once everything is covered)
@@ -817,6 +820,7 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     u32 *h_picks = (u32 *)(H + sizeof(GreedyState) + 16 * (size_t)gblocks);
     unsigned long long *h_keys = (unsigned long long *)(H + sizeof(GreedyState) + 16 * (size_t)gblocks +
                                                          ((4 * (size_t)nsets + 7) & ~(size_t)7));
+    u32 *h_info = (u32 *)((u8 *)h_keys + 8 * (size_t)nsets);
     PhaseTimer tr(ctx, PHASE_GREEDY_ROUNDS);   // the round launches only
     for (;;) {
         for (int r = 0; r < per_sync; ++r, ++rounds) {
@@ -831,6 +835,7 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
         HIP_TRY(hipMemcpyAsync(h_blk, fa.blkcnt, 16 * (size_t)gblocks, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(h_picks, fa.picks, 4 * (size_t)nsets, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(h_keys, fa.pick_key, 8 * (size_t)nsets, hipMemcpyDeviceToHost, s));
+        if (d_info) HIP_TRY(hipMemcpyAsync(h_info, d_info, 16 * sizeof(u32), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (h_st->done || h_st->n_need == 0) break;
         if (rounds > max_rounds) { chip_set_error("setcover: round cap exceeded"); return CATCHHIP_EINVAL; }
@@ -841,6 +846,15 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     tr.launch(2 * rounds);
     tr.finish();
     tm.finish();
+    if (d_info) {
+        // the scan was never synchronised on its own: collect its timers and counters now
+        chip_phase_collect(ctx, PHASE_SCAN);
+        chip_phase_collect(ctx, PHASE_ROWS);
+        ctx->counters[0] = h_info[2];
+        ctx->counters[1] = h_info[9];
+        ctx->counters[7] = h_info[4];   // rows of the deferred table
+        if (h_st->done == 3) { *retry = 1; return 0; }
+    }
     i64 n_rec = 0, n_wrd = 0;
     for (unsigned b = 0; b < gblocks; ++b) { n_rec += (i64)h_blk[2 * b]; n_wrd += (i64)h_blk[2 * b + 1]; }
     ctx->phase_launches[PHASE_GREEDY] = h_st->iters;
@@ -865,6 +879,31 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     return 0;
 }
 
+// dense ranks: index into sorted(set(ranks.values())) (set_cover.py:353-354)
+static u32 dense_ranks(const i64 *ranks, u32 nsets, std::vector<u32> &h_rank) {
+    h_rank.assign(nsets, 0);
+    if (!ranks) return 1;
+    std::vector<i64> vals(ranks, ranks + nsets);
+    std::sort(vals.begin(), vals.end());
+    vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+    for (u32 i = 0; i < nsets; ++i)
+        h_rank[i] = (u32)(std::lower_bound(vals.begin(), vals.end(), ranks[i]) - vals.begin());
+    return (u32)vals.size();
+}
+
+int chip_greedy_deferred(catchhip_ctx *ctx, catchhip_rows *R, i64 num_sets, const i64 *ranks, i64 *out_ids,
+                         i64 *n_out, int *retry) {
+    *retry = 0;
+    *n_out = 0;
+    if (num_sets <= 0 || num_sets >= (i64)ID_MASK || !R->deferred) { *retry = 1; return 0; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    PoolScope pool_scope(ctx);
+    std::vector<u32> h_rank;
+    const u32 nrank = dense_ranks(ranks, (u32)num_sets, h_rank);
+    int rc = greedy_frontier(ctx, R, (u32)num_sets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out, retry);
+    return rc;
+}
+
 extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *R, i64 num_sets, const i64 *ranks,
                                         const double *universe_p, i64 *out_ids, i64 *n_out) {
     ARG_CHECK(ctx && R && n_out && num_sets >= 0 && R->ctx == ctx);
@@ -880,17 +919,8 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     // a communicator (even of one rank) selects the sharded multi-launch solver
     const bool distributed = ctx->comm != nullptr;
 
-    // dense ranks: index into sorted(set(ranks.values())) (set_cover.py:353-354)
-    std::vector<u32> h_rank(nsets, 0);
-    u32 nrank = 1;
-    if (ranks) {
-        std::vector<i64> vals(ranks, ranks + nsets);
-        std::sort(vals.begin(), vals.end());
-        vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
-        nrank = (u32)vals.size();
-        for (u32 i = 0; i < nsets; ++i)
-            h_rank[i] = (u32)(std::lower_bound(vals.begin(), vals.end(), ranks[i]) - vals.begin());
-    }
+    std::vector<u32> h_rank;
+    const u32 nrank = dense_ranks(ranks, nsets, h_rank);
     if (universe_p)
         for (u32 u = 0; u < nuniv; ++u)
             if (!(universe_p[u] >= 0.0 && universe_p[u] <= 1.0)) {
@@ -904,7 +934,8 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     if (universe_p)
         for (u32 u = 0; u < nuniv && batched; ++u) batched = universe_p[u] == 1.0;
 
-    if (batched) return greedy_frontier(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out);
+    int no_retry = 0;
+    if (batched) return greedy_frontier(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out, &no_retry);
 
     DevBuf<u32> set_ptr, flag, idx, tmp, seg_row, seg_univ, seg_set, row_seg, set_seg_ptr, usize, can, left, rank,
         picked, picks;

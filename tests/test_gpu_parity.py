@@ -577,3 +577,25 @@ def test_seed_work_list_overflow_retries(ctx, oracle, monkeypatch):
     monkeypatch.setenv("CATCHHIP_SEED_CAP", "100")
     assert _scan_rows(ctx, probes, genomes, 2, 100, 0, 50, engine.SCAN_SEED) == exp
     assert ctx.counters()["seed_hits"] > 100
+
+
+def test_fused_filter_falls_back_when_rows_are_long(ctx, oracle):
+    """cover_extension = 100 makes rows 300 bases long: the sync-free fused
+    path notices on the device that they exceed the frontier solver's 5-word
+    rows and the group is redone through the synchronous calls."""
+    engine, probe = _engine(), _probe_mod()
+    genomes = small_species(seed=61, n=5)
+    cand = candidates(genomes, 100, 50)
+    k, uniq, owner, ep, eo = probe.anchor_table(cand, 2, 100)
+    t = engine.Targets(ctx, genomes)
+    p = engine.Probes(ctx, uniq, owner, ep, eo, k)
+    rows = engine.Rows.scan(ctx, p, t, 2, 100, 0, 100)
+    want = (rows.greedy(len(cand)), rows.n)
+    _, _, st, en = rows.fetch()
+    assert int((en - st).max()) > 257
+    rows.close()
+    assert engine.setcover_filter(ctx, p, t, 2, 100, 0, 100, len(cand)) == want
+    sel = oracle.set_cover_filter([cand], [genomes], 2, 100, coverage=1.0,
+                                  cover_extension=100)
+    assert sorted(want[0]) == sorted(sel[0])
+    p.close(); t.close()
