@@ -196,47 +196,80 @@ class SetCoverFilter(BaseFilter):
 
     def _filter(self, input, target_genomes_grouped):
         """input = [p_1, ..., p_m] candidate probes per group; returns the
-        selected probes per group (:902-930)."""
-        ctx = None   # created on first use: empty input needs no device
-        selected_probes = []
+        selected probes per group (:902-930).  Groups are independent
+        instances: up to CATCHHIP_GROUPS_IN_FLIGHT (default 4) of them run at
+        once, each on its own context / HIP stream
+        (catchhip_setcover_filter_many)."""
+        import os
+        input = [list(pp) for pp in input]
+        selected_probes = [[] for _ in input]
         timings = dict(scan_ms=0.0, rows_ms=0.0, greedy_ms=0.0, picks=0,
                        rows=0, scan_launches=0, greedy_launches=0)
-        for group_i, (possible_probes, target_genomes) in enumerate(
-                zip(input, target_genomes_grouped)):
-            possible_probes = list(possible_probes)
-            if len(possible_probes) == 0:
-                selected_probes.append([])
-                continue
-            if ctx is None:
-                ctx = self._context()
-            logger.info("Building set cover sets input (group %d of %d)",
-                        group_i + 1, len(input))
-            rows = self._make_sets(possible_probes, target_genomes, ctx)
+        todo = [i for i, pp in enumerate(input) if len(pp) > 0]
+        width = max(1, int(os.environ.get("CATCHHIP_GROUPS_IN_FLIGHT", "4")))
+        for c0 in range(0, len(todo), width):
+            chunk = todo[c0:c0 + width]
+            ctxs = _contexts(len(chunk))
+            specs, held, all_ranks = [], [], []
             try:
+                for ctx, gi in zip(ctxs, chunk):
+                    possible_probes, target_genomes = \
+                        input[gi], target_genomes_grouped[gi]
+                    logger.info("Building set cover sets input (group %d of %d)",
+                                gi + 1, len(input))
+                    strs = [p.seq_str for p in possible_probes]
+                    k, uniq, owner, ep, eo = probe.anchor_table(
+                        strs, self.mismatches, self.lcf_thres,
+                        min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
+                    targets = engine.Targets(ctx, [g.seqs for g in target_genomes])
+                    held.append(targets)
+                    probes = engine.Probes(ctx, uniq, owner, ep, eo, k)
+                    held.append(probes)
+                    ranks = self._make_ranks(possible_probes,
+                                             target_genomes_grouped, ctx)
+                    all_ranks.append(ranks)
+                    specs.append((ctx, probes, targets, len(possible_probes),
+                                  ranks if ranks.any() else None,
+                                  self._make_universe_p(target_genomes)))
+                logger.info("Solving set cover instances (groups %s of %d)",
+                            [gi + 1 for gi in chunk], len(input))
+                results = engine.setcover_filter_many(
+                    specs, self.mismatches, self.lcf_thres,
+                    self.island_of_exact_match, self.cover_extension,
+                    self.scan_mode)
+            finally:
+                for h in held:
+                    h.close()
+            for ctx, gi, ranks, (ids, nrows) in zip(ctxs, chunk, all_ranks,
+                                                    results):
                 ms, nl = ctx.kernel_ms(engine.PHASE_SCAN)
                 timings["scan_ms"] += ms
                 timings["scan_launches"] += nl
                 timings["rows_ms"] += ctx.kernel_ms(engine.PHASE_ROWS)[0]
-                timings["rows"] += rows.n
-                ranks = self._make_ranks(possible_probes,
-                                         target_genomes_grouped, ctx)
-                universe_p = self._make_universe_p(target_genomes)
-                logger.info("Solving set cover instance (group %d of %d)",
-                            group_i + 1, len(input))
-                ids = rows.greedy(len(possible_probes), ranks, universe_p)
+                timings["rows"] += nrows
                 ms, nl = ctx.kernel_ms(engine.PHASE_GREEDY)
                 timings["greedy_ms"] += ms
                 timings["greedy_launches"] += nl
                 timings["picks"] += len(ids)
-            finally:
-                rows.close()
-            num_bad = int(np.count_nonzero(ranks[ids] > 0)) if len(ids) else 0
-            if num_bad > 0:
-                logger.warning(("Group %d: forced to choose %d less-than-ideal "
-                                "probe%s (i.e., probes that 'hit' more than "
-                                "one grouping during identification or probes "
-                                "that cover an avoided genome)"), group_i + 1,
-                               num_bad, "" if num_bad == 1 else "s")
-            selected_probes.append([possible_probes[i] for i in ids])
+                num_bad = int(np.count_nonzero(ranks[ids] > 0)) if len(ids) else 0
+                if num_bad > 0:
+                    logger.warning(("Group %d: forced to choose %d less-than-ideal "
+                                    "probe%s (i.e., probes that 'hit' more than "
+                                    "one grouping during identification or probes "
+                                    "that cover an avoided genome)"), gi + 1,
+                                   num_bad, "" if num_bad == 1 else "s")
+                selected_probes[gi] = [input[gi][i] for i in ids]
         self.last_timings = timings
         return selected_probes
+
+
+_extra_ctxs = []
+
+
+def _contexts(n):
+    """The default context plus cached extra ones on the same device, one per
+    group in flight."""
+    first = engine.default_context()
+    while len(_extra_ctxs) < n - 1:
+        _extra_ctxs.append(engine.Context(first.device))
+    return [first] + _extra_ctxs[:n - 1]

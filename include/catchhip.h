@@ -54,15 +54,16 @@ int catchhip_ctx_sync(catchhip_ctx *ctx);
  * the named phase (HIP events on the context's stream).  phase: 0 = cover
  * scan kernels (K1 hit search), 1 = row build (sort/merge), 2 = greedy
  * set-cover kernels (set-up + solver), 3 = near-duplicate kernels, 4 = only the
- * (select, re-count) launch pairs of the batched greedy solver. *launches =
- * kernel launches timed. */
+ * (count+claim, check+apply) launch pairs of the frontier solver's rounds.
+ * *launches = kernel launches timed. */
 int catchhip_ctx_last_kernel_ms(catchhip_ctx *ctx, int phase, double *ms,
                                 int64_t *launches);
 /* Work counters of the most recent calls (for roofline accounting), 8 values:
- * [0] raw hits found by the last cover scan, [1] seed hits (general path),
- * [2] greedy iterations, [3] picks, [4] winner rows applied,
- * [5] rows re-counted by the greedy solver, [6] bitmap words read while
- * re-counting, [7] reserved. */
+ * [0] raw hits found by the last cover scan, [1] seeds verified (seed scan /
+ * seed join), [2] greedy iterations (rounds), [3] picks, [4] winner rows applied
+ * (sequential solver), [5] rows re-counted by the greedy solver, [6] bitmap
+ * words read while re-counting, [7] cover rows of the last fused
+ * catchhip_setcover_filter call. */
 int catchhip_ctx_last_counters(catchhip_ctx *ctx, int64_t *out8);
 
 /* ---- inputs ------------------------------------------------------------ */
@@ -91,7 +92,7 @@ int catchhip_probes_create(catchhip_ctx *ctx, const uint8_t *bytes,
 int catchhip_probes_destroy(catchhip_probes *p);
 
 /* ---- K1: coverage scan -------------------------------------------------- */
-#define CATCHHIP_SCAN_AUTO 0     /* fast kernel when its preconditions hold */
+#define CATCHHIP_SCAN_AUTO 0     /* seed scan when its preconditions hold, else general */
 #define CATCHHIP_SCAN_GENERAL 1  /* force the seed-join + extension path */
 #define CATCHHIP_SCAN_FAST 2     /* force the tiled Hamming kernel (EINVAL if
                                     preconditions do not hold) */
@@ -142,11 +143,12 @@ int catchhip_tolerant_bp(catchhip_ctx *ctx, const catchhip_probes *probes,
  * candidate probes (set ids 0..num_sets-1); ranks[num_sets] (NULL = all
  * equal); universe_p[ngenomes] float64 coverage fraction per universe
  * (NULL = 1.0).  out_ids (capacity num_sets) receives the chosen set ids,
- * *n_out their number.  The SET of ids equals the reference's (which returns
- * a Python set).  Order: when some universe_p < 1, or rows exceed 257
- * elements, or a communicator is attached, ids are in the sequential pick
- * order; otherwise the solver takes all locally-maximal sets per round
- * (setcover_batched.inc) and ids are ordered by round. */
+ * *n_out their number, in the order in which the sequential algorithm picks
+ * them (the reference returns a Python set; the order is the one of its loop).
+ * When every universe_p is 1 and rows are at most 257 elements the solver takes
+ * all locally-maximal sets per round (setcover_batched.inc) and restores that
+ * order by sorting on the accept-time key; otherwise it picks one set per
+ * iteration. */
 int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *rows,
                              int64_t num_sets, const int64_t *ranks,
                              const double *universe_p, int64_t *out_ids,
