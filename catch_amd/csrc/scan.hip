@@ -806,7 +806,10 @@ struct SeedRun {
 static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm, SeedRun &S,
                           const HitSink &sink, u32 nb, u32 *res, PhaseTimer &tm) {
     const bool use_n = P->has_n || T->has_n;
-    const int k = P->k, nanchor = P->L / P->k, kb = std::min(k, 32);
+    // a window with <= mm mismatches leaves at least one of ANY mm+1 disjoint
+    // anchors exact, so the first mm+1 anchors are all the table needs (fewer
+    // seeds to verify; fast_path_ok guarantees L/k > mm)
+    const int k = P->k, nanchor = std::min(P->L / P->k, mm + 1), kb = std::min(k, 32);
     const u64 nent64 = (u64)P->nprobes * nanchor;
     if (nent64 >= ((u64)1 << 31)) { chip_set_error("seed scan: too many anchors"); return CATCHHIP_EINVAL; }
     const u32 nent = (u32)nent64;
