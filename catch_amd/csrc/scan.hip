@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(1024)
 seed_alloc_kernel(SeedTable t, u32 *__restrict__ cursor) {
     __shared__ u32 s_part[16], s_base;
     const u32 s = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u32 n = s <= t.mask ? __hip_atomic_load(&t.cnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const u32 n = s <= t.mask ? t.cnt[s] : 0u;
     u32 total;
     const u32 ex = wave_excl_scan(n, &total);
     if (lane == 0) s_part[wave] = total;
@@ -374,9 +374,7 @@ seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const
             const unsigned long long key = plane_key(tplanes, tplanes + nwords, i, kb);
             u32 s = seed_hash(key) & t.mask;
             for (;;) {
-                // keys[] was written by atomicCAS: agent-scope load (plain loads of
-                // atomically written lines are slow, see setcover_batched.inc)
-                const unsigned long long ks = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long ks = t.keys[s];   // written by the table-build launches
                 if (ks == key) { r = t.range[s]; break; }
                 if (ks == SEED_EMPTY) break;
                 s = (s + 1) & t.mask;

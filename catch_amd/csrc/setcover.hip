@@ -768,7 +768,11 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     const u32 *d_info = R->deferred ? R->info.p : nullptr;
     const u32 nrows = (u32)R->n, nuniv = (u32)R->ngenomes;
     const size_t nwords = (size_t)(R->total / 64 + 2);
-    const unsigned gblocks = (unsigned)std::min<i64>(div_up(nsets, GF_SETS), (i64)ctx->num_cus * 16);
+    // lanes per set (setcover_batched.inc): by the average rows per set, or --
+    // when the row count is still on the device -- by the number of genomes
+    const bool wide = d_info ? nuniv >= 256 : (i64)nrows >= 32 * (i64)nsets;
+    const u32 sets_per_wg = GF_THREADS / (wide ? 64 : 16);
+    const unsigned gblocks = (unsigned)std::min<i64>(div_up(nsets, sets_per_wg), (i64)ctx->num_cus * 16);
     // arena: the zero-initialised part first
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -824,8 +828,13 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     PhaseTimer tr(ctx, PHASE_GREEDY_ROUNDS);   // the round launches only
     for (;;) {
         for (int r = 0; r < per_sync; ++r, ++rounds) {
-            hipLaunchKernelGGL(gf_count_claim_kernel, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
-            hipLaunchKernelGGL(gf_check_apply_kernel, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
+            if (wide) {
+                hipLaunchKernelGGL(gf_count_claim_kernel<64>, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
+                hipLaunchKernelGGL(gf_check_apply_kernel<64>, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
+            } else {
+                hipLaunchKernelGGL(gf_count_claim_kernel<16>, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
+                hipLaunchKernelGGL(gf_check_apply_kernel<16>, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
+            }
         }
         tm.launch(2 * per_sync);
         tr.stop();
