@@ -1,21 +1,23 @@
 // K1: probe -> target coverage scan.
 //
-//  * scan_fast_kernel: the tiled Hamming kernel.  Valid when every probe has
-//    the same length L, anchors are the pigeonhole anchors {0,k,..,L-k} with
-//    L/k > mismatches, lcf_thres == L, island == 0 and every target sequence
-//    is at least L long: then a probe covers offset o iff
-//    Hamming(probe, seq[o:o+L]) <= mismatches (character equality, N == N),
-//    and the cover range is exactly (o, o+L).  Targets and probes are 3
-//    bit-planes of 32 bases per word; each lane owns OPL offsets and keeps
-//    their L-base windows in VGPRs, a probe tile is staged in LDS and read
-//    with wave-uniform (broadcast) ds_read_b128, mismatches are counted with
-//    XOR/OR + v_bcnt, and a wave skips a probe after the first 32 bases when
-//    no lane can still be within the mismatch budget (__ballot).
+// Three exact ways to find the (probe, offset) pairs that the reference's
+// find_probe_covers_in_sequence reports (catch/probe.py:1008-1271):
+//  * seed scan (K1c, default): valid when every probe has the same length L,
+//    anchors are the pigeonhole anchors {0,k,..,L-k} with L/k > mismatches,
+//    lcf_thres == L, island == 0, the alphabet is A/C/G/T/N and every target
+//    sequence is at least L long: then a probe covers
+//    offset o iff Hamming(probe, seq[o:o+L]) <= mismatches (character
+//    equality, N == N) and the cover range is exactly (o, o+L).  A hash table
+//    of the anchor k-mers seeds the pairs, one thread per seed verifies on the
+//    3 bit-planes (32 bases per word, XOR/OR + v_bcnt).
+//  * tiled scan (scan_fast3_kernel, CATCHHIP_SCAN_FAST): same conditions,
+//    every probe against every offset with a 32-base lower-bound filter; the
+//    O(P*G) cross-check of the seed scan.
 //  * general path (any alphabet, any anchors, truncated alignments,
 //    lcf_thres < L, island): seed join (hash every target k-mer, binary
 //    search in the sorted anchor-hash table) + one lane per seed hit that
 //    evaluates the reference's cover function on the raw bytes.
-//  * rows: cover_extension / clip / (set, start) radix sort / merge.
+// All three hand their hits to the bucketed row build (rows_bucket.inc).
 #include <algorithm>
 
 #include "internal.h"
@@ -44,114 +46,15 @@ struct HitBuf {
 };
 
 // ------------------------------------------------------------------------
-// fast kernel
-// ------------------------------------------------------------------------
-#define SF_THREADS 256
-#define SF_OPL 4                       // offsets per lane
-#define SF_TILE (SF_THREADS * SF_OPL)  // offsets per workgroup
-#define SF_PT 256                      // probes per LDS stage
-
-template <int NW, bool USE_N>
-__global__ void __launch_bounds__(SF_THREADS)
-scan_fast_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total,
-                 const u32 *__restrict__ seq_off, u32 nseq,
-                 const uint4 *__restrict__ pplanes, u32 nprobes, u32 probes_per_block,
-                 int L, int mm, u32 tailmask, HitBuf hb) {
-    __shared__ uint4 lds[SF_PT * NW];
-    const int tid = threadIdx.x;
-    const u32 tile0 = blockIdx.x * SF_TILE;
-    const u32 p_begin = blockIdx.y * probes_per_block;
-    const u32 p_end = min(nprobes, p_begin + probes_per_block);
-
-    // L-base windows of this lane's offsets, 3 planes x NW words each
-    u32 T0[SF_OPL][NW], T1[SF_OPL][NW], T2[SF_OPL][NW];
-#pragma unroll
-    for (int w = 0; w < SF_OPL; ++w) {
-        u32 o = tile0 + w * SF_THREADS + tid;
-        u32 wi = o >> 5, sh = o & 31;
-        const u32 *p0 = tplanes + wi, *p1 = tplanes + nwords + wi, *p2 = tplanes + 2 * nwords + wi;
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            T0[w][j] = __builtin_amdgcn_alignbit(p0[j + 1], p0[j], sh);
-            T1[w][j] = __builtin_amdgcn_alignbit(p1[j + 1], p1[j], sh);
-            if (USE_N) T2[w][j] = __builtin_amdgcn_alignbit(p2[j + 1], p2[j], sh);
-            else T2[w][j] = 0;
-        }
-    }
-
-    for (u32 ps = p_begin; ps < p_end; ps += SF_PT) {
-        const u32 cnt = min((u32)SF_PT, p_end - ps);
-        __syncthreads();
-        for (u32 i = tid; i < cnt * NW; i += SF_THREADS) lds[i] = pplanes[(size_t)ps * NW + i];
-        __syncthreads();
-
-        for (u32 q = 0; q < cnt; ++q) {
-            const uint4 q0 = lds[q * NW];
-            u32 c[SF_OPL];
-            bool any = false;
-#pragma unroll
-            for (int w = 0; w < SF_OPL; ++w) {
-                u32 x = (T0[w][0] ^ q0.x) | (T1[w][0] ^ q0.y);
-                if (USE_N) x |= (T2[w][0] ^ q0.z);
-                if (NW == 1) x &= tailmask;
-                c[w] = __popc(x);
-                any |= (c[w] <= (u32)mm);
-            }
-            if (__ballot(any) == 0ull) continue;  // wave-uniform early out
-#pragma unroll
-            for (int j = 1; j < NW; ++j) {
-                const uint4 qj = lds[q * NW + j];
-#pragma unroll
-                for (int w = 0; w < SF_OPL; ++w) {
-                    u32 x = (T0[w][j] ^ qj.x) | (T1[w][j] ^ qj.y);
-                    if (USE_N) x |= (T2[w][j] ^ qj.z);
-                    if (j == NW - 1) x &= tailmask;
-                    c[w] += __popc(x);
-                }
-            }
-#pragma unroll
-            for (int w = 0; w < SF_OPL; ++w) {
-                if (c[w] <= (u32)mm) {
-                    u32 o = tile0 + w * SF_THREADS + tid;
-                    if (o < total && o + (u32)L <= total) {
-                        u32 s = find_segment(seq_off, nseq, o);
-                        if (o + (u32)L <= seq_off[s + 1]) {  // window inside one sequence
-                            u32 slot = atomicAdd(hb.count, 1u);
-                            if (slot < hb.cap) { hb.a[slot] = ps + q; hb.b[slot] = o; }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-typedef void (*scan_fast_fn)(const u32 *, i64, u32, const u32 *, u32, const uint4 *, u32, u32, int,
-                             int, u32, HitBuf);
-
-template <bool USE_N> static scan_fast_fn pick_fast(int nw) {
-    switch (nw) {
-    case 1: return scan_fast_kernel<1, USE_N>;
-    case 2: return scan_fast_kernel<2, USE_N>;
-    case 3: return scan_fast_kernel<3, USE_N>;
-    case 4: return scan_fast_kernel<4, USE_N>;
-    case 5: return scan_fast_kernel<5, USE_N>;
-    case 6: return scan_fast_kernel<6, USE_N>;
-    case 7: return scan_fast_kernel<7, USE_N>;
-    case 8: return scan_fast_kernel<8, USE_N>;
-    }
-    return nullptr;
-}
-
-// ------------------------------------------------------------------------
-// fast kernel, second form: filter on the first 32 bases, verify the rest.
+// tiled scan: filter on the first 32 bases, verify the rest.
 //
 // The hot loop only needs a LOWER bound of the mismatch count to reject a
 // (probe, offset) pair: the XOR/OR of planes 0 and 1 over the first 32 bases
 // never over-counts (plane 2 -- "is not A/C/G/T" -- and the remaining words can
 // only add mismatches).  So each lane keeps just word 0 of planes 0/1 for
-// SF2_OPL = 16 offsets (32 VGPRs), a probe costs one 8-byte LDS broadcast,
-// and per pair the loop issues  v_xor, v_bitop3/(xor+or), v_bcnt, 1/2 v_min3.
+// SF2_OPL = 16 offsets (32 VGPRs), a probe's word 0 arrives through the scalar
+// cache (wave-uniform address -> s_load into SGPRs, used directly as the scalar
+// operand), and per pair the loop issues v_xor, v_bitop3, v_bcnt, 1/2 v_min3.
 // When some lane of the wave stays within the budget (rare: only near true
 // homology) the wave verifies those offsets exactly, reading the target
 // windows and the probe's full bit-planes from global memory (L2-resident).
@@ -159,7 +62,6 @@ template <bool USE_N> static scan_fast_fn pick_fast(int nw) {
 #define SF2_THREADS 256
 #define SF2_OPL 16
 #define SF2_TILE (SF2_THREADS * SF2_OPL)
-#define SF2_PT 2048   // probes (word 0, planes 0/1) per LDS stage = 16 KB
 
 __device__ __forceinline__ u32 full_mismatches(const u32 *__restrict__ tplanes, i64 nwords, u32 o,
                                                const uint4 *__restrict__ pq, int NW, bool use_n, u32 tailmask,
@@ -177,63 +79,6 @@ __device__ __forceinline__ u32 full_mismatches(const u32 *__restrict__ tplanes, 
         if (cnt > budget) break;
     }
     return cnt;
-}
-
-__global__ void __launch_bounds__(SF2_THREADS)
-scan_fast2_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const u32 *__restrict__ seq_off,
-                  u32 nseq, const uint4 *__restrict__ pplanes, u32 nprobes, u32 probes_per_block, int L,
-                  int NW, int mm, u32 tailmask, int use_n, HitBuf hb) {
-    __shared__ uint2 lds[SF2_PT];
-    const int tid = threadIdx.x;
-    const u32 tile0 = blockIdx.x * SF2_TILE;
-    const u32 p_begin = blockIdx.y * probes_per_block;
-    const u32 p_end = min(nprobes, p_begin + probes_per_block);
-    const u32 mask0 = NW == 1 ? tailmask : 0xffffffffu;   // probes shorter than 32 bases
-
-    u32 T0[SF2_OPL], T1[SF2_OPL];
-#pragma unroll
-    for (int w = 0; w < SF2_OPL; ++w) {
-        const u32 o = tile0 + w * SF2_THREADS + tid;
-        const u32 wi = o >> 5, sh = o & 31;
-        const u32 *p0 = tplanes + wi, *p1 = tplanes + nwords + wi;
-        T0[w] = __builtin_amdgcn_alignbit(p0[1], p0[0], sh) & mask0;
-        T1[w] = __builtin_amdgcn_alignbit(p1[1], p1[0], sh) & mask0;
-    }
-
-    for (u32 ps = p_begin; ps < p_end; ps += SF2_PT) {
-        const u32 cnt = min((u32)SF2_PT, p_end - ps);
-        __syncthreads();
-        for (u32 i = tid; i < cnt; i += SF2_THREADS) {
-            const uint4 q = pplanes[(size_t)(ps + i) * NW];
-            lds[i] = make_uint2(q.x & mask0, q.y & mask0);
-        }
-        __syncthreads();
-        for (u32 q = 0; q < cnt; ++q) {
-            const uint2 qq = lds[q];
-            u32 mn = 64;
-#pragma unroll
-            for (int w = 0; w < SF2_OPL; ++w) {
-                // (T1 ^ q1) | (T0 ^ q0) as v_xor + v_bitop3 (truth table 0xde = (a ^ c) | b)
-                const u32 x = __builtin_amdgcn_bitop3_b32(T1[w], T0[w] ^ qq.x, qq.y, 0xde);
-                mn = min(mn, (u32)__popc(x));
-            }
-            if (__ballot(mn <= (u32)mm) == 0ull) continue;   // wave-uniform: nothing can match
-            if (mn > (u32)mm) continue;
-            // verify this lane's surviving offsets exactly
-            const uint4 *pq = pplanes + (size_t)(ps + q) * NW;
-#pragma unroll 1
-            for (int w = 0; w < SF2_OPL; ++w) {
-                if ((u32)__popc((T0[w] ^ qq.x) | (T1[w] ^ qq.y)) > (u32)mm) continue;
-                const u32 o = tile0 + w * SF2_THREADS + tid;
-                if (o >= total || o + (u32)L > total) continue;
-                if (full_mismatches(tplanes, nwords, o, pq, NW, use_n != 0, tailmask, (u32)mm) > (u32)mm) continue;
-                const u32 s = find_segment(seq_off, nseq, o);
-                if (o + (u32)L > seq_off[s + 1]) continue;   // window must lie inside one sequence
-                const u32 slot = atomicAdd(hb.count, 1u);
-                if (slot < hb.cap) { hb.a[slot] = ps + q; hb.b[slot] = o; }
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------------
@@ -486,9 +331,7 @@ static seed_verify_fn pick_seed_verify(int nw) {
     return nullptr;
 }
 
-// Third form: same filter, but the probe's word 0 comes through the scalar
-// cache (wave-uniform address -> s_load into SGPRs, used directly as the
-// scalar operand of v_xor / v_bitop3): no LDS, no staging barriers.
+// The tiled scan kernel (see the comment above full_mismatches).
 __global__ void __launch_bounds__(SF2_THREADS)
 scan_fast3_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const u32 *__restrict__ seq_off,
                   u32 nseq, const uint2 *__restrict__ pw0, const uint4 *__restrict__ pplanes, u32 nprobes,
@@ -738,46 +581,25 @@ static bool fast_path_ok(const catchhip_probes *P, const catchhip_targets *T, in
 static int run_fast(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm,
                     RawHits &H, PhaseTimer &tm) {
     const bool use_n = P->has_n || T->has_n;
-    scan_fast_fn fn = use_n ? pick_fast<true>(P->pwords) : pick_fast<false>(P->pwords);
-    if (!fn) { chip_set_error("fast scan: unsupported probe length"); return CATCHHIP_EINVAL; }
-    const u32 ntiles = (u32)div_up(T->total, SF_TILE);
-    // enough workgroups to fill 256 CUs several times over
-    u32 want_chunks = (u32)div_up((i64)ctx->num_cus * 16, ntiles);
-    u32 ppb = (u32)div_up(P->nprobes, want_chunks ? want_chunks : 1);
-    ppb = (u32)(div_up(ppb, SF_PT) * SF_PT);
-    u32 nchunks = (u32)div_up(P->nprobes, ppb);
-    if (nchunks > 65535) { ppb = (u32)(div_up(div_up(P->nprobes, 65535), SF_PT) * SF_PT); nchunks = (u32)div_up(P->nprobes, ppb); }
     const u32 tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
     u32 cap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(P->nprobes * 64, (i64)1 << 28));
     TRY(H.count.alloc(1));
-    // second form (32-base filter + verification) unless CATCHHIP_SCAN_V1 is set
-    const bool v2 = getenv("CATCHHIP_SCAN_V1") == nullptr;
-    const u32 ntiles2 = (u32)div_up(T->total, SF2_TILE);
-    u32 want2 = (u32)div_up((i64)ctx->num_cus * 16, ntiles2);
-    u32 ppb2 = (u32)div_up(P->nprobes, want2 ? want2 : 1);
-    ppb2 = std::max<u32>(ppb2, 64u);
-    u32 nchunks2 = (u32)div_up(P->nprobes, ppb2);
-    if (nchunks2 > 65535) { ppb2 = (u32)div_up(P->nprobes, 65535); nchunks2 = (u32)div_up(P->nprobes, ppb2); }
+    // enough workgroups to fill 256 CUs several times over
+    const u32 ntiles = (u32)div_up(T->total, SF2_TILE);
+    u32 want = (u32)div_up((i64)ctx->num_cus * 16, ntiles);
+    u32 ppb = (u32)div_up(P->nprobes, want ? want : 1);
+    ppb = std::max<u32>(ppb, 64u);
+    u32 nchunks = (u32)div_up(P->nprobes, ppb);
+    if (nchunks > 65535) { ppb = (u32)div_up(P->nprobes, 65535); nchunks = (u32)div_up(P->nprobes, ppb); }
     for (int attempt = 0; attempt < 3; ++attempt) {
         TRY(H.a.reserve(cap));
         TRY(H.b.reserve(cap));
         HIP_TRY(hipMemsetAsync(H.count.p, 0, sizeof(u32), ctx->stream));
-        HitBuf hb = {H.a.p, H.b.p, nullptr, H.count.p, cap};
         tm.restart();  // time exactly the scan kernel (HIP events on this stream)
-        if (v2 && getenv("CATCHHIP_SCAN_V2") == nullptr)
-            hipLaunchKernelGGL(scan_fast3_kernel, dim3(ntiles2, nchunks2), dim3(SF2_THREADS), 0, ctx->stream,
-                               T->planes.p, T->nwords, (u32)T->total, T->seq_off.p, (u32)T->nseq, P->w0.p,
-                               (const uint4 *)P->planes.p, (u32)P->nprobes, ppb2, (int)P->L, (int)P->pwords, mm,
-                               tailmask, use_n ? 1 : 0, H.a.p, H.b.p, H.count.p, cap);
-        else if (v2)
-            hipLaunchKernelGGL(scan_fast2_kernel, dim3(ntiles2, nchunks2), dim3(SF2_THREADS), 0, ctx->stream,
-                               T->planes.p, T->nwords, (u32)T->total, T->seq_off.p, (u32)T->nseq,
-                               (const uint4 *)P->planes.p, (u32)P->nprobes, ppb2, (int)P->L, (int)P->pwords, mm,
-                               tailmask, use_n ? 1 : 0, hb);
-        else
-        hipLaunchKernelGGL(fn, dim3(ntiles, nchunks), dim3(SF_THREADS), 0, ctx->stream, T->planes.p,
-                           T->nwords, (u32)T->total, T->seq_off.p, (u32)T->nseq,
-                           (const uint4 *)P->planes.p, (u32)P->nprobes, ppb, (int)P->L, mm, tailmask, hb);
+        hipLaunchKernelGGL(scan_fast3_kernel, dim3(ntiles, nchunks), dim3(SF2_THREADS), 0, ctx->stream,
+                           T->planes.p, T->nwords, (u32)T->total, T->seq_off.p, (u32)T->nseq, P->w0.p,
+                           (const uint4 *)P->planes.p, (u32)P->nprobes, ppb, (int)P->L, (int)P->pwords, mm,
+                           tailmask, use_n ? 1 : 0, H.a.p, H.b.p, H.count.p, cap);
         tm.launch();
         tm.stop();
         HIP_TRY(hipGetLastError());

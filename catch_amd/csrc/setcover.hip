@@ -359,18 +359,17 @@ __device__ __forceinline__ void patch_segment(const GreedyArgs &a, u32 q, u32 *s
 __global__ void __launch_bounds__(GW_THREADS)
 greedy_wg_kernel(GreedyArgs a) {
     __shared__ unsigned long long s_red[GW_WAVES];
-    __shared__ unsigned long long s_key;
     __shared__ u32 s_cdirty[GW_THREADS];  // this thread's chunk of sets must be re-scanned
     __shared__ u32 s_bind[GW_MAXBIND];
     __shared__ u32 s_clr[GW_MAXWSEG];     // bits cleared per winner segment
     __shared__ u32 s_dirty[GW_MAXDIRTY];
-    __shared__ u32 s_nbind, s_ndirty, s_need, s_rank, s_stop, s_npicks, s_iters;
+    __shared__ u32 s_nbind, s_ndirty, s_need, s_stop, s_npicks, s_iters;
     __shared__ unsigned long long s_nwrows, s_nrecount, s_nwords;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     GreedyState *st = a.st;
 
     if (tid == 0) {
-        s_need = st->n_need; s_rank = st->cur_rank; s_stop = st->done;
+        s_need = st->n_need; s_stop = st->done;
         s_nbind = 0; s_ndirty = 0; s_npicks = 0; s_iters = 0;
         s_nwrows = 0; s_nrecount = 0; s_nwords = 0;
     }
