@@ -448,6 +448,25 @@ extern "C" int catchhip_probes_create(catchhip_ctx *ctx, const u8 *bytes, const 
                 break;
             }
         }
+        if (nent) {   // anchors grouped by probe, ascending position
+            std::vector<u64> key((size_t)nent);
+            for (i64 e = 0; e < nent; ++e) key[e] = ((u64)(u32)ent_probe[e] << 32) | (u32)ent_pos[e];
+            std::sort(key.begin(), key.end());
+            std::vector<u32> sp((size_t)nent), so((size_t)nent), ptr((size_t)nprobes + 1, 0);
+            for (i64 e = 0; e < nent; ++e) { sp[e] = (u32)(key[e] >> 32); so[e] = (u32)key[e]; ptr[sp[e] + 1]++; }
+            for (i64 i = 0; i < nprobes; ++i) ptr[i + 1] += ptr[i];
+            if ((rc = p->sent_probe.alloc((size_t)nent))) break;
+            if ((rc = p->sent_pos.alloc((size_t)nent))) break;
+            if ((rc = p->ent_ptr.alloc((size_t)nprobes + 1))) break;
+            if (hipMemcpyAsync(p->sent_probe.p, sp.data(), sizeof(u32) * nent, hipMemcpyHostToDevice, s) != hipSuccess ||
+                hipMemcpyAsync(p->sent_pos.p, so.data(), sizeof(u32) * nent, hipMemcpyHostToDevice, s) != hipSuccess ||
+                hipMemcpyAsync(p->ent_ptr.p, ptr.data(), sizeof(u32) * (nprobes + 1), hipMemcpyHostToDevice, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess) {
+                chip_set_error("probes upload failed");
+                rc = CATCHHIP_EHIP;
+                break;
+            }
+        }
         if (p->dna5 && p->L > 0 && p->L <= 256) {
             p->pwords = (p->L + 31) / 32;
             size_t nw = (size_t)nprobes * p->pwords * 4;

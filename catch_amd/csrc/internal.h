@@ -169,6 +169,8 @@ struct catchhip_probes {
     DevBuf<u32> bucket_of;   // nprobes: dense rank of the probe's set id (row-table order)
     DevBuf<i32> bucket_set;  // nbuckets: set id of each bucket, ascending
     DevBuf<i32> ent_probe, ent_pos;
+    // the same anchors sorted by (probe, position) + first entry of every probe (seed scan)
+    DevBuf<u32> sent_probe, sent_pos, ent_ptr;
     i32 pwords = 0;          // 32-base words per probe (ceil(L/32))
     DevBuf<u32> planes;      // [probe][word][4] = planes 0,1,2 + pad per 32-base word
     DevBuf<uint2> w0;        // [probe] word 0 of planes 0/1 (the scan's 32-base filter), masked to L

@@ -133,15 +133,20 @@ __device__ __forceinline__ unsigned long long plane_key(const u32 *__restrict__ 
     return ((unsigned long long)b << 32) | a;
 }
 
-// table build 1/3: claim the key's slot, count the entries per slot
+// table build 1/3: claim the key's slot, count the entries per slot.  Entries
+// are the probes' anchors sorted by (probe, position); with pigeonhole anchors
+// only positions below pos_limit enter the table (see run_seed_async).
+#define SEED_SKIP 0xffffffffu
 __global__ void __launch_bounds__(256)
-seed_count_kernel(const uint4 *__restrict__ pplanes, u32 nent, int NW, int k, int nanchor, int kb, SeedTable t,
+seed_count_kernel(const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent_probe,
+                  const u32 *__restrict__ ent_pos, u32 nent, u32 pos_limit, int NW, int kb, SeedTable t,
                   u32 *__restrict__ slot_of) {
-    const u32 e = blockIdx.x * blockDim.x + threadIdx.x;   // entry = probe * nanchor + anchor
+    const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nent) return;
-    const u32 p = e / nanchor, a = e % nanchor;
+    const u32 p = ent_probe[e], o = ent_pos[e];
+    if (o >= pos_limit) { slot_of[e] = SEED_SKIP; return; }
     // the probe image is [word][4]: planes 0/1 of the two words the k-mer starts in
-    const u32 o = a * k, wi = o >> 5, sh = o & 31;
+    const u32 wi = o >> 5, sh = o & 31;
     const uint4 w0 = pplanes[(size_t)p * NW + wi];
     const uint4 w1 = (int)(wi + 1) < NW ? pplanes[(size_t)p * NW + wi + 1] : make_uint4(0, 0, 0, 0);
     const u32 m = kb >= 32 ? 0xffffffffu : ((1u << kb) - 1u);
@@ -191,6 +196,7 @@ seed_fill_kernel(u32 nent, SeedTable t, const u32 *__restrict__ slot_of) {
     const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nent) return;
     const u32 s = slot_of[e];
+    if (s == SEED_SKIP) return;
     const u32 j = atomicSub(&t.cnt[s], 1u) - 1u;
     t.ents[t.range[s].x + j] = e;
 }
@@ -276,17 +282,18 @@ __device__ __forceinline__ bool mask_range_zero(const u32 (&mw)[NW], int pos, in
 template <int NW>
 __global__ void __launch_bounds__(256)
 seed_verify_kernel(const u32 *__restrict__ tplanes, i64 nwords, const u32 *__restrict__ seq_off,
-                   const uint4 *__restrict__ pplanes, int L, int k, int nanchor, int mm, u32 tailmask, int use_n,
-                   const u32 *__restrict__ seed_pos, const u32 *__restrict__ seed_ent,
+                   const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent_probe,
+                   const u32 *__restrict__ ent_pos, const u32 *__restrict__ ent_ptr, int L, int k, int mm,
+                   u32 tailmask, int use_n, const u32 *__restrict__ seed_pos, const u32 *__restrict__ seed_ent,
                    const u32 *__restrict__ seed_seq, const u32 *__restrict__ seed_count, u32 seed_cap,
                    HitSink sink) {
     const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= min(*seed_count, seed_cap)) return;
     const u32 i = seed_pos[d], e = seed_ent[d], sq = seed_seq[d];
-    const u32 p = e / nanchor, a = e % nanchor;
+    const u32 p = ent_probe[e], apos = ent_pos[e];
     const u32 lo = seq_off[sq], hi = seq_off[sq + 1];
-    bool ok = i >= lo + a * (u32)k;
-    const u32 o = i - a * (u32)k;               // where the probe would start
+    bool ok = i >= lo + apos;
+    const u32 o = i - apos;                     // where the probe would start
     ok = ok && o + (u32)L <= hi;                // window inside this sequence
     if (ok) {
         const u32 wi = o >> 5, sh = o & 31;
@@ -307,16 +314,18 @@ seed_verify_kernel(const u32 *__restrict__ tplanes, i64 nwords, const u32 *__res
         ok = cnt <= (u32)mm;
         // the seeding anchor must be exact on all planes (the key ignores plane 2 and
         // bases beyond 32), and the pair is reported from its lowest exact anchor only
-        ok = ok && mask_range_zero<NW>(mw, (int)a * k, k);
-        for (u32 b = 0; ok && b < a; ++b)
-            if (mask_range_zero<NW>(mw, (int)b * k, k)) ok = false;
+        // (the probe's anchors are sorted by position; lower ones precede entry e)
+        ok = ok && mask_range_zero<NW>(mw, (int)apos, k);
+        for (u32 j = ent_ptr[p]; ok && j < e; ++j)
+            if (mask_range_zero<NW>(mw, (int)ent_pos[j], k)) ok = false;
     }
     if (ok) hit_record(sink, d, p, o, o + (u32)L, sq, lo, hi);
     else sink.rank[d] = BK_NONE;
 }
 
-typedef void (*seed_verify_fn)(const u32 *, i64, const u32 *, const uint4 *, int, int, int, int, u32, int,
-                               const u32 *, const u32 *, const u32 *, const u32 *, u32, HitSink);
+typedef void (*seed_verify_fn)(const u32 *, i64, const u32 *, const uint4 *, const u32 *, const u32 *, const u32 *,
+                               int, int, int, u32, int, const u32 *, const u32 *, const u32 *, const u32 *, u32,
+                               HitSink);
 static seed_verify_fn pick_seed_verify(int nw) {
     switch (nw) {
     case 1: return seed_verify_kernel<1>;
@@ -567,15 +576,24 @@ static int read_count(catchhip_ctx *ctx, const u32 *d, u32 *out) {
     return 0;
 }
 
-static bool fast_path_ok(const catchhip_probes *P, const catchhip_targets *T, int mm, int lcf_thres,
-                         int island) {
+// seed scan: equal-length DNA probes with anchors, full-length cover threshold,
+// no island, every sequence at least one probe long (SURVEY.md App. A.8 without
+// the pigeonhole requirement: pairs are found through the anchors given)
+static bool seed_path_ok(const catchhip_probes *P, const catchhip_targets *T, int mm, int lcf_thres, int island) {
     if (!P->dna5 || !T->dna5) return false;
     if (P->L <= 0 || P->L > 256 || P->pwords < 1 || P->pwords > 8) return false;
-    if (!P->pigeonhole) return false;
-    if (mm < 0 || P->L / P->k <= mm) return false;   // some anchor survives any <= mm mismatches
+    if (P->nent <= 0 || P->k <= 0 || P->k > P->L) return false;
+    if (mm < 0) return false;
     if (lcf_thres != P->L || island != 0) return false;
     if (T->nseq == 0 || T->min_seq_len < P->L) return false;
     return true;
+}
+// tiled scan (every probe at every offset): additionally the anchors must be
+// the pigeonhole anchors with L/k > mm, so that some anchor survives any <= mm
+// mismatches and the anchor requirement is implied
+static bool fast_path_ok(const catchhip_probes *P, const catchhip_targets *T, int mm, int lcf_thres,
+                         int island) {
+    return seed_path_ok(P, T, mm, lcf_thres, island) && P->pigeonhole && P->L / P->k > mm;
 }
 
 static int run_fast(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm,
@@ -626,11 +644,14 @@ struct SeedRun {
 static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm, SeedRun &S,
                           const HitSink &sink, u32 nb, u32 *res, PhaseTimer &tm) {
     const bool use_n = P->has_n || T->has_n;
-    // a window with <= mm mismatches leaves at least one of ANY mm+1 disjoint
-    // anchors exact, so the first mm+1 anchors are all the table needs (fewer
-    // seeds to verify; fast_path_ok guarantees L/k > mm)
-    const int k = P->k, nanchor = std::min(P->L / P->k, mm + 1), kb = std::min(k, 32);
-    const u64 nent64 = (u64)P->nprobes * nanchor;
+    // Pigeonhole anchors {0,k,..,L-k}: a window with <= mm mismatches leaves at
+    // least one of ANY mm+1 disjoint anchors exact, so the first mm+1 anchors are
+    // all the table needs (fewer seeds to verify).  Any other anchor table (the
+    // reference's random anchors) enters completely: a pair is reported iff one
+    // of ITS anchors matches exactly, as the reference finds it.
+    const int k = P->k, kb = std::min(k, 32);
+    const u32 pos_limit = P->pigeonhole ? (u32)std::min<i64>((i64)(mm + 1) * k, P->L) : 0xffffffffu;
+    const u64 nent64 = (u64)P->nent;
     if (nent64 >= ((u64)1 << 31)) { chip_set_error("seed scan: too many anchors"); return CATCHHIP_EINVAL; }
     const u32 nent = (u32)nent64;
     seed_verify_fn verify = pick_seed_verify((int)P->pwords);
@@ -651,8 +672,9 @@ static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     const dim3 eb((unsigned)div_up((i64)nent, 256)), tb(256);
     hipLaunchKernelGGL(seed_init_kernel, dim3((unsigned)std::min<i64>(div_up((i64)capacity, 256), 2048)), tb, 0,
                        ctx->stream, S.keys.p, S.cnt.p, capacity, S.ctr.p, sink.bcnt, nb, res);
-    hipLaunchKernelGGL(seed_count_kernel, eb, tb, 0, ctx->stream, (const uint4 *)P->planes.p, nent,
-                       (int)P->pwords, k, nanchor, kb, t, S.slot_of.p);
+    hipLaunchKernelGGL(seed_count_kernel, eb, tb, 0, ctx->stream, (const uint4 *)P->planes.p,
+                       (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p, nent, pos_limit, (int)P->pwords, kb, t,
+                       S.slot_of.p);
     hipLaunchKernelGGL(seed_alloc_kernel, dim3(capacity / 1024), dim3(1024), 0, ctx->stream, t, S.ctr.p);
     hipLaunchKernelGGL(seed_fill_kernel, eb, tb, 0, ctx->stream, nent, t, (const u32 *)S.slot_of.p);
     hipLaunchKernelGGL(seed_lookup_kernel, dim3((unsigned)div_up(T->total, SL_TILE)), dim3(SL_THREADS), 0, ctx->stream,
@@ -660,7 +682,8 @@ static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const cat
                        (u32)T->nseq, k, kb, t, S.spos.p, S.sent.p, S.sseq.p, S.ctr.p + 1, S.scap);
     hipLaunchKernelGGL(verify, dim3((unsigned)div_up((i64)S.scap, 256)), tb, 0, ctx->stream,
                        (const u32 *)T->planes.p, T->nwords, (const u32 *)T->seq_off.p,
-                       (const uint4 *)P->planes.p, (int)P->L, k, nanchor, mm, tailmask, use_n ? 1 : 0,
+                       (const uint4 *)P->planes.p, (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p,
+                       (const u32 *)P->ent_ptr.p, (int)P->L, k, mm, tailmask, use_n ? 1 : 0,
                        (const u32 *)S.spos.p, (const u32 *)S.sent.p, (const u32 *)S.sseq.p,
                        (const u32 *)(S.ctr.p + 1), S.scap, sink);
     tm.launch(6);
@@ -875,10 +898,11 @@ struct ScanOut {
 
 static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mismatches,
                           int lcf_thres, int island, u32 ext, bool by_sequence, int mode, ScanOut &O) {
-    const bool fast_ok = fast_path_ok(P, T, mismatches, lcf_thres, island);
-    const bool use_seed = fast_ok && (mode == CATCHHIP_SCAN_SEED ||
-                                      (mode == CATCHHIP_SCAN_AUTO && !getenv("CATCHHIP_SCAN_TILED")));
-    const bool use_fast = fast_ok && !use_seed && mode != CATCHHIP_SCAN_GENERAL;
+    const bool seed_ok = seed_path_ok(P, T, mismatches, lcf_thres, island);
+    const bool tiled_ok = fast_path_ok(P, T, mismatches, lcf_thres, island);
+    const bool want_tiled = mode == CATCHHIP_SCAN_FAST || (mode == CATCHHIP_SCAN_AUTO && getenv("CATCHHIP_SCAN_TILED"));
+    const bool use_fast = tiled_ok && want_tiled;
+    const bool use_seed = seed_ok && !use_fast && mode != CATCHHIP_SCAN_GENERAL && mode != CATCHHIP_SCAN_FAST;
     const u32 nb = by_sequence ? (u32)P->nprobes : (u32)P->nbuckets;
     const bool force_radix = getenv("CATCHHIP_ROWS_RADIX") != nullptr;
     HitSink sink;
@@ -961,7 +985,7 @@ int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const ca
                            i32 lcf_thres, i32 island, i32 cover_extension, i32 mode, catchhip_rows **out) {
     *out = nullptr;
     if (P->nprobes == 0 || T->total == 0) return 1;
-    if (!fast_path_ok(P, T, mismatches, lcf_thres, island)) return 1;
+    if (!seed_path_ok(P, T, mismatches, lcf_thres, island)) return 1;
     if (!(mode == CATCHHIP_SCAN_SEED || (mode == CATCHHIP_SCAN_AUTO && !getenv("CATCHHIP_SCAN_TILED")))) return 1;
     if (getenv("CATCHHIP_ROWS_RADIX") || getenv("CATCHHIP_SEED_CAP") || getenv("CATCHHIP_FUSED_SYNC")) return 1;
     const i64 scap64 = std::max<i64>((i64)1 << 20, T->total * 4);
@@ -1026,17 +1050,19 @@ extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, 
     if (nrows) *nrows = 0;
     HIP_TRY(hipSetDevice(ctx->device));
     const bool fast_ok = fast_path_ok(P, T, mismatches, lcf_thres, island);
+    const bool seed_ok = seed_path_ok(P, T, mismatches, lcf_thres, island);
     if (mode == CATCHHIP_SCAN_FAST && !fast_ok) {
         chip_set_error("cover_scan: fast-path preconditions do not hold");
         return CATCHHIP_EINVAL;
     }
-    if (mode == CATCHHIP_SCAN_SEED && !fast_ok) {
+    if (mode == CATCHHIP_SCAN_SEED && !seed_ok) {
         chip_set_error("cover_scan: seed-filter preconditions do not hold");
         return CATCHHIP_EINVAL;
     }
-    // AUTO: all paths are exact.  When the pigeonhole/full-length conditions
-    // hold the seed filter (O(G + seeds)) is used; CATCHHIP_SCAN_FAST forces the
-    // tiled O(P*G) scan, CATCHHIP_SCAN_GENERAL the byte-exact seed join.
+    // AUTO: all paths are exact.  With a full-length cover threshold on DNA the
+    // seed scan (O(G + seeds)) is used, whatever the anchor table;
+    // CATCHHIP_SCAN_FAST forces the tiled O(P*G) scan (pigeonhole anchors only),
+    // CATCHHIP_SCAN_GENERAL the byte-exact seed join.
     catchhip_rows *R = new catchhip_rows();
     R->ctx = ctx;
     R->total = T->total;

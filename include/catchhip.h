@@ -94,10 +94,14 @@ int catchhip_probes_destroy(catchhip_probes *p);
 /* ---- K1: coverage scan -------------------------------------------------- */
 #define CATCHHIP_SCAN_AUTO 0     /* seed scan when its preconditions hold, else general */
 #define CATCHHIP_SCAN_GENERAL 1  /* force the seed-join + extension path */
-#define CATCHHIP_SCAN_FAST 2     /* force the tiled Hamming kernel (EINVAL if
-                                    preconditions do not hold) */
-#define CATCHHIP_SCAN_SEED 3     /* force the hash-seeded Hamming kernel (same
-                                    preconditions as the tiled kernel) */
+#define CATCHHIP_SCAN_FAST 2     /* force the tiled Hamming kernel: the seed
+                                    kernel's conditions + pigeonhole anchors
+                                    {0,k,..,L-k} with L/k > mismatches (EINVAL
+                                    otherwise) */
+#define CATCHHIP_SCAN_SEED 3     /* force the hash-seeded Hamming kernel: equal-
+                                    length DNA probes, lcf_thres == probe length,
+                                    island == 0, sequences >= probe length; any
+                                    anchor table (EINVAL otherwise) */
 /* Replaces SetCoverFilter._make_sets (catch/filter/set_cover_filter.py
  * :359-470) = for every target sequence, probe.find_probe_covers_in_sequence
  * (catch/probe.py:1008-1271) under the default hybridization model

@@ -88,6 +88,8 @@ def test_scan_fast_no_n_two_planes(ctx, oracle):
     (75, 25, 2, 75, 30, 0, None),   # island of exact match
     (100, 50, 3, 80, 25, 10, 13),
     (75, 25, 1, 40, 0, 3, 14),
+    (100, 50, 6, 100, 0, 20, 15),   # random anchors, full-length threshold, more mismatches
+    (60, 30, 4, 60, 0, 0, 16),
 ])
 def test_scan_general_matches_oracle(ctx, oracle, L, stride, m, thres, island,
                                      ext, seed):
@@ -100,6 +102,14 @@ def test_scan_general_matches_oracle(ctx, oracle, L, stride, m, thres, island,
         np.random.seed(seed)
     got = _scan_rows(ctx, probes, genomes, m, thres, island, ext)
     assert got == exp
+    if thres == L and island == 0:
+        # full-length threshold: the seed scan takes any anchor table (here the
+        # reference's random anchors) and must agree with the seed join
+        engine = _engine()
+        for mode in (engine.SCAN_SEED, engine.SCAN_GENERAL):
+            if seed is not None:
+                np.random.seed(seed)
+            assert _scan_rows(ctx, probes, genomes, m, thres, island, ext, mode) == exp
 
 
 @pytest.mark.parametrize("copies", [40, 700, 9000])
