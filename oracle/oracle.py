@@ -45,6 +45,11 @@ def lib():
             build()
         L = ctypes.CDLL(_LIB_PATH)
         L.orc_free.argtypes = [ctypes.c_void_p]
+        L.orc_pyhash_seed0.argtypes = [_u8p, ctypes.c_int64]
+        L.orc_pyhash_seed0.restype = ctypes.c_int64
+        L.orc_minhash.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int64,
+                                  ctypes.c_int64, ctypes.c_int64]
+        L.orc_minhash.restype = ctypes.c_int64
         L.orc_k_lcf_around_anchor.argtypes = [
             _u8p, ctypes.c_int64, _u8p, ctypes.c_int64, ctypes.c_int64,
             ctypes.c_int64, ctypes.c_int64, _i64p, _i64p]
@@ -476,5 +481,80 @@ def ndf_hamming(probe_strs, dist_thres, positions):
                 if len(q) != len(p):
                     raise ValueError("Sequences must be of same length")
                 if int(np.count_nonzero(arr[p] != arr[q])) <= dist_thres:
+                    exclude.add(q)
+    return kept
+
+
+# --------------------------------------------------------------------------
+# near-duplicate filter, MinHash family: catch/utils/lsh.py:48-215,
+# catch/filter/near_duplicate_filter.py:148-190
+# --------------------------------------------------------------------------
+MINHASH_P = 2 ** 31 - 1
+
+
+def pyhash_seed0(s):
+    """hash(s) of CPython 3.4-3.10 for an ASCII str under PYTHONHASHSEED=0
+    (see catch_oracle.c: the reference's MinHash uses abs(hash(kmer)))."""
+    b = _bytes_arr(s)
+    return int(lib().orc_pyhash_seed0(_p(b, _u8p), len(s)))
+
+
+def minhash_num_tables(dist_thres, k=3, reporting_prob=0.80):
+    """lsh.py:268-276 with MinHashFamily.P1 (:160-174) = 1 - dist."""
+    P1 = 1.0 - dist_thres
+    if P1 == 1.0:
+        return 1
+    return int(math.ceil(math.log(1.0 - reporting_prob,
+                                  1.0 - math.pow(P1, k))))
+
+
+def minhash_draw_params(num_tables, k):
+    """(a, b) of every hash function in the order the reference draws them:
+    per table, k times make_h(): a = random.randint(1, p), b =
+    random.randint(0, p) (lsh.py:284-287 -> :224 -> :95-96)."""
+    return [[(random.randint(1, MINHASH_P), random.randint(0, MINHASH_P))
+             for _ in range(k)] for _ in range(num_tables)]
+
+
+def jaccard_dist(a, b, kmer_size):
+    """near_duplicate_filter.py:148-157."""
+    ak = set(a[i:i + kmer_size] for i in range(len(a) - kmer_size + 1))
+    bk = set(b[i:i + kmer_size] for i in range(len(b) - kmer_size + 1))
+    return 1.0 - float(len(ak & bk)) / len(ak | bk)
+
+
+def ndf_minhash(probe_strs, dist_thres, params, kmer_size=10):
+    """NearDuplicateFilter._filter with the MinHash family (N = 1, hash(str)
+    under PYTHONHASHSEED=0); `params` = minhash_draw_params(...).  Returns the
+    kept probe strings in inclusion order."""
+    occ = {}
+    for p in probe_strs:
+        occ[p] = occ.get(p, 0) + 1
+    order = [p for p, _ in sorted(occ.items(), key=lambda kv: kv[1],
+                                  reverse=True)]
+    L = lib()
+
+    def g(p, fns):
+        b = _bytes_arr(p)
+        return tuple(int(L.orc_minhash(_p(b, _u8p), len(p), kmer_size, a_, b_))
+                     for a_, b_ in fns)
+    keys = {p: [g(p, fns) for fns in params] for p in occ.keys()}
+    tables = []
+    for t in range(len(params)):
+        ht = {}
+        for p in occ.keys():
+            ht.setdefault(keys[p][t], []).append(p)
+        tables.append(ht)
+    include, exclude, kept = set(), set(), []
+    for p in order:
+        if p in exclude:
+            continue
+        include.add(p)
+        kept.append(p)
+        for t, ht in enumerate(tables):
+            for q in ht[keys[p][t]]:
+                if q in include:
+                    continue
+                if jaccard_dist(p, q, kmer_size) <= dist_thres:
                     exclude.add(q)
     return kept

@@ -45,6 +45,7 @@ from catch.utils import seq_io  # noqa: E402
 from catch_amd.utils import synthetic  # noqa: E402
 
 REC = {"lcs": [], "lcf": [], "scan": [], "setcover": [], "scf": [], "ndf": [],
+       "ndf_minhash": [],
        "merge": []}
 MAX_SEQ = 6000          # do not record scans of sequences longer than this
 MAX_PER_KIND = 4000
@@ -305,6 +306,22 @@ def rec_ndf_filter(self, input):
         out = _orig_ndf_filter(self, input)
     finally:
         lsh.random = old
+    is_minhash = isinstance(self.lsh_family, lsh.MinHashFamily)
+    if (is_minhash and os.environ.get("PYTHONHASHSEED") == "0"
+            and os.getpid() == _in_worker_guard["pid"]
+            and len(REC["ndf_minhash"]) < 200 and len(input) <= 5000):
+        # hash(str) is reproducible only with PYTHONHASHSEED=0; (a, b) of
+        # every hash function in draw order
+        k = self.k
+        ab = [[proxy.log[i], proxy.log[i + 1]]
+              for i in range(0, len(proxy.log), 2)]
+        REC["ndf_minhash"].append(dict(
+            probes=[p.seq_str for p in input],
+            dist_thres=float(self.dist_thres), k=int(k),
+            kmer_size=int(self.lsh_family.kmer_size),
+            reporting_prob=float(self.reporting_prob),
+            params=[ab[i:i + k] for i in range(0, len(ab), k)],
+            out=sorted(p.seq_str for p in out)))
     if (is_hamming and os.getpid() == _in_worker_guard["pid"]
             and len(REC["ndf"]) < 200 and len(input) <= 5000):
         k = self.k
@@ -493,7 +510,57 @@ def dump(name, obj):
     print("wrote", path, os.path.getsize(path), "bytes", flush=True)
 
 
+def ndf_minhash_cases():
+    """The reference's MinHash near-duplicate filter on seeded synthetic
+    candidates (hash(str) pinned by PYTHONHASHSEED=0, a/b by random.seed)."""
+    out = []
+    rng = np.random.Generator(np.random.PCG64(19))
+    base = synthetic.make_species(rng, [3000], 8, 2, 0.04, 0.01, with_n=True)
+    for L, d, ks, seed in ((100, 0.6, 10, 31), (75, 0.5, 10, 32),
+                           (100, 0.3, 8, 33)):
+        ps = []
+        for g in base:
+            ps += candidate_probes.make_candidate_probes_from_sequences(
+                g, probe_length=L, probe_stride=L // 2)
+        random.seed(seed)
+        f = ndf.NearDuplicateFilterWithMinHash(d, ks)
+        f.filter(ps)
+        rec = REC["ndf_minhash"].pop()
+        rec["seed"] = seed
+        out.append(rec)
+        print("ndf minhash", L, d, ks, len(rec["probes"]), "->",
+              len(rec["out"]), "tables", len(rec["params"]), flush=True)
+    return out
+
+
+def minhash_main():
+    """`make_golden.py minhash-only`: only tests/golden/ndf_minhash.json.gz.
+    Re-executes itself with PYTHONHASHSEED=0 (the setting has to be in place
+    when the interpreter starts)."""
+    if os.environ.get("PYTHONHASHSEED") != "0":
+        env = dict(os.environ, PYTHONHASHSEED="0")
+        os.execve(sys.executable, [sys.executable] + sys.argv, env)
+    ndf.NearDuplicateFilter._filter = rec_ndf_filter
+    suite = unittest.TestLoader().loadTestsFromName(
+        "catch.filter.tests.test_near_duplicate_filter")
+    res = unittest.TextTestRunner(verbosity=0).run(suite)
+    if res.failures or res.errors:
+        raise SystemExit("reference tests failed under the recorder")
+    tests = list(REC["ndf_minhash"])
+    REC["ndf_minhash"].clear()
+    syn = ndf_minhash_cases()
+    # known answers of the interpreter's str hash itself
+    strs = ["A", "ACGTACGTAC", "TTTTTTTTTT", "ACGTNNACGTACGTAAAAC", "GATTACA" * 9]
+    dump("ndf_minhash", dict(
+        python=sys.version.split()[0],
+        str_hash=[[x, hash(x)] for x in strs],
+        from_reference_tests=tests, synthetic=syn))
+    print("ndf_minhash", len(tests), len(syn))
+
+
 def main():
+    if "minhash-only" in sys.argv:
+        return minhash_main()
     install()
     run_reference_tests()
     if "probe-only" in sys.argv:

@@ -85,6 +85,44 @@ def test_ndf_hamming(oracle):
         assert sorted(kept) == c["out"]
 
 
+def test_ndf_minhash(oracle):
+    """MinHash near-duplicate filter: vectors recorded from the reference run
+    under PYTHONHASHSEED=0 (its MinHash family uses hash(str)); includes the
+    known answers of the interpreter's str hash that the oracle restates."""
+    import random
+    g = load_golden("ndf_minhash")
+    for x, h in g["str_hash"]:
+        assert oracle.pyhash_seed0(x) == h
+    recs = g["from_reference_tests"] + g["synthetic"]
+    assert len(recs) >= 6
+    for c in recs:
+        assert oracle.minhash_num_tables(c["dist_thres"], c["k"],
+                                         c["reporting_prob"]) == len(c["params"])
+        kept = oracle.ndf_minhash(c["probes"], c["dist_thres"], c["params"],
+                                  c["kmer_size"])
+        assert sorted(kept) == c["out"]
+    for c in g["synthetic"]:   # the draw order of (a, b)
+        random.seed(c["seed"])
+        got = oracle.minhash_draw_params(len(c["params"]), c["k"])
+        assert [[list(ab) for ab in t] for t in got] == c["params"]
+
+
+def test_pyhash_matches_this_interpreter(oracle):
+    """Where the interpreter still hashes str with SipHash-2-4 (CPython <=
+    3.10) the restatement must equal hash() under PYTHONHASHSEED=0."""
+    import subprocess
+    import sys
+    if sys.version_info >= (3, 11):
+        pytest.skip("CPython >= 3.11 hashes str with SipHash-1-3")
+    strs = ["ACGTACGTAC", "NNNNNNNNNN", "GATTACAGAT", "C" * 37]
+    out = subprocess.run(
+        [sys.executable, "-c",
+         "import sys; print([hash(x) for x in %r])" % (strs,)],
+        env={"PYTHONHASHSEED": "0", "PATH": "/usr/bin:/bin"},
+        capture_output=True, text=True, check=True).stdout
+    assert eval(out) == [oracle.pyhash_seed0(x) for x in strs]
+
+
 def test_merge_overlapping(oracle):
     assert oracle.merge_overlapping([(1, 5), (3, 7), (9, 12)]) == [(1, 7), (9, 12)]
     assert oracle.merge_overlapping([(1, 3), (3, 5)]) == [(1, 5)]
