@@ -48,6 +48,9 @@ PROTOTYPES = {
         c_i64p]),
     "catchhip_setcover_greedy": (ctypes.c_int, [
         c_vp, c_vp, ctypes.c_int64, c_i64p, c_f64p, c_i64p, c_i64p]),
+    "catchhip_ndf_minhash": (ctypes.c_int, [
+        c_vp, c_u8p, c_i64p, ctypes.c_int64, ctypes.c_int32, c_i64p,
+        ctypes.c_int32, ctypes.c_int32, ctypes.c_double, c_u8p]),
     "catchhip_setcover_filter": (ctypes.c_int, [
         c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, c_i64p, c_f64p,

@@ -91,6 +91,35 @@ ndf_node_round_kernel(u32 *__restrict__ status, u32 *__restrict__ flags, u32 n, 
     else atomicAdd(undecided, 1u);
 }
 
+// greedy resolution rounds over the edge list + read-back (shared by the two
+// LSH families)
+static int ndf_resolve(catchhip_ctx *ctx, u32 nn, u32 ne, DevBuf<u32> &e_i, DevBuf<u32> &e_j, DevBuf<u32> &count,
+                       DevBuf<u32> &status, DevBuf<u32> &flags, PhaseTimer &tm, u8 *keep) {
+    hipStream_t s = ctx->stream;
+    const unsigned nb = (unsigned)div_up(nn, 256);
+    for (u32 round = 0; round <= nn + 1; ++round) {
+        HIP_TRY(hipMemsetAsync(count.p + 1, 0, sizeof(u32), s));
+        if (ne)
+            hipLaunchKernelGGL(ndf_edge_round_kernel, dim3((unsigned)div_up(ne, 256)), dim3(256), 0, s, e_i.p,
+                               e_j.p, ne, status.p, flags.p);
+        hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, count.p + 1);
+        tm.launch(2);
+        HIP_TRY(hipMemcpyAsync(ctx->h_pin, count.p + 1, sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (*(volatile u32 *)ctx->h_pin == 0) break;
+    }
+    tm.stop();
+    std::vector<u32> h_status(nn);
+    HIP_TRY(hipMemcpyAsync(h_status.data(), status.p, sizeof(u32) * nn, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    tm.finish();
+    for (u32 i = 0; i < nn; ++i) {
+        if (h_status[i] == 0) { chip_set_error("ndf: unresolved probe"); return CATCHHIP_EINVAL; }
+        keep[i] = h_status[i] == 1 ? 1 : 0;
+    }
+    return 0;
+}
+
 extern "C" int catchhip_ndf_hamming(catchhip_ctx *ctx, const u8 *bytes, i64 n, i32 L, const i32 *positions,
                                     i32 ntables, i32 k, i32 dist_thres, u8 *keep) {
     ARG_CHECK(ctx && n >= 0 && L > 0 && ntables >= 1 && k >= 1 && positions);
@@ -144,26 +173,266 @@ extern "C" int catchhip_ndf_hamming(catchhip_ctx *ctx, const u8 *bytes, i64 n, i
         if (attempt >= 2) { chip_set_error("ndf: edge buffer overflow"); return CATCHHIP_ENOMEM; }
         cap = ne;
     }
-    // greedy resolution rounds
-    for (u32 round = 0; round <= nn + 1; ++round) {
-        HIP_TRY(hipMemsetAsync(count.p + 1, 0, sizeof(u32), s));
-        if (ne)
-            hipLaunchKernelGGL(ndf_edge_round_kernel, dim3((unsigned)div_up(ne, 256)), dim3(256), 0, s, e_i.p,
-                               e_j.p, ne, status.p, flags.p);
-        hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, count.p + 1);
-        tm.launch(2);
-        HIP_TRY(hipMemcpyAsync(ctx->h_pin, count.p + 1, sizeof(u32), hipMemcpyDeviceToHost, s));
+    return ndf_resolve(ctx, nn, ne, e_i, e_j, count, status, flags, tm, keep);
+}
+
+// ------------------------------------------------------------------------
+// MinHash family (catch/filter/near_duplicate_filter.py:148-190,
+// catch/utils/lsh.py:48-215 with N = 1 and use_fast_str_hash = True).
+//
+// A hash function of the family is  h(s) = min over the k-mers x of s of
+// (a * |hash(x)| + b) mod (2^31 - 1)  where hash() is the interpreter's str
+// hash: SipHash-2-4 of the characters in CPython <= 3.10, keyed by the
+// process-wide secret -- all-zero under PYTHONHASHSEED=0, the only setting
+// under which the reference's filter is reproducible; that is the hash
+// computed here (oracle/catch_oracle.c restates it, tests pin both to the
+// interpreter and to vectors recorded from the reference).  A table key is the
+// tuple of k such minima; two probes are near-duplicates when they share a key
+// in some table and the Jaccard distance of their k-mer SETS is <= dist_thres
+// (float64, evaluated exactly as the reference's expression).  The sequential
+// pass is the same maximal-independent-set resolution as for Hamming.
+//   mh_kmer_kernel      one wavefront per probe: |hash| mod p of every k-mer
+//                       and the sorted list of its DISTINCT k-mers (the bytes
+//                       themselves, <= 16 per k-mer in two u64 words; rank
+//                       sort in LDS)
+//   mh_key_kernel       per table: the k minima of every probe -> signature,
+//                       64-bit grouping key
+//   (radix sort)        buckets = runs of equal keys, indices ascending
+//   mh_edge_kernel      one lane per sorted slot walks left over its run:
+//                       same signature (exact) and Jaccard distance <= d
+// ------------------------------------------------------------------------
+#define MH_P 2147483647ull
+#define MH_MAXK 256   // k-mers per probe one wavefront sorts
+
+__device__ __forceinline__ u64 mh_rotl(u64 x, int b) { return (x << b) | (x >> (64 - b)); }
+
+// CPython <= 3.10 str hash of `len` ASCII characters, zero key (see above)
+__device__ __forceinline__ long long mh_pyhash(const u8 *__restrict__ src, int len) {
+    u64 v0 = 0x736f6d6570736575ull, v1 = 0x646f72616e646f6dull, v2 = 0x6c7967656e657261ull,
+        v3 = 0x7465646279746573ull;
+#define MH_ROUND do { \
+    v0 += v1; v1 = mh_rotl(v1, 13); v1 ^= v0; v0 = mh_rotl(v0, 32); \
+    v2 += v3; v3 = mh_rotl(v3, 16); v3 ^= v2; \
+    v0 += v3; v3 = mh_rotl(v3, 21); v3 ^= v0; \
+    v2 += v1; v1 = mh_rotl(v1, 17); v1 ^= v2; v2 = mh_rotl(v2, 32); } while (0)
+    u64 b = (u64)len << 56;
+    int n = len;
+    const u8 *p = src;
+    while (n >= 8) {
+        u64 mi = 0;
+        for (int i = 0; i < 8; ++i) mi |= (u64)p[i] << (8 * i);
+        v3 ^= mi; MH_ROUND; MH_ROUND; v0 ^= mi;
+        p += 8; n -= 8;
+    }
+    u64 t = 0;
+    for (int i = 0; i < n; ++i) t |= (u64)p[i] << (8 * i);
+    b |= t;
+    v3 ^= b; MH_ROUND; MH_ROUND; v0 ^= b;
+    v2 ^= 0xff; MH_ROUND; MH_ROUND; MH_ROUND; MH_ROUND;
+#undef MH_ROUND
+    long long x = (long long)((v0 ^ v1) ^ (v2 ^ v3));
+    if (x == -1) x = -2;
+    return x;
+}
+
+__global__ void __launch_bounds__(64)
+mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, const u32 *__restrict__ koff, u32 n,
+               int ks, u32 *__restrict__ xs, u64 *__restrict__ id_hi, u64 *__restrict__ id_lo,
+               u32 *__restrict__ nuniq) {
+    __shared__ u64 s_hi[MH_MAXK], s_lo[MH_MAXK];
+    const u32 lane = threadIdx.x;
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        const u8 *p = bytes + probe_off[i];
+        const u32 k0 = koff[i], nk = koff[i + 1] - k0;
+        __syncthreads();
+        for (u32 j = lane; j < nk; j += 64) {
+            const long long h = mh_pyhash(p + j, ks);
+            xs[k0 + j] = (u32)((u64)(h < 0 ? -h : h) % MH_P);
+            u64 lo = 0, hi = 0;   // the k-mer's bytes, big endian: order = string order
+            for (int c = 0; c < ks; ++c) {
+                const u64 ch = p[j + c];
+                if (c < ks - 8) hi = (hi << 8) | ch; else lo = (lo << 8) | ch;
+            }
+            if (ks <= 8) hi = 0;
+            s_hi[j] = hi; s_lo[j] = lo;
+        }
+        __syncthreads();
+        // rank sort; equal k-mers get consecutive ranks, the first of each group is kept
+        u64 mh[MH_MAXK / 64], ml[MH_MAXK / 64];
+        u32 rk[MH_MAXK / 64];
+#pragma unroll
+        for (int q = 0; q < MH_MAXK / 64; ++q) {
+            const u32 j = lane + q * 64;
+            rk[q] = 0;
+            mh[q] = j < nk ? s_hi[j] : 0; ml[q] = j < nk ? s_lo[j] : 0;
+        }
+        for (u32 y = 0; y < nk; ++y) {
+            const u64 h = s_hi[y], l = s_lo[y];
+#pragma unroll
+            for (int q = 0; q < MH_MAXK / 64; ++q) {
+                const u32 j = lane + q * 64;
+                const bool less = h < mh[q] || (h == mh[q] && (l < ml[q] || (l == ml[q] && y < j)));
+                rk[q] += less ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < MH_MAXK / 64; ++q) {
+            const u32 j = lane + q * 64;
+            if (j < nk) { s_hi[rk[q]] = mh[q]; s_lo[rk[q]] = ml[q]; }
+        }
+        __syncthreads();
+        u32 out = 0;
+        for (u32 c0 = 0; c0 < nk; c0 += 64) {
+            const u32 j = c0 + lane;
+            const bool first = j < nk && (j == 0 || s_hi[j] != s_hi[j - 1] || s_lo[j] != s_lo[j - 1]);
+            const unsigned long long bal = __ballot(first);
+            if (first) {
+                const u32 o = out + (u32)__popcll(bal & ((1ull << lane) - 1ull));
+                id_hi[k0 + o] = s_hi[j]; id_lo[k0 + o] = s_lo[j];
+            }
+            out += (u32)__popcll(bal);
+        }
+        if (lane == 0) nuniq[i] = out;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+mh_key_kernel(const u32 *__restrict__ xs, const u32 *__restrict__ koff, u32 n, const u64 *__restrict__ ab, int k,
+              u32 *__restrict__ sig, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 k0 = koff[i], nk = koff[i + 1] - k0;
+    u64 h = 0xcbf29ce484222325ull;
+    for (int f = 0; f < k; ++f) {
+        const u64 a = ab[2 * f] % MH_P, b = ab[2 * f + 1];
+        u64 best = ~0ull;
+        for (u32 j = 0; j < nk; ++j) {
+            const u64 v = (a * (u64)xs[k0 + j] + b) % MH_P;
+            best = v < best ? v : best;
+        }
+        sig[(size_t)i * k + f] = (u32)best;
+        h = (h ^ best) * 0x100000001b3ull;
+    }
+    keys[i] = h;
+    vals[i] = i;
+}
+
+// exact Jaccard distance of two sorted lists of distinct k-mers <= thres ?
+__device__ __forceinline__ bool mh_near(const u64 *__restrict__ ah, const u64 *__restrict__ al, u32 na,
+                                        const u64 *__restrict__ bh, const u64 *__restrict__ bl, u32 nb,
+                                        double thres) {
+    u32 x = 0, y = 0, inter = 0;
+    while (x < na && y < nb) {
+        const u64 h1 = ah[x], l1 = al[x], h2 = bh[y], l2 = bl[y];
+        if (h1 == h2 && l1 == l2) { ++inter; ++x; ++y; }
+        else if (h1 < h2 || (h1 == h2 && l1 < l2)) ++x;
+        else ++y;
+    }
+    const u32 uni = na + nb - inter;
+    // 1.0 - float(len(a & b)) / len(a | b)   (near_duplicate_filter.py:155-157)
+    const double sim = __ddiv_rn((double)inter, (double)uni);
+    return __dsub_rn(1.0, sim) <= thres;
+}
+
+__global__ void __launch_bounds__(256)
+mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, const u64 *__restrict__ id_hi,
+               const u64 *__restrict__ id_lo, const u32 *__restrict__ sig, int k, double thres, u32 n,
+               const u64 *__restrict__ keys, const u32 *__restrict__ vals, u32 *__restrict__ e_i,
+               u32 *__restrict__ e_j, u32 *__restrict__ count, u32 cap) {
+    const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    const u64 key = keys[x];
+    const u32 i = vals[x];
+    for (u32 y = x; y-- > 0;) {
+        if (keys[y] != key) break;
+        const u32 j = vals[y];  // j < i: stable sort keeps indices ascending in a run
+        bool same = true;       // same bucket = same signature (the key only groups)
+        for (int f = 0; f < k; ++f) same = same && sig[(size_t)i * k + f] == sig[(size_t)j * k + f];
+        if (same && mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j],
+                            thres)) {
+            const u32 slot = atomicAdd(count, 1u);
+            if (slot < cap) { e_i[slot] = i; e_j[slot] = j; }
+        }
+    }
+}
+
+extern "C" int catchhip_ndf_minhash(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off, i64 n, i32 kmer_size,
+                                    const i64 *ab, i32 ntables, i32 k, double dist_thres, u8 *keep) {
+    ARG_CHECK(ctx && n >= 0 && kmer_size >= 1 && kmer_size <= 16 && ntables >= 1 && k >= 1 && k <= 16 && ab);
+    PoolScope pool_scope(ctx);
+    if (n == 0) return 0;
+    ARG_CHECK(bytes && probe_off && keep && probe_off[0] == 0);
+    ARG_CHECK(n < ((i64)1 << 31) && probe_off[n] < ((i64)1 << 32));
+    std::vector<u32> h_off((size_t)n + 1), h_koff((size_t)n + 1, 0);
+    for (i64 i = 0; i <= n; ++i) h_off[i] = (u32)probe_off[i];
+    for (i64 i = 0; i < n; ++i) {
+        const i64 len = probe_off[i + 1] - probe_off[i];
+        // lsh.py:113 asserts kmer_size <= len(s)
+        if (len < kmer_size) { chip_set_error("ndf minhash: probe %lld shorter than the k-mer size", (long long)i); return CATCHHIP_EINVAL; }
+        const i64 nk = len - kmer_size + 1;
+        if (nk > MH_MAXK) { chip_set_error("ndf minhash: more than %d k-mers per probe not supported", MH_MAXK); return CATCHHIP_EINVAL; }
+        h_koff[i + 1] = h_koff[i] + (u32)nk;
+    }
+    for (i64 t = 0; t < (i64)ntables * k; ++t)
+        ARG_CHECK(ab[2 * t] >= 1 && ab[2 * t] <= (i64)MH_P && ab[2 * t + 1] >= 0 && ab[2 * t + 1] <= (i64)MH_P);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const u32 nn = (u32)n;
+    const size_t total = (size_t)probe_off[n], nkm = h_koff[n];
+    DevBuf<u8> d_bytes;
+    DevBuf<u64> d_ab, keys, keys_alt, id_hi, id_lo;
+    DevBuf<u32> d_off, d_koff, xs, nuniq, sig, vals, vals_alt, e_i, e_j, count, status, flags;
+    TRY(d_bytes.alloc(total + 16));
+    TRY(d_ab.alloc((size_t)ntables * k * 2));
+    TRY(d_off.alloc((size_t)n + 1));
+    TRY(d_koff.alloc((size_t)n + 1));
+    TRY(xs.alloc(nkm));
+    TRY(id_hi.alloc(nkm));
+    TRY(id_lo.alloc(nkm));
+    TRY(nuniq.alloc(nn));
+    TRY(sig.alloc((size_t)nn * k));
+    TRY(keys.alloc(nn));
+    TRY(vals.alloc(nn));
+    TRY(count.alloc(2));
+    TRY(status.alloc(nn));
+    TRY(flags.alloc(nn));
+    HIP_TRY(hipMemcpyAsync(d_bytes.p, bytes, total, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_ab.p, ab, sizeof(i64) * ntables * k * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_koff.p, h_koff.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(count.p, 0, 2 * sizeof(u32), s));
+    HIP_TRY(hipMemsetAsync(status.p, 0, sizeof(u32) * nn, s));
+    HIP_TRY(hipMemsetAsync(flags.p, 0, sizeof(u32) * nn, s));
+
+    PhaseTimer tm(ctx, PHASE_NDF);
+    const unsigned nb = (unsigned)div_up(nn, 256);
+    hipLaunchKernelGGL(mh_kmer_kernel, dim3((unsigned)std::min<i64>(n, (i64)1 << 20)), dim3(64), 0, s,
+                       (const u8 *)d_bytes.p, (const u32 *)d_off.p, (const u32 *)d_koff.p, nn, (int)kmer_size, xs.p,
+                       id_hi.p, id_lo.p, nuniq.p);
+    tm.launch(1);
+    u32 cap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(n * 16, (i64)1 << 28));
+    u32 ne = 0;
+    for (int attempt = 0;; ++attempt) {
+        TRY(e_i.reserve(cap));
+        TRY(e_j.reserve(cap));
+        HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(u32), s));
+        for (int t = 0; t < ntables; ++t) {
+            hipLaunchKernelGGL(mh_key_kernel, dim3(nb), dim3(256), 0, s, (const u32 *)xs.p, (const u32 *)d_koff.p, nn,
+                               (const u64 *)(d_ab.p + (size_t)t * k * 2), (int)k, sig.p, keys.p, vals.p);
+            TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nn, 64));
+            hipLaunchKernelGGL(mh_edge_kernel, dim3(nb), dim3(256), 0, s, (const u32 *)d_koff.p, (const u32 *)nuniq.p,
+                               (const u64 *)id_hi.p, (const u64 *)id_lo.p, (const u32 *)sig.p, (int)k, dist_thres, nn,
+                               (const u64 *)keys.p, (const u32 *)vals.p, e_i.p, e_j.p, count.p, cap);
+            tm.launch(2 + 24);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ctx->h_pin, count.p, sizeof(u32), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (*(volatile u32 *)ctx->h_pin == 0) break;
+        ne = *(volatile u32 *)ctx->h_pin;
+        if (ne <= cap) break;
+        if (attempt >= 2) { chip_set_error("ndf: edge buffer overflow"); return CATCHHIP_ENOMEM; }
+        cap = ne;
     }
-    tm.stop();
-    std::vector<u32> h_status(nn);
-    HIP_TRY(hipMemcpyAsync(h_status.data(), status.p, sizeof(u32) * nn, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    tm.finish();
-    for (u32 i = 0; i < nn; ++i) {
-        if (h_status[i] == 0) { chip_set_error("ndf: unresolved probe"); return CATCHHIP_EINVAL; }
-        keep[i] = h_status[i] == 1 ? 1 : 0;
-    }
-    return 0;
+    return ndf_resolve(ctx, nn, ne, e_i, e_j, count, status, flags, tm, keep);
 }

@@ -4,11 +4,11 @@
 The hot-path subset of the reference CLI (bin/design.py:448-980), same option
 names and defaults ("basic" profile): every FASTA file is one dataset = one
 group of target genomes (bin/design.py:91-99), one Genome per record.  Filter
-list as bin/design.py:296-340 builds it: exact duplicate filter (or the
-Hamming near-duplicate filter with --filter-with-lsh-hamming), then the set
-cover filter.  Options outside the accelerated path (clustering, adapters,
-reverse complements, N expansion, custom hybridization functions, MinHash
-near-duplicate filter) are not offered.
+list as bin/design.py:296-340 builds it: exact duplicate filter (or a
+near-duplicate filter with --filter-with-lsh-hamming / --filter-with-lsh-
+minhash), then the set cover filter.  Options outside the accelerated path
+(clustering, adapters, reverse complements, N expansion, custom hybridization
+functions) are not offered.
 """
 import argparse
 import logging
@@ -41,6 +41,9 @@ def parse_args(argv=None):
     p.add_argument("--island-of-exact-match-tolerant", type=int, default=0)
     p.add_argument("--filter-with-lsh-hamming", type=int,
                    help="Hamming threshold of the near-duplicate filter")
+    p.add_argument("--filter-with-lsh-minhash", type=float,
+                   help="Jaccard-distance threshold of the MinHash "
+                        "near-duplicate filter")
     p.add_argument("--small-seq-skip", type=int)
     p.add_argument("--small-seq-min", type=int)
     p.add_argument("--kmer-probe-map-k", type=int, default=20)
@@ -58,6 +61,10 @@ def main(args):
     genomes_grouped = [seq_io.read_genomes_from_fasta(fn) for fn in args.dataset]
 
     filters = []
+    if (args.filter_with_lsh_hamming is not None and
+            args.filter_with_lsh_minhash is not None):
+        raise Exception("Cannot use both --filter-with-lsh-hamming "
+                        "and --filter-with-lsh-minhash")
     if args.filter_with_lsh_hamming is not None:
         if args.filter_with_lsh_hamming > args.mismatches:
             logger.warning("Nearly duplicate probes are filtered by calling "
@@ -65,6 +72,14 @@ def main(args):
                            "that exceeds --mismatches")
         filters.append(near_duplicate_filter.NearDuplicateFilterWithHammingDistance(
             args.filter_with_lsh_hamming, args.probe_length))
+    elif args.filter_with_lsh_minhash is not None:
+        if args.mismatches < 3:
+            logger.warning("MISMATCHES is set to %d; at low values using "
+                           "--filter-with-lsh-minhash may cause the probes to "
+                           "achieve less than the desired coverage",
+                           args.mismatches)
+        filters.append(near_duplicate_filter.NearDuplicateFilterWithMinHash(
+            args.filter_with_lsh_minhash))
     else:
         filters.append(duplicate_filter.DuplicateFilter())
     scf = set_cover_filter.SetCoverFilter(

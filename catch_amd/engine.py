@@ -111,6 +111,19 @@ class Context:
         return keep[:n].astype(bool)
 
 
+    def ndf_minhash(self, probe_strs, kmer_size, params, dist_thres):
+        """catchhip_ndf_minhash; params[table][fn] = (a, b)."""
+        n = len(probe_strs)
+        buf, off = _concat(probe_strs)
+        ab = np.ascontiguousarray(params, dtype=np.int64)
+        ntables, k = ab.shape[0], ab.shape[1]
+        keep = np.zeros(max(n, 1), dtype=np.uint8)
+        check(self._L.catchhip_ndf_minhash(
+            self._h, _ptr(buf, c_u8p), _ptr(off, c_i64p), n, int(kmer_size),
+            _ptr(ab, c_i64p), ntables, k, float(dist_thres), _ptr(keep, c_u8p)))
+        return keep[:n].astype(bool)
+
+
 class Targets:
     """Device-resident target sequences (catchhip_targets).
     genomes: list of genomes, each a list of sequence strings."""

@@ -69,3 +69,51 @@ class NearDuplicateFilterWithHammingDistance(NearDuplicateFilter):
         keep = ctx.ndf_hamming([p.seq_str for p in order], self.dim,
                                positions, self.dist_thres)
         return [p for p, kp in zip(order, keep) if kp]
+
+
+class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
+    """catch/filter/near_duplicate_filter.py:159-190: MinHash family over
+    `kmer_size`-mers (N = 1), k = 3 concatenated functions, Jaccard distance of
+    the k-mer sets for verification.
+
+    The reference's family hashes k-mers with the interpreter's salted
+    hash(str) (lsh.py:97-104 via use_fast_str_hash=True), so two runs of the
+    reference agree only under PYTHONHASHSEED=0; the device computes exactly
+    that variant (CPython <= 3.10: SipHash-2-4 with an all-zero key), whatever
+    this process' own hash seed is.  (a, b) of every hash function are drawn
+    from Python's `random` in the reference's order (lsh.py:284-287 -> :224 ->
+    :95-96)."""
+
+    P = 2 ** 31 - 1
+
+    def __init__(self, dist_thres, kmer_size=10):
+        super().__init__(k=3)
+        self.kmer_size = kmer_size
+        self.dist_thres = dist_thres
+
+    def num_tables(self):
+        """lsh.py:268-276 with MinHashFamily.P1 = 1 - dist (:160-174)."""
+        P1 = 1.0 - self.dist_thres
+        if P1 == 1.0:
+            return 1
+        return int(math.ceil(math.log(1.0 - self.reporting_prob,
+                                      1.0 - math.pow(P1, self.k))))
+
+    def _draw_params(self):
+        return [[(random.randint(1, self.P), random.randint(0, self.P))
+                 for _ in range(self.k)] for _ in range(self.num_tables())]
+
+    def _filter(self, input):
+        input = list(input)
+        order = self._order_by_multiplicity(input)
+        params = self._draw_params()
+        if not order:
+            return []
+        for p in order:
+            # lsh.py:113 asserts kmer_size <= len(s)
+            if len(p.seq_str) < self.kmer_size:
+                raise AssertionError("k-mer size exceeds a sequence's length")
+        ctx = engine.default_context()
+        keep = ctx.ndf_minhash([p.seq_str for p in order], self.kmer_size,
+                               params, self.dist_thres)
+        return [p for p, kp in zip(order, keep) if kp]

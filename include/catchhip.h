@@ -208,6 +208,24 @@ int catchhip_ndf_hamming(catchhip_ctx *ctx, const uint8_t *bytes, int64_t n,
                          int32_t L, const int32_t *positions, int32_t ntables,
                          int32_t k, int32_t dist_thres, uint8_t *keep);
 
+/* Replaces NearDuplicateFilter._filter for NearDuplicateFilterWithMinHash
+ * (catch/filter/near_duplicate_filter.py:148-190) with lsh.MinHashFamily(
+ * kmer_size, N=1, use_fast_str_hash=True) and lsh.NearNeighborLookup
+ * (catch/utils/lsh.py:48-215, :239-320).  The family's inner hash is the
+ * interpreter's hash(str); this library computes it as CPython <= 3.10 does
+ * under PYTHONHASHSEED=0 (SipHash-2-4, zero key) -- the only setting that
+ * makes the reference's filter reproducible, and the one the golden vectors
+ * were recorded with.  n UNIQUE probes in priority order (bytes / probe_off[n+1];
+ * lengths may differ, each >= kmer_size <= 16, at most 256 k-mers per probe);
+ * ab[ntables*k*2] = (a, b) of every hash function in the order the reference
+ * draws them; a table key is the tuple of k minima of (a*|hash(kmer)|+b) mod
+ * (2^31-1); two probes are near-duplicates when they share a key in some table
+ * and the Jaccard distance of their k-mer sets (float64) is <= dist_thres. */
+int catchhip_ndf_minhash(catchhip_ctx *ctx, const uint8_t *bytes,
+                         const int64_t *probe_off, int64_t n, int32_t kmer_size,
+                         const int64_t *ab, int32_t ntables, int32_t k,
+                         double dist_thres, uint8_t *keep);
+
 #ifdef __cplusplus
 }
 #endif
