@@ -174,7 +174,18 @@ def main():
     if world > 1:
         import torch.distributed as dist   # plumbing only: rendezvous/barrier
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its connections on stdout; rank 0 must print ONE line
+        import ctypes
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     ndev = max(1, engine.device_count())
     ctx = engine.Context(local_rank % ndev)   # one rank per GPU on a real node
