@@ -142,14 +142,17 @@ class SetCoverFilter(BaseFilter):
         return bp
 
     def _make_ranks(self, candidate_probes, target_genomes_grouped, ctx=None):
+        return self._make_ranks_strs([p.seq_str for p in candidate_probes],
+                                     target_genomes_grouped, ctx)
+
+    def _make_ranks_strs(self, strs, target_genomes_grouped, ctx=None):
         """Rank per candidate (:614-735): (0, #groups hit) under --identify,
         (1, avoided bp) for probes that touch an avoided genome, densified."""
-        n = len(candidate_probes)
+        n = len(strs)
         need = self.identify or len(self.avoided_genomes) > 0
         if not need:
             return np.zeros(n, dtype=np.int64)
         ctx = ctx or self._context()
-        strs = [p.seq_str for p in candidate_probes]
         k, uniq, _owner, ep, eo = probe.anchor_table(
             strs, self.mismatches_tolerant, self.lcf_thres_tolerant,
             min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
@@ -196,16 +199,25 @@ class SetCoverFilter(BaseFilter):
 
     def _filter(self, input, target_genomes_grouped):
         """input = [p_1, ..., p_m] candidate probes per group; returns the
-        selected probes per group (:902-930).  Groups are independent
-        instances: up to CATCHHIP_GROUPS_IN_FLIGHT (default 4) of them run at
-        once, each on its own context / HIP stream
-        (catchhip_setcover_filter_many)."""
-        import os
+        selected probes per group (:902-930)."""
         input = [list(pp) for pp in input]
-        selected_probes = [[] for _ in input]
+        ids = self._filter_strs([[p.seq_str for p in pp] for pp in input],
+                                target_genomes_grouped)
+        return [[pp[i] for i in sel] for pp, sel in zip(input, ids)]
+
+    def _filter_strs(self, input_strs, target_genomes_grouped,
+                     assume_unique=False):
+        """The filter on plain probe strings: per group the indices of the
+        selected candidates, in pick order.  Groups are independent instances:
+        up to CATCHHIP_GROUPS_IN_FLIGHT (default 4) of them run at once, each
+        on its own context / HIP stream (catchhip_setcover_filter_many).
+        assume_unique: the strings of a group are pairwise distinct (they come
+        out of the duplicate filter)."""
+        import os
+        selected = [[] for _ in input_strs]
         timings = dict(scan_ms=0.0, rows_ms=0.0, greedy_ms=0.0, picks=0,
                        rows=0, scan_launches=0, greedy_launches=0)
-        todo = [i for i, pp in enumerate(input) if len(pp) > 0]
+        todo = [i for i, pp in enumerate(input_strs) if len(pp) > 0]
         width = max(1, int(os.environ.get("CATCHHIP_GROUPS_IN_FLIGHT", "4")))
         for c0 in range(0, len(todo), width):
             chunk = todo[c0:c0 + width]
@@ -213,26 +225,26 @@ class SetCoverFilter(BaseFilter):
             specs, held, all_ranks = [], [], []
             try:
                 for ctx, gi in zip(ctxs, chunk):
-                    possible_probes, target_genomes = \
-                        input[gi], target_genomes_grouped[gi]
+                    strs, target_genomes = \
+                        input_strs[gi], target_genomes_grouped[gi]
                     logger.info("Building set cover sets input (group %d of %d)",
-                                gi + 1, len(input))
-                    strs = [p.seq_str for p in possible_probes]
+                                gi + 1, len(input_strs))
                     k, uniq, owner, ep, eo = probe.anchor_table(
                         strs, self.mismatches, self.lcf_thres,
-                        min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
+                        min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k,
+                        assume_unique=assume_unique)
                     targets = engine.Targets(ctx, [g.seqs for g in target_genomes])
                     held.append(targets)
                     probes = engine.Probes(ctx, uniq, owner, ep, eo, k)
                     held.append(probes)
-                    ranks = self._make_ranks(possible_probes,
-                                             target_genomes_grouped, ctx)
+                    ranks = self._make_ranks_strs(strs, target_genomes_grouped,
+                                                  ctx)
                     all_ranks.append(ranks)
-                    specs.append((ctx, probes, targets, len(possible_probes),
+                    specs.append((ctx, probes, targets, len(strs),
                                   ranks if ranks.any() else None,
                                   self._make_universe_p(target_genomes)))
                 logger.info("Solving set cover instances (groups %s of %d)",
-                            [gi + 1 for gi in chunk], len(input))
+                            [gi + 1 for gi in chunk], len(input_strs))
                 results = engine.setcover_filter_many(
                     specs, self.mismatches, self.lcf_thres,
                     self.island_of_exact_match, self.cover_extension,
@@ -258,9 +270,9 @@ class SetCoverFilter(BaseFilter):
                                     "one grouping during identification or probes "
                                     "that cover an avoided genome)"), gi + 1,
                                    num_bad, "" if num_bad == 1 else "s")
-                selected_probes[gi] = [input[gi][i] for i in ids]
+                selected[gi] = list(ids)
         self.last_timings = timings
-        return selected_probes
+        return selected
 
 
 _extra_ctxs = []

@@ -90,7 +90,7 @@ def pigeonhole_kmer_length(probe_length, mismatches):
 
 
 def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
-                 num_kmers_per_probe=20):
+                 num_kmers_per_probe=20, assume_unique=False):
     """Anchors of construct_kmer_probe_map_to_find_probe_covers
     (catch/probe.py:507-577) for `probe_strs` (duplicates allowed).
 
@@ -106,19 +106,25 @@ def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
     np.random.choice(n_kmers, size=20, replace=True) once per input probe in
     input order, like catch/probe.py:391-401.
     """
-    first = {}
-    last = {}
-    for i, p in enumerate(probe_strs):
-        if p not in first:
-            first[p] = len(first)
-        last[p] = i
-    uniq = list(first.keys())
-    owner = np.fromiter((last[p] for p in uniq), dtype=np.int32,
-                        count=len(uniq))
+    if assume_unique:
+        # the caller de-duplicated already: every string owns itself
+        uniq = list(probe_strs)
+        owner = np.arange(len(uniq), dtype=np.int32)
+        first = None
+    else:
+        first = {}
+        last = {}
+        for i, p in enumerate(probe_strs):
+            if p not in first:
+                first[p] = len(first)
+            last[p] = i
+        uniq = list(first.keys())
+        owner = np.fromiter((last[p] for p in uniq), dtype=np.int32,
+                            count=len(uniq))
     if not uniq:
         return None, uniq, owner, np.zeros(0, np.int32), np.zeros(0, np.int32)
     L = len(probe_strs[0])
-    differ = any(len(p) != L for p in probe_strs)
+    differ = len(set(map(len, probe_strs))) > 1
     use_random = (mismatches is None or lcf_thres is None or differ
                   or lcf_thres < L)
     kk = None
@@ -129,11 +135,11 @@ def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
     if use_random:
         kk = k
         pairs = set()
-        for p in probe_strs:
+        for idx, p in enumerate(probe_strs):
             if kk > len(p):
                 raise ValueError("k is larger than the length of a probe")
             n_kmers = len(p) - kk + 1
-            pi = first[p]
+            pi = first[p] if first is not None else idx
             for pos in np.random.choice(n_kmers, size=num_kmers_per_probe,
                                         replace=True):
                 pairs.add((pi, int(pos)))

@@ -83,8 +83,26 @@ def test_candidate_probes_golden():
         got = candidate_probes.make_candidate_probes_from_sequences(
             c["seqs"], c["probe_length"], c["probe_stride"])
         assert [p.seq_str for p in got] == c["out"]
+        # the string fast path of the front end gives the same list
+        assert candidate_probes.candidate_strings_from_sequences(
+            c["seqs"], c["probe_length"], c["probe_stride"]) == c["out"]
+    import random
+    rnd = random.Random(7)
+    for _ in range(200):   # N runs, ends that are not a multiple of the stride, short tails
+        n = rnd.randrange(30, 400)
+        seq = "".join(rnd.choice("ACGTN" if rnd.random() < 0.3 else "ACGT")
+                      for _ in range(n))
+        if rnd.random() < 0.5:
+            i = rnd.randrange(0, n)
+            seq = seq[:i] + "N" * rnd.randrange(1, 6) + seq[i:]
+        L, st = rnd.choice([(20, 7), (30, 15), (25, 25)])
+        want = [p.seq_str for p in
+                candidate_probes.make_candidate_probes_from_sequences([seq], L, st)]
+        assert candidate_probes.candidate_strings_from_sequences([seq], L, st) == want
     with pytest.raises(ValueError):
         candidate_probes.make_candidate_probes_from_sequences(["ACGT"], 10, 5)
+    with pytest.raises(ValueError):
+        candidate_probes.candidate_strings_from_sequences(["ACGT"], 10, 5)
     with pytest.raises(TypeError):
         candidate_probes.make_candidate_probes_from_sequences("ACGT", 2, 1)
 
