@@ -139,11 +139,12 @@ __device__ __forceinline__ unsigned long long plane_key(const u32 *__restrict__ 
 #define SEED_SKIP 0xffffffffu
 __global__ void __launch_bounds__(256)
 seed_count_kernel(const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent_probe,
-                  const u32 *__restrict__ ent_pos, u32 nent, u32 pos_limit, int NW, int kb, SeedTable t,
-                  u32 *__restrict__ slot_of) {
+                  const u32 *__restrict__ ent_pos, u32 nent, u32 pos_limit, int nanch, int k, int NW, int kb,
+                  SeedTable t, u32 *__restrict__ slot_of) {
     const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nent) return;
-    const u32 p = ent_probe[e], o = ent_pos[e];
+    const u32 p = nanch ? e / (u32)nanch : ent_probe[e];
+    const u32 o = nanch ? (e % (u32)nanch) * (u32)k : ent_pos[e];
     if (o >= pos_limit) { slot_of[e] = SEED_SKIP; return; }
     // the probe image is [word][4]: planes 0/1 of the two words the k-mer starts in
     const u32 wi = o >> 5, sh = o & 31;
@@ -283,14 +284,16 @@ template <int NW>
 __global__ void __launch_bounds__(256)
 seed_verify_kernel(const u32 *__restrict__ tplanes, i64 nwords, const u32 *__restrict__ seq_off,
                    const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent_probe,
-                   const u32 *__restrict__ ent_pos, const u32 *__restrict__ ent_ptr, int L, int k, int mm,
+                   const u32 *__restrict__ ent_pos, const u32 *__restrict__ ent_ptr, int nanch, int L, int k, int mm,
                    u32 tailmask, int use_n, const u32 *__restrict__ seed_pos, const u32 *__restrict__ seed_ent,
                    const u32 *__restrict__ seed_seq, const u32 *__restrict__ seed_count, u32 seed_cap,
                    HitSink sink) {
     const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= min(*seed_count, seed_cap)) return;
     const u32 i = seed_pos[d], e = seed_ent[d], sq = seed_seq[d];
-    const u32 p = ent_probe[e], apos = ent_pos[e];
+    // pigeonhole tables (nanch = L/k anchors per probe, sorted) need no look-ups
+    const u32 p = nanch ? e / (u32)nanch : ent_probe[e];
+    const u32 apos = nanch ? (e % (u32)nanch) * (u32)k : ent_pos[e];
     const u32 lo = seq_off[sq], hi = seq_off[sq + 1];
     bool ok = i >= lo + apos;
     const u32 o = i - apos;                     // where the probe would start
@@ -316,15 +319,20 @@ seed_verify_kernel(const u32 *__restrict__ tplanes, i64 nwords, const u32 *__res
         // bases beyond 32), and the pair is reported from its lowest exact anchor only
         // (the probe's anchors are sorted by position; lower ones precede entry e)
         ok = ok && mask_range_zero<NW>(mw, (int)apos, k);
-        for (u32 j = ent_ptr[p]; ok && j < e; ++j)
-            if (mask_range_zero<NW>(mw, (int)ent_pos[j], k)) ok = false;
+        if (nanch) {
+            for (u32 b = 0; ok && b * (u32)k < apos; ++b)
+                if (mask_range_zero<NW>(mw, (int)(b * k), k)) ok = false;
+        } else {
+            for (u32 j = ent_ptr[p]; ok && j < e; ++j)
+                if (mask_range_zero<NW>(mw, (int)ent_pos[j], k)) ok = false;
+        }
     }
     if (ok) hit_record(sink, d, p, o, o + (u32)L, sq, lo, hi);
     else sink.rank[d] = BK_NONE;
 }
 
 typedef void (*seed_verify_fn)(const u32 *, i64, const u32 *, const uint4 *, const u32 *, const u32 *, const u32 *,
-                               int, int, int, u32, int, const u32 *, const u32 *, const u32 *, const u32 *, u32,
+                               int, int, int, int, u32, int, const u32 *, const u32 *, const u32 *, const u32 *, u32,
                                HitSink);
 static seed_verify_fn pick_seed_verify(int nw) {
     switch (nw) {
@@ -673,8 +681,8 @@ static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     hipLaunchKernelGGL(seed_init_kernel, dim3((unsigned)std::min<i64>(div_up((i64)capacity, 256), 2048)), tb, 0,
                        ctx->stream, S.keys.p, S.cnt.p, capacity, S.ctr.p, sink.bcnt, nb, res);
     hipLaunchKernelGGL(seed_count_kernel, eb, tb, 0, ctx->stream, (const uint4 *)P->planes.p,
-                       (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p, nent, pos_limit, (int)P->pwords, kb, t,
-                       S.slot_of.p);
+                       (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p, nent, pos_limit,
+                       P->pigeonhole ? (int)(P->L / k) : 0, k, (int)P->pwords, kb, t, S.slot_of.p);
     hipLaunchKernelGGL(seed_alloc_kernel, dim3(capacity / 1024), dim3(1024), 0, ctx->stream, t, S.ctr.p);
     hipLaunchKernelGGL(seed_fill_kernel, eb, tb, 0, ctx->stream, nent, t, (const u32 *)S.slot_of.p);
     hipLaunchKernelGGL(seed_lookup_kernel, dim3((unsigned)div_up(T->total, SL_TILE)), dim3(SL_THREADS), 0, ctx->stream,
@@ -683,7 +691,8 @@ static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     hipLaunchKernelGGL(verify, dim3((unsigned)div_up((i64)S.scap, 256)), tb, 0, ctx->stream,
                        (const u32 *)T->planes.p, T->nwords, (const u32 *)T->seq_off.p,
                        (const uint4 *)P->planes.p, (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p,
-                       (const u32 *)P->ent_ptr.p, (int)P->L, k, mm, tailmask, use_n ? 1 : 0,
+                       (const u32 *)P->ent_ptr.p, P->pigeonhole ? (int)(P->L / k) : 0, (int)P->L, k, mm, tailmask,
+                       use_n ? 1 : 0,
                        (const u32 *)S.spos.p, (const u32 *)S.sent.p, (const u32 *)S.sseq.p,
                        (const u32 *)(S.ctr.p + 1), S.scap, sink);
     tm.launch(6);
