@@ -1,0 +1,131 @@
+"""Randomised differential test of the HIP path against the CPU oracle (GPU box).
+    python tools/fuzz_parity.py [seconds] [seed]
+Random groups of genomes (several chromosomes, N runs, repeats, short
+sequences), random -pl/-ps/-m/-l/-e/-c/island/identify settings, with and
+without duplicate candidates; compares the cover rows and the selected probe
+sets, and the near-duplicate filters.  Not part of the pytest suite: run by
+hand after kernel changes; every failure prints the seed that reproduces it."""
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from catch_amd import engine, genome, probe  # noqa: E402
+from catch_amd.filter import candidate_probes, near_duplicate_filter  # noqa: E402
+from catch_amd.filter.set_cover_filter import SetCoverFilter  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def rand_group(rnd):
+    n_genomes = rnd.randrange(1, 9)
+    root = "".join(rnd.choice("ACGT") for _ in range(rnd.randrange(300, 5000)))
+    if rnd.random() < 0.3:   # a tandem repeat
+        unit = root[:rnd.randrange(40, 200)]
+        root += unit * rnd.randrange(2, 30)
+    genomes = []
+    for _ in range(n_genomes):
+        s = list(root)
+        for i in range(len(s)):
+            if rnd.random() < rnd.choice([0.0, 0.01, 0.03]):
+                s[i] = rnd.choice("ACGT")
+        if rnd.random() < 0.4:
+            i = rnd.randrange(len(s))
+            s[i:i + rnd.randrange(1, 30)] = "N" * rnd.randrange(1, 30)
+        s = "".join(s)
+        if rnd.random() < 0.3:   # chromosomes
+            c = sorted(rnd.sample(range(1, len(s)), min(3, len(s) - 1)))
+            seqs = [s[a:b] for a, b in zip([0] + c, c + [len(s)])]
+        else:
+            seqs = [s]
+        genomes.append(seqs)
+    return genomes
+
+
+def one_case(seed, ctx):
+    rnd = random.Random(seed)
+    L = rnd.choice([40, 60, 75, 100, 120])
+    stride = rnd.choice([L // 4, L // 2, L])
+    m = rnd.choice([0, 1, 2, 3, 5])
+    thres = L if rnd.random() < 0.7 else rnd.randrange(L // 2, L)
+    island = 0 if rnd.random() < 0.8 else rnd.randrange(5, 30)
+    ext = rnd.choice([0, 0, 10, 50])
+    coverage = rnd.choice([1.0, 1.0, 1.0, 0.9, 0.5])
+    groups = [rand_group(rnd) for _ in range(rnd.randrange(1, 4))]
+    cands = []
+    for g in groups:
+        seqs = [s for gen in g for s in gen if len(s) >= L]
+        if not seqs:
+            seqs = ["".join(rnd.choice("ACGT") for _ in range(L + 10))]
+            g.append(seqs)
+        c = candidate_probes.candidate_strings_from_sequences(seqs, L, stride)
+        if rnd.random() < 0.7:
+            c = list(dict.fromkeys(c))
+        cands.append(c)
+    np_seed = rnd.randrange(1 << 30)
+    desc = dict(seed=seed, L=L, stride=stride, m=m, thres=thres, island=island, ext=ext,
+                coverage=coverage, groups=[(len(g), sum(len(s) for gen in g for s in gen)) for g in groups])
+    np.random.seed(np_seed)
+    want = oracle.set_cover_filter(cands, groups, m, thres, island=island, coverage=coverage,
+                                   cover_extension=ext)
+    np.random.seed(np_seed)
+    f = SetCoverFilter(mismatches=m, lcf_thres=thres, island_of_exact_match=island,
+                       coverage=coverage, cover_extension=ext)
+    def mk(gen):
+        if len(gen) == 1:
+            return genome.Genome.from_one_seq(gen[0])
+        return genome.Genome.from_chrs(dict(("c%d" % i, x) for i, x in enumerate(gen)))
+    got = f._filter_strs(cands, [[mk(gen) for gen in g] for g in groups])
+    assert [sorted(a) for a in got] == [sorted(b) for b in want], desc
+    # rows of the first group through every scan mode that applies
+    np.random.seed(np_seed)
+    k, entries = oracle.anchor_table(cands[0], m, thres)
+    uniq, owner = oracle._unique_last(cands[0])
+    pr, un, st, en = oracle.make_sets(uniq, entries, k, groups[0], m, thres, island, ext)
+    own = np.array(owner, dtype=np.int32)
+    exp = sorted(zip((own[pr] if pr.size else pr).tolist(), un.tolist(), st.tolist(), en.tolist()))
+    for mode in (engine.SCAN_AUTO, engine.SCAN_GENERAL):
+        np.random.seed(np_seed)
+        kk, uq, ow, ep, eo = probe.anchor_table(cands[0], m, thres)
+        t = engine.Targets(ctx, groups[0])
+        p = engine.Probes(ctx, uq, ow, ep, eo, kk)
+        rows = engine.Rows.scan(ctx, p, t, m, thres, island, ext, mode)
+        a = rows.fetch()
+        got_rows = sorted(zip(a[0].tolist(), a[1].tolist(), a[2].tolist(), a[3].tolist()))
+        rows.close(); p.close(); t.close()
+        assert got_rows == exp, (desc, mode)
+    # near-duplicate filters on the first group's candidates (equal lengths)
+    strs = [s for s in cands[0] if len(s) == L][:1500]
+    if len(strs) > 3:
+        d = rnd.choice([1, 2, 3])
+        random.seed(seed)
+        fh = near_duplicate_filter.NearDuplicateFilterWithHammingDistance(d, L)
+        pos = fh._draw_positions()
+        fh._draw_positions = lambda: pos
+        gh = sorted(p.seq_str for p in fh.filter([probe.Probe.from_str(s) for s in strs]))
+        assert gh == sorted(oracle.ndf_hamming(strs, d, pos)), (desc, "ndf hamming")
+        dj = rnd.choice([0.3, 0.5, 0.6])
+        fm = near_duplicate_filter.NearDuplicateFilterWithMinHash(dj, rnd.choice([8, 10]))
+        par = fm._draw_params()
+        fm._draw_params = lambda: par
+        gm = sorted(p.seq_str for p in fm.filter([probe.Probe.from_str(s) for s in strs]))
+        assert gm == sorted(oracle.ndf_minhash(strs, dj, par, fm.kmer_size)), (desc, "ndf minhash")
+    return desc
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    ctx = engine.default_context()
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < budget:
+        one_case(seed0 + n, ctx)
+        n += 1
+    print("fuzz: %d cases ok (seeds %d..%d) in %.0f s" % (n, seed0, seed0 + n - 1, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
