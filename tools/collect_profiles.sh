@@ -6,6 +6,7 @@
 #   tools/collect_profiles.sh <tag>     -> gpurun_out/profiles_<tag>/
 tag=${1:-r01}
 out=/root/repo/gpurun_out/profiles_$tag
+rm -rf $out
 mkdir -p $out
 cd /root/repo
 python bench.py > $out/bench.json 2> $out/bench.err
@@ -17,12 +18,12 @@ cd /root/repo
 OUT=$out python - <<'PY'
 import csv, glob, json, collections, shutil, os
 out = os.environ["OUT"]
-ks = glob.glob(out + "/trace/*/*kernel_stats.csv")[0]
-ds = glob.glob(out + "/trace/*/*domain_stats.csv")
+ks = max(glob.glob(out + "/trace/*/*kernel_stats.csv"), key=os.path.getmtime)
+ds = sorted(glob.glob(out + "/trace/*/*domain_stats.csv"), key=os.path.getmtime)[-1:]
 shutil.copy(ks, out + "/bench_kernel_stats.csv")
 if ds: shutil.copy(ds[0], out + "/bench_domain_stats.csv")
 def pmc(dirname, counter):
-    f = glob.glob(out + "/" + dirname + "/*/*counter_collection.csv")
+    f = sorted(glob.glob(out + "/" + dirname + "/*/*counter_collection.csv"), key=os.path.getmtime)[-1:]
     acc = collections.defaultdict(lambda: [0.0, 0])
     if not f: return acc
     for r in csv.DictReader(open(f[0])):
@@ -47,7 +48,7 @@ rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                "each); on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md), "
                "bench.py doubles it; other widths and WRITE_SIZE are uncalibrated",
        "workload": "S2",
-       "units": {"solver_round": unit(["gf_count_claim_kernel", "gf_check_apply_kernel"]),
+       "units": {"solver_round": unit([k for k in kern if k.startswith(("gf_count_claim", "gf_check_apply"))]),
                  "seed_scan": unit(seed), "rows_build": unit(rows)},
        "kernels": kern}
 json.dump(rec, open(out + "/pmc_traffic.json", "w"), indent=1)
