@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcatchhip.so")
+# CATCHHIP_LIB: another build of the same ABI (A/B runs of two kernel versions)
+LIB_PATH = os.environ.get("CATCHHIP_LIB") or os.path.join(_HERE, "libcatchhip.so")
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)

@@ -53,6 +53,8 @@ void *chip_pool_alloc(size_t bytes) {
     const size_t cls = pool_class(bytes);
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
+        // exact size class only: a looser fit lets one request take the block the
+        // next one needs and the steady state (no hipMalloc at all) is lost
         auto it = g_pool_free.find(std::make_pair(owner, cls));
         if (it != g_pool_free.end()) {
             void *p = it->second;

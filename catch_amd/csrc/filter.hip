@@ -1,6 +1,7 @@
 // Fused entry points: cover scan + greedy solve per group, and several
 // independent groups at once on their own streams
 // (catch/filter/set_cover_filter.py:816-846 per group).
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -30,6 +31,7 @@ extern "C" int catchhip_setcover_filter(catchhip_ctx *ctx, const catchhip_probes
         if (rc == 0) {
             int retry = 0;
             rc = chip_greedy_deferred(ctx, R, num_sets, ranks, out_ids, n_out, &retry);
+            if (R->seed_ratio_seen > P->seed_ratio_hint) P->seed_ratio_hint = R->seed_ratio_seen;   // sizes the next work list
             (void)catchhip_rows_destroy(R);
             R = nullptr;
             if (rc) return rc;
@@ -39,11 +41,19 @@ extern "C" int catchhip_setcover_filter(catchhip_ctx *ctx, const catchhip_probes
             }
         }
     }
+    const bool timing = getenv("CATCHHIP_TIMING") != nullptr;   // host wall time of the two halves (stderr)
+    const auto t0 = std::chrono::steady_clock::now();
     rc = catchhip_cover_scan(ctx, P, T, mismatches, lcf_thres, island, cover_extension, mode, &R, &nr);
     if (rc) return rc;
     if (nrows) *nrows = nr;
+    const auto t1 = std::chrono::steady_clock::now();
     rc = catchhip_setcover_greedy(ctx, R, num_sets, ranks, universe_p, out_ids, n_out);
+    const auto t2 = std::chrono::steady_clock::now();
     (void)catchhip_rows_destroy(R);
+    if (timing)
+        fprintf(stderr, "[catchhip] filter: scan %.3f ms, solve %.3f ms (host wall)\n",
+                std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(t2 - t1).count());
     return rc;
 }
 

@@ -161,6 +161,8 @@ struct catchhip_probes {
     bool dna5 = false;
     bool has_n = false;
     bool pigeonhole = false;  // anchors are exactly {0,k,2k,..,L-k} for every probe
+    // seeds per target base seen by earlier seed scans with these probes (sizes the work list)
+    mutable double seed_ratio_hint = 0.0;
     i64 max_set_id = 0;
     DevBuf<u8> bytes;
     DevBuf<u32> probe_off;   // nprobes+1
@@ -190,6 +192,7 @@ struct catchhip_rows {
     // seed counters ([9] seeds), info[12] = seed capacity
     bool deferred = false;
     DevBuf<u32> info;
+    mutable double seed_ratio_seen = 0.0;   // filled by the deferred solve: seeds per target base of the scan
     DevBuf<i32> set_id;
     DevBuf<i32> univ;
     DevBuf<u32> gs, ge;

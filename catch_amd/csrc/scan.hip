@@ -19,6 +19,7 @@
 //    evaluates the reference's cover function on the raw bytes.
 // All three hand their hits to the bucketed row build (rows_bucket.inc).
 #include <algorithm>
+#include <chrono>
 
 #include "internal.h"
 
@@ -638,6 +639,16 @@ static int run_fast(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
     return CATCHHIP_ENOMEM;
 }
 
+// Capacity of the seed work list: 6 seeds per target base covers the data seen
+// so far (S4: 3.6 on average, above 4 for some groups); once these probes have
+// been scanned the observed ratio (+25 %) sizes the list instead.  An overflow
+// is detected on the device and costs a second scan with the exact size.
+static u32 seed_capacity(const catchhip_probes *P, const catchhip_targets *T) {
+    const double per_base = P->seed_ratio_hint > 0.0 ? std::max(1.0, 1.25 * P->seed_ratio_hint) : 6.0;
+    const double want = per_base * (double)T->total;
+    return (u32)std::max<double>((double)((i64)1 << 20), std::min<double>(want, (double)((i64)1 << 30)));
+}
+
 // K1c host side: hash table of the anchor k-mers, one lookup per target
 // position, one exact verification per seed.  Everything is stream-ordered;
 // the number of seeds stays on the device (S.ctr[1]) and the hits go straight
@@ -920,13 +931,17 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     sink.ext = ext;
     PhaseTimer ts(ctx, PHASE_SCAN), tr(ctx, PHASE_ROWS);
     if (use_seed) {
-        O.S.scap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(T->total * 4, (i64)1 << 30));
+        O.S.scap = seed_capacity(P, T);
         if (const char *e = getenv("CATCHHIP_SEED_CAP")) O.S.scap = (u32)std::max(1, atoi(e));   // tests: force the retry
         for (int attempt = 0;; ++attempt) {
+            const auto dbg0 = std::chrono::steady_clock::now();
             TRY(bucket_prepare(O.B, nb, O.S.scap, by_sequence));
             sink.rec = O.B.rec.p; sink.rank = O.B.rank.p; sink.bcnt = O.B.bcnt.p;
             ts.restart();
             TRY(run_seed_async(ctx, P, T, mismatches, O.S, sink, nb, O.B.res.p, ts));
+            if (getenv("CATCHHIP_TIMING"))
+                fprintf(stderr, "[catchhip]   seed scan attempt %d: work list of %u seeds, %.3f ms to queue\n", attempt,
+                        O.S.scap, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg0).count());
             ts.stop();
             O.nrec = O.S.scap; O.nrec_dev = O.S.ctr.p + 1;
             tr.restart();
@@ -944,6 +959,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
                 continue;
             }
             ctx->counters[1] = nseeds;
+            P->seed_ratio_hint = std::max(P->seed_ratio_hint, (double)nseeds / (double)std::max<i64>(T->total, 1));   // see seed_capacity
             break;
         }
     } else {
@@ -997,7 +1013,7 @@ int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const ca
     if (!seed_path_ok(P, T, mismatches, lcf_thres, island)) return 1;
     if (!(mode == CATCHHIP_SCAN_SEED || (mode == CATCHHIP_SCAN_AUTO && !getenv("CATCHHIP_SCAN_TILED")))) return 1;
     if (getenv("CATCHHIP_ROWS_RADIX") || getenv("CATCHHIP_SEED_CAP") || getenv("CATCHHIP_FUSED_SYNC")) return 1;
-    const i64 scap64 = std::max<i64>((i64)1 << 20, T->total * 4);
+    const i64 scap64 = seed_capacity(P, T);
     if (scap64 > ((i64)1 << 26)) return 1;   // keep the capacity-sized row arrays small
     HIP_TRY(hipSetDevice(ctx->device));
     PoolScope pool_scope(ctx);
