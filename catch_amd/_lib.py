@@ -38,6 +38,9 @@ PROTOTYPES = {
     "catchhip_cover_scan": (ctypes.c_int, [
         c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_int32, c_vpp, c_i64p]),
+    "catchhip_cover_ranges": (ctypes.c_int, [
+        c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_int32, c_vpp, c_i64p]),
     "catchhip_rows_fetch": (ctypes.c_int, [
         c_vp, c_vp, c_i32p, c_i32p, c_i64p, c_i64p]),
     "catchhip_rows_from_host": (ctypes.c_int, [

@@ -821,7 +821,7 @@ static int bucket_scan(catchhip_ctx *ctx, BucketBuild &B, const u32 *in, u32 *ou
 // merged counts.  nrec = hit records to look at (a device count, bounded by
 // B.cap, when nrec_dev is given).
 static int bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, const u32 *nrec_dev, bool want_sum,
-                               bool merge, PhaseTimer &tm) {
+                               bool merge, PhaseTimer &tm, bool dedupe = false) {
     hipStream_t s = ctx->stream;
     TRY(bucket_scan(ctx, B, B.bcnt.p, B.bstart.p, B.nb, B.res.p + 2, nullptr, nullptr, tm));
     if (!merge) return 0;   // radix build: only the bucket offsets are needed
@@ -831,7 +831,8 @@ static int bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, cons
                            B.S_es.p, B.S_ee.p, B.S_seg.p);
     unsigned long long *bsum = want_sum ? B.bsum.p : nullptr;
     hipLaunchKernelGGL((bucket_merge_kernel<64, BK_SMALL>), dim3((unsigned)std::min<i64>(B.nb, (i64)1 << 20)), dim3(64),
-                       0, s, (const u32 *)B.bstart.p, B.nb, B.S_es.p, B.S_ee.p, B.S_seg.p, B.mcnt.p, B.blmax.p, bsum);
+                       0, s, (const u32 *)B.bstart.p, B.nb, B.S_es.p, B.S_ee.p, B.S_seg.p, B.mcnt.p, B.blmax.p, bsum,
+                       dedupe ? 1 : 0);
     static bool big_attr_set = false;
     if (!big_attr_set) {
         (void)hipFuncSetAttribute((const void *)bucket_merge_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -840,7 +841,7 @@ static int bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, cons
     }
     hipLaunchKernelGGL(bucket_merge_big_kernel, dim3((unsigned)ctx->num_cus), dim3(1024), 3 * BK_BIG * sizeof(u32), s,
                        (const u32 *)B.bstart.p, B.nb, B.S_es.p, B.S_ee.p, B.S_seg.p, B.mcnt.p, B.blmax.p, bsum,
-                       B.res.p + 1);
+                       B.res.p + 1, dedupe ? 1 : 0);
     tm.launch(3);
     TRY(bucket_scan(ctx, B, B.mcnt.p, B.rstart.p, B.nb, B.res.p + 4, B.blmax.p, B.res.p + 5, tm));
     return 0;
@@ -917,14 +918,15 @@ struct ScanOut {
 };
 
 static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mismatches,
-                          int lcf_thres, int island, u32 ext, bool by_sequence, int mode, ScanOut &O) {
+                          int lcf_thres, int island, u32 ext, bool by_sequence, int mode, ScanOut &O,
+                          bool dedupe = false) {
     const bool seed_ok = seed_path_ok(P, T, mismatches, lcf_thres, island);
     const bool tiled_ok = fast_path_ok(P, T, mismatches, lcf_thres, island);
     const bool want_tiled = mode == CATCHHIP_SCAN_FAST || (mode == CATCHHIP_SCAN_AUTO && getenv("CATCHHIP_SCAN_TILED"));
     const bool use_fast = tiled_ok && want_tiled;
     const bool use_seed = seed_ok && !use_fast && mode != CATCHHIP_SCAN_GENERAL && mode != CATCHHIP_SCAN_FAST;
     const u32 nb = by_sequence ? (u32)P->nprobes : (u32)P->nbuckets;
-    const bool force_radix = getenv("CATCHHIP_ROWS_RADIX") != nullptr;
+    const bool force_radix = getenv("CATCHHIP_ROWS_RADIX") != nullptr && !dedupe;
     HitSink sink;
     sink.bucket_of = by_sequence ? nullptr : P->bucket_of.p;
     sink.seq_genome = by_sequence ? nullptr : T->seq_genome.p;
@@ -945,7 +947,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
             ts.stop();
             O.nrec = O.S.scap; O.nrec_dev = O.S.ctr.p + 1;
             tr.restart();
-            TRY(bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, by_sequence, !force_radix, tr));
+            TRY(bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, by_sequence, !force_radix, tr, dedupe));
             tr.stop();
             HIP_TRY(hipGetLastError());
             u32 *h = (u32 *)ctx->h_pin;
@@ -982,7 +984,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
                                (u32)(P->L > 0 ? P->L : 0), H.n, (const u32 *)T->seq_off.p, (u32)T->nseq, sink);
             tr.launch();
         }
-        TRY(bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, by_sequence, !force_radix, tr));
+        TRY(bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, by_sequence, !force_radix, tr, dedupe));
         tr.stop();
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(ctx->h_pin, O.B.res.p, 8 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
@@ -1065,9 +1067,9 @@ int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const ca
     return 0;
 }
 
-extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,
-                                   i32 mismatches, i32 lcf_thres, i32 island, i32 cover_extension, i32 mode,
-                                   catchhip_rows **out, i64 *nrows) {
+static int cover_scan_impl(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,
+                           i32 mismatches, i32 lcf_thres, i32 island, i32 cover_extension, i32 mode, bool merge,
+                           catchhip_rows **out, i64 *nrows) {
     ARG_CHECK(ctx && P && T && out && cover_extension >= 0);
     PoolScope pool_scope(ctx);
     ARG_CHECK(P->ctx == ctx && T->ctx == ctx);
@@ -1100,7 +1102,13 @@ extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, 
                            hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
         if (P->nprobes == 0 || T->total == 0) break;   // no rows
         ScanOut O;
-        if ((rc = scan_and_group(ctx, P, T, mismatches, lcf_thres, island, (u32)cover_extension, false, mode, O))) break;
+        if ((rc = scan_and_group(ctx, P, T, mismatches, lcf_thres, island, (u32)cover_extension, false, mode, O,
+                                 !merge))) break;
+        if (!merge && O.overflow) {
+            chip_set_error("cover_ranges: a probe has more than %d cover ranges", BK_BIG);
+            rc = CATCHHIP_EINVAL;
+            break;
+        }
         PhaseTimer tm(ctx, PHASE_ROWS, true);   // continues the row-build phase (adds to its time)
         if (!O.overflow) {
             R->n = O.nrows;
@@ -1152,6 +1160,18 @@ extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, 
     *out = R;
     if (nrows) *nrows = R->n;
     return 0;
+}
+
+extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,
+                                   i32 mismatches, i32 lcf_thres, i32 island, i32 cover_extension, i32 mode,
+                                   catchhip_rows **out, i64 *nrows) {
+    return cover_scan_impl(ctx, P, T, mismatches, lcf_thres, island, cover_extension, mode, true, out, nrows);
+}
+
+extern "C" int catchhip_cover_ranges(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,
+                                     i32 mismatches, i32 lcf_thres, i32 island, i32 cover_extension, i32 mode,
+                                     catchhip_rows **out, i64 *nrows) {
+    return cover_scan_impl(ctx, P, T, mismatches, lcf_thres, island, cover_extension, mode, false, out, nrows);
 }
 
 extern "C" int catchhip_tolerant_bp(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,

@@ -8,7 +8,8 @@ list as bin/design.py:296-340 builds it: exact duplicate filter (or a
 near-duplicate filter with --filter-with-lsh-hamming / --filter-with-lsh-
 minhash), then the set cover filter.  Options outside the accelerated path
 (clustering, adapters, reverse complements, N expansion, custom hybridization
-functions) are not offered.
+functions) are not offered.  --print-analysis and the three --write-...
+options run the coverage analysis of the designed probes (bin/design.py:417-442).
 """
 import argparse
 import logging
@@ -47,6 +48,11 @@ def parse_args(argv=None):
     p.add_argument("--small-seq-skip", type=int)
     p.add_argument("--small-seq-min", type=int)
     p.add_argument("--kmer-probe-map-k", type=int, default=20)
+    p.add_argument("--print-analysis", action="store_true",
+                   help="print coverage of the target genomes by the probes")
+    p.add_argument("--write-analysis-to-tsv")
+    p.add_argument("--write-sliding-window-coverage")
+    p.add_argument("--write-probe-map-counts-to-tsv")
     p.add_argument("--verbose", action="store_true")
     return p.parse_args(argv)
 
@@ -100,6 +106,31 @@ def main(args):
     pb.design()
     if args.write_probe_fasta:
         seq_io.write_probe_fasta(pb.final_probes, args.write_probe_fasta)
+    if (args.print_analysis or args.write_analysis_to_tsv or
+            args.write_sliding_window_coverage or
+            args.write_probe_map_counts_to_tsv):
+        # bin/design.py:417-442; no reverse-complement probes are added by this
+        # CLI, so the reverse strands are not analysed (rc_too follows
+        # --add-reverse-complements there)
+        from catch_amd import coverage_analysis
+        analyzer = coverage_analysis.Analyzer(
+            pb.final_probes, args.mismatches, lcf_thres, genomes_grouped,
+            target_genomes_names=args.dataset,
+            island_of_exact_match=args.island_of_exact_match,
+            cover_extension=args.cover_extension,
+            kmer_probe_map_k=(10 if args.kmer_probe_map_k == 20
+                              else args.kmer_probe_map_k),
+            rc_too=False)
+        analyzer.run()
+        if args.write_analysis_to_tsv:
+            analyzer.write_data_matrix_as_tsv(args.write_analysis_to_tsv)
+        if args.write_sliding_window_coverage:
+            analyzer.write_sliding_window_coverage(
+                args.write_sliding_window_coverage)
+        if args.write_probe_map_counts_to_tsv:
+            analyzer.write_probe_map_counts(args.write_probe_map_counts_to_tsv)
+        if args.print_analysis:
+            analyzer.print_analysis()
     print(len(pb.final_probes))          # bin/design.py:445
     return pb
 

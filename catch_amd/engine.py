@@ -203,10 +203,13 @@ class Rows:
 
     @staticmethod
     def scan(ctx, probes, targets, mismatches, lcf_thres, island=0,
-             cover_extension=0, mode=SCAN_AUTO):
+             cover_extension=0, mode=SCAN_AUTO, merge=True):
+        """catchhip_cover_scan, or with merge=False catchhip_cover_ranges
+        (every distinct cover range of every probe, nothing merged)."""
         h = ctypes.c_void_p()
         n = ctypes.c_int64(0)
-        check(ctx._L.catchhip_cover_scan(
+        fn = ctx._L.catchhip_cover_scan if merge else ctx._L.catchhip_cover_ranges
+        check(fn(
             ctx._h, probes._h, targets._h, int(mismatches), int(lcf_thres),
             int(island), int(cover_extension), int(mode), ctypes.byref(h),
             ctypes.byref(n)))

@@ -116,6 +116,19 @@ int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *probes,
                         int32_t lcf_thres, int32_t island,
                         int32_t cover_extension, int32_t mode,
                         catchhip_rows **out, int64_t *nrows);
+/* The same scan without the interval merge: what coverage_analysis.Analyzer
+ * ._find_covers_in_target_genomes collects (catch/coverage_analysis.py
+ * :183-280) = for every sequence probe.find_probe_covers_in_sequence(
+ * merge_overlapping=False) (catch/probe.py:1263-1270: duplicate ranges of a
+ * probe removed, nothing merged), every range extended by cover_extension and
+ * clipped to its sequence.  Rows (set id, universe, start, end) sorted by (set
+ * id, start, end) in genome coordinates; pass one genome per sequence to keep
+ * sequences apart.  EINVAL if one probe has more than 8192 ranges. */
+int catchhip_cover_ranges(catchhip_ctx *ctx, const catchhip_probes *probes,
+                          const catchhip_targets *targets, int32_t mismatches,
+                          int32_t lcf_thres, int32_t island,
+                          int32_t cover_extension, int32_t mode,
+                          catchhip_rows **out, int64_t *nrows);
 /* Copy rows to the host (arrays of length nrows). */
 int catchhip_rows_fetch(catchhip_ctx *ctx, const catchhip_rows *rows,
                         int32_t *set_id, int32_t *universe, int64_t *start,

@@ -558,3 +558,53 @@ def ndf_minhash(probe_strs, dist_thres, params, kmer_size=10):
                 if jaccard_dist(p, q, kmer_size) <= dist_thres:
                     exclude.add(q)
     return kept
+
+
+# --------------------------------------------------------------------------
+# coverage analysis: catch/coverage_analysis.py:183-335
+# --------------------------------------------------------------------------
+def coverage_analysis(probe_strs, genomes_grouped, mismatches, lcf_thres,
+                      island=0, cover_extension=0, kmer_probe_map_k=10,
+                      rc_too=True):
+    """Analyzer._find_covers_in_target_genomes + _compute_bp_covered... +
+    _compute_average_coverage... .  genomes_grouped[i][j] = list of sequence
+    strings.  Returns (target_covers, bp_covered, average_coverage,
+    probe_map_counts) with target_covers[i][j][r] a sorted list of (start, end)
+    (r = 0 forward, 1 reverse complement), average_coverage[i][j][r] =
+    (over all bases, over unambiguous bases), probe_map_counts per probe."""
+    k, entries = anchor_table(probe_strs, mismatches, lcf_thres,
+                              min_k=kmer_probe_map_k, k=kmer_probe_map_k)
+    uniq, owner = _unique_last(probe_strs)
+    counts = [0] * len(probe_strs)
+    covers, bp, avg = [], [], []
+    for grp in genomes_grouped:
+        cg, bg, ag = [], [], []
+        for gnm in grp:
+            cj, bj, aj = [], [], []
+            size_all = sum(len(s) for s in gnm)
+            size_unambig = sum(s.count(b) for s in gnm for b in "ATCG")
+            for rc in ((False, True) if rc_too else (False,)):
+                out, so_far = [], 0
+                for seq in gnm:
+                    s = reverse_complement(seq) if rc else seq
+                    cov = scan_sequence(s, uniq, entries, k, mismatches,
+                                        lcf_thres, island, merge=False)
+                    for p, ranges in cov.items():
+                        if not rc:
+                            counts[owner[p]] += 1
+                        for a, b in ranges:
+                            out.append((max(0, a - cover_extension) + so_far,
+                                        min(len(s), b + cover_extension) + so_far))
+                    so_far += len(s)
+                out.sort()
+                cj.append(out)
+                bj.append(sum(b - a for a, b in merge_overlapping(out)))
+                total = sum(b - a for a, b in out)
+                aj.append((float(total) / size_all, float(total) / size_unambig))
+            cg.append(cj)
+            bg.append(bj)
+            ag.append(aj)
+        covers.append(cg)
+        bp.append(bg)
+        avg.append(ag)
+    return covers, bp, avg, counts

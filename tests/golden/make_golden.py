@@ -558,9 +558,77 @@ def minhash_main():
     print("ndf_minhash", len(tests), len(syn))
 
 
+def coverage_main():
+    """`make_golden.py coverage-only`: tests/golden/coverage_analysis.json.gz =
+    the unmerged scans (find_probe_covers_in_sequence(merge_overlapping=False))
+    and the Analyzer results of the reference's coverage-analysis tests plus
+    seeded synthetic cases."""
+    from catch import coverage_analysis as ca
+    install()
+    results = []
+    orig_run = ca.Analyzer.run
+
+    def rec_run(self, *a, **kw):
+        out = orig_run(self, *a, **kw)
+        genomes = [[list(g.seqs) for g in grp] for grp in self.target_genomes]
+        rec = dict(
+            probes=[p.seq_str for p in self.probes],
+            mismatches=self.mismatches, lcf_thres=self.lcf_thres,
+            cover_extension=int(self.cover_extension),
+            kmer_probe_map_k=int(self.kmer_probe_map_k), rc_too=bool(self.rc_too),
+            genomes=genomes,
+            target_covers=[[[sorted([int(a), int(b)] for a, b in
+                                    self.target_covers[i][j][rc])
+                             for rc in ((False, True) if self.rc_too else (False,))]
+                            for j in range(len(grp))]
+                           for i, grp in enumerate(self.target_genomes)],
+            bp_covered=[[[int(self.bp_covered[i][j][rc])
+                          for rc in ((False, True) if self.rc_too else (False,))]
+                         for j in range(len(grp))]
+                        for i, grp in enumerate(self.target_genomes)],
+            average_coverage=[[[list(map(float, self.average_coverage[i][j][rc]))
+                                for rc in ((False, True) if self.rc_too else (False,))]
+                               for j in range(len(grp))]
+                              for i, grp in enumerate(self.target_genomes)],
+            probe_map_counts=[int(self.probe_map_counts[p]) for p in self.probes],
+            table=self._make_data_matrix_string())
+        if self.mismatches is not None:
+            results.append(rec)
+        return out
+    ca.Analyzer.run = rec_run
+    suite = unittest.TestLoader().loadTestsFromName("catch.tests.test_coverage_analysis")
+    res = unittest.TextTestRunner(verbosity=0).run(suite)
+    if res.failures or res.errors:
+        raise SystemExit("reference tests failed under the recorder")
+    tests = list(results)
+    results.clear()
+    # synthetic: designed probes of a small species analysed against its genomes
+    rng = np.random.Generator(np.random.PCG64(23))
+    base = synthetic.make_species(rng, [2500, 900], 4, 2, 0.03, 0.01, with_n=True)
+    gens = [genome.Genome.from_chrs(OrderedDict(("c%d" % i, s) for i, s in enumerate(g)))
+            for g in base]
+    for L, stride, m, ext, seed in ((100, 50, 2, 0, 1), (75, 25, 3, 20, 2), (100, 100, 5, 10, 3)):
+        ps = []
+        for g in gens:
+            ps += candidate_probes.make_candidate_probes_from_sequences(
+                g.seqs, probe_length=L, probe_stride=stride)
+        ps = list(OrderedDict.fromkeys(ps))[::3]
+        np.random.seed(seed)
+        a = ca.Analyzer(ps, m, L, [gens[:2], gens[2:]], cover_extension=ext)
+        a.run()
+        results[-1]["np_seed"] = seed
+        print("coverage", L, m, ext, len(ps), flush=True)
+    unmerged = [c for c in REC["scan"] if not c["merge"]][:300]
+    dump("coverage_analysis", dict(from_reference_tests=tests, synthetic=list(results),
+                                   scans_unmerged=unmerged))
+    print("coverage_analysis", len(tests), len(results), len(unmerged))
+
+
 def main():
     if "minhash-only" in sys.argv:
         return minhash_main()
+    if "coverage-only" in sys.argv:
+        return coverage_main()
     install()
     run_reference_tests()
     if "probe-only" in sys.argv:

@@ -23,7 +23,7 @@ def _probe_mod():
 
 
 def _scan_rows(ctx, probe_strs, genomes, m, thres, island=0, ext=0, mode=0,
-               min_k=20, entries=None, k=None):
+               min_k=20, entries=None, k=None, merge=True):
     """Rows (set, universe, start, end) from the HIP path."""
     engine, probe = _engine(), _probe_mod()
     if entries is None:
@@ -36,7 +36,7 @@ def _scan_rows(ctx, probe_strs, genomes, m, thres, island=0, ext=0, mode=0,
         eo = np.array([e[1] for e in entries], dtype=np.int32)
     t = engine.Targets(ctx, genomes)
     p = engine.Probes(ctx, uniq, owner, ep, eo, k)
-    rows = engine.Rows.scan(ctx, p, t, m, thres, island, ext, mode)
+    rows = engine.Rows.scan(ctx, p, t, m, thres, island, ext, mode, merge)
     out = rows_as_tuples(*rows.fetch())
     rows.close(); p.close(); t.close()
     return out
@@ -190,6 +190,41 @@ def test_scan_reference_test_vectors(ctx):
         exp = sorted((int(p), 0, s, e) for p, v in c["out"].items()
                      for s, e in v)
         assert got == exp, (c["probes"], c["sequence"][:60])
+
+
+def test_cover_ranges_unmerged(ctx, oracle):
+    """catchhip_cover_ranges = find_probe_covers_in_sequence(merge_overlapping=
+    False): the reference's unmerged known answers, and the oracle on repeats
+    (overlapping ranges of one probe stay apart, duplicates collapse)."""
+    engine = _engine()
+    recs = load_golden("coverage_analysis")["scans_unmerged"]
+    assert len(recs) >= 50
+    for c in recs:
+        got = _scan_rows(ctx, c["probes"], [[c["sequence"]]], c["mismatches"],
+                         c["lcf_thres"], c["island"], 0,
+                         entries=c["entries"], k=c["k"], merge=False)
+        exp = sorted((int(p), 0, s, e) for p, v in c["out"].items()
+                     for s, e in v)
+        assert got == exp, (c["probes"], c["sequence"][:60])
+    rng = random.Random(17)
+    unit = "".join(rng.choice("ACGT") for _ in range(60))
+    seq = unit * 12 + "".join(rng.choice("ACGT") for _ in range(200)) + unit * 3
+    probes = candidates([[seq]], 50, 10)
+    for m, thres, mode in ((1, 50, engine.SCAN_AUTO), (2, 35, engine.SCAN_AUTO),
+                           (1, 50, engine.SCAN_GENERAL), (1, 50, engine.SCAN_FAST)):
+        np.random.seed(3)
+        k, entries = oracle.anchor_table(probes, m, thres, min_k=10, k=10)
+        uniq, owner = oracle._unique_last(probes)
+        cov = oracle.scan_sequence(seq, uniq, entries, k, m, thres, 0, merge=False)
+        exp = sorted((int(owner[p]), 0, max(0, a - 5), min(len(seq), b + 5))
+                     for p, v in cov.items() for a, b in v)
+        exp = sorted(set(exp))
+        np.random.seed(3)
+        got = _scan_rows(ctx, probes, [[seq]], m, thres, 0, 5, mode, min_k=10,
+                         merge=False)
+        assert got == exp, (m, thres, mode)
+        merged = _scan_rows(ctx, probes, [[seq]], m, thres, 0, 5, mode, min_k=10)
+        assert len(merged) < len(got)
 
 
 def test_scan_empty_inputs(ctx):
@@ -651,3 +686,51 @@ def test_ndf_minhash_matches_oracle_large(ctx, oracle):
         want = sorted(oracle.ndf_minhash(strs, d, params, ks))
         assert got == want
         assert len(got) < len(set(strs))
+
+
+def test_coverage_analyzer_golden(ctx, oracle, tmp_path):
+    """catch_amd.coverage_analysis.Analyzer against the results recorded from
+    the reference's Analyzer (its own tests + seeded synthetic runs): cover
+    ranges per genome and strand, bases covered, average depth, sequences
+    mapped per probe, and the table strings."""
+    from catch_amd import coverage_analysis as ca
+    from catch_amd import genome, probe
+    g = load_golden("coverage_analysis")
+    recs = g["from_reference_tests"] + g["synthetic"]
+    assert len(recs) >= 10
+    for c in recs:
+        gens = [[genome.Genome.from_one_seq(s[0]) if len(s) == 1 else
+                 genome.Genome.from_chrs(dict(("c%d" % i, x) for i, x in enumerate(s)))
+                 for s in grp] for grp in c["genomes"]]
+        ps = [probe.Probe.from_str(s) for s in c["probes"]]
+        if "np_seed" in c:
+            np.random.seed(c["np_seed"])
+        a = ca.Analyzer(ps, c["mismatches"], c["lcf_thres"], gens,
+                        cover_extension=c["cover_extension"],
+                        kmer_probe_map_k=c["kmer_probe_map_k"], rc_too=c["rc_too"])
+        a.run()
+        strands = (False, True) if c["rc_too"] else (False,)
+        for i, grp in enumerate(c["genomes"]):
+            for j in range(len(grp)):
+                for r, rc in enumerate(strands):
+                    assert sorted(map(list, a.target_covers[i][j][rc])) == \
+                        c["target_covers"][i][j][r]
+                    assert a.bp_covered[i][j][rc] == c["bp_covered"][i][j][r]
+                    assert list(a.average_coverage[i][j][rc]) == \
+                        c["average_coverage"][i][j][r]
+        assert [a.probe_map_counts[p] for p in ps] == c["probe_map_counts"]
+        # (the reference tests name their groups; the names were not recorded)
+        assert [row[1:] for row in a._make_data_matrix_string()] == \
+            [row[1:] for row in c["table"]]
+    a.write_data_matrix_as_tsv(str(tmp_path / "a.tsv"))
+    a.write_sliding_window_coverage(str(tmp_path / "s.tsv"))
+    a.write_probe_map_counts(str(tmp_path / "c.tsv"))
+    assert (tmp_path / "a.tsv").read_text().startswith("Genome\tNum bases covered")
+    # sliding coverage against a direct count on the ranges
+    cov = a.target_covers[0][0][False]
+    n = gens[0][0].size()
+    depth = np.zeros(n, dtype=np.int64)
+    for s0, e0 in cov:
+        depth[s0:e0] += 1
+    sl = a.sliding_coverage[0][0][False]
+    assert sl[25.0] == np.average(depth[0:50])

@@ -123,6 +123,34 @@ def test_pyhash_matches_this_interpreter(oracle):
     assert eval(out) == [oracle.pyhash_seed0(x) for x in strs]
 
 
+def test_scan_unmerged_and_coverage_analysis(oracle):
+    """find_probe_covers_in_sequence(merge_overlapping=False) and the
+    Analyzer's derived numbers (catch/coverage_analysis.py), recorded from the
+    reference's own tests and seeded synthetic runs."""
+    g = load_golden("coverage_analysis")
+    assert len(g["scans_unmerged"]) >= 50
+    for c in g["scans_unmerged"]:
+        entries = [(int(a), int(b)) for a, b in c["entries"]]
+        got = oracle.scan_sequence(c["sequence"], c["probes"], entries, c["k"],
+                                   c["mismatches"], c["lcf_thres"], c["island"],
+                                   merge=False)
+        exp = {int(p): [tuple(x) for x in v] for p, v in c["out"].items()}
+        assert got == exp
+    recs = g["from_reference_tests"] + g["synthetic"]
+    assert len(recs) >= 10
+    for c in recs:
+        if "np_seed" in c:
+            np.random.seed(c["np_seed"])
+        covers, bp, avg, counts = oracle.coverage_analysis(
+            c["probes"], c["genomes"], c["mismatches"], c["lcf_thres"], 0,
+            c["cover_extension"], c["kmer_probe_map_k"], c["rc_too"])
+        assert [[[[list(x) for x in r] for r in j] for j in i] for i in covers] \
+            == c["target_covers"]
+        assert bp == c["bp_covered"]
+        assert [[[list(r) for r in j] for j in i] for i in avg] == c["average_coverage"]
+        assert counts == c["probe_map_counts"]
+
+
 def test_merge_overlapping(oracle):
     assert oracle.merge_overlapping([(1, 5), (3, 7), (9, 12)]) == [(1, 7), (9, 12)]
     assert oracle.merge_overlapping([(1, 3), (3, 5)]) == [(1, 5)]
