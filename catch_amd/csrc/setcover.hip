@@ -42,6 +42,7 @@ struct GreedyState {
     u32 lmax;      // longest row
     u32 smax;      // largest (set, universe) element count
     u32 fr_claim[2];   // batched solver: some set of the current rank claimed, by round parity
+    u32 fr_live[2];    // batched solver: sizes of the live-set lists (large instances), by round parity
     unsigned long long prof[8];  // shader-clock ticks per phase (thread 0)
     unsigned long long n_wrows, n_recount, n_words;  // work counters
 };
@@ -781,8 +782,11 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
                  o_rank = take(4 * (size_t)nsets);
     const size_t zero_bytes = off;
     const size_t o_usize = take(4 * (size_t)nuniv), o_gain = take(4 * (size_t)nsets),
-                 o_setptr = take(4 * ((size_t)nsets + 1)), o_frow = take(16 * (size_t)nrows),
+                 o_setptr = take(4 * ((size_t)nsets + 1)), o_frow = take(8 * (size_t)nrows),
                  o_flag = take(nrows), o_picks = take(4 * (size_t)nsets), o_keys = take(8 * (size_t)nsets);
+    // live-set lists only where walking every set each round would dominate
+    const bool use_list = nsets > 65536 && !getenv("CATCHHIP_GF_NOLIST");
+    const size_t o_live0 = use_list ? take(4 * (size_t)nsets) : 0, o_live1 = use_list ? take(4 * (size_t)nsets) : 0;
     DevBuf<u8> arena;
     TRY(arena.alloc(off));
     u8 *A = arena.p;
@@ -797,17 +801,19 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     FrontArgs fa;
     fa.bm = (unsigned long long *)(A + o_bm);
     fa.owner[0] = (unsigned long long *)(A + o_ow0); fa.owner[1] = (unsigned long long *)(A + o_ow1);
-    fa.frow = (const uint4 *)(A + o_frow); fa.set_ptr = (const u32 *)(A + o_setptr); fa.rank = (const u32 *)(A + o_rank);
+    fa.frow = (const uint2 *)(A + o_frow); fa.row_univ = (const i32 *)R->univ.p; fa.set_ptr = (const u32 *)(A + o_setptr); fa.rank = (const u32 *)(A + o_rank);
     fa.usize = (u32 *)(A + o_usize); fa.gain = (u32 *)(A + o_gain); fa.claimed = (u32 *)(A + o_claimed);
     fa.picked = (u32 *)(A + o_picked); fa.picks = (u32 *)(A + o_picks);
     fa.pick_key = (unsigned long long *)(A + o_keys); fa.rowflag = A + o_flag;
     fa.blkcnt = (unsigned long long *)(A + o_blk); fa.st = (GreedyState *)(A + o_st);
     fa.nsets = nsets; fa.nwords = (u32)nwords;
+    fa.live[0] = use_list ? (u32 *)(A + o_live0) : nullptr;
+    fa.live[1] = use_list ? (u32 *)(A + o_live1) : nullptr;
 
     PhaseTimer tm(ctx, PHASE_GREEDY);
     hipLaunchKernelGGL(gf_build_kernel, dim3((unsigned)div_up(std::max(nrows, nsets + 1), 256)), dim3(256), 0, s,
                        (const i32 *)R->set_id.p, (const i32 *)R->univ.p, (const u32 *)R->gs.p, (const u32 *)R->ge.p,
-                       nrows, d_info ? d_info + 4 : (const u32 *)nullptr, nsets, nrank, (uint4 *)(A + o_frow), fa.bm,
+                       nrows, d_info ? d_info + 4 : (const u32 *)nullptr, nsets, nrank, (uint2 *)(A + o_frow), fa.bm,
                        (u32 *)(A + o_setptr), fa.st);
     hipLaunchKernelGGL(gf_universe_kernel, dim3(nuniv), dim3(256), 0, s, (const unsigned long long *)fa.bm,
                        (const u32 *)R->genome_off.p, fa.usize, fa.st, d_info);
@@ -841,11 +847,24 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_st, fa.st, sizeof(GreedyState), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(h_blk, fa.blkcnt, 16 * (size_t)gblocks, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(h_picks, fa.picks, 4 * (size_t)nsets, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(h_keys, fa.pick_key, 8 * (size_t)nsets, hipMemcpyDeviceToHost, s));
+        // small instances: picks and keys ride along (one synchronisation in all);
+        // large ones: 12 B per candidate set per batch would be tens of MB, so
+        // only the picks made are fetched, once the solver has finished
+        const bool eager = nsets <= 65536;
+        if (eager) {
+            HIP_TRY(hipMemcpyAsync(h_picks, fa.picks, 4 * (size_t)nsets, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(h_keys, fa.pick_key, 8 * (size_t)nsets, hipMemcpyDeviceToHost, s));
+        }
         if (d_info) HIP_TRY(hipMemcpyAsync(h_info, d_info, 16 * sizeof(u32), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (h_st->done || h_st->n_need == 0) break;
+        if (h_st->done || h_st->n_need == 0) {
+            if (!eager && h_st->npicks) {
+                HIP_TRY(hipMemcpyAsync(h_picks, fa.picks, 4 * (size_t)h_st->npicks, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipMemcpyAsync(h_keys, fa.pick_key, 8 * (size_t)h_st->npicks, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+            }
+            break;
+        }
         if (rounds > max_rounds) { chip_set_error("setcover: round cap exceeded"); return CATCHHIP_EINVAL; }
         per_sync = 6;
         tr.stopped = false;   // further rounds extend both phases
