@@ -371,7 +371,6 @@ scan_fast3_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const 
         T0[w] = __builtin_amdgcn_alignbit(p0[1], p0[0], sh) & mask0;
         T1[w] = __builtin_amdgcn_alignbit(p1[1], p1[0], sh) & mask0;
     }
-#pragma unroll 4
     for (u32 q = p_begin; q < p_end; ++q) {
         const uint2 qq = pw0[q];   // uniform
         u32 mn = 64;
