@@ -233,10 +233,14 @@ seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const
                 s = (s + 1) & t.mask;
             }
         }
+        if (r.y) {
+            const u32 sq = find_segment(seq_off, nseq, i);
+            s_sq[q] = sq;
+            if (i + (u32)k > seq_off[sq + 1]) r.y = 0;   // the k-mer must lie inside one sequence
+        }
         s_rx[q] = r.x;
         cnt[j] = r.y;
         mine += r.y;
-        if (r.y) s_sq[q] = find_segment(seq_off, nseq, i);
     }
     u32 wtotal;
     const u32 ex = wave_excl_scan(mine, &wtotal);
@@ -654,26 +658,21 @@ static u32 seed_capacity(const catchhip_probes *P, const catchhip_targets *T) {
 // into the bucketed row build as records indexed like the seeds.
 struct SeedRun {
     DevBuf<unsigned long long> keys;
-    DevBuf<u32> cnt, ents, slot_of, ctr, spos, sent, sseq;
+    DevBuf<u32> cnt, ents, slot_of, ctr, spos, sent, sseq, dummy;
     DevBuf<uint2> range;
     u32 scap = 0;
 };
 
-static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm, SeedRun &S,
-                          const HitSink &sink, u32 nb, u32 *res, PhaseTimer &tm) {
-    const bool use_n = P->has_n || T->has_n;
-    // Pigeonhole anchors {0,k,..,L-k}: a window with <= mm mismatches leaves at
-    // least one of ANY mm+1 disjoint anchors exact, so the first mm+1 anchors are
-    // all the table needs (fewer seeds to verify).  Any other anchor table (the
-    // reference's random anchors) enters completely: a pair is reported iff one
-    // of ITS anchors matches exactly, as the reference finds it.
+// table of the anchor k-mers + one lookup per target position -> seed work
+// list (S.spos / S.sent / S.sseq, count in S.ctr[1]).  pos_limit: anchors at or
+// beyond this probe offset stay out of the table.  bcnt/nb/res: arrays of the
+// bucketed row build zeroed by the same init launch (may be null / 0).
+static int seed_table_lookup_async(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, u32 pos_limit,
+                                   SeedRun &S, u32 *bcnt, u32 nb, u32 *res, PhaseTimer &tm) {
     const int k = P->k, kb = std::min(k, 32);
-    const u32 pos_limit = P->pigeonhole ? (u32)std::min<i64>((i64)(mm + 1) * k, P->L) : 0xffffffffu;
     const u64 nent64 = (u64)P->nent;
     if (nent64 >= ((u64)1 << 31)) { chip_set_error("seed scan: too many anchors"); return CATCHHIP_EINVAL; }
     const u32 nent = (u32)nent64;
-    seed_verify_fn verify = pick_seed_verify((int)P->pwords);
-    if (!verify) { chip_set_error("seed scan: unsupported probe length"); return CATCHHIP_EINVAL; }
     u32 capacity = 1024;
     while ((u64)capacity < 2 * nent64) capacity <<= 1;
     TRY(S.keys.reserve(capacity));
@@ -685,11 +684,11 @@ static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     TRY(S.spos.reserve(S.scap));
     TRY(S.sent.reserve(S.scap));
     TRY(S.sseq.reserve(S.scap));
-    const u32 tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
+    if (!res) { TRY(S.dummy.reserve(8)); res = S.dummy.p; }
     SeedTable t = {S.keys.p, S.cnt.p, S.range.p, S.ents.p, capacity - 1};
     const dim3 eb((unsigned)div_up((i64)nent, 256)), tb(256);
     hipLaunchKernelGGL(seed_init_kernel, dim3((unsigned)std::min<i64>(div_up((i64)capacity, 256), 2048)), tb, 0,
-                       ctx->stream, S.keys.p, S.cnt.p, capacity, S.ctr.p, sink.bcnt, nb, res);
+                       ctx->stream, S.keys.p, S.cnt.p, capacity, S.ctr.p, bcnt, nb, res);
     hipLaunchKernelGGL(seed_count_kernel, eb, tb, 0, ctx->stream, (const uint4 *)P->planes.p,
                        (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p, nent, pos_limit,
                        P->pigeonhole ? (int)(P->L / k) : 0, k, (int)P->pwords, kb, t, S.slot_of.p);
@@ -698,14 +697,32 @@ static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     hipLaunchKernelGGL(seed_lookup_kernel, dim3((unsigned)div_up(T->total, SL_TILE)), dim3(SL_THREADS), 0, ctx->stream,
                        (const u32 *)T->planes.p, T->nwords, (u32)T->total, (const u32 *)T->seq_off.p,
                        (u32)T->nseq, k, kb, t, S.spos.p, S.sent.p, S.sseq.p, S.ctr.p + 1, S.scap);
-    hipLaunchKernelGGL(verify, dim3((unsigned)div_up((i64)S.scap, 256)), tb, 0, ctx->stream,
+    tm.launch(5);
+    return 0;
+}
+
+static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm, SeedRun &S,
+                          const HitSink &sink, u32 nb, u32 *res, PhaseTimer &tm) {
+    const bool use_n = P->has_n || T->has_n;
+    // Pigeonhole anchors {0,k,..,L-k}: a window with <= mm mismatches leaves at
+    // least one of ANY mm+1 disjoint anchors exact, so the first mm+1 anchors are
+    // all the table needs (fewer seeds to verify).  Any other anchor table (the
+    // reference's random anchors) enters completely: a pair is reported iff one
+    // of ITS anchors matches exactly, as the reference finds it.
+    const int k = P->k;
+    const u32 pos_limit = P->pigeonhole ? (u32)std::min<i64>((i64)(mm + 1) * k, P->L) : 0xffffffffu;
+    seed_verify_fn verify = pick_seed_verify((int)P->pwords);
+    if (!verify) { chip_set_error("seed scan: unsupported probe length"); return CATCHHIP_EINVAL; }
+    TRY(seed_table_lookup_async(ctx, P, T, pos_limit, S, sink.bcnt, nb, res, tm));
+    const u32 tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
+    hipLaunchKernelGGL(verify, dim3((unsigned)div_up((i64)S.scap, 256)), dim3(256), 0, ctx->stream,
                        (const u32 *)T->planes.p, T->nwords, (const u32 *)T->seq_off.p,
                        (const uint4 *)P->planes.p, (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p,
                        (const u32 *)P->ent_ptr.p, P->pigeonhole ? (int)(P->L / k) : 0, (int)P->L, k, mm, tailmask,
                        use_n ? 1 : 0,
                        (const u32 *)S.spos.p, (const u32 *)S.sent.p, (const u32 *)S.sseq.p,
                        (const u32 *)(S.ctr.p + 1), S.scap, sink);
-    tm.launch(6);
+    tm.launch(1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -717,34 +734,57 @@ static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchh
     if (P->nent == 0 || T->total == 0) return 0;
     if (mm > MAX_MM) { chip_set_error("mismatches > %d not supported", MAX_MM); return CATCHHIP_EINVAL; }
     const u32 nent = (u32)P->nent;
+    // Seeds = exact matches of anchor k-mers.  Equal-length DNA probes have a
+    // packed image: their anchors go into the hash table of the seed scan and
+    // every target position does one look-up (the extension below re-checks the
+    // k-mer on the bytes).  Anything else is joined through a sort of byte hashes.
+    const bool table = P->dna5 && T->dna5 && P->L > 0 && P->L <= 256 && P->pwords >= 1 && P->k <= P->L &&
+                       !getenv("CATCHHIP_GENERAL_SORTJOIN");
+    SeedRun S;
     DevBuf<u64> keys, keys_alt;
-    DevBuf<u32> vals, vals_alt;
-    TRY(keys.alloc(nent));
-    TRY(vals.alloc(nent));
-    hipLaunchKernelGGL(anchor_hash_kernel, dim3((unsigned)div_up(nent, 256)), dim3(256), 0, ctx->stream,
-                       P->bytes.p, P->probe_off.p, P->ent_probe.p, P->ent_pos.p, nent, (int)P->k, keys.p,
-                       vals.p);
-    tm.launch();
-    TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nent, 64));
-    // seed hits
-    DevBuf<u32> sa, sb, scount;
-    TRY(scount.alloc(1));
-    u32 cap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(T->total * 2, (i64)1 << 28));
+    DevBuf<u32> vals, vals_alt, sa, sb, scount;
+    const u32 *seed_ent = nullptr, *seed_pos = nullptr;
+    const i32 *e_probe = P->ent_probe.p, *e_pos = P->ent_pos.p;
     u32 nseeds = 0;
-    for (int attempt = 0;; ++attempt) {
-        TRY(sa.reserve(cap));
-        TRY(sb.reserve(cap));
-        HIP_TRY(hipMemsetAsync(scount.p, 0, sizeof(u32), ctx->stream));
-        HitBuf hb = {sa.p, sb.p, nullptr, scount.p, cap};
-        hipLaunchKernelGGL(seed_join_kernel, dim3((unsigned)div_up(T->total, 256)), dim3(256), 0, ctx->stream,
-                           T->bytes.p, (u32)T->total, T->seq_off.p, (u32)T->nseq, (int)P->k, keys.p, vals.p,
-                           nent, hb);
+    if (table) {
+        S.scap = seed_capacity(P, T);
+        for (int attempt = 0;; ++attempt) {
+            TRY(seed_table_lookup_async(ctx, P, T, 0xffffffffu, S, nullptr, 0, nullptr, tm));
+            HIP_TRY(hipGetLastError());
+            TRY(read_count(ctx, S.ctr.p + 1, &nseeds));
+            if (nseeds <= S.scap) break;
+            if (attempt >= 2) { chip_set_error("seed lookup: work list overflow"); return CATCHHIP_ENOMEM; }
+            S.scap = nseeds;
+        }
+        seed_ent = S.sent.p; seed_pos = S.spos.p;
+        // the table's entries are the anchors sorted by (probe, position)
+        e_probe = (const i32 *)P->sent_probe.p; e_pos = (const i32 *)P->sent_pos.p;
+    } else {
+        TRY(keys.alloc(nent));
+        TRY(vals.alloc(nent));
+        hipLaunchKernelGGL(anchor_hash_kernel, dim3((unsigned)div_up(nent, 256)), dim3(256), 0, ctx->stream,
+                           P->bytes.p, P->probe_off.p, P->ent_probe.p, P->ent_pos.p, nent, (int)P->k, keys.p,
+                           vals.p);
         tm.launch();
-        HIP_TRY(hipGetLastError());
-        TRY(read_count(ctx, scount.p, &nseeds));
-        if (nseeds <= cap) break;
-        if (attempt >= 2) { chip_set_error("seed join: hit buffer overflow"); return CATCHHIP_ENOMEM; }
-        cap = nseeds;
+        TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nent, 64));
+        TRY(scount.alloc(1));
+        u32 cap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(T->total * 2, (i64)1 << 28));
+        for (int attempt = 0;; ++attempt) {
+            TRY(sa.reserve(cap));
+            TRY(sb.reserve(cap));
+            HIP_TRY(hipMemsetAsync(scount.p, 0, sizeof(u32), ctx->stream));
+            HitBuf hb = {sa.p, sb.p, nullptr, scount.p, cap};
+            hipLaunchKernelGGL(seed_join_kernel, dim3((unsigned)div_up(T->total, 256)), dim3(256), 0, ctx->stream,
+                               T->bytes.p, (u32)T->total, T->seq_off.p, (u32)T->nseq, (int)P->k, keys.p, vals.p,
+                               nent, hb);
+            tm.launch();
+            HIP_TRY(hipGetLastError());
+            TRY(read_count(ctx, scount.p, &nseeds));
+            if (nseeds <= cap) break;
+            if (attempt >= 2) { chip_set_error("seed join: hit buffer overflow"); return CATCHHIP_ENOMEM; }
+            cap = nseeds;
+        }
+        seed_ent = sa.p; seed_pos = sb.p;
     }
     if (nseeds == 0) return 0;
     // extension: at most one range per seed
@@ -755,8 +795,8 @@ static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchh
     HIP_TRY(hipMemsetAsync(H.count.p, 0, sizeof(u32), ctx->stream));
     HitBuf ob = {H.a.p, H.b.p, H.c.p, H.count.p, nseeds};
     hipLaunchKernelGGL(extend_kernel, dim3((unsigned)div_up(nseeds, 256)), dim3(256), 0, ctx->stream, T->bytes.p,
-                       T->seq_off.p, (u32)T->nseq, P->bytes.p, P->probe_off.p, P->ent_probe.p, P->ent_pos.p,
-                       (int)P->k, mm, lcf_thres, island, sa.p, sb.p, nseeds, ob);
+                       T->seq_off.p, (u32)T->nseq, P->bytes.p, P->probe_off.p, e_probe, e_pos,
+                       (int)P->k, mm, lcf_thres, island, seed_ent, seed_pos, nseeds, ob);
     tm.launch();
     HIP_TRY(hipGetLastError());
     TRY(read_count(ctx, H.count.p, &H.n));
