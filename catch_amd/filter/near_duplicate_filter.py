@@ -37,6 +37,14 @@ class NearDuplicateFilter(BaseFilter):
                                      reverse=True)]
 
 
+def _order_strs_by_multiplicity(strs):
+    """The same order on plain strings (Counter keeps first-seen order, the
+    sort is stable)."""
+    from collections import Counter
+    return [s for s, _ in sorted(Counter(strs).items(),
+                                 key=operator.itemgetter(1), reverse=True)]
+
+
 class NearDuplicateFilterWithHammingDistance(NearDuplicateFilter):
     def __init__(self, dist_thres, probe_length):
         super().__init__(k=20)
@@ -69,6 +77,18 @@ class NearDuplicateFilterWithHammingDistance(NearDuplicateFilter):
         keep = ctx.ndf_hamming([p.seq_str for p in order], self.dim,
                                positions, self.dist_thres)
         return [p for p, kp in zip(order, keep) if kp]
+
+    def _filter_strs(self, strs):
+        """_filter on plain probe strings (the front end's string pipeline)."""
+        order = _order_strs_by_multiplicity(strs)
+        positions = self._draw_positions()
+        if not order:
+            return []
+        if len(set(map(len, order))) != 1 or len(order[0]) != self.dim:
+            raise ValueError("Sequences must be of same length")
+        keep = engine.default_context().ndf_hamming(order, self.dim, positions,
+                                                    self.dist_thres)
+        return [s for s, kp in zip(order, keep) if kp]
 
 
 class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
@@ -117,3 +137,15 @@ class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
         keep = ctx.ndf_minhash([p.seq_str for p in order], self.kmer_size,
                                params, self.dist_thres)
         return [p for p, kp in zip(order, keep) if kp]
+
+    def _filter_strs(self, strs):
+        """_filter on plain probe strings (the front end's string pipeline)."""
+        order = _order_strs_by_multiplicity(strs)
+        params = self._draw_params()
+        if not order:
+            return []
+        if min(map(len, order)) < self.kmer_size:
+            raise AssertionError("k-mer size exceeds a sequence's length")
+        keep = engine.default_context().ndf_minhash(order, self.kmer_size, params,
+                                                    self.dist_thres)
+        return [s for s, kp in zip(order, keep) if kp]

@@ -734,3 +734,35 @@ def test_coverage_analyzer_golden(ctx, oracle, tmp_path):
         depth[s0:e0] += 1
     sl = a.sliding_coverage[0][0][False]
     assert sl[25.0] == np.average(depth[0:50])
+
+
+@pytest.mark.parametrize("first", ["dup", "hamming", "minhash"])
+def test_string_pipeline_equals_object_pipeline(ctx, first):
+    """ProbeDesigner's string pipeline (no Probe object per candidate) selects
+    what the filter-by-filter pipeline on Probe objects selects, for every
+    first filter bin/design.py can put before the set cover filter."""
+    from catch_amd import genome
+    from catch_amd.filter import (duplicate_filter, near_duplicate_filter,
+                                  probe_designer, set_cover_filter)
+    rng = np.random.Generator(np.random.PCG64(71))
+    from catch_amd.utils import synthetic
+    groups = [[genome.Genome.from_one_seq(g[0]) for g in
+               synthetic.make_species(rng, [3000], 5, 2, 0.04, 0.01)],
+              [genome.Genome.from_one_seq(g[0]) for g in
+               synthetic.make_species(rng, [2200], 4, 2, 0.05, 0.02)]]
+
+    def filters():
+        f0 = {"dup": duplicate_filter.DuplicateFilter,
+              "hamming": lambda: near_duplicate_filter.NearDuplicateFilterWithHammingDistance(2, 100),
+              "minhash": lambda: near_duplicate_filter.NearDuplicateFilterWithMinHash(0.5)}[first]()
+        return [f0, set_cover_filter.SetCoverFilter(mismatches=3, lcf_thres=100,
+                                                    cover_extension=20)]
+    random.seed(9)
+    a = probe_designer.ProbeDesigner(groups, filters(), 100, 50)
+    a.design()                                   # string pipeline
+    random.seed(9)
+    b = probe_designer.ProbeDesigner(groups, filters(), 100, 50)
+    cands, probes = b._design_for_genomes(groups, b.filters)   # object pipeline
+    want = list(dict.fromkeys(p for g in probes for p in g))
+    assert sorted(p.seq_str for p in a.final_probes) == sorted(p.seq_str for p in want)
+    assert [p.seq_str for p in a.candidate_probes] == [p.seq_str for g in cands for p in g]
