@@ -5,8 +5,9 @@ K2 greedy set cover) on MI355X.
     python bench.py --gpus N --steps K --warmup W
 
 A step = one full pass of the hot path over the workload with the packed
-inputs already resident in HBM: for every group, catchhip_cover_scan (tiled
-Hamming scan, sort/merge into cover rows) and catchhip_setcover_greedy.
+inputs already resident in HBM: one catchhip_setcover_filter_many call = for
+every group (each on its own stream) the hash-seeded coverage scan, the
+bucketed row build and the frontier set-cover solver.
 Workload at N=1: BASELINE.json configs[1] -- ~100 Ebola+Lassa-like genomes,
 `design.py -pl 100 -ps 50 -m 2 -e 50` -- as the seeded synthetic set S2
 (catch_amd/utils/synthetic.py; the reference ships no input at this scale).

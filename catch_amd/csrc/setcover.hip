@@ -11,10 +11,17 @@
 // iteration order of the reference's set of dense ids), ranks gate which sets
 // may be considered (set_cover.py:497-526).
 //
-// Single-GPU solver: after grid-wide set-up kernels, ONE persistent workgroup
-// runs the whole greedy loop (the picks are inherently sequential; a
-// workgroup barrier costs a fraction of a microsecond where a kernel boundary
-// costs several).  Per pick it (1) takes the arg-max of a two-level max
+// Three solvers, all exact (catchhip_setcover_greedy picks one):
+//
+// Frontier rounds (setcover_batched.inc; every universe fully covered, rows of
+// at most 257 bases -- the default): all locally-maximal sets are accepted per
+// round, two grid-wide launches each; the picks come back in the sequential
+// order.
+//
+// Sequential solver (partial coverage, long rows): after grid-wide set-up
+// kernels ONE persistent workgroup runs the whole greedy loop (a workgroup
+// barrier costs a fraction of a microsecond where a kernel boundary costs
+// several).  Per pick it (1) takes the arg-max of a two-level max
 // structure over the gains, (2) clears the winner's bits, (3) re-counts only
 // the rows that overlap the cleared ranges (found through a position-sorted
 // row index) and patches the affected gains, (4) for universes whose
@@ -41,8 +48,8 @@ struct GreedyState {
     u32 iters;
     u32 lmax;      // longest row
     u32 smax;      // largest (set, universe) element count
-    u32 fr_claim[2];   // batched solver: some set of the current rank claimed, by round parity
-    u32 fr_live[2];    // batched solver: sizes of the live-set lists (large instances), by round parity
+    u32 fr_claim[2];   // frontier solver: some set of the current rank claimed, by round parity
+    u32 fr_live[2];    // frontier solver: sizes of the live-set lists (large instances), by round parity
     unsigned long long prof[8];  // shader-clock ticks per phase (thread 0)
     unsigned long long n_wrows, n_recount, n_words;  // work counters
 };
@@ -312,7 +319,6 @@ useg_ptr_kernel(const u64 *__restrict__ ukeys, u32 nseg, u32 nuniv, u32 *__restr
 // ------------------------------------------------------------------------
 struct GreedyArgs {
     unsigned long long *bm;
-    unsigned long long *owner;   // per bitmap word: largest candidate key claiming it (batched solver)
     const uint4 *wrow;    // rows in set order: {gs, ge, prev_ge (same universe, else 0), segment}
     const u32 *set_ptr, *set_seg_ptr;
     const u32 *seg_univ, *seg_set;
