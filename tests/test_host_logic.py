@@ -188,3 +188,35 @@ def test_set_cover_filter_constructor_surface():
     g = [Genome.from_one_seq("A" * 50), Genome.from_one_seq("C" * 200)]
     assert scf.SetCoverFilter(2, 100, coverage=100)._make_universe_p(g) == [1.0, 0.5]
     assert scf.SetCoverFilter(2, 100, coverage=0.25)._make_universe_p(g) == [0.25, 0.25]
+
+
+def test_multiplicity_order_on_strings_matches_objects():
+    """The string pipeline's multiplicity order (Counter + stable sort) is the
+    object pipeline's (near_duplicate_filter.py:60-66)."""
+    import random
+    from catch_amd import probe
+    from catch_amd.filter import near_duplicate_filter as ndf
+    rnd = random.Random(3)
+    pool = ["".join(rnd.choice("ACGT") for _ in range(12)) for _ in range(40)]
+    strs = [rnd.choice(pool) for _ in range(500)]
+    f = ndf.NearDuplicateFilterWithHammingDistance(1, 12)
+    objs = f._order_by_multiplicity([probe.Probe.from_str(s) for s in strs])
+    assert ndf._order_strs_by_multiplicity(strs) == [p.seq_str for p in objs]
+    assert ndf.NearDuplicateFilterWithMinHash(0.6).num_tables() == 25
+    assert ndf.NearDuplicateFilterWithHammingDistance(2, 100).num_tables() == 2
+
+
+def test_anchor_table_assume_unique_matches_general():
+    from catch_amd import probe
+    import random
+    rnd = random.Random(5)
+    strs = list(dict.fromkeys("".join(rnd.choice("ACGT") for _ in range(100))
+                              for _ in range(50)))
+    for m, thres in ((2, 100), (5, 100), (2, 60)):
+        np.random.seed(4)
+        a = probe.anchor_table(strs, m, thres)
+        np.random.seed(4)
+        b = probe.anchor_table(strs, m, thres, assume_unique=True)
+        assert a[0] == b[0] and a[1] == b[1]
+        for x, y in zip(a[2:], b[2:]):
+            assert np.array_equal(x, y)
