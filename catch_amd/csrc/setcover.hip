@@ -35,6 +35,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 
 #include "internal.h"
 
@@ -862,7 +863,11 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
             HIP_TRY(hipMemcpyAsync(h_keys, fa.pick_key, 8 * (size_t)nsets, hipMemcpyDeviceToHost, s));
         }
         if (d_info) HIP_TRY(hipMemcpyAsync(h_info, d_info, 16 * sizeof(u32), hipMemcpyDeviceToHost, s));
+        const auto t_queued = std::chrono::steady_clock::now();
         HIP_TRY(hipStreamSynchronize(s));
+        if (getenv("CATCHHIP_TIMING"))
+            fprintf(stderr, "[catchhip]   solver batch: waited %.1f us for the device after queueing\n",
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_queued).count());
         if (h_st->done || h_st->n_need == 0) {
             if (!eager && h_st->npicks) {
                 HIP_TRY(hipMemcpyAsync(h_picks, fa.picks, 4 * (size_t)h_st->npicks, hipMemcpyDeviceToHost, s));

@@ -257,7 +257,7 @@ class Rows:
             None if rk is None else _ptr(rk, c_i64p),
             None if up is None else _ptr(up, c_f64p),
             _ptr(out, c_i64p), ctypes.byref(n_out)))
-        return [int(x) for x in out[:n_out.value]]
+        return out[:n_out.value].tolist()
 
     def close(self):
         if self._h:
@@ -323,8 +323,7 @@ def setcover_filter_many(groups, mismatches, lcf_thres, island,
             n, ctxs, prs, tgs, int(mismatches), int(lcf_thres), int(island),
             int(cover_extension), int(mode), _ptr(nsets, c_i64p), rk_p, up_p,
             out_p, _ptr(n_out, c_i64p), _ptr(nrows, c_i64p)))
-    return [([int(x) for x in outs[g][:n_out[g]]], int(nrows[g]))
-            for g in range(n)]
+    return [(outs[g][:n_out[g]].tolist(), int(nrows[g])) for g in range(n)]
 
 
 _default_ctx = None
