@@ -253,7 +253,7 @@ def main():
         #    the probe image (64 B) and the hit record (20 B)
         #  rows: per hit 20 B record read + 12 B scatter + 12 B sort read; per
         #    merged row 12 B write + 12 B read + 16 B final row
-        #  K2 round: per re-counted row 16 B record + 1 B flag, per bitmap word
+        #  K2 round: per re-counted row 8 B record + 1 B flag, per bitmap word
         #    8 B read + 8 B owner word, per set and round 12 B of state
         seeds_step = stats.get("seed_hits", 0) / K
         hits_step = stats.get("raw_hits", 0) / K
@@ -267,7 +267,7 @@ def main():
         picks_per_step = stats["picks"] / K
         k2_ms = stats["greedy_ms"] / K
         rounds_step = stats.get("greedy_iters", 0) / K
-        k2_bytes_step = (17.0 * stats.get("rows_recounted", 0)
+        k2_bytes_step = (9.0 * stats.get("rows_recounted", 0)
                          + 16.0 * stats.get("bitmap_words_read", 0)) / K \
             + 12.0 * P * rounds_step
         k2_rounds_ms = stats.get("rounds_ms", 0.0) / K     # the round launches only
