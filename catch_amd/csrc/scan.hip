@@ -810,7 +810,8 @@ static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchh
 // ------------------------------------------------------------------------
 struct BucketBuild {
     DevBuf<uint4> rec;
-    DevBuf<u32> rank, bcnt, bstart, S_es, S_ee, S_seg, mcnt, blmax, rstart, res, tsum, tamax;
+    DevBuf<uint4> S;   // hits grouped by bucket, then the merged rows, {start, end, segment, bucket}
+    DevBuf<u32> rank, bcnt, bstart, mcnt, blmax, rstart, res, tsum, tamax;
     DevBuf<unsigned long long> bsum;
     u32 nb = 0, cap = 0;
 };
@@ -821,9 +822,7 @@ static int bucket_prepare(BucketBuild &B, u32 nb, u32 cap, bool want_sum) {
     B.nb = nb; B.cap = cap;
     TRY(B.rec.reserve(cap));
     TRY(B.rank.reserve(cap));
-    TRY(B.S_es.reserve(cap));
-    TRY(B.S_ee.reserve(cap));
-    TRY(B.S_seg.reserve(cap));
+    TRY(B.S.reserve(cap));
     TRY(B.bcnt.reserve((size_t)nb + 1));
     TRY(B.bstart.reserve((size_t)nb + 2));
     TRY(B.mcnt.reserve((size_t)nb + 1));
@@ -867,10 +866,10 @@ static int bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, cons
     if (nrec)
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)div_up((i64)nrec, 256)), dim3(256), 0, s,
                            (const uint4 *)B.rec.p, (const u32 *)B.rank.p, nrec, nrec_dev, (const u32 *)B.bstart.p,
-                           B.S_es.p, B.S_ee.p, B.S_seg.p);
+                           B.S.p);
     unsigned long long *bsum = want_sum ? B.bsum.p : nullptr;
     hipLaunchKernelGGL((bucket_merge_kernel<64, BK_SMALL>), dim3((unsigned)std::min<i64>(B.nb, (i64)1 << 20)), dim3(64),
-                       0, s, (const u32 *)B.bstart.p, B.nb, B.S_es.p, B.S_ee.p, B.S_seg.p, B.mcnt.p, B.blmax.p, bsum,
+                       0, s, (const u32 *)B.bstart.p, B.nb, B.S.p, B.mcnt.p, B.blmax.p, bsum,
                        dedupe ? 1 : 0);
     static bool big_attr_set = false;
     if (!big_attr_set) {
@@ -879,7 +878,7 @@ static int bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, cons
         big_attr_set = true;
     }
     hipLaunchKernelGGL(bucket_merge_big_kernel, dim3((unsigned)ctx->num_cus), dim3(1024), 3 * BK_BIG * sizeof(u32), s,
-                       (const u32 *)B.bstart.p, B.nb, B.S_es.p, B.S_ee.p, B.S_seg.p, B.mcnt.p, B.blmax.p, bsum,
+                       (const u32 *)B.bstart.p, B.nb, B.S.p, B.mcnt.p, B.blmax.p, bsum,
                        B.res.p + 1, dedupe ? 1 : 0);
     tm.launch(3);
     TRY(bucket_scan(ctx, B, B.mcnt.p, B.rstart.p, B.nb, B.res.p + 4, B.blmax.p, B.res.p + 5, tm));
@@ -1091,7 +1090,7 @@ int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const ca
         if ((rc = bucket_finish_async(ctx, O.B, O.S.scap, O.S.ctr.p + 1, false, true, tr))) break;
         hipLaunchKernelGGL(rows_emit_kernel, dim3((unsigned)div_up(R->n, 256)), dim3(256), 0, ctx->stream,
                            (const u32 *)O.B.rstart.p, O.B.nb, (const u32 *)O.B.bstart.p, (const i32 *)P->bucket_set.p,
-                           (const u32 *)O.B.S_es.p, (const u32 *)O.B.S_ee.p, (const u32 *)O.B.S_seg.p, (u32)R->n,
+                           (const uint4 *)O.B.S.p, (u32)R->n,
                            (const u32 *)(O.B.res.p + 4), R->set_id.p, R->univ.p, R->gs.p, R->ge.p);
         hipLaunchKernelGGL(rows_info_kernel, dim3(1), dim3(64), 0, ctx->stream, (const u32 *)O.B.res.p,
                            (const u32 *)O.S.ctr.p, O.S.scap, R->info.p);
@@ -1159,8 +1158,7 @@ static int cover_scan_impl(catchhip_ctx *ctx, const catchhip_probes *P, const ca
             if (R->n) {
                 hipLaunchKernelGGL(rows_emit_kernel, dim3((unsigned)div_up(R->n, 256)), dim3(256), 0, ctx->stream,
                                    (const u32 *)O.B.rstart.p, O.B.nb, (const u32 *)O.B.bstart.p,
-                                   (const i32 *)P->bucket_set.p, (const u32 *)O.B.S_es.p, (const u32 *)O.B.S_ee.p,
-                                   (const u32 *)O.B.S_seg.p, (u32)R->n, (const u32 *)nullptr, R->set_id.p, R->univ.p,
+                                   (const i32 *)P->bucket_set.p, (const uint4 *)O.B.S.p, (u32)R->n, (const u32 *)nullptr, R->set_id.p, R->univ.p,
                                    R->gs.p, R->ge.p);
                 tm.launch();
             }
