@@ -15,6 +15,10 @@ c_i64p = ctypes.POINTER(ctypes.c_int64)
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
 c_f64p = ctypes.POINTER(ctypes.c_double)
 c_vp = ctypes.c_void_p
+c_u16p = ctypes.POINTER(ctypes.c_uint16)
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_f32p = ctypes.POINTER(ctypes.c_float)
 c_vpp = ctypes.POINTER(ctypes.c_void_p)
 
 # name -> (restype, argtypes); must list every symbol declared in catchhip.h
@@ -71,6 +75,14 @@ PROTOTYPES = {
     "catchhip_ndf_hamming": (ctypes.c_int, [
         c_vp, c_u8p, ctypes.c_int64, ctypes.c_int32, c_i32p, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_int32, c_u8p]),
+    "catchhip_sigs_create": (ctypes.c_int, [
+        c_vp, c_u8p, c_u64p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_uint32,
+        ctypes.c_uint32, ctypes.c_uint32, c_vpp]),
+    "catchhip_sigs_destroy": (None, [c_vp]),
+    "catchhip_sigs_fetch": (ctypes.c_int, [c_vp, c_vp, c_u32p]),
+    "catchhip_sigs_common_row": (ctypes.c_int, [
+        c_vp, c_vp, ctypes.c_uint32, c_u16p]),
+    "catchhip_sigs_condensed": (ctypes.c_int, [c_vp, c_vp, c_f32p, c_f32p]),
 }
 
 _lib = None

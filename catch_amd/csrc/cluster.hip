@@ -1,0 +1,424 @@
+// Sequence clustering pre-step: MinHash signatures and signature distances.
+//
+// Replaces, for `--cluster-and-design-separately` (catch/utils/cluster.py:358-430):
+//   * lsh.MinHashFamily(k, N).make_h() / h(s)   (catch/utils/lsh.py:75-153): the
+//     signature of a sequence is the N smallest values, kept with multiplicity
+//     and sorted, of (a * md5(kmer) + b) mod (2^31 - 1) over every k-mer of the
+//     sequence (md5 read as a 128-bit big-endian integer, :106-111); a sequence
+//     with fewer than N k-mers repeats its k-mers in whole rounds (:126-135);
+//   * MinHashFamily.estimate_jaccard_dist (:170-215): a merge walk of two
+//     sorted signatures that stops after N union steps and counts the common
+//     values -- since both signatures hold exactly N values the walk always
+//     makes exactly N steps, so the distance is 1 - common / N.
+//
+// Kernels (all HBM- or integer-issue-bound, nothing GEMM-shaped):
+//   kmer_md5_kernel    one thread per k-mer start: a 1024-position tile of the
+//                      raw characters is staged in LDS, the single-block MD5 of
+//                      the k <= 55 characters runs in registers, the 31-bit hash
+//                      is written to H[position].  Positions whose k-mer would
+//                      cross a sequence end hold garbage that nobody reads.
+//   sig_select_kernel  one workgroup per sequence: a three-level radix select
+//                      (11 + 10 + 10 bits, LDS histograms) finds the N-th
+//                      smallest hash, the values below it are gathered, padded
+//                      with copies of it, rank-sorted in LDS and written out.
+//   sig_transpose_kernel  [seq][N] -> [N][seq] so the walks below read coalesced.
+//   sig_row_kernel     one thread per sequence: walk against signature j (LDS).
+//   sig_pairs_kernel   a T x T tile of pairs per workgroup, both signature
+//                      tiles in LDS; writes float32 distances at the condensed
+//                      index SciPy expects (cluster.py:86-100).
+#include <algorithm>
+
+#include "internal.h"
+
+struct catchhip_sigs {
+    catchhip_ctx *ctx = nullptr;
+    u32 nseq = 0, N = 0;
+    DevBuf<u32> sig;    // [nseq][N], ascending
+    DevBuf<u32> sigT;   // [N][nseq]
+};
+
+#define MD5_P 0x7FFFFFFFu
+#define KM_THREADS 256
+#define KM_PPT 4
+#define KM_TILE (KM_THREADS * KM_PPT)
+#define KM_MAXK 55
+#define SS_THREADS 256
+#define SS_MAXN 1024
+
+__constant__ u32 c_md5_k[64];
+__device__ __forceinline__ u32 rotl32(u32 x, int s) { return (x << s) | (x >> (32 - s)); }
+
+// MD5 (RFC 1321) of one 64-byte block held as 16 little-endian words; returns
+// the digest read as a big-endian 128-bit integer, reduced mod 2^31 - 1
+// (2^32 = 2, 2^64 = 4, 2^96 = 8 mod 2^31 - 1).
+__device__ __forceinline__ u32 md5_block_mod_p(const u32 (&M)[16]) {
+    u32 a = 0x67452301u, b = 0xefcdab89u, c = 0x98badcfeu, d = 0x10325476u;
+#define MD5_STEP(f, g, i, s)                                                  \
+    {                                                                         \
+        const u32 t = (f) + a + c_md5_k[i] + M[g];                            \
+        a = d; d = c; c = b; b = b + rotl32(t, s);                            \
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int s = (i & 3) == 0 ? 7 : (i & 3) == 1 ? 12 : (i & 3) == 2 ? 17 : 22;
+        MD5_STEP((b & c) | (~b & d), i, i, s);
+    }
+#pragma unroll
+    for (int i = 16; i < 32; ++i) {
+        const int s = (i & 3) == 0 ? 5 : (i & 3) == 1 ? 9 : (i & 3) == 2 ? 14 : 20;
+        MD5_STEP((d & b) | (~d & c), (5 * i + 1) & 15, i, s);
+    }
+#pragma unroll
+    for (int i = 32; i < 48; ++i) {
+        const int s = (i & 3) == 0 ? 4 : (i & 3) == 1 ? 11 : (i & 3) == 2 ? 16 : 23;
+        MD5_STEP(b ^ c ^ d, (3 * i + 5) & 15, i, s);
+    }
+#pragma unroll
+    for (int i = 48; i < 64; ++i) {
+        const int s = (i & 3) == 0 ? 6 : (i & 3) == 1 ? 10 : (i & 3) == 2 ? 15 : 21;
+        MD5_STEP(c ^ (b | ~d), (7 * i) & 15, i, s);
+    }
+#undef MD5_STEP
+    a += 0x67452301u; b += 0xefcdab89u; c += 0x98badcfeu; d += 0x10325476u;
+    const u64 wa = __builtin_bswap32(a), wb = __builtin_bswap32(b), wc = __builtin_bswap32(c),
+              wd = __builtin_bswap32(d);
+    return (u32)((8 * wa + 4 * wb + 2 * wc + wd) % MD5_P);
+}
+
+__global__ __launch_bounds__(KM_THREADS) void kmer_md5_kernel(const u32 *__restrict__ words, u64 total, int k,
+                                                              u32 am, u32 b, u32 *__restrict__ H) {
+    __shared__ u32 s_w[KM_TILE / 4 + 16];
+    const u64 tile0 = (u64)blockIdx.x * KM_TILE;
+    // the buffer is padded past `total`, so whole tiles (+ 64 bytes) can be read
+    for (int w = threadIdx.x; w < KM_TILE / 4 + 16; w += KM_THREADS) s_w[w] = words[tile0 / 4 + w];
+    __syncthreads();
+    const int kfull = k >> 2, rem = k & 3;
+#pragma unroll
+    for (int q = 0; q < KM_PPT; ++q) {
+        // consecutive lanes take consecutive positions (coalesced H writes)
+        const int local = q * KM_THREADS + threadIdx.x;
+        const u64 g = tile0 + local;
+        if (g >= total) continue;
+        const int w0 = local >> 2, sh = (local & 3) * 8;
+        u32 M[16];
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+            u32 v = 0;
+            if (t <= kfull) {
+                const u32 lo = s_w[w0 + t], hi = s_w[w0 + t + 1];
+                v = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+                if (t == kfull) v = (v & ((1u << (8 * rem)) - 1u)) | (0x80u << (8 * rem));
+            }
+            M[t] = v;
+        }
+        M[14] = (u32)k * 8u;
+        M[15] = 0;
+        const u64 x = md5_block_mod_p(M);
+        H[g] = (u32)(((u64)am * x + b) % MD5_P);
+    }
+}
+
+// block-wide: which of the nbins weighted histogram bins holds the element of
+// (1-based) rank `need`; returns the bin and the weighted count before it
+__device__ __forceinline__ void select_bin(const u32 *hist, int nbins, u32 reps, u32 need, u32 *s_part, u32 *s_res) {
+    const int per = nbins / SS_THREADS;   // 8 or 4
+    u32 mine = 0;
+    for (int t = 0; t < per; ++t) mine += hist[threadIdx.x * per + t] * reps;
+    s_part[threadIdx.x] = mine;
+    __syncthreads();
+    // inclusive scan of 256 partial sums (Hillis-Steele)
+    for (int off = 1; off < SS_THREADS; off <<= 1) {
+        const u32 v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const u32 incl = s_part[threadIdx.x], excl = incl - mine;
+    if (need > excl && need <= incl) {
+        u32 run = excl;
+        for (int t = 0; t < per; ++t) {
+            const u32 c = hist[threadIdx.x * per + t] * reps;
+            if (need <= run + c) {
+                s_res[0] = (u32)(threadIdx.x * per + t);
+                s_res[1] = run;
+                break;
+            }
+            run += c;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SS_THREADS) void sig_select_kernel(const u32 *__restrict__ H, const u64 *__restrict__ off,
+                                                                u32 nseq, int k, u32 N, u32 *__restrict__ sig) {
+    __shared__ u32 s_hist[2048];
+    __shared__ u32 s_part[SS_THREADS];
+    __shared__ u32 s_res[2];
+    __shared__ u32 s_list[SS_MAXN];
+    __shared__ u32 s_cnt;
+    for (u32 s = blockIdx.x; s < nseq; s += gridDim.x) {
+        const u64 base = off[s];
+        const u64 nk = off[s + 1] - base - (u64)k + 1;
+        // fewer k-mers than N: whole extra rounds over the k-mers (lsh.py:126-135)
+        const u32 reps = nk >= N ? 1u : (u32)((N + nk - 1) / nk);
+        u32 need = N, prefix = 0, pmask = 0, less = 0;
+        for (int level = 0; level < 3; ++level) {
+            const int shift = level == 0 ? 20 : level == 1 ? 10 : 0;
+            const int nbins = level == 0 ? 2048 : 1024;
+            for (int t = threadIdx.x; t < nbins; t += SS_THREADS) s_hist[t] = 0;
+            __syncthreads();
+            for (u64 i = threadIdx.x; i < nk; i += SS_THREADS) {
+                const u32 v = H[base + i];
+                if ((v & pmask) == prefix) atomicAdd(&s_hist[(v >> shift) & (nbins - 1)], 1u);
+            }
+            __syncthreads();
+            select_bin(s_hist, nbins, reps, need, s_part, s_res);
+            need -= s_res[1];
+            less += s_res[1];
+            prefix |= s_res[0] << shift;
+            pmask |= (u32)(nbins - 1) << shift;
+            __syncthreads();
+        }
+        // prefix is the N-th smallest value; `less` (< N) weighted values lie below it
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        for (u64 i = threadIdx.x; i < nk; i += SS_THREADS) {
+            const u32 v = H[base + i];
+            if (v < prefix) {
+                const u32 at = atomicAdd(&s_cnt, reps);
+                for (u32 r = 0; r < reps; ++r) s_list[at + r] = v;
+            }
+        }
+        for (u32 t = less + threadIdx.x; t < N; t += SS_THREADS) s_list[t] = prefix;
+        __syncthreads();
+        for (u32 t = threadIdx.x; t < N; t += SS_THREADS) {
+            const u32 v = s_list[t];
+            u32 r = 0;
+            for (u32 u = 0; u < N; ++u) {
+                const u32 w = s_list[u];
+                r += (w < v || (w == v && u < t)) ? 1u : 0u;
+            }
+            sig[(size_t)s * N + r] = v;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void sig_transpose_kernel(const u32 *__restrict__ sig, u32 nseq, u32 N, u32 *__restrict__ sigT) {
+    __shared__ u32 tile[32][33];
+    const u32 s0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int y = threadIdx.y; y < 32; y += blockDim.y) {
+        const u32 s = s0 + y, r = r0 + threadIdx.x;
+        tile[y][threadIdx.x] = (s < nseq && r < N) ? sig[(size_t)s * N + r] : 0;
+    }
+    __syncthreads();
+    for (int y = threadIdx.y; y < 32; y += blockDim.y) {
+        const u32 r = r0 + y, s = s0 + threadIdx.x;
+        if (s < nseq && r < N) sigT[(size_t)r * nseq + s] = tile[threadIdx.x][y];
+    }
+}
+
+// common values met by the N-step merge walk of two ascending N-value lists
+template <typename FA, typename FB> __device__ __forceinline__ u32 walk_common(u32 N, FA a_at, FB b_at) {
+    u32 ia = 0, ib = 0, common = 0;
+    u32 a = a_at(0), b = b_at(0);
+    for (u32 step = 0; step < N; ++step) {
+        if (a < b) {
+            if (++ia == N) break;
+            a = a_at(ia);
+        } else if (a > b) {
+            if (++ib == N) break;
+            b = b_at(ib);
+        } else {
+            ++common;
+            ++ia; ++ib;
+            if (ia == N || ib == N) break;
+            a = a_at(ia);
+            b = b_at(ib);
+        }
+    }
+    return common;
+}
+
+__global__ __launch_bounds__(256) void sig_row_kernel(const u32 *__restrict__ sig, const u32 *__restrict__ sigT,
+                                                      u32 nseq, u32 N, u32 j, uint16_t *__restrict__ common) {
+    extern __shared__ u32 s_a[];
+    for (u32 t = threadIdx.x; t < N; t += blockDim.x) s_a[t] = sig[(size_t)j * N + t];
+    __syncthreads();
+    const u32 kq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kq >= nseq) return;
+    common[kq] = (uint16_t)walk_common(
+        N, [&](u32 i) { return s_a[i]; }, [&](u32 i) { return sigT[(size_t)i * nseq + kq]; });
+}
+
+__global__ __launch_bounds__(256) void sig_pairs_kernel(const u32 *__restrict__ sig, u32 nseq, u32 N, u32 T,
+                                                        const float *__restrict__ lut, float *__restrict__ out) {
+    extern __shared__ u32 s_ab[];
+    const u32 bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;   // upper triangle of tiles only
+    u32 *s_i = s_ab, *s_j = s_ab + (size_t)T * N;
+    const u32 i0 = bi * T, j0 = bj * T;
+    for (u32 t = threadIdx.x; t < T * N; t += blockDim.x) {
+        const u32 r = t / N, c = t - r * N;
+        s_i[t] = (i0 + r < nseq) ? sig[(size_t)(i0 + r) * N + c] : 0;
+        s_j[t] = (j0 + r < nseq) ? sig[(size_t)(j0 + r) * N + c] : 0;
+    }
+    __syncthreads();
+    for (u32 t = threadIdx.x; t < T * T; t += blockDim.x) {
+        const u32 li = t / T, lj = t - li * T;
+        const u64 i = i0 + li, j = j0 + lj;
+        if (i >= j || j >= nseq) continue;
+        const u32 *pa = s_i + (size_t)li * N, *pb = s_j + (size_t)lj * N;
+        const u32 common = walk_common(
+            N, [&](u32 x) { return pa[x]; }, [&](u32 x) { return pb[x]; });
+        // condensed index of (i, j), i < j (cluster.py:94-99)
+        const u64 idx = i * (u64)nseq - i * (i + 1) / 2 + (j - i - 1);
+        out[idx] = lut[common];
+    }
+}
+
+static bool g_md5_table_ready[64] = {};
+
+static int md5_table_upload(catchhip_ctx *ctx) {
+    if (ctx->device < 64 && g_md5_table_ready[ctx->device]) return 0;
+    // RFC 1321 3.4: T[i] = floor(2^32 * |sin(i + 1)|), i in radians
+    static const u32 T[64] = {
+        0xd76aa478u, 0xe8c7b756u, 0x242070dbu, 0xc1bdceeeu, 0xf57c0fafu, 0x4787c62au, 0xa8304613u, 0xfd469501u,
+        0x698098d8u, 0x8b44f7afu, 0xffff5bb1u, 0x895cd7beu, 0x6b901122u, 0xfd987193u, 0xa679438eu, 0x49b40821u,
+        0xf61e2562u, 0xc040b340u, 0x265e5a51u, 0xe9b6c7aau, 0xd62f105du, 0x02441453u, 0xd8a1e681u, 0xe7d3fbc8u,
+        0x21e1cde6u, 0xc33707d6u, 0xf4d50d87u, 0x455a14edu, 0xa9e3e905u, 0xfcefa3f8u, 0x676f02d9u, 0x8d2a4c8au,
+        0xfffa3942u, 0x8771f681u, 0x6d9d6122u, 0xfde5380cu, 0xa4beea44u, 0x4bdecfa9u, 0xf6bb4b60u, 0xbebfbc70u,
+        0x289b7ec6u, 0xeaa127fau, 0xd4ef3085u, 0x04881d05u, 0xd9d4d039u, 0xe6db99e5u, 0x1fa27cf8u, 0xc4ac5665u,
+        0xf4292244u, 0x432aff97u, 0xab9423a7u, 0xfc93a039u, 0x655b59c3u, 0x8f0ccc92u, 0xffeff47du, 0x85845dd1u,
+        0x6fa87e4fu, 0xfe2ce6e0u, 0xa3014314u, 0x4e0811a1u, 0xf7537e82u, 0xbd3af235u, 0x2ad7d2bbu, 0xeb86d391u};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_md5_k), T, sizeof(T)));
+    if (ctx->device < 64) g_md5_table_ready[ctx->device] = true;
+    return 0;
+}
+
+extern "C" int catchhip_sigs_create(catchhip_ctx *ctx, const u8 *bytes, const u64 *offsets, u32 nseq, i32 k, u32 N,
+                                    u32 a, u32 b, catchhip_sigs **out) {
+    ARG_CHECK(ctx && out && k >= 1 && k <= KM_MAXK && N >= 1 && N <= SS_MAXN && nseq < (1u << 30));
+    ARG_CHECK(a >= 1 && a <= MD5_P && b <= MD5_P);
+    PoolScope pool_scope(ctx);
+    *out = nullptr;
+    catchhip_sigs *S = new catchhip_sigs();
+    S->ctx = ctx;
+    S->nseq = nseq;
+    S->N = N;
+    if (nseq == 0) { *out = S; return 0; }
+    if (!(bytes && offsets && offsets[0] == 0)) {
+        delete S;
+        ARG_CHECK(bytes && offsets && offsets[0] == 0);
+    }
+    for (u32 s = 0; s < nseq; ++s) {
+        // lsh.py:113 asserts kmer_size <= len(s)
+        if (offsets[s + 1] < offsets[s] || offsets[s + 1] - offsets[s] < (u64)k) {
+            delete S;
+            chip_set_error("signatures: sequence %u is shorter than the k-mer size %d", s, (int)k);
+            return CATCHHIP_EINVAL;
+        }
+    }
+    const u64 total = offsets[nseq];
+    int rc = 0;
+    do {
+        if ((rc = hipSetDevice(ctx->device) == hipSuccess ? 0 : CATCHHIP_EHIP)) break;
+        if ((rc = md5_table_upload(ctx))) break;
+        hipStream_t st = ctx->stream;
+        const u64 ntiles = (total + KM_TILE - 1) / KM_TILE;
+        DevBuf<u32> d_words, H;
+        DevBuf<u64> d_off;
+        const size_t padded = (size_t)ntiles * KM_TILE + 64;
+        if ((rc = d_words.alloc(padded / 4)) || (rc = H.alloc((size_t)total)) || (rc = d_off.alloc((size_t)nseq + 1)) ||
+            (rc = S->sig.alloc((size_t)nseq * N)) || (rc = S->sigT.alloc((size_t)nseq * N)))
+            break;
+#define CL_HIP(expr)                                                                        \
+    if ((expr) != hipSuccess) {                                                             \
+        chip_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(hipGetLastError())); \
+        rc = CATCHHIP_EHIP;                                                                 \
+        break;                                                                              \
+    }
+        CL_HIP(hipMemsetAsync((u8 *)d_words.p + (total & ~(u64)3), 0, padded - (total & ~(u64)3), st));
+        CL_HIP(hipMemcpyAsync(d_words.p, bytes, total, hipMemcpyHostToDevice, st));
+        CL_HIP(hipMemcpyAsync(d_off.p, offsets, sizeof(u64) * ((size_t)nseq + 1), hipMemcpyHostToDevice, st));
+        PhaseTimer tm(ctx, PHASE_NDF);
+        hipLaunchKernelGGL(kmer_md5_kernel, dim3((unsigned)ntiles), dim3(KM_THREADS), 0, st, (const u32 *)d_words.p,
+                           total, (int)k, (u32)(a % MD5_P), b, H.p);
+        hipLaunchKernelGGL(sig_select_kernel, dim3((unsigned)std::min<u64>(nseq, (u64)ctx->num_cus * 32)),
+                           dim3(SS_THREADS), 0, st, (const u32 *)H.p, (const u64 *)d_off.p, nseq, (int)k, N, S->sig.p);
+        hipLaunchKernelGGL(sig_transpose_kernel, dim3((nseq + 31) / 32, (N + 31) / 32), dim3(32, 8), 0, st,
+                           (const u32 *)S->sig.p, nseq, N, S->sigT.p);
+        tm.launch(3);
+        CL_HIP(hipGetLastError());
+        CL_HIP(hipStreamSynchronize(st));
+        tm.finish();
+    } while (0);
+    if (rc) { delete S; return rc; }
+    *out = S;
+    return 0;
+}
+
+extern "C" void catchhip_sigs_destroy(catchhip_sigs *S) {
+    if (!S) return;
+    PoolScope pool_scope(S->ctx);
+    delete S;
+}
+
+extern "C" int catchhip_sigs_fetch(catchhip_ctx *ctx, const catchhip_sigs *S, u32 *out) {
+    ARG_CHECK(ctx && S && S->ctx == ctx);
+    if (S->nseq == 0) return 0;
+    ARG_CHECK(out);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(out, S->sig.p, sizeof(u32) * (size_t)S->nseq * S->N, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int catchhip_sigs_common_row(catchhip_ctx *ctx, const catchhip_sigs *S, u32 j, uint16_t *common) {
+    ARG_CHECK(ctx && S && S->ctx == ctx && common && j < S->nseq);
+    PoolScope pool_scope(ctx);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf<uint16_t> d;
+    TRY(d.alloc(S->nseq));
+    TRY(chip_pinned_reserve(ctx, sizeof(uint16_t) * (size_t)S->nseq));
+    PhaseTimer tm(ctx, PHASE_NDF);
+    hipLaunchKernelGGL(sig_row_kernel, dim3((S->nseq + 255) / 256), dim3(256), sizeof(u32) * S->N, st,
+                       (const u32 *)S->sig.p, (const u32 *)S->sigT.p, S->nseq, S->N, j, d.p);
+    tm.launch(1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ctx->h_big, d.p, sizeof(uint16_t) * (size_t)S->nseq, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    tm.finish();
+    memcpy(common, ctx->h_big, sizeof(uint16_t) * (size_t)S->nseq);
+    return 0;
+}
+
+extern "C" int catchhip_sigs_condensed(catchhip_ctx *ctx, const catchhip_sigs *S, const float *lut, float *out) {
+    ARG_CHECK(ctx && S && S->ctx == ctx && lut);
+    PoolScope pool_scope(ctx);
+    const u64 n = S->nseq;
+    if (n < 2) return 0;
+    ARG_CHECK(out);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const u64 npairs = n * (n - 1) / 2;
+    DevBuf<float> d_out, d_lut;
+    TRY(d_out.alloc((size_t)npairs));
+    TRY(d_lut.alloc((size_t)S->N + 1));
+    HIP_TRY(hipMemcpyAsync(d_lut.p, lut, sizeof(float) * ((size_t)S->N + 1), hipMemcpyHostToDevice, st));
+    // both signature tiles of a workgroup live in LDS (<= 48 KB)
+    u32 T = 32;
+    while (T > 4 && sizeof(u32) * 2 * (size_t)T * S->N > 48 * 1024) T >>= 1;
+    const u32 nt = (u32)((n + T - 1) / T);
+    ARG_CHECK(nt <= 65535);
+    PhaseTimer tm(ctx, PHASE_NDF);
+    hipLaunchKernelGGL(sig_pairs_kernel, dim3(nt, nt), dim3(256), sizeof(u32) * 2 * (size_t)T * S->N, st,
+                       (const u32 *)S->sig.p, S->nseq, S->N, T, (const float *)d_lut.p, d_out.p);
+    tm.launch(1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_out.p, sizeof(float) * (size_t)npairs, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    tm.finish();
+    return 0;
+}

@@ -6,9 +6,10 @@ names and defaults ("basic" profile): every FASTA file is one dataset = one
 group of target genomes (bin/design.py:91-99), one Genome per record.  Filter
 list as bin/design.py:296-340 builds it: exact duplicate filter (or a
 near-duplicate filter with --filter-with-lsh-hamming / --filter-with-lsh-
-minhash), then the set cover filter.  Options outside the accelerated path
-(clustering, adapters, reverse complements, N expansion, custom hybridization
-functions) are not offered.  --print-analysis and the three --write-...
+minhash), then the set cover filter; --cluster-and-design-separately clusters
+the input sequences first and designs per cluster (:387-411).  Options outside
+the accelerated path (adapters, reverse complements, N expansion, custom
+hybridization functions) are not offered.  --print-analysis and the three --write-...
 options run the coverage analysis of the designed probes (bin/design.py:417-442).
 """
 import argparse
@@ -53,6 +54,22 @@ def parse_args(argv=None):
     p.add_argument("--write-analysis-to-tsv")
     p.add_argument("--write-sliding-window-coverage")
     p.add_argument("--write-probe-map-counts-to-tsv")
+    def dissimilarity(val):
+        fval = float(val)
+        if 0 < fval <= 0.5:
+            return fval
+        raise argparse.ArgumentTypeError(
+            "%s is an invalid average nucleotide dissimilarity" % val)
+    p.add_argument("--cluster-and-design-separately", type=dissimilarity,
+                   help="cluster all input sequences by MinHash signature "
+                        "(threshold in 1-ANI, (0, 0.5]), design per cluster "
+                        "and merge")
+    p.add_argument("--cluster-and-design-separately-method",
+                   choices=["choose", "simple", "hierarchical"],
+                   default="choose")
+    p.add_argument("--cluster-from-fragments", type=int,
+                   help="cluster fragments of this length instead of whole "
+                        "sequences")
     p.add_argument("--verbose", action="store_true")
     return p.parse_args(argv)
 
@@ -64,6 +81,14 @@ def main(args):
     lcf_thres = args.lcf_thres if args.lcf_thres is not None else args.probe_length
     if args.coverage > 1:
         args.coverage = int(args.coverage)
+    # bin/design.py:236-244
+    if args.cluster_and_design_separately and args.identify:
+        raise Exception(("Cannot use --cluster-and-design-separately with "
+                         "--identify, because clustering collapses genome "
+                         "groupings into one"))
+    if args.cluster_from_fragments and not args.cluster_and_design_separately:
+        raise Exception(("Cannot use --cluster-from-fragments without also "
+                         "setting --cluster-and-design-separately"))
     genomes_grouped = [seq_io.read_genomes_from_fasta(fn) for fn in args.dataset]
 
     filters = []
@@ -102,7 +127,15 @@ def main(args):
     pb = probe_designer.ProbeDesigner(
         genomes_grouped, filters, probe_length=args.probe_length,
         probe_stride=args.probe_stride, allow_small_seqs=args.small_seq_min,
-        seq_length_to_skip=args.small_seq_skip)
+        seq_length_to_skip=args.small_seq_skip,
+        cluster_threshold=args.cluster_and_design_separately,
+        cluster_merge_after=(scf if args.cluster_and_design_separately
+                             else None),
+        cluster_method=(args.cluster_and_design_separately_method
+                        if args.cluster_and_design_separately else None),
+        cluster_fragment_length=(args.cluster_from_fragments
+                                 if args.cluster_and_design_separately
+                                 else None))
     pb.design()
     if args.write_probe_fasta:
         seq_io.write_probe_fasta(pb.final_probes, args.write_probe_fasta)

@@ -8,7 +8,8 @@ import ctypes
 import numpy as np
 
 from catch_amd import _lib
-from catch_amd._lib import c_f64p, c_i32p, c_i64p, c_u8p, check
+from catch_amd._lib import (c_f32p, c_f64p, c_i32p, c_i64p, c_u16p, c_u32p,
+                            c_u64p, c_u8p, check)
 
 SCAN_AUTO, SCAN_GENERAL, SCAN_FAST, SCAN_SEED = 0, 1, 2, 3
 PHASE_SCAN, PHASE_ROWS, PHASE_GREEDY, PHASE_NDF, PHASE_GREEDY_ROUNDS = 0, 1, 2, 3, 4
@@ -269,6 +270,67 @@ class Rows:
             self.close()
         except Exception:
             pass
+
+
+class Signatures:
+    """Device-resident MinHash signatures of sequences (catchhip_sigs): the N
+    smallest values of (a * md5(kmer) + b) mod (2^31 - 1) per sequence."""
+
+    def __init__(self, ctx, seqs, kmer_size, N, a, b):
+        self.ctx = ctx
+        self.n = len(seqs)
+        self.N = int(N)
+        try:
+            raw = "".join(seqs).encode("ascii")
+        except UnicodeEncodeError:
+            raise ValueError("sequences must be ASCII")
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        if buf.size == 0:
+            buf = np.zeros(1, dtype=np.uint8)
+        off = np.zeros(self.n + 1, dtype=np.uint64)
+        if seqs:
+            np.cumsum([len(s) for s in seqs], out=off[1:])
+        self._h = ctypes.c_void_p()
+        check(ctx._L.catchhip_sigs_create(
+            ctx._h, _ptr(np.ascontiguousarray(buf), c_u8p), _ptr(off, c_u64p),
+            self.n, int(kmer_size), self.N, int(a), int(b),
+            ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self.ctx._L.catchhip_sigs_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def fetch(self):
+        """(n, N) uint32, each row ascending."""
+        out = np.zeros((max(self.n, 1), self.N), dtype=np.uint32)
+        check(self.ctx._L.catchhip_sigs_fetch(self.ctx._h, self._h,
+                                              _ptr(out, c_u32p)))
+        return out[:self.n]
+
+    def common_row(self, j):
+        """values signature j shares with every signature under the N-step
+        merge walk of estimate_jaccard_dist (uint16[n])."""
+        out = np.zeros(max(self.n, 1), dtype=np.uint16)
+        check(self.ctx._L.catchhip_sigs_common_row(self.ctx._h, self._h,
+                                                   int(j), _ptr(out, c_u16p)))
+        return out[:self.n]
+
+    def condensed(self, lut):
+        """float32[n(n-1)/2] in SciPy's condensed order; entry = lut[common]."""
+        lut = np.ascontiguousarray(lut, dtype=np.float32)
+        assert lut.size == self.N + 1
+        npairs = self.n * (self.n - 1) // 2
+        out = np.zeros(max(npairs, 1), dtype=np.float32)
+        check(self.ctx._L.catchhip_sigs_condensed(
+            self.ctx._h, self._h, _ptr(lut, c_f32p), _ptr(out, c_f32p)))
+        return out[:npairs]
 
 
 def tolerant_bp(ctx, probes, targets, mismatches, lcf_thres, island, out):

@@ -1,16 +1,18 @@
-"""ProbeDesigner for the unclustered case: candidate probes per group, then the
-filter list over grouped input (mirrors catch/filter/probe_designer.py
-:186-207, :230-271, :273-289; `--cluster-and-design-separately` is out of scope
-of this round)."""
+"""ProbeDesigner: candidate probes per group (or per cluster of sequences), then
+the filter list over grouped input (mirrors catch/filter/probe_designer.py:
+_cluster_genomes :78-184, _pass_through_filters :186-228, _design_for_genomes
+:230-271, design :273-315)."""
 import itertools
 import logging
 
+from catch_amd import genome
 from catch_amd import probe
 from catch_amd.filter import candidate_probes
 from catch_amd.filter.duplicate_filter import DuplicateFilter
 from catch_amd.filter.near_duplicate_filter import (
     NearDuplicateFilterWithHammingDistance, NearDuplicateFilterWithMinHash)
 from catch_amd.filter.set_cover_filter import SetCoverFilter
+from catch_amd.utils import cluster
 
 logger = logging.getLogger(__name__)
 
@@ -18,19 +20,74 @@ logger = logging.getLogger(__name__)
 class ProbeDesigner:
     def __init__(self, genomes, filters, probe_length, probe_stride,
                  allow_small_seqs=None, seq_length_to_skip=None,
-                 cluster_threshold=None, **_unused):
-        if cluster_threshold is not None:
-            raise NotImplementedError(
-                "--cluster-and-design-separately is not built yet")
+                 cluster_threshold=None, cluster_merge_after=None,
+                 cluster_method=None, cluster_fragment_length=None):
         self.genomes = genomes
         self.filters = filters
         self.probe_length = probe_length
         self.probe_stride = probe_stride
         self.allow_small_seqs = allow_small_seqs
         self.seq_length_to_skip = seq_length_to_skip
+        self.cluster_threshold = cluster_threshold
+        self.cluster_merge_after = cluster_merge_after
+        self.cluster_method = cluster_method
+        self.cluster_fragment_length = cluster_fragment_length
         self._candidates = None
         self._candidate_strs = None
         self.final_probes = None
+
+    def _cluster_genomes(self):
+        """All sequences of all groups and genomes (optionally cut into
+        fragments), clustered by MinHash signature; returns one list of
+        single-sequence Genomes per cluster, largest cluster first
+        (probe_designer.py:78-184)."""
+        if len(self.genomes) > 1:
+            logger.warning(("There are >1 groups of genomes in the input, but "
+                            "clustering these will override those groupings; "
+                            "differential identification or other tasks that "
+                            "rely on group separation may no longer work as "
+                            "intended"))
+        seqs = {}
+        for genomes_from_group in self.genomes:
+            for g in genomes_from_group:
+                if self.cluster_fragment_length is not None:
+                    g_seqs = g.break_into_fragments(
+                        self.cluster_fragment_length,
+                        include_full_end=True).seqs
+                else:
+                    g_seqs = g.seqs
+                for s in g_seqs:
+                    if (self.seq_length_to_skip is not None and
+                            len(s) <= self.seq_length_to_skip):
+                        continue
+                    seqs[len(seqs)] = s
+        method = self.cluster_method
+        if method == "choose":
+            # fragments of several long genomes chain into one giant connected
+            # component; average linkage does not (:113-158)
+            method = "simple"
+            if self.cluster_fragment_length is not None:
+                num_sequences = sum(len(g.seqs) for grp in self.genomes
+                                    for g in grp)
+                total_len = sum(g.size() for grp in self.genomes for g in grp)
+                if (num_sequences > 1 and total_len / num_sequences >
+                        self.cluster_fragment_length):
+                    method = "hierarchical"
+        logger.info(("Clustering %d sequences using MinHash signatures, at an "
+                     "average nucleotide dissimilarity threshold of %f"),
+                    len(seqs), self.cluster_threshold)
+        clusters = cluster.cluster_with_minhash_signatures(
+            seqs, threshold=self.cluster_threshold, cluster_method=method)
+        logger.info("Found %d clusters with sizes: %s", len(clusters),
+                    [len(c) for c in clusters])
+        return [[genome.Genome.from_one_seq(seqs[i]) for i in c]
+                for c in clusters]
+
+    def _pass_through_filters_ungrouped(self, probes, genomes, filters):
+        for f in filters:
+            logger.info("Starting filter %s", f.__class__.__name__)
+            probes = f.filter(probes, genomes, input_is_grouped=False)
+        return probes
 
     def _pass_through_filters(self, probes, genomes, filters):
         assert len(probes) == len(genomes)
@@ -56,16 +113,16 @@ class ProbeDesigner:
         return candidates, self._pass_through_filters(candidates, genomes,
                                                       filters)
 
-    def _design_on_strings(self):
+    def _design_on_strings(self, genomes, filters):
         """[DuplicateFilter | near-duplicate filter, SetCoverFilter] -- the
         filter lists bin/design.py:296-340 builds -- on plain strings:
         candidates are sliced, de-duplicated (dict, or the LSH filter on the
         device) and handed to the set cover filter without a Probe object per
         candidate (a design over 8,000 genomes spent 0.85 of its 1.0 s building
         them); only the selected probes become objects."""
-        first, scf = self.filters
+        first, scf = filters
         cand = []
-        for genomes_from_group in self.genomes:
+        for genomes_from_group in genomes:
             c = []
             for g in genomes_from_group:
                 c += candidate_probes.candidate_strings_from_sequences(
@@ -82,10 +139,17 @@ class ProbeDesigner:
             uniq = [list(dict.fromkeys(c)) for c in cand]
         else:   # one _filter call per group, in order, like BaseFilter.filter
             uniq = [first._filter_strs(c) for c in cand]
-        ids = scf._filter_strs(uniq, self.genomes, assume_unique=True)
+        ids = scf._filter_strs(uniq, genomes, assume_unique=True)
         chosen = [[u[i] for i in sel] for u, sel in zip(uniq, ids)]
-        self.final_probes = [probe.Probe.from_str(s) for s in
-                             dict.fromkeys(itertools.chain(*chosen))]
+        return [probe.Probe.from_str(s) for s in
+                dict.fromkeys(itertools.chain(*chosen))]
+
+    @staticmethod
+    def _strings_path_ok(filters):
+        return (len(filters) == 2 and type(filters[0]) in (
+            DuplicateFilter, NearDuplicateFilterWithHammingDistance,
+            NearDuplicateFilterWithMinHash)
+            and type(filters[1]) is SetCoverFilter)
 
     @property
     def candidate_probes(self):
@@ -99,14 +163,25 @@ class ProbeDesigner:
         self._candidates = value
 
     def design(self):
-        if (len(self.filters) == 2 and type(self.filters[0]) in (
-                DuplicateFilter, NearDuplicateFilterWithHammingDistance,
-                NearDuplicateFilterWithMinHash)
-                and type(self.filters[1]) is SetCoverFilter):
-            return self._design_on_strings()
-        candidates, probes = self._design_for_genomes(self.genomes,
-                                                      self.filters)
-        self.candidate_probes = list(itertools.chain(*candidates))
-        # the reference takes list(set(...)) (CPython set order); a stable
-        # order-preserving de-duplication gives the same set reproducibly
-        self.final_probes = list(dict.fromkeys(itertools.chain(*probes)))
+        if self.cluster_threshold is None:
+            genomes, before, after = self.genomes, self.filters, []
+        else:
+            # design per cluster up to cluster_merge_after, then run the
+            # remaining filters on the merged probes (:291-315)
+            assert self.cluster_merge_after is not None
+            assert self.cluster_merge_after in self.filters
+            merge_idx = self.filters.index(self.cluster_merge_after) + 1
+            before, after = self.filters[:merge_idx], self.filters[merge_idx:]
+            genomes = self._cluster_genomes()
+        if self._strings_path_ok(before):
+            probes = self._design_on_strings(genomes, before)
+        else:
+            candidates, grouped = self._design_for_genomes(genomes, before)
+            self.candidate_probes = list(itertools.chain(*candidates))
+            # the reference takes list(set(...)) (CPython set order); a stable
+            # order-preserving de-duplication gives the same set reproducibly
+            probes = list(dict.fromkeys(itertools.chain(*grouped)))
+        if after:
+            probes = self._pass_through_filters_ungrouped(probes, genomes,
+                                                          after)
+        self.final_probes = probes

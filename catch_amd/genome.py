@@ -22,6 +22,27 @@ class Genome:
             self._size = sum(len(seq) for seq in self.seqs)
         return self._size
 
+    def break_into_fragments(self, fragment_length, include_full_end=False):
+        """New Genome whose sequences are these cut into pieces of
+        fragment_length; with include_full_end a short last piece is replaced
+        by the last fragment_length bases (catch/genome.py:64-100)."""
+        def pieces(seq):
+            for i in range(0, len(seq), fragment_length):
+                piece = seq[i:i + fragment_length]
+                if include_full_end and len(piece) < fragment_length:
+                    piece = seq[max(0, len(seq) - fragment_length):]
+                yield piece
+        out = OrderedDict()
+        if self.chrs is None:
+            assert len(self.seqs) == 1
+            for idx, piece in enumerate(pieces(self.seqs[0])):
+                out[str(idx)] = piece
+        else:
+            for name, seq in self.chrs.items():
+                for idx, piece in enumerate(pieces(seq)):
+                    out[name + "-" + str(idx)] = piece
+        return Genome.from_chrs(out)
+
     def __hash__(self):
         return hash(tuple(self.seqs))
 

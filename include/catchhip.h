@@ -239,6 +239,39 @@ int catchhip_ndf_minhash(catchhip_ctx *ctx, const uint8_t *bytes,
                          const int64_t *ab, int32_t ntables, int32_t k,
                          double dist_thres, uint8_t *keep);
 
+/* ---- clustering pre-step (next row: catch/utils/cluster.py) --------------
+ * MinHash signatures of sequences, replacing lsh.MinHashFamily(kmer_size, N)
+ * .make_h() / h(s) (catch/utils/lsh.py:75-153) with the deterministic md5 inner
+ * hash (:106-111) as cluster.make_signatures_with_minhash calls it
+ * (catch/utils/cluster.py:28-44): per sequence the N smallest values, with
+ * multiplicity, ascending, of (a * md5(kmer) + b) mod (2^31 - 1) over all
+ * k-mers (md5 digest read as a big-endian 128-bit integer); a sequence with
+ * fewer than N k-mers repeats them in whole rounds.  bytes = the sequences'
+ * characters back to back (ASCII, as given -- no case folding), offsets[nseq+1]
+ * their starts; 1 <= kmer_size <= 55 <= every sequence length; N <= 1024;
+ * (a, b) as the reference draws them (1 <= a <= 2^31-1, 0 <= b <= 2^31-1). */
+typedef struct catchhip_sigs catchhip_sigs;
+int catchhip_sigs_create(catchhip_ctx *ctx, const uint8_t *bytes,
+                         const uint64_t *offsets, uint32_t nseq,
+                         int32_t kmer_size, uint32_t N, uint32_t a, uint32_t b,
+                         catchhip_sigs **out);
+void catchhip_sigs_destroy(catchhip_sigs *sigs);
+/* out[nseq * N]: signature of sequence s at out[s*N .. s*N+N) */
+int catchhip_sigs_fetch(catchhip_ctx *ctx, const catchhip_sigs *sigs,
+                        uint32_t *out);
+/* MinHashFamily.estimate_jaccard_dist (catch/utils/lsh.py:170-215) of signature
+ * j against every signature: common[k] = values the merge walk finds in both
+ * (the walk always makes exactly N union steps, so the reference's distance is
+ * 1.0 - common[k] / N in float64, which the caller forms). */
+int catchhip_sigs_common_row(catchhip_ctx *ctx, const catchhip_sigs *sigs,
+                             uint32_t j, uint16_t *common);
+/* cluster.create_condensed_dist_matrix (catch/utils/cluster.py:102-194) for the
+ * signature distance: out[n(n-1)/2] float32 in SciPy's condensed order, entry
+ * (i, j) = lut[common(i, j)] with lut[N+1] supplied by the caller (the float32
+ * roundings of 1.0 - c / N, which is what the reference's c_float array holds). */
+int catchhip_sigs_condensed(catchhip_ctx *ctx, const catchhip_sigs *sigs,
+                            const float *lut, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -608,3 +608,150 @@ def coverage_analysis(probe_strs, genomes_grouped, mismatches, lcf_thres,
         bp.append(bg)
         avg.append(ag)
     return covers, bp, avg, counts
+
+
+# --------------------------------------------------------------------------
+# clustering pre-step: catch/utils/cluster.py + lsh.MinHashFamily (md5 hash)
+# --------------------------------------------------------------------------
+def md5_kmer_hash(kmer, a, b):
+    """lsh.py:106-111: (a * int(md5(kmer).hexdigest(), 16) + b) mod (2^31-1)."""
+    import hashlib
+    x = int(hashlib.md5(kmer.encode("utf-8")).hexdigest(), 16)
+    return (a * x + b) % MINHASH_P
+
+
+def minhash_signature(s, kmer_size, N, a, b):
+    """MinHashFamily.make_h()'s h(s) (lsh.py:113-153): the N smallest k-mer
+    hashes (with multiplicity), ascending; when the sequence has fewer than N
+    k-mers they are taken in whole extra rounds."""
+    assert kmer_size <= len(s)
+    num_kmers = len(s) - kmer_size + 1
+    vals = [md5_kmer_hash(s[i:i + kmer_size], a, b) for i in range(num_kmers)]
+    rounds = 1
+    while rounds * num_kmers < N:
+        rounds += 1
+    return tuple(sorted(vals * rounds)[:N])
+
+
+def signature_common(hA, hB, N):
+    """The walk of MinHashFamily.estimate_jaccard_dist (lsh.py:190-210):
+    returns (intersect_count, union_count)."""
+    i = j = inter = union = 0
+    while i < len(hA) and j < len(hB):
+        if union == N:
+            break
+        if hA[i] < hB[j]:
+            i += 1
+        elif hA[i] > hB[j]:
+            j += 1
+        else:
+            inter += 1
+            i += 1
+            j += 1
+        union += 1
+    return inter, union
+
+
+def estimate_jaccard_dist(hA, hB, N):
+    inter, union = signature_common(hA, hB, N)
+    return 1.0 - float(inter) / union
+
+
+def jaccard_dist_from_mash_dist(mash_dist, k):
+    """cluster.py:47-68 (Mash eq. 4 solved for j)."""
+    return 1.0 - 1.0 / (2.0 * np.exp(k * mash_dist) - 1)
+
+
+def condensed_dist_matrix(n, dist_fn):
+    """cluster.py:102-194: float32 (c_float) condensed matrix, SciPy order."""
+    out = np.zeros(n * (n - 1) // 2, dtype=np.float32)
+    idx = 0
+    for i in range(n):
+        for j in range(i + 1, n):
+            out[idx] = dist_fn(i, j)
+            idx += 1
+    return out
+
+
+def cluster_hierarchically(dist_matrix, threshold):
+    """cluster.py:197-232: average linkage, cut at `threshold`, clusters by
+    descending size (ties keep cluster-number order)."""
+    from scipy.cluster import hierarchy
+    if len(dist_matrix) == 0:
+        return [[0]]
+    link = hierarchy.linkage(dist_matrix, method="average")
+    labels = hierarchy.fcluster(link, threshold, criterion="distance")
+    members = {}
+    for i, c in enumerate(labels):
+        members.setdefault(int(c), []).append(i)
+    order = sorted(range(min(members), max(members) + 1),
+                   key=lambda c: -len(members[c]))
+    return [members[c] for c in order]
+
+
+def find_connected_components(n, dist_fn, threshold, early_stop_threshold=None):
+    """cluster.py:235-355.  Depth-first search with the early-stop heuristic:
+    a neighbour within `early_stop_threshold` is absorbed without being
+    explored.  The outcome can depend on the order in which neighbours are
+    examined, which in the reference is the iteration order of a Python set
+    difference; the same set operations are performed here so the order is the
+    interpreter's own."""
+    if early_stop_threshold is None:
+        early_stop_threshold = jaccard_dist_from_mash_dist(0.02, 12)
+    remaining = set(range(n))
+    done = set()
+    comps = []
+    for i in range(n):
+        if i in done:
+            continue
+        seen = set()
+        stack = [i]
+        queued = {i}
+        while len(stack) > 0:
+            j = stack.pop()
+            if j in seen:
+                continue
+            seen.add(j)
+            for k in list(remaining - queued):
+                d = dist_fn(j, k)
+                if d <= threshold:
+                    if d <= early_stop_threshold:
+                        seen.add(k)
+                    else:
+                        stack.append(k)
+                    queued.add(k)
+        done.update(seen)
+        remaining -= seen
+        comps.append(sorted(seen))
+    comps.sort(key=len, reverse=True)
+    return comps
+
+
+def cluster_with_minhash_signatures(seqs, k=12, N=100, threshold=0.1,
+                                    cluster_method="simple"):
+    """cluster.py:358-430 on a list of sequences (indices stand for the
+    reference's dict keys).  Consumes random.randint twice (a, b)."""
+    a = random.randint(1, MINHASH_P)
+    b = random.randint(0, MINHASH_P)
+    sigs = [minhash_signature(s, k, N, a, b) for s in seqs]
+    thr = jaccard_dist_from_mash_dist(threshold, k)
+
+    def dist(i, j):
+        return estimate_jaccard_dist(sigs[i], sigs[j], N)
+    if cluster_method == "simple":
+        return find_connected_components(len(seqs), dist, thr)
+    if cluster_method == "hierarchical":
+        return cluster_hierarchically(condensed_dist_matrix(len(seqs), dist),
+                                      thr)
+    raise ValueError("Unknown cluster_method '%s'" % cluster_method)
+
+
+def fragments_of(seq, fragment_length):
+    """genome.py:64-100 with include_full_end=True."""
+    out = []
+    for i in range(0, len(seq), fragment_length):
+        f = seq[i:i + fragment_length]
+        if len(f) < fragment_length:
+            f = seq[max(0, len(seq) - fragment_length):]
+        out.append(f)
+    return out

@@ -624,7 +624,143 @@ def coverage_main():
     print("coverage_analysis", len(tests), len(results), len(unmerged))
 
 
+def cluster_main():
+    """`make_golden.py cluster-only`: tests/golden/cluster.json.gz = the
+    clustering pre-step (catch/utils/cluster.py, ProbeDesigner with
+    cluster_threshold) of the reference's own tests plus seeded synthetic
+    cases: signatures, distances, connected components / hierarchical
+    clusters, clustered genomes and the final probes of a clustered design."""
+    from catch.utils import cluster
+    from catch.filter import probe_designer
+    install()
+    P = 2 ** 31 - 1
+    rec_cc, rec_hier, rec_mh = [], [], []
+    orig_cc = cluster.find_connected_components
+    orig_hier = cluster.cluster_hierarchically_from_dist_matrix
+    orig_mh = cluster.cluster_with_minhash_signatures
+    orig_sigs = cluster.make_signatures_with_minhash
+    last_sigs = {}
+
+    def w_cc(n, dist_fn, threshold, *a, **kw):
+        out = orig_cc(n, dist_fn, threshold, *a, **kw)
+        if n <= 400:
+            rec = dict(n=n, threshold=float(threshold), out=[list(map(int, c)) for c in out],
+                       dist=[[float(dist_fn(i, j)) for j in range(i + 1, n)] for i in range(n)])
+            if a or kw:
+                rec["early_stop_threshold"] = float(a[0] if a else kw["early_stop_threshold"])
+            rec_cc.append(rec)
+        return out
+
+    def w_hier(dist_matrix, threshold):
+        out = orig_hier(dist_matrix, threshold)
+        rec_hier.append(dict(dist_matrix=[float(x) for x in dist_matrix], threshold=float(threshold),
+                             out=[list(map(int, c)) for c in out]))
+        return out
+
+    def w_sigs(family, seqs):
+        out = orig_sigs(family, seqs)
+        last_sigs.clear()
+        last_sigs.update(out)
+        return out
+
+    def w_mh(seqs, k=12, N=100, threshold=0.1, cluster_method="simple"):
+        state = random.getstate()
+        a, b = random.randint(1, P), random.randint(0, P)
+        random.setstate(state)
+        out = orig_mh(seqs, k=k, N=N, threshold=threshold, cluster_method=cluster_method)
+        names = list(seqs.keys())
+        rec_mh.append(dict(names=[str(x) for x in names], seqs=[seqs[x] for x in names], k=k, N=N,
+                           threshold=float(threshold), method=cluster_method, a=a, b=b,
+                           signatures=[list(map(int, last_sigs[x])) for x in names],
+                           out=[[str(x) for x in c] for c in out]))
+        return out
+    cluster.find_connected_components = w_cc
+    cluster.cluster_hierarchically_from_dist_matrix = w_hier
+    cluster.make_signatures_with_minhash = w_sigs
+    cluster.cluster_with_minhash_signatures = w_mh
+    suite = unittest.TestSuite()
+    suite.addTests(unittest.TestLoader().loadTestsFromName("catch.utils.tests.test_cluster"))
+    suite.addTests(unittest.TestLoader().loadTestsFromName("catch.filter.tests.test_probe_designer"))
+    res = unittest.TextTestRunner(verbosity=0).run(suite)
+    if res.failures or res.errors:
+        raise SystemExit("reference tests failed under the recorder")
+    tests = dict(cc=list(rec_cc), hier=list(rec_hier), minhash=list(rec_mh))
+    del rec_cc[:], rec_hier[:], rec_mh[:]
+
+    # connected components where the early-stop heuristic makes the visiting
+    # order matter: random graphs over three distance classes
+    rnd = random.Random(99)
+    stress = []
+    for n, p_near, p_adj in ((12, 0.1, 0.1), (40, 0.03, 0.04), (120, 0.01, 0.012), (200, 0.004, 0.008),
+                             (200, 0.01, 0.002), (300, 0.002, 0.004)):
+        for _ in range(3):
+            cls = {}
+            for i in range(n):
+                for j in range(i + 1, n):
+                    r = rnd.random()
+                    cls[(i, j)] = 0 if r < p_near else (1 if r < p_near + p_adj else 2)
+            vals = (0.05, 0.3, 0.9)
+
+            def dist(i, j, cls=cls):
+                return vals[cls[(min(i, j), max(i, j))]]
+            out = orig_cc(n, dist, 0.5, 0.1)
+            stress.append(dict(n=n, threshold=0.5, early_stop_threshold=0.1,
+                               classes="".join(str(cls[(i, j)]) for i in range(n) for j in range(i + 1, n)),
+                               out=[list(map(int, c)) for c in out]))
+            print("cc stress", n, [len(c) for c in out][:8], flush=True)
+
+    # synthetic sequences: species / strains (+ fragments), both methods
+    rng = np.random.Generator(np.random.PCG64(41))
+    sp = [synthetic.make_species(rng, [3000], 6, 2, 0.06, 0.01, with_n=True),
+          synthetic.make_species(rng, [2200, 1500], 4, 2, 0.10, 0.02, with_n=True),
+          synthetic.make_species(rng, [4100], 5, 1, 0.0, 0.03, with_n=False)]
+    flat = [s for grp in sp for g in grp for s in g]
+    syn = []
+    for k, N, thr, method, seed, frag in ((12, 100, 0.1, "simple", 1, None), (12, 100, 0.1, "hierarchical", 2, None),
+                                          (12, 100, 0.15, "simple", 3, 1000), (12, 100, 0.15, "hierarchical", 4, 1000),
+                                          (8, 20, 0.2, "simple", 5, None), (12, 100, 0.3, "simple", 6, 100),
+                                          (16, 50, 0.05, "hierarchical", 7, 700), (12, 100, 0.02, "simple", 8, None)):
+        seqs = flat
+        if frag is not None:
+            seqs = [f for s in flat for f in
+                    genome.Genome.from_one_seq(s).break_into_fragments(frag, include_full_end=True).seqs]
+        random.seed(seed)
+        w_mh(OrderedDict(enumerate(seqs)), k=k, N=N, threshold=thr, cluster_method=method)
+        rec = rec_mh.pop()
+        rec["seed"] = seed
+        syn.append(rec)
+        print("cluster", k, N, thr, method, len(seqs), "->", [len(c) for c in rec["out"]][:10], flush=True)
+    del rec_cc[:], rec_hier[:]
+
+    # ProbeDesigner with clustering: clustered genomes and the final probes
+    designs = []
+    groups = [[genome.Genome.from_chrs(OrderedDict(("c%d" % i, s) for i, s in enumerate(g)))
+               if len(g) > 1 else genome.Genome.from_one_seq(g[0]) for g in grp] for grp in sp]
+    for thr, method, frag, skip, seed in ((0.1, "simple", None, None, 11), (0.15, "choose", 1000, None, 12),
+                                          (0.15, "hierarchical", 1500, 120, 13), (0.3, "choose", None, None, 14)):
+        random.seed(seed)
+        df = duplicate_filter.DuplicateFilter()
+        f = scf.SetCoverFilter(mismatches=2, lcf_thres=100, coverage=1.0, cover_extension=20)
+        pd = probe_designer.ProbeDesigner(groups, [df, f], probe_length=100, probe_stride=50,
+                                          seq_length_to_skip=skip, cluster_threshold=thr, cluster_merge_after=f,
+                                          cluster_method=method, cluster_fragment_length=frag)
+        random.seed(seed)
+        clustered = pd._cluster_genomes()
+        random.seed(seed)
+        pd.design()
+        designs.append(dict(genomes=[[list(g.seqs) for g in grp] for grp in groups], threshold=thr, method=method,
+                            fragment_length=frag, seq_length_to_skip=skip, seed=seed,
+                            clustered=[[g.seqs[0] for g in cl] for cl in clustered],
+                            final=sorted(p.seq_str for p in pd.final_probes),
+                            n_candidates=len(pd.candidate_probes)))
+        print("design", thr, method, frag, len(clustered), "clusters ->", len(pd.final_probes), "probes", flush=True)
+    dump("cluster", dict(python=sys.version.split()[0], from_reference_tests=tests, cc_stress=stress,
+                         synthetic=syn, designs=designs))
+
+
 def main():
+    if "cluster-only" in sys.argv:
+        return cluster_main()
     if "minhash-only" in sys.argv:
         return minhash_main()
     if "coverage-only" in sys.argv:

@@ -766,3 +766,144 @@ def test_string_pipeline_equals_object_pipeline(ctx, first):
     want = list(dict.fromkeys(p for g in probes for p in g))
     assert sorted(p.seq_str for p in a.final_probes) == sorted(p.seq_str for p in want)
     assert [p.seq_str for p in a.candidate_probes] == [p.seq_str for g in cands for p in g]
+
+
+# ---------------------------------------------------------------- clustering pre-step
+def test_signatures_golden(ctx):
+    """MinHash signatures (md5 of every k-mer, N smallest) == the reference's
+    (lsh.MinHashFamily.make_h, recorded), incl. sequences with fewer than N
+    k-mers."""
+    engine = _engine()
+    g = load_golden("cluster")
+    recs = g["from_reference_tests"]["minhash"] + g["synthetic"]
+    assert len(recs) >= 8
+    for c in recs:
+        s = engine.Signatures(ctx, c["seqs"], c["k"], c["N"], c["a"], c["b"])
+        got = s.fetch()
+        s.close()
+        assert got.tolist() == c["signatures"]
+
+
+def test_signatures_and_distances_match_oracle(ctx, oracle):
+    """Random sequences of ragged lengths (down to the k-mer size), any
+    characters, several (k, N): signatures, the row walk and the condensed
+    float32 matrix against the CPU restatement."""
+    engine = _engine()
+    rnd = random.Random(17)
+    for k, N, nseq, maxlen in [(12, 100, 40, 900), (1, 5, 9, 30), (3, 64, 30, 200), (16, 1, 25, 300),
+                               (31, 300, 12, 1500), (55, 1024, 6, 1400), (12, 100, 7, 40), (20, 257, 21, 500)]:
+        root = "".join(rnd.choice("ACGT") for _ in range(maxlen))
+        seqs = []
+        for i in range(nseq):
+            ln = rnd.randrange(k, maxlen + 1)
+            st = rnd.randrange(0, maxlen - ln + 1)
+            s = list(root[st:st + ln])
+            for _ in range(rnd.choice([0, 0, 1, 3, 10, 40])):
+                s[rnd.randrange(ln)] = rnd.choice("ACGTNacgtRY-")
+            seqs.append("".join(s))
+        seqs[0] = seqs[-1]                      # identical pair
+        a, b = rnd.randint(1, 2 ** 31 - 1), rnd.randint(0, 2 ** 31 - 1)
+        if k == 1:
+            a, b = 2 ** 31 - 1, 2 ** 31 - 1     # extremes of the draw
+        sigs = engine.Signatures(ctx, seqs, k, N, a, b)
+        got = sigs.fetch()
+        want = [oracle.minhash_signature(s, k, N, a, b) for s in seqs]
+        assert got.tolist() == [list(w) for w in want]
+        for j in (0, nseq // 2, nseq - 1):
+            row = sigs.common_row(j)
+            for q in range(nseq):
+                inter, union = oracle.signature_common(want[j], want[q], N)
+                assert union == N
+                assert int(row[q]) == inter
+        lut = (1.0 - np.arange(N + 1, dtype=np.float64) / float(N)).astype(np.float32)
+        cond = sigs.condensed(lut)
+        ref = oracle.condensed_dist_matrix(
+            nseq, lambda i, j: oracle.estimate_jaccard_dist(want[i], want[j], N))
+        assert cond.dtype == np.float32 and np.array_equal(cond, ref)
+        sigs.close()
+    e = engine.Signatures(ctx, [], 12, 100, 1, 0)
+    assert e.fetch().shape == (0, 100)
+    e.close()
+    with pytest.raises(Exception):
+        engine.Signatures(ctx, ["ACGT"], 12, 100, 1, 0)     # shorter than k
+
+
+def test_signatures_of_long_sequences(ctx, oracle):
+    """One 300-kb and many 5-kb sequences: radix select over long hash arrays,
+    tiles crossing sequence ends."""
+    engine = _engine()
+    rng = np.random.Generator(np.random.PCG64(3))
+    seqs = ["".join("ACGT"[x] for x in rng.integers(0, 4, size=300_000))]
+    seqs += ["".join("ACGT"[x] for x in rng.integers(0, 4, size=int(n)))
+             for n in rng.integers(1000, 5000, size=60)]
+    seqs.append("AC" * 20_000)                  # two distinct 12-mers, heavy multiplicity
+    a, b = 123456789, 987654321
+    sigs = engine.Signatures(ctx, seqs, 12, 100, a, b)
+    got = sigs.fetch()
+    sigs.close()
+    for i in (0, 1, 30, 60, 61):
+        assert got[i].tolist() == list(oracle.minhash_signature(seqs[i], 12, 100, a, b))
+
+
+def test_cluster_with_minhash_signatures_golden(ctx):
+    """cluster.cluster_with_minhash_signatures (signatures + distances on the
+    device, search / linkage on the host) == the reference's clusters, same
+    order, for both methods."""
+    from catch_amd.utils import cluster
+    g = load_golden("cluster")
+    recs = [c for c in g["from_reference_tests"]["minhash"]] + g["synthetic"]
+    for c in recs:
+        if "seed" not in c:
+            continue
+        random.seed(c["seed"])
+        seqs = dict(zip(c["names"], c["seqs"]))
+        got = cluster.cluster_with_minhash_signatures(
+            seqs, k=c["k"], N=c["N"], threshold=c["threshold"], cluster_method=c["method"])
+        assert got == c["out"]
+    # the reference's own test inputs (catch/utils/tests/test_cluster.py:193-226):
+    # recorded (a, b) are replayed through the family
+    from catch_amd.utils import lsh
+    for c in g["from_reference_tests"]["minhash"]:
+        fam = lsh.MinHashFamily(c["k"], N=c["N"])
+        sigs = fam.signatures(c["seqs"], ab=(c["a"], c["b"]))
+        thr = cluster._jaccard_dist_from_mash_dist(c["threshold"], c["k"])
+        if c["method"] == "simple":
+            cl = cluster._components_of_signatures(sigs, thr)
+        else:
+            lut = (1.0 - np.arange(c["N"] + 1, dtype=np.float64) / float(c["N"])).astype(np.float32)
+            cl = cluster.cluster_hierarchically_from_dist_matrix(sigs.condensed(lut), thr)
+        sigs.close()
+        assert [[c["names"][i] for i in x] for x in cl] == c["out"]
+
+
+def test_probe_designer_with_clustering_golden(ctx):
+    """ProbeDesigner with cluster_threshold: the clustered genomes and the
+    final probe set of the reference (DuplicateFilter + SetCoverFilter per
+    cluster, merged after the set cover filter)."""
+    from catch_amd.filter import duplicate_filter, probe_designer, set_cover_filter
+    from catch_amd.genome import Genome
+    from collections import OrderedDict
+    g = load_golden("cluster")
+    assert len(g["designs"]) >= 4
+    for c in g["designs"]:
+        groups = [[Genome.from_chrs(OrderedDict(("c%d" % i, s) for i, s in enumerate(gn)))
+                   if len(gn) > 1 else Genome.from_one_seq(gn[0]) for gn in grp]
+                  for grp in c["genomes"]]
+        for use_strings in (True, False):
+            df = duplicate_filter.DuplicateFilter()
+            f = set_cover_filter.SetCoverFilter(mismatches=2, lcf_thres=100, coverage=1.0,
+                                                cover_extension=20)
+            pd = probe_designer.ProbeDesigner(
+                groups, [df, f], probe_length=100, probe_stride=50,
+                seq_length_to_skip=c["seq_length_to_skip"], cluster_threshold=c["threshold"],
+                cluster_merge_after=f, cluster_method=c["method"],
+                cluster_fragment_length=c["fragment_length"])
+            if not use_strings:
+                pd._strings_path_ok = lambda filters: False
+            random.seed(c["seed"])
+            clustered = pd._cluster_genomes()
+            assert [[x.seqs[0] for x in cl] for cl in clustered] == c["clustered"]
+            random.seed(c["seed"])
+            pd.design()
+            assert sorted(p.seq_str for p in pd.final_probes) == c["final"]
+            assert len(pd.candidate_probes) == c["n_candidates"]

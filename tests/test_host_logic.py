@@ -220,3 +220,54 @@ def test_anchor_table_assume_unique_matches_general():
         assert a[0] == b[0] and a[1] == b[1]
         for x, y in zip(a[2:], b[2:]):
             assert np.array_equal(x, y)
+
+
+def test_connected_components_and_linkage_golden():
+    """Host side of the clustering pre-step (catch_amd/utils/cluster.py): the
+    depth-first search with the early-stop heuristic and the hierarchical
+    cut, on distance functions recorded from the reference's tests and on
+    random graphs where the visiting order decides the outcome."""
+    import sys
+    from catch_amd.utils import cluster
+    g = load_golden("cluster")
+
+    def dist_of(rows):
+        return lambda i, j: rows[min(i, j)][max(i, j) - min(i, j) - 1]
+    t = g["from_reference_tests"]
+    for c in t["cc"]:
+        kw = ({"early_stop_threshold": c["early_stop_threshold"]}
+              if "early_stop_threshold" in c else {})
+        assert cluster.find_connected_components(
+            c["n"], dist_of(c["dist"]), c["threshold"], **kw) == c["out"]
+    for c in t["hier"]:
+        assert cluster.cluster_hierarchically_from_dist_matrix(
+            np.asarray(c["dist_matrix"], dtype=np.float32), c["threshold"]) == c["out"]
+    same_python = g["python"].split(".")[:2] == sys.version.split()[0].split(".")[:2]
+    vals = (0.05, 0.3, 0.9)
+    for c in g["cc_stress"]:
+        n, cls = c["n"], c["classes"]
+        rows, at = [], 0
+        for i in range(n):
+            rows.append([vals[int(x)] for x in cls[at:at + n - i - 1]])
+            at += n - i - 1
+        got = cluster.find_connected_components(n, dist_of(rows), c["threshold"],
+                                                c["early_stop_threshold"])
+        if same_python:
+            assert got == c["out"]
+        assert sorted(x for comp in got for x in comp) == list(range(n))
+    assert cluster.find_connected_components(0, None, 1) == []
+    m = cluster.create_condensed_dist_matrix(3, lambda i, j: [[0, 1, 100], [1, 0, 2], [100, 2, 0]][i][j])
+    assert m.dtype == np.float32 and m.tolist() == [1.0, 100.0, 2.0]
+    assert abs(cluster._jaccard_dist_from_mash_dist(0.1, 12) - (1.0 - 1.0 / (2.0 * np.exp(12 * 0.1) - 1))) == 0
+
+
+def test_genome_fragments():
+    from collections import OrderedDict
+    from catch_amd.genome import Genome
+    g = Genome.from_one_seq("ABCDEFGHIJ")
+    assert g.break_into_fragments(4).seqs == ["ABCD", "EFGH", "IJ"]
+    assert g.break_into_fragments(4, include_full_end=True).seqs == ["ABCD", "EFGH", "GHIJ"]
+    assert g.break_into_fragments(20, include_full_end=True).seqs == ["ABCDEFGHIJ"]
+    h = Genome.from_chrs(OrderedDict([("x", "AAAAAB"), ("y", "CC")]))
+    f = h.break_into_fragments(3, include_full_end=True)
+    assert list(f.chrs.items()) == [("x-0", "AAA"), ("x-1", "AAB"), ("y-0", "CC")]

@@ -156,3 +156,54 @@ def test_merge_overlapping(oracle):
     assert oracle.merge_overlapping([(1, 3), (3, 5)]) == [(1, 5)]
     assert oracle.merge_overlapping([]) == []
     assert oracle.merge_overlapping([(5, 6), (1, 2)]) == [(1, 2), (5, 6)]
+
+
+def _dist_from_rows(rows):
+    def dist(i, j):
+        i, j = min(i, j), max(i, j)
+        return rows[i][j - i - 1]
+    return dist
+
+
+def test_cluster_restatement_matches_reference(oracle):
+    """Clustering pre-step (catch/utils/cluster.py, lsh.MinHashFamily with the
+    md5 hash): signatures, connected components (including graphs where the
+    early-stop heuristic makes the visiting order matter), hierarchical
+    clusters, and whole clusterings, as recorded from the reference."""
+    import random
+    import sys
+    g = load_golden("cluster")
+    t = g["from_reference_tests"]
+    assert len(t["cc"]) >= 4 and len(t["hier"]) >= 4 and len(t["minhash"]) >= 2
+    same_python = g["python"].split(".")[:2] == sys.version.split()[0].split(".")[:2]
+    for c in t["cc"]:
+        got = oracle.find_connected_components(
+            c["n"], _dist_from_rows(c["dist"]), c["threshold"],
+            c.get("early_stop_threshold"))
+        assert got == c["out"]
+    for c in t["hier"]:
+        got = oracle.cluster_hierarchically(np.asarray(c["dist_matrix"], dtype=np.float32),
+                                            c["threshold"])
+        assert got == c["out"]
+    vals = (0.05, 0.3, 0.9)
+    for c in g["cc_stress"]:
+        n, cls = c["n"], c["classes"]
+        rows, at = [], 0
+        for i in range(n):
+            rows.append([vals[int(x)] for x in cls[at:at + n - i - 1]])
+            at += n - i - 1
+        got = oracle.find_connected_components(n, _dist_from_rows(rows), c["threshold"],
+                                               c["early_stop_threshold"])
+        if same_python:      # the order of a set difference is the interpreter's
+            assert got == c["out"]
+        assert sorted(map(len, got), reverse=True) == [len(x) for x in got]
+    for c in t["minhash"] + g["synthetic"]:
+        sigs = [oracle.minhash_signature(s, c["k"], c["N"], c["a"], c["b"]) for s in c["seqs"]]
+        assert [list(x) for x in sigs] == c["signatures"]
+        if "seed" in c:
+            random.seed(c["seed"])
+            got = oracle.cluster_with_minhash_signatures(c["seqs"], c["k"], c["N"], c["threshold"],
+                                                         c["method"])
+            names = c["names"]
+            assert [[names[i] for i in cl] for cl in got] == c["out"]
+    assert any(len(s) - c["k"] + 1 < c["N"] for c in g["synthetic"] for s in c["seqs"])
