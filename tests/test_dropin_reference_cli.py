@@ -55,3 +55,41 @@ def test_reference_design_cli_reaches_gpu_filter(tmp_path, monkeypatch):
     assert seen["genomes"] == [2] and seen["groups"][0] > 20
     assert seen["params"] == (2, 75, 50)
     sys.modules.pop("design", None)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_reference_probe_designer_reaches_gpu_clustering(monkeypatch):
+    """--cluster-and-design-separately: the reference's ProbeDesigner calls
+    catch.utils.cluster.cluster_with_minhash_signatures; with catch_amd's
+    module registered there it receives the sequences (and, with a GPU, would
+    return the same clusters -- tests/test_gpu_parity.py checks that against
+    recorded reference output)."""
+    from catch_amd import _lib, engine
+    from catch_amd.utils import cluster as gpu_cluster
+    monkeypatch.syspath_prepend(REF)
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    import catch.utils
+    from catch import genome
+    from catch.filter import duplicate_filter, probe_designer
+    monkeypatch.setitem(sys.modules, "catch.utils.cluster", gpu_cluster)
+    monkeypatch.setattr(catch.utils, "cluster", gpu_cluster, raising=False)
+    monkeypatch.setattr(probe_designer, "cluster", gpu_cluster)
+    seen = {}
+    orig = gpu_cluster.cluster_with_minhash_signatures
+
+    def spy(seqs, **kw):
+        seen["n"] = len(seqs)
+        seen["kw"] = kw
+        return orig(seqs, **kw)
+    monkeypatch.setattr(gpu_cluster, "cluster_with_minhash_signatures", spy)
+    gs = [[genome.Genome.from_one_seq("ATTA" * 500), genome.Genome.from_one_seq("CGGC" * 500)]]
+    df = duplicate_filter.DuplicateFilter()
+    pd = probe_designer.ProbeDesigner(gs, [df], probe_length=100, probe_stride=50,
+                                      cluster_threshold=0.1, cluster_merge_after=df,
+                                      cluster_method="simple", cluster_fragment_length=500)
+    if engine.device_count() > 0:
+        assert len(pd._cluster_genomes()) == 2
+    else:
+        with pytest.raises(_lib.CatchHipError):
+            pd._cluster_genomes()
+    assert seen["n"] == 8 and seen["kw"] == dict(threshold=0.1, cluster_method="simple")
