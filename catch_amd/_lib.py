@@ -83,6 +83,10 @@ PROTOTYPES = {
     "catchhip_sigs_common_row": (ctypes.c_int, [
         c_vp, c_vp, ctypes.c_uint32, c_u16p]),
     "catchhip_sigs_condensed": (ctypes.c_int, [c_vp, c_vp, c_f32p, c_f32p]),
+    "catchhip_cover_scan_first_seen": (ctypes.c_int, [
+        c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_int32, ctypes.c_int32, c_u32p, c_vpp, c_i64p]),
+    "catchhip_rows_fetch_first_seen": (ctypes.c_int, [c_vp, c_vp, c_u64p]),
 }
 
 _lib = None

@@ -412,6 +412,10 @@ extern "C" int catchhip_probes_create(catchhip_ctx *ctx, const u8 *bytes, const 
         if (nent != (i64)want * nprobes) pigeon = false;
     }
     p->pigeonhole = pigeon && nprobes > 0;
+    p->sorted_unique = true;
+    for (i64 e = 1; e < nent && p->sorted_unique; ++e)
+        if (ent_probe[e] < ent_probe[e - 1] || (ent_probe[e] == ent_probe[e - 1] && ent_pos[e] <= ent_pos[e - 1]))
+            p->sorted_unique = false;
     alphabet_scan(bytes, total, &p->dna5, &p->has_n);
 
     int rc = 0;

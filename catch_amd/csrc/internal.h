@@ -161,6 +161,7 @@ struct catchhip_probes {
     bool dna5 = false;
     bool has_n = false;
     bool pigeonhole = false;  // anchors are exactly {0,k,2k,..,L-k} for every probe
+    bool sorted_unique = false;   // the caller's anchor entries were sorted by (probe, position), no duplicates
     // seeds per target base seen by earlier seed scans with these probes (sizes the work list)
     mutable double seed_ratio_hint = 0.0;
     i64 max_set_id = 0;
@@ -196,6 +197,8 @@ struct catchhip_rows {
     DevBuf<i32> set_id;
     DevBuf<i32> univ;
     DevBuf<u32> gs, ge;
+    // catchhip_cover_scan_first_seen only: per row, the first-discovery key of its (set, universe) group
+    DevBuf<unsigned long long> first_key;
     DevBuf<u32> genome_off;  // ngenomes+1
     std::vector<i64> h_genome_off;
 };

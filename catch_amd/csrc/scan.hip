@@ -44,6 +44,8 @@ struct HitBuf {
     u32 *c;      // global end (general path) -- may be null in fast path
     u32 *count;  // device counter
     u32 cap;
+    u32 *d;      // optional (general path): global position of the seeding k-mer
+    u32 *e;      // optional (general path): anchor entry of the seed
 };
 
 // ------------------------------------------------------------------------
@@ -497,7 +499,10 @@ extend_kernel(const u8 *__restrict__ tbytes, const u32 *__restrict__ seq_off, u3
     }
     u32 gs = (u32)(lo + sub_l + best_start);
     u32 slot = atomicAdd(out.count, 1u);
-    if (slot < out.cap) { out.a[slot] = (u32)p; out.b[slot] = gs; out.c[slot] = gs + (u32)best_len; }
+    if (slot < out.cap) {
+        out.a[slot] = (u32)p; out.b[slot] = gs; out.c[slot] = gs + (u32)best_len;
+        if (out.d) { out.d[slot] = gi; out.e[slot] = e; }
+    }
 }
 
 // ------------------------------------------------------------------------
@@ -577,6 +582,8 @@ rows_bp_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ head,
 // ------------------------------------------------------------------------
 struct RawHits {
     DevBuf<u32> a, b, c, count;
+    DevBuf<u32> d, e;          // seed position / anchor entry per hit (first-seen scans only)
+    bool want_seed = false;
     u32 n = 0;
     bool has_end = false;
 };
@@ -793,7 +800,12 @@ static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchh
     TRY(H.c.reserve(nseeds));
     TRY(H.count.alloc(1));
     HIP_TRY(hipMemsetAsync(H.count.p, 0, sizeof(u32), ctx->stream));
-    HitBuf ob = {H.a.p, H.b.p, H.c.p, H.count.p, nseeds};
+    if (H.want_seed) {
+        TRY(H.d.reserve(nseeds));
+        TRY(H.e.reserve(nseeds));
+    }
+    HitBuf ob = {H.a.p, H.b.p, H.c.p, H.count.p, nseeds, H.want_seed ? H.d.p : nullptr,
+                 H.want_seed ? H.e.p : nullptr};
     hipLaunchKernelGGL(extend_kernel, dim3((unsigned)div_up(nseeds, 256)), dim3(256), 0, ctx->stream, T->bytes.p,
                        T->seq_off.p, (u32)T->nseq, P->bytes.p, P->probe_off.p, e_probe, e_pos,
                        (int)P->k, mm, lcf_thres, island, seed_ent, seed_pos, nseeds, ob);
@@ -949,6 +961,8 @@ static int build_rows_radix(catchhip_ctx *ctx, const BucketBuild &B, u32 nrec, c
 struct ScanOut {
     BucketBuild B;
     SeedRun S;
+    RawHits H;                 // general path (kept for the first-seen pass)
+    bool from_seeds = false;   // records come from the seed work list (S), not from H
     u32 nrec = 0;              // records to look at (grid size)
     const u32 *nrec_dev = nullptr;
     u32 nhits = 0, nrows = 0, lmax = 0, maxbucket = 0;
@@ -957,11 +971,16 @@ struct ScanOut {
 
 static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mismatches,
                           int lcf_thres, int island, u32 ext, bool by_sequence, int mode, ScanOut &O,
-                          bool dedupe = false) {
+                          bool dedupe = false, bool want_first = false) {
     const bool seed_ok = seed_path_ok(P, T, mismatches, lcf_thres, island);
     const bool tiled_ok = fast_path_ok(P, T, mismatches, lcf_thres, island);
     const bool want_tiled = mode == CATCHHIP_SCAN_FAST || (mode == CATCHHIP_SCAN_AUTO && getenv("CATCHHIP_SCAN_TILED"));
-    const bool use_fast = tiled_ok && want_tiled;
+    const bool use_fast = tiled_ok && want_tiled && !(want_first && mode == CATCHHIP_SCAN_AUTO);
+    if (use_fast && want_first) {
+        chip_set_error("cover_scan_first_seen: the tiled scan does not know which anchor seeded a hit");
+        return CATCHHIP_EINVAL;
+    }
+    O.from_seeds = false;
     const bool use_seed = seed_ok && !use_fast && mode != CATCHHIP_SCAN_GENERAL && mode != CATCHHIP_SCAN_FAST;
     const u32 nb = by_sequence ? (u32)P->nprobes : (u32)P->nbuckets;
     const bool force_radix = getenv("CATCHHIP_ROWS_RADIX") != nullptr && !dedupe;
@@ -971,6 +990,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     sink.ext = ext;
     PhaseTimer ts(ctx, PHASE_SCAN), tr(ctx, PHASE_ROWS);
     if (use_seed) {
+        O.from_seeds = true;
         O.S.scap = seed_capacity(P, T);
         if (const char *e = getenv("CATCHHIP_SEED_CAP")) O.S.scap = (u32)std::max(1, atoi(e));   // tests: force the retry
         for (int attempt = 0;; ++attempt) {
@@ -1003,7 +1023,8 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
             break;
         }
     } else {
-        RawHits H;
+        RawHits &H = O.H;
+        H.want_seed = want_first;
         int rc = 0;
         if (P->nprobes > 0 && T->total > 0)
             rc = use_fast ? run_fast(ctx, P, T, mismatches, H, ts)
@@ -1026,7 +1047,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
         tr.stop();
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(ctx->h_pin, O.B.res.p, 8 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));   // H's buffers are released after this
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     ts.finish();
     const volatile u32 *h = (const volatile u32 *)ctx->h_pin;
@@ -1105,9 +1126,69 @@ int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const ca
     return 0;
 }
 
+// ------------------------------------------------------------------------
+// first-discovery keys (catchhip_cover_scan_first_seen)
+// ------------------------------------------------------------------------
+// rows are sorted by (set id, global start); first row with (set, start) >= (s, x)
+__device__ __forceinline__ u32 rows_lower_bound(const i32 *__restrict__ set_id, const u32 *__restrict__ gs, u32 n,
+                                                i32 s, u32 x) {
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        const i32 ms = set_id[mid];
+        if (ms < s || (ms == s && gs[mid] < x)) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// One thread per accepted seed: the row holding the seed's k-mer, the first row
+// of that row's (set, universe) group, and there the minimum of
+// (k-mer position << 32 | caller's rank of the anchor entry).
+__global__ void __launch_bounds__(256)
+first_seen_kernel(int from_seeds, const uint4 *__restrict__ rec, const u32 *__restrict__ rank,
+                  const u32 *__restrict__ spos, const u32 *__restrict__ sent, const u32 *__restrict__ nrec_dev, u32 cap,
+                  const u32 *__restrict__ hp, const u32 *__restrict__ hd, const u32 *__restrict__ he,
+                  const u32 *__restrict__ bucket_of, const i32 *__restrict__ bucket_set,
+                  const u32 *__restrict__ anchor_order, const i32 *__restrict__ set_id, const i32 *__restrict__ univ,
+                  const u32 *__restrict__ gs, const u32 *__restrict__ ge, const u32 *__restrict__ genome_off,
+                  u32 nrows, unsigned long long *__restrict__ first) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 b, i, e;
+    if (from_seeds) {
+        if (t >= min(*nrec_dev, cap) || rank[t] == BK_NONE) return;
+        b = rec[t].w; i = spos[t]; e = sent[t];
+    } else {
+        if (t >= cap) return;
+        b = bucket_of[hp[t]]; i = hd[t]; e = he[t];
+    }
+    const i32 s = bucket_set[b];
+    // last row with (set, start) <= (s, i): the cover range of an accepted seed contains its k-mer
+    const u32 ub = rows_lower_bound(set_id, gs, nrows, s, i + 1u);
+    if (ub == 0) return;
+    const u32 r = ub - 1;
+    if (set_id[r] != s || i >= ge[r]) return;   // cannot happen
+    const u32 g0 = genome_off[univ[r]];
+    const u32 head = rows_lower_bound(set_id, gs, nrows, s, g0);
+    const unsigned long long key = ((unsigned long long)(i - g0) << 32) | (anchor_order ? anchor_order[e] : 0u);
+    atomicMin(&first[head], key);
+}
+
+// every row takes the key of its group's first row
+__global__ void __launch_bounds__(256)
+first_seen_spread_kernel(const i32 *__restrict__ set_id, const i32 *__restrict__ univ, const u32 *__restrict__ gs,
+                         const u32 *__restrict__ genome_off, u32 nrows, const unsigned long long *__restrict__ first,
+                         unsigned long long *__restrict__ out) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const u32 head = rows_lower_bound(set_id, gs, nrows, set_id[r], genome_off[univ[r]]);
+    out[r] = first[head];
+}
+
 static int cover_scan_impl(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,
                            i32 mismatches, i32 lcf_thres, i32 island, i32 cover_extension, i32 mode, bool merge,
-                           catchhip_rows **out, i64 *nrows) {
+                           catchhip_rows **out, i64 *nrows, bool want_first = false,
+                           const u32 *anchor_order = nullptr) {
     ARG_CHECK(ctx && P && T && out && cover_extension >= 0);
     PoolScope pool_scope(ctx);
     ARG_CHECK(P->ctx == ctx && T->ctx == ctx);
@@ -1141,7 +1222,7 @@ static int cover_scan_impl(catchhip_ctx *ctx, const catchhip_probes *P, const ca
         if (P->nprobes == 0 || T->total == 0) break;   // no rows
         ScanOut O;
         if ((rc = scan_and_group(ctx, P, T, mismatches, lcf_thres, island, (u32)cover_extension, false, mode, O,
-                                 !merge))) break;
+                                 !merge, want_first))) break;
         if (!merge && O.overflow) {
             chip_set_error("cover_ranges: a probe has more than %d cover ranges", BK_BIG);
             rc = CATCHHIP_EINVAL;
@@ -1184,6 +1265,37 @@ static int cover_scan_impl(catchhip_ctx *ctx, const catchhip_probes *P, const ca
                 R->lmax = *(volatile u32 *)ctx->h_pin;
             }
         }
+        if (want_first && R->n) {
+            DevBuf<unsigned long long> first;
+            DevBuf<u32> d_order;
+            if ((rc = first.alloc(R->n)) || (rc = R->first_key.alloc(R->n))) break;
+            if (anchor_order) {
+                if ((rc = d_order.alloc((size_t)P->nent))) break;
+                if (hipMemcpyAsync(d_order.p, anchor_order, sizeof(u32) * (size_t)P->nent, hipMemcpyHostToDevice,
+                                   ctx->stream) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
+            }
+            if (hipMemsetAsync(first.p, 0xff, sizeof(unsigned long long) * (size_t)R->n, ctx->stream) != hipSuccess) {
+                rc = CATCHHIP_EHIP;
+                break;
+            }
+            const u32 nsrc = O.from_seeds ? O.nrec : O.H.n;
+            if (nsrc)
+                hipLaunchKernelGGL(first_seen_kernel, dim3((unsigned)div_up((i64)nsrc, 256)), dim3(256), 0, ctx->stream,
+                                   O.from_seeds ? 1 : 0, (const uint4 *)O.B.rec.p, (const u32 *)O.B.rank.p,
+                                   (const u32 *)O.S.spos.p, (const u32 *)O.S.sent.p, O.nrec_dev, nsrc,
+                                   (const u32 *)O.H.a.p, (const u32 *)O.H.d.p, (const u32 *)O.H.e.p,
+                                   (const u32 *)P->bucket_of.p, (const i32 *)P->bucket_set.p,
+                                   anchor_order ? (const u32 *)d_order.p : (const u32 *)nullptr, (const i32 *)R->set_id.p,
+                                   (const i32 *)R->univ.p, (const u32 *)R->gs.p, (const u32 *)R->ge.p,
+                                   (const u32 *)R->genome_off.p, (u32)R->n, first.p);
+            hipLaunchKernelGGL(first_seen_spread_kernel, dim3((unsigned)div_up(R->n, 256)), dim3(256), 0, ctx->stream,
+                               (const i32 *)R->set_id.p, (const i32 *)R->univ.p, (const u32 *)R->gs.p,
+                               (const u32 *)R->genome_off.p, (u32)R->n, (const unsigned long long *)first.p,
+                               R->first_key.p);
+            tm.launch(2);
+            // `first` and the order table go back to the pool after the synchronisation below
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
+        }
         tm.stop();
         // the scratch buffers of the build are released when O goes out of scope
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
@@ -1203,6 +1315,33 @@ extern "C" int catchhip_cover_scan(catchhip_ctx *ctx, const catchhip_probes *P, 
                                    i32 mismatches, i32 lcf_thres, i32 island, i32 cover_extension, i32 mode,
                                    catchhip_rows **out, i64 *nrows) {
     return cover_scan_impl(ctx, P, T, mismatches, lcf_thres, island, cover_extension, mode, true, out, nrows);
+}
+
+extern "C" int catchhip_cover_scan_first_seen(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,
+                                              i32 mismatches, i32 lcf_thres, i32 island, i32 cover_extension,
+                                              i32 mode, const u32 *anchor_order, catchhip_rows **out, i64 *nrows) {
+    ARG_CHECK(P);
+    if (!P->sorted_unique) {
+        chip_set_error("cover_scan_first_seen: the probes' anchors must have been given sorted by (probe, position) "
+                       "without duplicates");
+        return CATCHHIP_EINVAL;
+    }
+    return cover_scan_impl(ctx, P, T, mismatches, lcf_thres, island, cover_extension, mode, true, out, nrows, true,
+                           anchor_order);
+}
+
+extern "C" int catchhip_rows_fetch_first_seen(catchhip_ctx *ctx, const catchhip_rows *R, u64 *first_key) {
+    ARG_CHECK(ctx && R);
+    if (R->n == 0) return 0;
+    ARG_CHECK(first_key);
+    if (!R->first_key.p) {
+        chip_set_error("rows_fetch_first_seen: these rows do not come from catchhip_cover_scan_first_seen");
+        return CATCHHIP_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(first_key, R->first_key.p, sizeof(u64) * R->n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 extern "C" int catchhip_cover_ranges(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T,

@@ -217,6 +217,30 @@ class Rows:
         return Rows(ctx, h, n.value)
 
     @staticmethod
+    def scan_first_seen(ctx, probes, targets, mismatches, lcf_thres, island=0,
+                        cover_extension=0, mode=SCAN_AUTO, anchor_order=None):
+        """catchhip_cover_scan_first_seen: merged rows that also carry, per
+        (set, universe) group, the key of the first accepted seed
+        (fetch_first_seen)."""
+        h = ctypes.c_void_p()
+        n = ctypes.c_int64(0)
+        order = (None if anchor_order is None
+                 else np.ascontiguousarray(anchor_order, dtype=np.uint32))
+        check(ctx._L.catchhip_cover_scan_first_seen(
+            ctx._h, probes._h, targets._h, int(mismatches), int(lcf_thres),
+            int(island), int(cover_extension), int(mode),
+            None if order is None else _ptr(order, c_u32p),
+            ctypes.byref(h), ctypes.byref(n)))
+        return Rows(ctx, h, n.value)
+
+    def fetch_first_seen(self):
+        """uint64[n]: (k-mer position in the universe << 32) | anchor order."""
+        out = np.zeros(max(self.n, 1), dtype=np.uint64)
+        check(self.ctx._L.catchhip_rows_fetch_first_seen(
+            self.ctx._h, self._h, _ptr(out, c_u64p)))
+        return out[:self.n]
+
+    @staticmethod
     def from_host(ctx, set_id, universe, start, end, genome_len):
         si = np.ascontiguousarray(set_id, dtype=np.int32)
         un = np.ascontiguousarray(universe, dtype=np.int32)

@@ -49,6 +49,20 @@ class Probe:
         rc_map = {"A": "T", "T": "A", "C": "G", "G": "C"}
         return Probe("".join(rc_map.get(b, b) for b in self.seq_str[::-1]))
 
+    def with_prepended_str(self, s):
+        """catch/probe.py:135-146."""
+        return Probe(s + self.seq_str)
+
+    def with_appended_str(self, s):
+        """catch/probe.py:148-159."""
+        return Probe(self.seq_str + s)
+
+    def identifier(self, length=10):
+        """Last `length` hex digits of the SHA-224 of the sequence
+        (catch/probe.py:301-321)."""
+        import hashlib
+        return hashlib.sha224(self.seq_str.encode()).hexdigest()[-length:]
+
     def __hash__(self):
         return hash(self.seq_str)
 
@@ -90,7 +104,8 @@ def pigeonhole_kmer_length(probe_length, mismatches):
 
 
 def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
-                 num_kmers_per_probe=20, assume_unique=False):
+                 num_kmers_per_probe=20, assume_unique=False,
+                 with_draws=False):
     """Anchors of construct_kmer_probe_map_to_find_probe_covers
     (catch/probe.py:507-577) for `probe_strs` (duplicates allowed).
 
@@ -105,6 +120,10 @@ def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
     lcf_thres < probe length, or pigeonhole k < min_k) draws
     np.random.choice(n_kmers, size=20, replace=True) once per input probe in
     input order, like catch/probe.py:391-401.
+    with_draws: a sixth value, the (input index, position) pairs in the order
+    the reference adds them to its k-mer map (one per drawn / pigeonholed
+    k-mer, repeats included) -- what the adapter filter needs to reproduce the
+    listing order of a k-mer's entries.
     """
     if assume_unique:
         # the caller de-duplicated already: every string owns itself
@@ -122,7 +141,9 @@ def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
         owner = np.fromiter((last[p] for p in uniq), dtype=np.int32,
                             count=len(uniq))
     if not uniq:
-        return None, uniq, owner, np.zeros(0, np.int32), np.zeros(0, np.int32)
+        empty = (None, uniq, owner, np.zeros(0, np.int32), np.zeros(0, np.int32))
+        return empty + ([],) if with_draws else empty
+    draws = []
     L = len(probe_strs[0])
     differ = len(set(map(len, probe_strs))) > 1
     use_random = (mismatches is None or lcf_thres is None or differ
@@ -143,6 +164,8 @@ def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
             for pos in np.random.choice(n_kmers, size=num_kmers_per_probe,
                                         replace=True):
                 pairs.add((pi, int(pos)))
+                if with_draws:
+                    draws.append((idx, int(pos)))
         pairs = sorted(pairs)
         ent_probe = np.fromiter((a for a, _ in pairs), dtype=np.int32,
                                 count=len(pairs))
@@ -152,4 +175,9 @@ def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
         per = L // kk
         ent_probe = np.repeat(np.arange(len(uniq), dtype=np.int32), per)
         ent_pos = np.tile(np.arange(0, L, kk, dtype=np.int32), len(uniq))
+        if with_draws:
+            draws = [(idx, pos) for idx in range(len(probe_strs))
+                     for pos in range(0, L, kk)]
+    if with_draws:
+        return kk, uniq, owner, ent_probe, ent_pos, draws
     return kk, uniq, owner, ent_probe, ent_pos

@@ -272,6 +272,33 @@ int catchhip_sigs_common_row(catchhip_ctx *ctx, const catchhip_sigs *sigs,
 int catchhip_sigs_condensed(catchhip_ctx *ctx, const catchhip_sigs *sigs,
                             const float *lut, float *out);
 
+/* ---- scan with first-discovery keys (next row: catch/filter/adapter_filter.py)
+ * catchhip_cover_scan, plus for every row the key that orders probes the way
+ * the reference's result dict does: find_probe_covers_in_sequence walks a
+ * sequence left to right, looks every k-mer up in the k-mer -> {(probe, pos)}
+ * map and inserts a probe into its result when the first of its seeds is
+ * accepted (catch/probe.py:1062-1108, :1253-1271); AdapterFilter's interval
+ * scheduling breaks ties between equal range ends by that insertion order
+ * (catch/filter/adapter_filter.py:191-240, catch/utils/interval.py:319-358).
+ * Per (set, universe) group: first_key = (position of that first accepted k-mer
+ * relative to the universe's start) << 32 | anchor_order[entry], where
+ * anchor_order[nanchors] (may be null = 0) is the caller's rank of each anchor
+ * entry inside its k-mer's entry list (the reference iterates a Python set
+ * there; the host mirrors it).  The probes must have been created with their
+ * anchors sorted by (probe, position) without duplicates; give every sequence
+ * its own universe to get per-sequence keys.  Not available with
+ * CATCHHIP_SCAN_FAST. */
+int catchhip_cover_scan_first_seen(catchhip_ctx *ctx, const catchhip_probes *probes,
+                                   const catchhip_targets *targets,
+                                   int32_t mismatches, int32_t lcf_thres,
+                                   int32_t island_of_exact_match,
+                                   int32_t cover_extension, int32_t mode,
+                                   const uint32_t *anchor_order,
+                                   catchhip_rows **out, int64_t *nrows);
+/* first_key[nrows], aligned with catchhip_rows_fetch */
+int catchhip_rows_fetch_first_seen(catchhip_ctx *ctx, const catchhip_rows *rows,
+                                   uint64_t *first_key);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,11 @@ def lib():
             ctypes.c_int, ctypes.POINTER(_i32p), ctypes.POINTER(_i64p),
             ctypes.POINTER(_i64p)]
         L.orc_scan_sequence.restype = ctypes.c_int64
+        L.orc_scan_first_seen.argtypes = [
+            _u8p, ctypes.c_int64, _u8p, _i64p, _i32p, _i32p, ctypes.c_int64,
+            ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+            _i32p, ctypes.c_int64, _i64p, _i64p]
+        L.orc_scan_first_seen.restype = None
         L.orc_make_sets.argtypes = [
             _u8p, _i64p, _i32p, ctypes.c_int64, _u8p, _i64p, _i32p, _i32p,
             ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
@@ -157,16 +162,17 @@ def pigeonhole_k(probe_length, mismatches, min_k):
 
 
 def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
-                 num_kmers_per_probe=20):
+                 num_kmers_per_probe=20, with_draws=False):
     """construct_kmer_probe_map_to_find_probe_covers (catch/probe.py:507-577).
     probe_strs may contain duplicates (the reference iterates every Probe
     object, so in random mode np.random is consumed once per input probe,
     :391-401, and equal probes pool their positions because Probe hashes by
     sequence).  Returns (k, entries): entries = sorted unique
     (unique_probe_index, position) pairs, unique indices in first-seen order
-    (see _unique_last)."""
+    (see _unique_last).  with_draws: also the (input index, position) pairs in
+    the order the reference adds them to its k-mer map."""
     if len(probe_strs) == 0:
-        return None, []
+        return (None, [], []) if with_draws else (None, [])
     uidx = {}
     for p in probe_strs:
         uidx.setdefault(p, len(uidx))
@@ -180,19 +186,24 @@ def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
         if kk is None:
             use_random = True
     entries = set()
+    draws = []
     if use_random:
-        for p in probe_strs:
+        for i, p in enumerate(probe_strs):
             if k > len(p):
                 raise ValueError("k is larger than the length of a probe")
             n_kmers = len(p) - k + 1
             for pos in np.random.choice(n_kmers, size=num_kmers_per_probe,
                                         replace=True):
                 entries.add((uidx[p], int(pos)))
+                draws.append((i, int(pos)))
         kk = k
     else:
-        for p in probe_strs:
+        for i, p in enumerate(probe_strs):
             for pos in range(0, L, kk):
                 entries.add((uidx[p], pos))
+                draws.append((i, pos))
+    if with_draws:
+        return kk, sorted(entries), draws
     return kk, sorted(entries)
 
 
@@ -754,4 +765,126 @@ def fragments_of(seq, fragment_length):
         if len(f) < fragment_length:
             f = seq[max(0, len(seq) - fragment_length):]
         out.append(f)
+    return out
+
+
+# --------------------------------------------------------------------------
+# adapter filter: catch/filter/adapter_filter.py:191-392
+# --------------------------------------------------------------------------
+class _HashedProbe:
+    """Stands for a reference Probe inside the k-mer map's sets: equal by
+    sequence, hash = hash_fn(sequence) (the reference's is hash(seq_str),
+    catch/probe.py:324-329; pyhash_seed0 reproduces it for PYTHONHASHSEED=0)."""
+    __slots__ = ("s", "h")
+
+    def __init__(self, s, h):
+        self.s, self.h = s, h
+
+    def __hash__(self):
+        return self.h
+
+    def __eq__(self, other):
+        return self.s == other.s
+
+
+def kmer_entry_ranks(probe_strs, entries, draws, k, hash_fn=None):
+    """Rank of every anchor entry inside its k-mer's entry list.  The
+    reference lists a k-mer's entries by iterating the Python set of
+    (Probe, pos) tuples built in `draws` order (probe.py:393-401 / :496-503,
+    SharedKmerProbeMap.construct :739-747); the same sets are built here from
+    stand-in objects with the same hashes."""
+    hash_fn = hash_fn or hash
+    uidx = {}
+    for p in probe_strs:
+        uidx.setdefault(p, len(uidx))
+    objs = [_HashedProbe(p, hash_fn(p)) for p in probe_strs]
+    kmap = {}
+    for i, pos in draws:
+        kmap.setdefault(probe_strs[i][pos:pos + k], set()).add((objs[i], pos))
+    rank = {}
+    for kmer, members in kmap.items():
+        for r, (o, pos) in enumerate(members):
+            rank[(uidx[o.s], pos)] = r
+    return [rank[e] for e in entries]
+
+
+def scan_first_seen(sequence, uniq, entries, k, mismatches, lcf_thres, island,
+                    ent_rank):
+    """{probe: (first accepted k-mer position, its entry)} for the probes that
+    hybridize somewhere in `sequence`."""
+    seq = _bytes_arr(sequence)
+    buf, off = _pack_probes(uniq)
+    ep, eo = _pack_entries(entries)
+    er = np.asarray(ent_rank, dtype=np.int32)
+    fi = np.zeros(max(len(uniq), 1), dtype=np.int64)
+    fe = np.zeros(max(len(uniq), 1), dtype=np.int64)
+    lib().orc_scan_first_seen(_p(seq, _u8p), seq.size, _p(buf, _u8p), _p(off, _i64p),
+                              _p(ep, _i32p), _p(eo, _i32p), len(entries), k,
+                              mismatches, lcf_thres, island, _p(er, _i32p),
+                              len(uniq), _p(fi, _i64p), _p(fe, _i64p))
+    return {p: (int(fi[p]), int(fe[p])) for p in range(len(uniq)) if fi[p] >= 0}
+
+
+def schedule(intervals):
+    """interval.schedule (catch/utils/interval.py:319-358): stable sort by end,
+    take every interval starting at or after the last chosen end."""
+    chosen, last_end = [], None
+    for (start, end), obj in sorted(intervals, key=lambda x: x[0][1]):
+        if last_end is None or start >= last_end:
+            chosen.append(obj)
+            last_end = end
+    return chosen
+
+
+def adapter_votes(probe_strs, sequences, mismatches, lcf_thres, island=0,
+                  kmer_probe_map_k=20, hash_fn=None, detail=None):
+    """AdapterFilter._make_votes_across_target_genomes (:299-361) over
+    `sequences` (all sequences of all genomes of all groups, in order).
+    Returns [(A votes, B votes)] per input probe.  Consumes np.random like the
+    reference when the anchors are random."""
+    k, entries, draws = anchor_table(probe_strs, mismatches, lcf_thres,
+                                     min_k=kmer_probe_map_k, k=kmer_probe_map_k,
+                                     with_draws=True)
+    uniq, _owner = _unique_last(probe_strs)
+    uidx = {p: i for i, p in enumerate(uniq)}
+    ent_rank = kmer_entry_ranks(probe_strs, entries, draws, k, hash_fn)
+    # equal input probes get equal votes and each counts in the reference's sums
+    mult = [0] * len(uniq)
+    for p in probe_strs:
+        mult[uidx[p]] += 1
+    cum = [[0, 0] for _ in uniq]
+    for sequence in sequences:
+        cov = scan_sequence(sequence, uniq, entries, k, mismatches, lcf_thres,
+                            island, merge=True)
+        first = scan_first_seen(sequence, uniq, entries, k, mismatches,
+                                lcf_thres, island, ent_rank)
+        assert set(cov) == set(first)
+        # the result dict lists probes in the order they were first met
+        order = sorted(cov, key=lambda p: (first[p][0], ent_rank[first[p][1]]))
+        intervals = [(r, p) for p in order for r in cov[p]]
+        chosen = set(schedule(intervals))
+        if detail is not None:
+            detail.append(dict(order=order, chosen=sorted(chosen)))
+        votes = {p: ((1, 0) if p in chosen else (0, 1)) for p in cov}
+        plain = sum(mult[p] * (max(cum[p][0] + a, cum[p][1] + b) - max(cum[p]))
+                    for p, (a, b) in votes.items())
+        flipped = sum(mult[p] * (max(cum[p][0] + b, cum[p][1] + a) - max(cum[p]))
+                      for p, (a, b) in votes.items())
+        for p, (a, b) in votes.items():
+            if flipped > plain:
+                a, b = b, a
+            cum[p][0] += a
+            cum[p][1] += b
+    return [tuple(cum[uidx[p]]) for p in probe_strs]
+
+
+def adapter_filter(probe_strs, sequences, adapter_a, adapter_b, mismatches,
+                   lcf_thres, island=0, kmer_probe_map_k=20, hash_fn=None):
+    """AdapterFilter._filter (:363-392): A adapters iff A votes > B votes."""
+    votes = adapter_votes(probe_strs, sequences, mismatches, lcf_thres, island,
+                          kmer_probe_map_k, hash_fn)
+    out = []
+    for p, (a, b) in zip(probe_strs, votes):
+        five, three = adapter_a if a > b else adapter_b
+        out.append(five + p + three)
     return out

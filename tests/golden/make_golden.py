@@ -758,7 +758,82 @@ def cluster_main():
                          synthetic=syn, designs=designs))
 
 
+def adapter_main():
+    """`make_golden.py adapter-only`: tests/golden/adapter_filter.json.gz = the
+    adapter filter (catch/filter/adapter_filter.py) of the reference's own
+    tests plus seeded synthetic cases, run under PYTHONHASHSEED=0: ties between
+    equal range ends are broken by the iteration order of Python sets of
+    (Probe, position) tuples, which depends on the string hash."""
+    if os.environ.get("PYTHONHASHSEED") != "0":
+        env = dict(os.environ, PYTHONHASHSEED="0")
+        os.execve(sys.executable, [sys.executable] + sys.argv, env)
+    from catch.filter import adapter_filter as af
+    recs = []
+    orig_votes = af.AdapterFilter._make_votes_across_target_genomes
+    orig_in_seq = af.AdapterFilter._votes_in_sequence
+    per_seq = []
+
+    def w_in_seq(self, probes, sequence):
+        out = orig_in_seq(self, probes, sequence)
+        per_seq.append([list(map(int, v)) for v in out])
+        return out
+
+    def w_votes(self, probes, target_genomes):
+        del per_seq[:]
+        state = np.random.get_state()
+        out = orig_votes(self, probes, target_genomes)
+        if self.mismatches is not None:
+            recs.append(dict(
+                probes=[p.seq_str for p in probes],
+                sequences=[s for grp in target_genomes for g in grp for s in g.seqs],
+                mismatches=self.mismatches, lcf_thres=self.lcf_thres,
+                island=int(getattr(self, "_island", 0)),
+                kmer_probe_map_k=int(self.kmer_probe_map_k),
+                adapters=[[self.adapter_a_5end, self.adapter_a_3end],
+                          [self.adapter_b_5end, self.adapter_b_3end]],
+                np_state=[state[0], state[1].tolist(), int(state[2]), int(state[3]), float(state[4])],
+                votes=[list(map(int, v)) for v in out],
+                votes_per_sequence=[list(v) for v in per_seq[:40]]))
+        return out
+    af.AdapterFilter._votes_in_sequence = w_in_seq
+    af.AdapterFilter._make_votes_across_target_genomes = w_votes
+    suite = unittest.TestLoader().loadTestsFromName("catch.filter.tests.test_adapter_filter")
+    res = unittest.TextTestRunner(verbosity=0).run(suite)
+    if res.failures or res.errors:
+        raise SystemExit("reference tests failed under the recorder")
+    tests = list(recs)
+    del recs[:]
+    rng = np.random.Generator(np.random.PCG64(61))
+    sp = synthetic.make_species(rng, [3000], 6, 2, 0.03, 0.004, with_n=True)
+    sp2 = synthetic.make_species(rng, [1400, 800], 4, 2, 0.05, 0.01, with_n=False)
+    gens = [[genome.Genome.from_one_seq(g[0]) for g in sp],
+            [genome.Genome.from_chrs(OrderedDict(("c%d" % i, s) for i, s in enumerate(g))) for g in sp2]]
+    for L, stride, m, lcf, island, kmap, seed, take in (
+            (100, 25, 2, 100, 0, 20, 1, 1), (100, 50, 3, 80, 0, 20, 2, 1), (75, 25, 2, 75, 30, 20, 3, 2),
+            (100, 20, 4, 100, 0, 10, 4, 3), (60, 15, 1, 60, 0, 20, 5, 1), (100, 25, 5, 100, 0, 20, 6, 2)):
+        ps = []
+        for grp in gens:
+            for g in grp:
+                ps += candidate_probes.make_candidate_probes_from_sequences(
+                    g.seqs, probe_length=L, probe_stride=stride)
+        ps = list(OrderedDict.fromkeys(ps))[::take]
+        if seed == 5:
+            ps = ps + ps[:7]          # equal probes given twice
+        np.random.seed(seed)
+        f = af.AdapterFilter(("AAAA", "CCCC"), ("GGGG", "TTTT"), mismatches=m, lcf_thres=lcf,
+                             island_of_exact_match=island, kmer_probe_map_k=kmap)
+        f._island = island
+        out = f.filter(ps, gens)
+        recs[-1]["out"] = [p.seq_str for p in out]
+        recs[-1]["np_seed"] = seed
+        va = sum(1 for a, b in recs[-1]["votes"] if a > b)
+        print("adapter", L, m, lcf, island, kmap, len(ps), "probes ->", va, "A", flush=True)
+    dump("adapter_filter", dict(python=sys.version.split()[0], from_reference_tests=tests, synthetic=list(recs)))
+
+
 def main():
+    if "adapter-only" in sys.argv:
+        return adapter_main()
     if "cluster-only" in sys.argv:
         return cluster_main()
     if "minhash-only" in sys.argv:

@@ -907,3 +907,125 @@ def test_probe_designer_with_clustering_golden(ctx):
             pd.design()
             assert sorted(p.seq_str for p in pd.final_probes) == c["final"]
             assert len(pd.candidate_probes) == c["n_candidates"]
+
+
+# ---------------------------------------------------------------- adapter filter
+def _first_seen_device(ctx, uniq, entries, k, seqs, m, thres, island, ent_rank, mode=0):
+    engine = _engine()
+    ep = np.array([e[0] for e in entries], dtype=np.int32)
+    eo = np.array([e[1] for e in entries], dtype=np.int32)
+    t = engine.Targets(ctx, [[s] for s in seqs])
+    p = engine.Probes(ctx, uniq, np.arange(len(uniq), dtype=np.int32), ep, eo, k)
+    rows = engine.Rows.scan_first_seen(ctx, p, t, m, thres, island, 0, mode,
+                                       np.asarray(ent_rank, dtype=np.uint32))
+    sid, univ, st, en = rows.fetch()
+    key = rows.fetch_first_seen()
+    rows.close(); p.close(); t.close()
+    return sid, univ, st, en, key
+
+
+@pytest.mark.parametrize("L,m,thres,island,min_k", [(100, 2, 100, 0, 20), (75, 2, 75, 0, 20), (100, 5, 100, 0, 20),
+                                                     (100, 3, 80, 0, 20), (75, 2, 60, 25, 10), (60, 1, 60, 0, 20)])
+def test_first_seen_keys_match_oracle(ctx, oracle, L, m, thres, island, min_k):
+    """catchhip_cover_scan_first_seen: merged rows as catchhip_cover_scan, and
+    for every (probe, sequence) the first accepted seed (position, caller's
+    entry rank) of the reference's left-to-right scan -- seed path (pigeonhole
+    and random anchors) and general path."""
+    genomes = small_species(seed=5, n=5, length=2500, d1=0.03, d2=0.004)
+    seqs = [g[0] for g in genomes]
+    strs = candidates(genomes, L, 20)[::2]
+    np.random.seed(3)
+    k, entries, draws = oracle.anchor_table(strs, m, thres, min_k=min_k, k=min_k, with_draws=True)
+    uniq, _ = oracle._unique_last(strs)
+    rnd = random.Random(1)
+    ent_rank = [rnd.randrange(0, 5) for _ in entries]      # ties on purpose
+    # distinct ranks inside a k-mer's entry list, as the host guarantees
+    seen = {}
+    for j, (p, pos) in enumerate(entries):
+        km = uniq[p][pos:pos + k]
+        ent_rank[j] = seen.get(km, 0)
+        seen[km] = ent_rank[j] + 1
+    sid, univ, st, en, key = _first_seen_device(ctx, uniq, entries, k, seqs, m, thres, island, ent_rank)
+    want_rows, want_key = [], {}
+    for u, s in enumerate(seqs):
+        cov = oracle.scan_sequence(s, uniq, entries, k, m, thres, island, merge=True)
+        first = oracle.scan_first_seen(s, uniq, entries, k, m, thres, island, ent_rank)
+        assert set(cov) == set(first)
+        for p, ranges in cov.items():
+            for a, b in ranges:
+                want_rows.append((p, u, a, b))
+            want_key[(p, u)] = (first[p][0] << 32) | ent_rank[first[p][1]]
+    assert rows_as_tuples(sid, univ, st, en) == sorted(want_rows)
+    assert len(want_rows) > 50
+    for i in range(len(sid)):
+        assert int(key[i]) == want_key[(int(sid[i]), int(univ[i]))]
+
+
+class _Seed0Probe:
+    """Probe whose hash is CPython's string hash under PYTHONHASHSEED=0
+    (computed by the oracle's SipHash): with these the product reproduces the
+    tie-breaks of the reference run that recorded the golden vectors."""
+
+    def __init__(self, s, h):
+        self.seq_str, self._h = s, h
+
+    def __hash__(self):
+        return self._h
+
+    def __eq__(self, other):
+        return self.seq_str == other.seq_str
+
+    def with_prepended_str(self, s):
+        return _Seed0Probe(s + self.seq_str, 0)
+
+    def with_appended_str(self, s):
+        return _Seed0Probe(self.seq_str + s, 0)
+
+
+def test_adapter_filter_golden(ctx, oracle):
+    """AdapterFilter votes and output == the reference's (its own tests + six
+    synthetic designs with many equal-end ties, random and pigeonhole anchors,
+    island, duplicate probes)."""
+    import sys
+    from catch_amd.filter.adapter_filter import AdapterFilter
+    from catch_amd.genome import Genome
+    g = load_golden("adapter_filter")
+    same_python = g["python"].split(".")[:2] == sys.version.split()[0].split(".")[:2]
+    for c in g["from_reference_tests"] + g["synthetic"]:
+        probes = [_Seed0Probe(s, oracle.pyhash_seed0(s)) for s in c["probes"]]
+        gens = [[Genome.from_one_seq(s) for s in c["sequences"]]]
+        f = AdapterFilter(tuple(c["adapters"][0]), tuple(c["adapters"][1]), c["mismatches"], c["lcf_thres"],
+                          island_of_exact_match=c.get("island", 0), kmer_probe_map_k=c["kmer_probe_map_k"])
+        np.random.set_state(np_state_from_json(c["np_state"]))
+        votes = f._make_votes_across_target_genomes(probes, gens)
+        assert [a + b for a, b in votes] == [a + b for a, b in c["votes"]]
+        if same_python:
+            assert [list(v) for v in votes] == c["votes"]
+            if "out" in c:
+                np.random.set_state(np_state_from_json(c["np_state"]))
+                out = f.filter(probes, gens)
+                assert [p.seq_str for p in out] == c["out"]
+
+
+def test_adapter_filter_matches_oracle_in_this_interpreter(ctx, oracle):
+    """With ordinary Probe objects the ties follow this interpreter's own
+    string hash -- what the reference would do in this very process."""
+    from catch_amd import probe
+    from catch_amd.filter.adapter_filter import AdapterFilter
+    from catch_amd.genome import Genome
+    genomes = small_species(seed=8, n=6, length=3000, d1=0.03, d2=0.005)
+    seqs = [g[0] for g in genomes]
+    for L, m, thres, kmap in ((100, 2, 100, 20), (100, 3, 70, 15)):
+        strs = candidates(genomes, L, 25)[::2]
+        strs = strs + strs[:5]
+        f = AdapterFilter(("AC", "GT"), ("TT", "GG"), m, thres, kmer_probe_map_k=kmap)
+        np.random.seed(4)
+        got = f.filter([probe.Probe.from_str(s) for s in strs], [[Genome.from_one_seq(s) for s in seqs]])
+        np.random.seed(4)
+        want = oracle.adapter_filter(strs, seqs, ("AC", "GT"), ("TT", "GG"), m, thres, 0, kmap, hash_fn=hash)
+        assert [p.seq_str for p in got] == want
+        assert len({w[:2] for w in want}) == 2      # both adapters in use
+    with pytest.raises(ValueError):
+        AdapterFilter(("A",), ("C", "G"), 1, 10)
+    with pytest.raises(NotImplementedError):
+        AdapterFilter(("A", "C"), ("C", "G"), 1, 10, custom_cover_range_fn=("x.py", "f"))
