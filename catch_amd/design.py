@@ -7,9 +7,10 @@ group of target genomes (bin/design.py:91-99), one Genome per record.  Filter
 list as bin/design.py:296-340 builds it: exact duplicate filter (or a
 near-duplicate filter with --filter-with-lsh-hamming / --filter-with-lsh-
 minhash), then the set cover filter; --cluster-and-design-separately clusters
-the input sequences first and designs per cluster (:387-411).  Options outside
-the accelerated path (adapters, reverse complements, N expansion, custom
-hybridization functions) are not offered.  --print-analysis and the three --write-...
+the input sequences first and designs per cluster (:387-411); --add-adapters
+appends the adapter filter (:345-365).  Options outside the accelerated path
+(reverse complements, N expansion, poly-A / FASTA filters, custom hybridization
+functions) are not offered.  --print-analysis and the three --write-...
 options run the coverage analysis of the designed probes (bin/design.py:417-442).
 """
 import argparse
@@ -70,6 +71,12 @@ def parse_args(argv=None):
     p.add_argument("--cluster-from-fragments", type=int,
                    help="cluster fragments of this length instead of whole "
                         "sequences")
+    p.add_argument("--add-adapters", action="store_true",
+                   help="add PCR adapters to both ends of every probe")
+    p.add_argument("--adapter-a", nargs=2,
+                   help="<5' end> <3' end> of the A adapter")
+    p.add_argument("--adapter-b", nargs=2,
+                   help="<5' end> <3' end> of the B adapter")
     p.add_argument("--verbose", action="store_true")
     return p.parse_args(argv)
 
@@ -89,6 +96,15 @@ def main(args):
     if args.cluster_from_fragments and not args.cluster_and_design_separately:
         raise Exception(("Cannot use --cluster-from-fragments without also "
                          "setting --cluster-and-design-separately"))
+    if args.add_adapters:
+        if not (args.adapter_a or args.adapter_b):
+            logger.warning("Adapter sequences will be added, but default "
+                           "sequences will be used; to provide adapter "
+                           "sequences, use --adapter-a and --adapter-b")
+    elif args.adapter_a or args.adapter_b:
+        raise Exception(("Adapter sequences were provided with --adapter-a "
+                         "and --adapter-b, but --add-adapters is required to "
+                         "add adapter sequences onto the ends of probes"))
     genomes_grouped = [seq_io.read_genomes_from_fasta(fn) for fn in args.dataset]
 
     filters = []
@@ -123,6 +139,16 @@ def main(args):
         coverage=args.coverage, cover_extension=args.cover_extension,
         kmer_probe_map_k=args.kmer_probe_map_k)
     filters.append(scf)
+    if args.add_adapters:      # bin/design.py:345-365 (default sequences :350, :354)
+        from catch_amd.filter import adapter_filter
+        filters.append(adapter_filter.AdapterFilter(
+            tuple(args.adapter_a) if args.adapter_a else
+            ("ATACGCCATGCTGGGTCTCC", "CGTACTTGGGAGTCGGCCAT"),
+            tuple(args.adapter_b) if args.adapter_b else
+            ("AGGCCCTGGCTGCTGATATG", "GACCTTTTGGGACAGCGGTG"),
+            mismatches=args.mismatches, lcf_thres=lcf_thres,
+            island_of_exact_match=args.island_of_exact_match,
+            kmer_probe_map_k=args.kmer_probe_map_k))
 
     pb = probe_designer.ProbeDesigner(
         genomes_grouped, filters, probe_length=args.probe_length,

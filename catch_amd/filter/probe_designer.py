@@ -141,12 +141,11 @@ class ProbeDesigner:
             uniq = [first._filter_strs(c) for c in cand]
         ids = scf._filter_strs(uniq, genomes, assume_unique=True)
         chosen = [[u[i] for i in sel] for u, sel in zip(uniq, ids)]
-        return [probe.Probe.from_str(s) for s in
-                dict.fromkeys(itertools.chain(*chosen))]
+        return [[probe.Probe.from_str(s) for s in grp] for grp in chosen]
 
     @staticmethod
     def _strings_path_ok(filters):
-        return (len(filters) == 2 and type(filters[0]) in (
+        return (len(filters) >= 2 and type(filters[0]) in (
             DuplicateFilter, NearDuplicateFilterWithHammingDistance,
             NearDuplicateFilterWithMinHash)
             and type(filters[1]) is SetCoverFilter)
@@ -174,7 +173,11 @@ class ProbeDesigner:
             before, after = self.filters[:merge_idx], self.filters[merge_idx:]
             genomes = self._cluster_genomes()
         if self._strings_path_ok(before):
-            probes = self._design_on_strings(genomes, before)
+            # the two expensive filters on strings, any later ones (adapters)
+            # on the few selected probes as objects
+            grouped = self._design_on_strings(genomes, before[:2])
+            grouped = self._pass_through_filters(grouped, genomes, before[2:])
+            probes = list(dict.fromkeys(itertools.chain(*grouped)))
         else:
             candidates, grouped = self._design_for_genomes(genomes, before)
             self.candidate_probes = list(itertools.chain(*candidates))

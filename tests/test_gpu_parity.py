@@ -1029,3 +1029,41 @@ def test_adapter_filter_matches_oracle_in_this_interpreter(ctx, oracle):
         AdapterFilter(("A",), ("C", "G"), 1, 10)
     with pytest.raises(NotImplementedError):
         AdapterFilter(("A", "C"), ("C", "G"), 1, 10, custom_cover_range_fn=("x.py", "f"))
+
+
+def test_design_cli_with_clustering_and_adapters(ctx, oracle, tmp_path, capsys):
+    """python -m catch_amd.design --cluster-and-design-separately ... --add-adapters:
+    clusters == oracle clustering of the same sequences, probes == oracle set
+    cover per cluster, adapters == oracle adapter votes over the clustered
+    sequences (this interpreter's string hash on both sides)."""
+    from catch_amd import design
+    from catch_amd.utils import synthetic, seq_io
+    rng = np.random.Generator(np.random.PCG64(45))
+    groups = [synthetic.make_species(rng, [2600], 4, 2, 0.05, 0.01, with_n=False),
+              synthetic.make_species(rng, [1900], 3, 1, 0.0, 0.02, with_n=False)]
+    files = []
+    for i, grp in enumerate(groups):
+        fn = tmp_path / ("d%d.fasta" % i)
+        fn.write_text("".join(">g%d\n%s\n" % (j, g[0]) for j, g in enumerate(grp)))
+        files.append(str(fn))
+    out = tmp_path / "probes.fasta"
+    random.seed(9)
+    pb = design.main(design.parse_args(files + [
+        "-pl", "100", "-ps", "50", "-m", "2", "-e", "20", "-o", str(out),
+        "--cluster-and-design-separately", "0.15", "--cluster-and-design-separately-method", "simple",
+        "--add-adapters", "--adapter-a", "AAAA", "CCCC", "--adapter-b", "GGGG", "TTTT"]))
+    capsys.readouterr()
+    seqs = [g[0] for grp in groups for g in grp]
+    random.seed(9)
+    clusters = oracle.cluster_with_minhash_signatures(seqs, threshold=0.15, cluster_method="simple")
+    assert len(clusters) == 2
+    cl_genomes = [[[seqs[i]] for i in c] for c in clusters]
+    cands = [candidates(g, 100, 50) for g in cl_genomes]
+    exp = oracle.set_cover_filter(cands, cl_genomes, 2, 100, coverage=1.0, cover_extension=20)
+    chosen = list(dict.fromkeys(cands[i][j] for i, ids in enumerate(exp) for j in ids))
+    all_seqs = [s for c in cl_genomes for g in c for s in g]
+    want = oracle.adapter_filter(chosen, all_seqs, ("AAAA", "CCCC"), ("GGGG", "TTTT"), 2, 100, 0, 20,
+                                 hash_fn=hash)
+    got = list(seq_io.read_fasta(str(out)).values())
+    assert sorted(got) == sorted(want)
+    assert len(pb.final_probes) == len(want)
