@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--scale", type=float, default=0.25)
     ap.add_argument("--fragment", type=int, default=50000)
     ap.add_argument("--cpu-sample", type=int, default=200000,
-                    help="bases hashed by the CPU restatement for comparison (0 = skip)")
+                    help="bases hashed by a hashlib loop for comparison (0 = skip)")
     ap.add_argument("--hierarchical-max", type=int, default=12000)
     a = ap.parse_args()
     groups = synthetic.dataset(a.workload, scale=a.scale)
@@ -81,7 +81,8 @@ def main():
         out[method + "_clusters"] = len(cl)
         out[method + "_largest"] = [len(c) for c in cl[:5]]
     if a.cpu_sample:
-        from oracle import oracle
+        import hashlib
+        import heapq
         sample, got = [], 0
         for s in seqs:
             sample.append(s)
@@ -89,8 +90,9 @@ def main():
             if got >= a.cpu_sample:
                 break
         t0 = time.perf_counter()
-        for s in sample:
-            oracle.minhash_signature(s, 12, 100, 12345, 678)
+        for s in sample:      # the same arithmetic, one core, stdlib only
+            heapq.nsmallest(100, ((12345 * int(hashlib.md5(s[i:i + 12].encode()).hexdigest(), 16) + 678)
+                                  % (2 ** 31 - 1) for i in range(len(s) - 11)))
         dt = time.perf_counter() - t0
         out["cpu_signature_kmers_per_s"] = got / dt
         out["cpu_sample_bases"] = got
