@@ -112,6 +112,40 @@ def one_case(seed, ctx):
         fm._draw_params = lambda: par
         gm = sorted(p.seq_str for p in fm.filter([probe.Probe.from_str(s) for s in strs]))
         assert gm == sorted(oracle.ndf_minhash(strs, dj, par, fm.kmer_size)), (desc, "ndf minhash")
+    # adapter filter on a subsample of the first group's candidates, votes from
+    # all sequences of all groups (this interpreter's string hash on both sides)
+    from catch_amd.filter.adapter_filter import AdapterFilter
+    sub = cands[0][::max(1, len(cands[0]) // 400)]
+    if len(set(map(len, sub))) >= 1 and sub:
+        kmap = rnd.choice([10, 15, 20])
+        if min(map(len, sub)) >= kmap:
+            all_seqs = [s for g in groups for gen in g for s in gen]
+            np.random.seed(np_seed)
+            want_a = oracle.adapter_filter(sub, all_seqs, ("AA", "CC"), ("GG", "TT"), m, thres, island, kmap,
+                                           hash_fn=hash)
+            np.random.seed(np_seed)
+            fa = AdapterFilter(("AA", "CC"), ("GG", "TT"), m, thres, island_of_exact_match=island,
+                               kmer_probe_map_k=kmap)
+            got_a = fa.filter([probe.Probe.from_str(s) for s in sub],
+                              [[mk(gen) for gen in g] for g in groups])
+            assert [p.seq_str for p in got_a] == want_a, (desc, "adapter filter", kmap)
+    # clustering of all sequences (whole and fragmented), both methods
+    from catch_amd.utils import cluster
+    all_seqs = [s for g in groups for gen in g for s in gen if len(s) >= 12]
+    if rnd.random() < 0.5:
+        fl = rnd.choice([200, 500, 1000])
+        all_seqs = [f for s in all_seqs for f in oracle.fragments_of(s, fl) if len(f) >= 12]
+    if all_seqs:
+        thr = rnd.choice([0.05, 0.1, 0.15, 0.3])
+        for method in ("simple", "hierarchical"):
+            if method == "hierarchical" and len(all_seqs) > 300:
+                continue
+            random.seed(seed)
+            want_c = oracle.cluster_with_minhash_signatures(all_seqs, threshold=thr, cluster_method=method)
+            random.seed(seed)
+            got_c = cluster.cluster_with_minhash_signatures(dict(enumerate(all_seqs)), threshold=thr,
+                                                            cluster_method=method)
+            assert got_c == want_c, (desc, "cluster", method, thr)
     return desc
 
 
