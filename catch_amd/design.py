@@ -24,19 +24,37 @@ from catch_amd.utils import seq_io
 logger = logging.getLogger("catch_amd.design")
 
 
-def parse_args(argv=None):
-    p = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+# defaults that differ between design.py ("basic") and design_large.py ("large"),
+# bin/design.py:502, :583, :753, :794, :846
+_PROFILES = {
+    "basic": dict(mismatches=0, cover_extension=0, cluster=None,
+                  fragments=None, minhash=None),
+    "large": dict(mismatches=5, cover_extension=50, cluster=0.15,
+                  fragments=50000, minhash=0.6),
+}
+
+
+def parse_args(argv=None, args_type="basic"):
+    if args_type not in _PROFILES:
+        raise ValueError("Argument type '%s' is invalid; it must be one of %s"
+                         % (args_type, tuple(_PROFILES)))
+    prof = _PROFILES[args_type]
+    p = argparse.ArgumentParser(
+        description=__doc__.split("\n")[0],
+        formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     p.add_argument("dataset", nargs="+", help="FASTA file(s); one group each")
     p.add_argument("-o", "--write-probe-fasta", help="output FASTA")
     p.add_argument("-pl", "--probe-length", type=int, default=100)
     p.add_argument("-ps", "--probe-stride", type=int, default=50)
-    p.add_argument("-m", "--mismatches", type=int, default=0)
+    p.add_argument("-m", "--mismatches", type=int,
+                   default=prof["mismatches"])
     p.add_argument("-l", "--lcf-thres", type=int, default=None,
                    help="default: the probe length")
     p.add_argument("--island-of-exact-match", type=int, default=0)
     p.add_argument("-c", "--coverage", type=float, default=1.0,
                    help="fraction (<= 1) or number of bp (> 1) per genome")
-    p.add_argument("-e", "--cover-extension", type=int, default=0)
+    p.add_argument("-e", "--cover-extension", type=int,
+                   default=prof["cover_extension"])
     p.add_argument("-i", "--identify", action="store_true")
     p.add_argument("--avoid-genomes", nargs="+", default=[])
     p.add_argument("-mt", "--mismatches-tolerant", type=int)
@@ -45,6 +63,7 @@ def parse_args(argv=None):
     p.add_argument("--filter-with-lsh-hamming", type=int,
                    help="Hamming threshold of the near-duplicate filter")
     p.add_argument("--filter-with-lsh-minhash", type=float,
+                   default=prof["minhash"],
                    help="Jaccard-distance threshold of the MinHash "
                         "near-duplicate filter")
     p.add_argument("--small-seq-skip", type=int)
@@ -62,6 +81,7 @@ def parse_args(argv=None):
         raise argparse.ArgumentTypeError(
             "%s is an invalid average nucleotide dissimilarity" % val)
     p.add_argument("--cluster-and-design-separately", type=dissimilarity,
+                   default=prof["cluster"],
                    help="cluster all input sequences by MinHash signature "
                         "(threshold in 1-ANI, (0, 0.5]), design per cluster "
                         "and merge")
@@ -69,6 +89,7 @@ def parse_args(argv=None):
                    choices=["choose", "simple", "hierarchical"],
                    default="choose")
     p.add_argument("--cluster-from-fragments", type=int,
+                   default=prof["fragments"],
                    help="cluster fragments of this length instead of whole "
                         "sequences")
     p.add_argument("--add-adapters", action="store_true",
@@ -78,13 +99,22 @@ def parse_args(argv=None):
     p.add_argument("--adapter-b", nargs=2,
                    help="<5' end> <3' end> of the B adapter")
     p.add_argument("--verbose", action="store_true")
-    return p.parse_args(argv)
+    args = p.parse_args(argv)
+    args.args_type = args_type
+    return args
 
 
 def main(args):
     logging.basicConfig(
         level=logging.INFO if args.verbose else logging.WARNING,
         format="%(asctime)s - %(name)s [%(levelname)s] %(message)s")
+    if getattr(args, "args_type", "basic") == "large":   # bin/design.py:52-57
+        logger.warning("With design_large.py, the default values for some "
+                       "arguments --- such as mismatches (-m) or cover "
+                       "extension (-e) --- might be more relaxed than "
+                       "desired. Run 'design_large.py --help' to see the "
+                       "default values; they can be overridden by specifying "
+                       "the argument.")
     lcf_thres = args.lcf_thres if args.lcf_thres is not None else args.probe_length
     if args.coverage > 1:
         args.coverage = int(args.coverage)

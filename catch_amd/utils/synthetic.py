@@ -61,6 +61,10 @@ def dataset(name, seed=None, scale=1.0):
       S3: 8 segments x (5,000*scale) strains in 40 clades, every segment its
           own genome record, d1 = 12 %, d2 = 2 % (config 3 shape)
       S4: 20 species = 20 groups (config 4 shape), sizes scaled by `scale`
+      S5: 588 species in ONE group (config 5 shape: `design_large` clusters
+          all sequences itself), strain counts Zipf(1.3) capped at 20,000,
+          scaled by `scale`; genome lengths log-uniform 3-200 kb; at scale 1
+          about 2 x 10^9 bases
     """
     if name == "S1":
         rng = np.random.Generator(np.random.PCG64(1 if seed is None else seed))
@@ -88,4 +92,14 @@ def dataset(name, seed=None, scale=1.0):
             n = max(1, int(round(int(rng.integers(50, 2001)) * scale)))
             groups.append(make_species(rng, [ln], n, min(8, n), 0.08, 0.015))
         return groups
+    if name == "S5":
+        rng = np.random.Generator(np.random.PCG64(5 if seed is None else seed))
+        genomes = []
+        for _ in range(588):
+            ln = int(np.exp(rng.uniform(np.log(3000), np.log(200000))))
+            n = min(int(rng.zipf(1.3)), 20000)
+            # keep the target of ~2e9 bases at scale 1: long genomes get fewer strains
+            n = max(1, int(round(min(n, 4.0e7 / ln) * scale)))
+            genomes += make_species(rng, [ln], n, min(6, n), 0.10, 0.02)
+        return [genomes]
     raise ValueError("unknown synthetic dataset %r" % (name,))

@@ -1067,3 +1067,41 @@ def test_design_cli_with_clustering_and_adapters(ctx, oracle, tmp_path, capsys):
     got = list(seq_io.read_fasta(str(out)).values())
     assert sorted(got) == sorted(want)
     assert len(pb.final_probes) == len(want)
+
+
+def test_config5_pipeline_large_profile_matches_oracle(ctx, oracle, tmp_path, capsys):
+    """config 5 shape (design_large defaults: -m 5 -e 50, cluster 0.15 from
+    fragments, MinHash near-duplicate filter 0.6, then the set cover per
+    cluster) == the oracle's chain of the same steps."""
+    from catch_amd import design
+    from catch_amd.utils import synthetic, seq_io
+    rng = np.random.Generator(np.random.PCG64(46))
+    sp = [synthetic.make_species(rng, [2600], 4, 2, 0.06, 0.01, with_n=False),
+          synthetic.make_species(rng, [2100], 3, 1, 0.0, 0.02, with_n=False),
+          synthetic.make_species(rng, [3300], 2, 1, 0.0, 0.03, with_n=False)]
+    fn = tmp_path / "all.fasta"
+    fn.write_text("".join(">s%d_%d\n%s\n" % (i, j, g[0]) for i, grp in enumerate(sp) for j, g in enumerate(grp)))
+    out = tmp_path / "probes.fasta"
+    args = design.parse_args([str(fn), "-o", str(out), "--cluster-from-fragments", "1000",
+                              "--cluster-and-design-separately-method", "simple"], args_type="large")
+    assert (args.mismatches, args.cover_extension, args.filter_with_lsh_minhash,
+            args.cluster_and_design_separately) == (5, 50, 0.6, 0.15)
+    random.seed(21)
+    np.random.seed(22)
+    pb = design.main(args)
+    capsys.readouterr()
+    frags = [f for grp in sp for g in grp for f in oracle.fragments_of(g[0], 1000)]
+    random.seed(21)
+    np.random.seed(22)
+    clusters = oracle.cluster_with_minhash_signatures(frags, threshold=0.15, cluster_method="simple")
+    assert 3 <= len(clusters) < len(frags)
+    cl_genomes = [[[frags[i]] for i in c] for c in clusters]
+    kept = []
+    for g in cl_genomes:
+        cands = candidates(g, 100, 50, dedup=False)
+        params = oracle.minhash_draw_params(oracle.minhash_num_tables(0.6), 3)
+        kept.append(oracle.ndf_minhash(cands, 0.6, params))
+    exp = oracle.set_cover_filter(kept, cl_genomes, 5, 100, coverage=1.0, cover_extension=50)
+    want = set(kept[i][j] for i, ids in enumerate(exp) for j in ids)
+    got = set(seq_io.read_fasta(str(out)).values())
+    assert got == want and len(pb.final_probes) == len(want) > 10
