@@ -59,6 +59,10 @@ PROTOTYPES = {
     "catchhip_ndf_minhash": (ctypes.c_int, [
         c_vp, c_u8p, c_i64p, ctypes.c_int64, ctypes.c_int32, c_i64p,
         ctypes.c_int32, ctypes.c_int32, ctypes.c_double, c_u8p]),
+    "catchhip_ndf_minhash_many": (ctypes.c_int, [
+        c_vp, c_u8p, c_i64p, ctypes.c_int64, c_i64p, ctypes.c_int64,
+        ctypes.c_int32, c_i64p, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_double, c_u8p]),
     "catchhip_setcover_filter": (ctypes.c_int, [
         c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, c_i64p, c_f64p,
@@ -87,6 +91,8 @@ PROTOTYPES = {
         c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_int32, c_u32p, c_vpp, c_i64p]),
     "catchhip_rows_fetch_first_seen": (ctypes.c_int, [c_vp, c_vp, c_u64p]),
+    "catchhip_probes_set_groups": (ctypes.c_int, [c_vp, c_vp, c_i32p]),
+    "catchhip_targets_set_groups": (ctypes.c_int, [c_vp, c_vp, c_i32p]),
 }
 
 _lib = None

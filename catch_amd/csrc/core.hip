@@ -507,3 +507,34 @@ extern "C" int catchhip_rows_destroy(catchhip_rows *r) {
     if (r) { (void)hipSetDevice(r->ctx->device); delete r; }
     return 0;
 }
+
+// ---- independent instances inside one probes / targets pair ----------------
+extern "C" int catchhip_probes_set_groups(catchhip_ctx *ctx, catchhip_probes *P, const i32 *group_of_probe) {
+    ARG_CHECK(ctx && P && P->ctx == ctx);
+    PoolScope pool_scope(ctx);
+    if (!group_of_probe) { P->has_groups = false; return 0; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    TRY(P->group.alloc((size_t)P->nprobes + 1));
+    if (P->nprobes) {
+        HIP_TRY(hipMemcpyAsync(P->group.p, group_of_probe, sizeof(i32) * (size_t)P->nprobes, hipMemcpyHostToDevice,
+                               ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    P->has_groups = true;
+    return 0;
+}
+
+extern "C" int catchhip_targets_set_groups(catchhip_ctx *ctx, catchhip_targets *T, const i32 *group_of_genome) {
+    ARG_CHECK(ctx && T && T->ctx == ctx);
+    PoolScope pool_scope(ctx);
+    if (!group_of_genome) { T->has_groups = false; return 0; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<i32> sg((size_t)T->nseq + 1, 0);
+    for (i64 s = 0; s < T->nseq; ++s) sg[(size_t)s] = group_of_genome[T->h_seq_genome[(size_t)s]];
+    TRY(T->seq_group.alloc((size_t)T->nseq + 1));
+    HIP_TRY(hipMemcpyAsync(T->seq_group.p, sg.data(), sizeof(i32) * ((size_t)T->nseq + 1), hipMemcpyHostToDevice,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    T->has_groups = true;
+    return 0;
+}

@@ -143,6 +143,8 @@ struct catchhip_targets {
     DevBuf<u8> bytes;        // raw characters
     DevBuf<u32> seq_off;     // nseq+1, global offsets (u32: total < 2^32)
     DevBuf<i32> seq_genome;  // nseq
+    bool has_groups = false;
+    DevBuf<i32> seq_group;   // nseq: instance of the sequence's genome (catchhip_targets_set_groups)
     DevBuf<u32> genome_off;  // ngenomes+1 global offset of each genome's first base
     i64 nwords = 0;          // 32-base words per plane (+ padding)
     DevBuf<u32> planes;      // 3 planes, SoA: plane b at planes + b*nwords
@@ -162,6 +164,8 @@ struct catchhip_probes {
     bool has_n = false;
     bool pigeonhole = false;  // anchors are exactly {0,k,2k,..,L-k} for every probe
     bool sorted_unique = false;   // the caller's anchor entries were sorted by (probe, position), no duplicates
+    bool has_groups = false;
+    DevBuf<i32> group;       // nprobes: instance of each probe (catchhip_probes_set_groups)
     // seeds per target base seen by earlier seed scans with these probes (sizes the work list)
     mutable double seed_ratio_hint = 0.0;
     i64 max_set_id = 0;

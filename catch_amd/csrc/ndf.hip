@@ -299,11 +299,16 @@ mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, 
 
 __global__ void __launch_bounds__(256)
 mh_key_kernel(const u32 *__restrict__ xs, const u32 *__restrict__ koff, u32 n, const u64 *__restrict__ ab, int k,
-              u32 *__restrict__ sig, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+              const u32 *__restrict__ grp, size_t ab_group_stride, u32 *__restrict__ sig, u64 *__restrict__ keys,
+              u32 *__restrict__ vals) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u32 k0 = koff[i], nk = koff[i + 1] - k0;
     u64 h = 0xcbf29ce484222325ull;
+    if (grp) {   // independent groups: own hash functions, and the group is part of the key
+        ab += (size_t)grp[i] * ab_group_stride;
+        h = (h ^ (u64)grp[i]) * 0x100000001b3ull;
+    }
     for (int f = 0; f < k; ++f) {
         const u64 a = ab[2 * f] % MH_P, b = ab[2 * f + 1];
         u64 best = ~0ull;
@@ -338,8 +343,8 @@ __device__ __forceinline__ bool mh_near(const u64 *__restrict__ ah, const u64 *_
 __global__ void __launch_bounds__(256)
 mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, const u64 *__restrict__ id_hi,
                const u64 *__restrict__ id_lo, const u32 *__restrict__ sig, int k, double thres, u32 n,
-               const u64 *__restrict__ keys, const u32 *__restrict__ vals, u32 *__restrict__ e_i,
-               u32 *__restrict__ e_j, u32 *__restrict__ count, u32 cap) {
+               const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ grp,
+               u32 *__restrict__ e_i, u32 *__restrict__ e_j, u32 *__restrict__ count, u32 cap) {
     const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n) return;
     const u64 key = keys[x];
@@ -347,7 +352,7 @@ mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
     for (u32 y = x; y-- > 0;) {
         if (keys[y] != key) break;
         const u32 j = vals[y];  // j < i: stable sort keeps indices ascending in a run
-        bool same = true;       // same bucket = same signature (the key only groups)
+        bool same = !grp || grp[i] == grp[j];   // same bucket = same group and signature (the key only groups)
         for (int f = 0; f < k; ++f) same = same && sig[(size_t)i * k + f] == sig[(size_t)j * k + f];
         if (same && mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j],
                             thres)) {
@@ -357,12 +362,24 @@ mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
     }
 }
 
-extern "C" int catchhip_ndf_minhash(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off, i64 n, i32 kmer_size,
-                                    const i64 *ab, i32 ntables, i32 k, double dist_thres, u8 *keep) {
+static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off, i64 n, const i64 *group_off,
+                            i64 ngroups, i32 kmer_size, const i64 *ab, i32 ntables, i32 k, double dist_thres,
+                            u8 *keep) {
     ARG_CHECK(ctx && n >= 0 && kmer_size >= 1 && kmer_size <= 16 && ntables >= 1 && k >= 1 && k <= 16 && ab);
     PoolScope pool_scope(ctx);
     if (n == 0) return 0;
     ARG_CHECK(bytes && probe_off && keep && probe_off[0] == 0);
+    std::vector<u32> h_grp;
+    if (group_off) {
+        ARG_CHECK(ngroups >= 1 && group_off[0] == 0 && group_off[ngroups] == n);
+        h_grp.resize((size_t)n);
+        for (i64 g = 0; g < ngroups; ++g) {
+            ARG_CHECK(group_off[g + 1] >= group_off[g]);
+            for (i64 i = group_off[g]; i < group_off[g + 1]; ++i) h_grp[(size_t)i] = (u32)g;
+        }
+    } else {
+        ngroups = 1;
+    }
     ARG_CHECK(n < ((i64)1 << 31) && probe_off[n] < ((i64)1 << 32));
     std::vector<u32> h_off((size_t)n + 1), h_koff((size_t)n + 1, 0);
     for (i64 i = 0; i <= n; ++i) h_off[i] = (u32)probe_off[i];
@@ -374,7 +391,7 @@ extern "C" int catchhip_ndf_minhash(catchhip_ctx *ctx, const u8 *bytes, const i6
         if (nk > MH_MAXK) { chip_set_error("ndf minhash: more than %d k-mers per probe not supported", MH_MAXK); return CATCHHIP_EINVAL; }
         h_koff[i + 1] = h_koff[i] + (u32)nk;
     }
-    for (i64 t = 0; t < (i64)ntables * k; ++t)
+    for (i64 t = 0; t < ngroups * (i64)ntables * k; ++t)
         ARG_CHECK(ab[2 * t] >= 1 && ab[2 * t] <= (i64)MH_P && ab[2 * t + 1] >= 0 && ab[2 * t + 1] <= (i64)MH_P);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -382,9 +399,10 @@ extern "C" int catchhip_ndf_minhash(catchhip_ctx *ctx, const u8 *bytes, const i6
     const size_t total = (size_t)probe_off[n], nkm = h_koff[n];
     DevBuf<u8> d_bytes;
     DevBuf<u64> d_ab, keys, keys_alt, id_hi, id_lo;
-    DevBuf<u32> d_off, d_koff, xs, nuniq, sig, vals, vals_alt, e_i, e_j, count, status, flags;
+    DevBuf<u32> d_off, d_koff, xs, nuniq, sig, vals, vals_alt, e_i, e_j, count, status, flags, d_grp;
     TRY(d_bytes.alloc(total + 16));
-    TRY(d_ab.alloc((size_t)ntables * k * 2));
+    TRY(d_ab.alloc((size_t)ngroups * ntables * k * 2));
+    if (group_off) TRY(d_grp.alloc((size_t)n));
     TRY(d_off.alloc((size_t)n + 1));
     TRY(d_koff.alloc((size_t)n + 1));
     TRY(xs.alloc(nkm));
@@ -398,7 +416,9 @@ extern "C" int catchhip_ndf_minhash(catchhip_ctx *ctx, const u8 *bytes, const i6
     TRY(status.alloc(nn));
     TRY(flags.alloc(nn));
     HIP_TRY(hipMemcpyAsync(d_bytes.p, bytes, total, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_ab.p, ab, sizeof(i64) * ntables * k * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_ab.p, ab, sizeof(i64) * (size_t)ngroups * ntables * k * 2, hipMemcpyHostToDevice, s));
+    if (group_off) HIP_TRY(hipMemcpyAsync(d_grp.p, h_grp.data(), sizeof(u32) * (size_t)n, hipMemcpyHostToDevice, s));
+    const u32 *grp = group_off ? (const u32 *)d_grp.p : (const u32 *)nullptr;
     HIP_TRY(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_koff.p, h_koff.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(count.p, 0, 2 * sizeof(u32), s));
@@ -419,11 +439,12 @@ extern "C" int catchhip_ndf_minhash(catchhip_ctx *ctx, const u8 *bytes, const i6
         HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(u32), s));
         for (int t = 0; t < ntables; ++t) {
             hipLaunchKernelGGL(mh_key_kernel, dim3(nb), dim3(256), 0, s, (const u32 *)xs.p, (const u32 *)d_koff.p, nn,
-                               (const u64 *)(d_ab.p + (size_t)t * k * 2), (int)k, sig.p, keys.p, vals.p);
+                               (const u64 *)(d_ab.p + (size_t)t * k * 2), (int)k, grp, (size_t)ntables * k * 2, sig.p,
+                               keys.p, vals.p);
             TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nn, 64));
             hipLaunchKernelGGL(mh_edge_kernel, dim3(nb), dim3(256), 0, s, (const u32 *)d_koff.p, (const u32 *)nuniq.p,
                                (const u64 *)id_hi.p, (const u64 *)id_lo.p, (const u32 *)sig.p, (int)k, dist_thres, nn,
-                               (const u64 *)keys.p, (const u32 *)vals.p, e_i.p, e_j.p, count.p, cap);
+                               (const u64 *)keys.p, (const u32 *)vals.p, grp, e_i.p, e_j.p, count.p, cap);
             tm.launch(2 + 24);
         }
         HIP_TRY(hipGetLastError());
@@ -435,4 +456,17 @@ extern "C" int catchhip_ndf_minhash(catchhip_ctx *ctx, const u8 *bytes, const i6
         cap = ne;
     }
     return ndf_resolve(ctx, nn, ne, e_i, e_j, count, status, flags, tm, keep);
+}
+
+extern "C" int catchhip_ndf_minhash(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off, i64 n, i32 kmer_size,
+                                    const i64 *ab, i32 ntables, i32 k, double dist_thres, u8 *keep) {
+    return ndf_minhash_impl(ctx, bytes, probe_off, n, nullptr, 1, kmer_size, ab, ntables, k, dist_thres, keep);
+}
+
+extern "C" int catchhip_ndf_minhash_many(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off, i64 n,
+                                         const i64 *group_off, i64 ngroups, i32 kmer_size, const i64 *ab,
+                                         i32 ntables, i32 k, double dist_thres, u8 *keep) {
+    ARG_CHECK(group_off && ngroups >= 1);
+    return ndf_minhash_impl(ctx, bytes, probe_off, n, group_off, ngroups, kmer_size, ab, ntables, k, dist_thres,
+                            keep);
 }

@@ -303,6 +303,7 @@ seed_verify_kernel(const u32 *__restrict__ tplanes, i64 nwords, const u32 *__res
     const u32 apos = nanch ? (e % (u32)nanch) * (u32)k : ent_pos[e];
     const u32 lo = seq_off[sq], hi = seq_off[sq + 1];
     bool ok = i >= lo + apos;
+    if (sink.probe_group) ok = ok && sink.probe_group[p] == sink.seq_group[sq];   // another instance's sequence
     const u32 o = i - apos;                     // where the probe would start
     ok = ok && o + (u32)L <= hi;                // window inside this sequence
     if (ok) {
@@ -988,6 +989,13 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     sink.bucket_of = by_sequence ? nullptr : P->bucket_of.p;
     sink.seq_genome = by_sequence ? nullptr : T->seq_genome.p;
     sink.ext = ext;
+    if (!by_sequence) {
+        if (P->has_groups != T->has_groups) {
+            chip_set_error("scan: groups must be set on both the probes and the targets, or on neither");
+            return CATCHHIP_EINVAL;
+        }
+        if (P->has_groups) { sink.probe_group = P->group.p; sink.seq_group = T->seq_group.p; }
+    }
     PhaseTimer ts(ctx, PHASE_SCAN), tr(ctx, PHASE_ROWS);
     if (use_seed) {
         O.from_seeds = true;
@@ -1085,6 +1093,8 @@ int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const ca
     sink.bucket_of = P->bucket_of.p;
     sink.seq_genome = T->seq_genome.p;
     sink.ext = (u32)cover_extension;
+    if (P->has_groups != T->has_groups) return 1;   // the synchronous path reports the error
+    if (P->has_groups) { sink.probe_group = P->group.p; sink.seq_group = T->seq_group.p; }
     TRY(bucket_prepare(O.B, nb, O.S.scap, false));
     sink.rec = O.B.rec.p; sink.rank = O.B.rank.p; sink.bcnt = O.B.bcnt.p;
     catchhip_rows *R = new catchhip_rows();

@@ -125,6 +125,28 @@ class Context:
         return keep[:n].astype(bool)
 
 
+    def ndf_minhash_many(self, groups, kmer_size, params, dist_thres):
+        """catchhip_ndf_minhash_many; groups = lists of probe strings,
+        params[group][table][fn] = (a, b).  Returns one bool array per group."""
+        flat = [s for g in groups for s in g]
+        n = len(flat)
+        if n == 0:
+            return [np.zeros(0, dtype=bool) for _ in groups]
+        buf, off = _concat(flat)
+        goff = np.zeros(len(groups) + 1, dtype=np.int64)
+        np.cumsum([len(g) for g in groups], out=goff[1:])
+        ab = np.ascontiguousarray(params, dtype=np.int64)
+        assert ab.ndim == 4 and ab.shape[0] == len(groups)
+        ntables, k = ab.shape[1], ab.shape[2]
+        keep = np.zeros(n, dtype=np.uint8)
+        check(self._L.catchhip_ndf_minhash_many(
+            self._h, _ptr(buf, c_u8p), _ptr(off, c_i64p), n, _ptr(goff, c_i64p),
+            len(groups), int(kmer_size), _ptr(ab, c_i64p), ntables, k,
+            float(dist_thres), _ptr(keep, c_u8p)))
+        keep = keep.astype(bool)
+        return [keep[goff[g]:goff[g + 1]] for g in range(len(groups))]
+
+
 class Targets:
     """Device-resident target sequences (catchhip_targets).
     genomes: list of genomes, each a list of sequence strings."""
@@ -147,6 +169,15 @@ class Targets:
         check(ctx._L.catchhip_targets_create(
             ctx._h, _ptr(buf, c_u8p), _ptr(off, c_i64p), _ptr(sgn, c_i32p),
             self.nseq, self.ngenomes, ctypes.byref(self._h)))
+
+    def set_groups(self, group_of_genome):
+        """catchhip_targets_set_groups (one entry per genome)."""
+        g = np.ascontiguousarray(group_of_genome, dtype=np.int32)
+        assert g.size == self.ngenomes
+        if g.size == 0:
+            g = np.zeros(1, dtype=np.int32)
+        check(self.ctx._L.catchhip_targets_set_groups(self.ctx._h, self._h,
+                                                      _ptr(g, c_i32p)))
 
     def close(self):
         if self._h:
@@ -181,6 +212,15 @@ class Probes:
             ctx._h, _ptr(buf, c_u8p), _ptr(off, c_i64p), self.n,
             _ptr(owner, c_i32p), _ptr(ep, c_i32p), _ptr(eo, c_i32p), nent,
             int(k or 0), ctypes.byref(self._h)))
+
+    def set_groups(self, group_of_probe):
+        """catchhip_probes_set_groups (one entry per unique probe)."""
+        g = np.ascontiguousarray(group_of_probe, dtype=np.int32)
+        assert g.size == self.n
+        if g.size == 0:
+            g = np.zeros(1, dtype=np.int32)
+        check(self.ctx._L.catchhip_probes_set_groups(self.ctx._h, self._h,
+                                                     _ptr(g, c_i32p)))
 
     def close(self):
         if self._h:

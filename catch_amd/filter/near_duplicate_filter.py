@@ -149,3 +149,18 @@ class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
         keep = engine.default_context().ndf_minhash(order, self.kmer_size, params,
                                                     self.dist_thres)
         return [s for s, kp in zip(order, keep) if kp]
+
+    def _filter_strs_many(self, groups):
+        """_filter_strs for every group (the clusters of a clustered design),
+        hash functions drawn per group in group order as one call per group
+        would, all groups in one pass over the device."""
+        orders, params = [], []
+        for strs in groups:
+            orders.append(_order_strs_by_multiplicity(strs))
+            params.append(self._draw_params())
+            if orders[-1] and min(map(len, orders[-1])) < self.kmer_size:
+                raise AssertionError("k-mer size exceeds a sequence's length")
+        keeps = engine.default_context().ndf_minhash_many(
+            orders, self.kmer_size, params, self.dist_thres)
+        return [[s for s, kp in zip(order, keep) if kp]
+                for order, keep in zip(orders, keeps)]

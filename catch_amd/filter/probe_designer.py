@@ -137,6 +137,8 @@ class ProbeDesigner:
         self._candidate_strs = cand
         if type(first) is DuplicateFilter:
             uniq = [list(dict.fromkeys(c)) for c in cand]
+        elif hasattr(first, "_filter_strs_many"):
+            uniq = first._filter_strs_many(cand)
         else:   # one _filter call per group, in order, like BaseFilter.filter
             uniq = [first._filter_strs(c) for c in cand]
         ids = scf._filter_strs(uniq, genomes, assume_unique=True)

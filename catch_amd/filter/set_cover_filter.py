@@ -219,6 +219,12 @@ class SetCoverFilter(BaseFilter):
                        rows=0, scan_launches=0, greedy_launches=0)
         todo = [i for i, pp in enumerate(input_strs) if len(pp) > 0]
         width = max(1, int(os.environ.get("CATCHHIP_GROUPS_IN_FLIGHT", "4")))
+        if (assume_unique and not self.identify and not self.avoided_genomes
+                and len(todo) >= int(os.environ.get("CATCHHIP_UNION_MIN_GROUPS", "8"))
+                and len({len(s) for gi in todo for s in input_strs[gi]}) == 1):
+            self._filter_strs_union(input_strs, target_genomes_grouped, todo,
+                                    selected, timings)
+            todo = []
         for c0 in range(0, len(todo), width):
             chunk = todo[c0:c0 + width]
             ctxs = _contexts(len(chunk))
@@ -273,6 +279,75 @@ class SetCoverFilter(BaseFilter):
                 selected[gi] = list(ids)
         self.last_timings = timings
         return selected
+
+
+    def _filter_strs_union(self, input_strs, target_genomes_grouped, todo,
+                           selected, timings, max_bases=1 << 30,
+                           max_candidates=1 << 24):
+        """Many independent groups (the clusters of a clustered design) as ONE
+        instance per chunk: the groups' candidates and genomes share a probes /
+        targets pair with group numbers (catchhip_*_set_groups), so the scan
+        only pairs a probe with its own group's genomes; the union of disjoint
+        set cover instances solved greedily makes, within every group, that
+        group's own picks in its own order (gains never cross groups, ties go to
+        the lowest id), and the solver's rounds cover all groups at once.
+        Requires equal-length candidates everywhere (then every group would
+        choose the same anchor rule and k as the union does, and the union's
+        np.random draws are the groups' draws back to back) and no ranks."""
+        ctx = engine.default_context()
+        at = 0
+        while at < len(todo):
+            chunk, bases, ncand = [], 0, 0
+            while at < len(todo):
+                gi = todo[at]
+                b = sum(g.size() for g in target_genomes_grouped[gi])
+                if chunk and (bases + b > max_bases or
+                              ncand + len(input_strs[gi]) > max_candidates):
+                    break
+                chunk.append(gi)
+                bases += b
+                ncand += len(input_strs[gi])
+                at += 1
+            logger.info("Set cover over groups %d..%d of %d as one instance",
+                        chunk[0] + 1, chunk[-1] + 1, len(input_strs))
+            counts = np.array([len(input_strs[gi]) for gi in chunk], dtype=np.int64)
+            offsets = np.concatenate(([0], np.cumsum(counts)))
+            strs = [s for gi in chunk for s in input_strs[gi]]
+            k, uniq, owner, ep, eo = probe.anchor_table(
+                strs, self.mismatches, self.lcf_thres,
+                min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k,
+                assume_unique=True)
+            genomes = [g.seqs for gi in chunk for g in target_genomes_grouped[gi]]
+            ngen = [len(target_genomes_grouped[gi]) for gi in chunk]
+            universe_p = [p for gi in chunk
+                          for p in self._make_universe_p(target_genomes_grouped[gi])]
+            targets = engine.Targets(ctx, genomes)
+            try:
+                probes = engine.Probes(ctx, uniq, owner, ep, eo, k)
+                try:
+                    probes.set_groups(np.repeat(np.arange(len(chunk)), counts))
+                    targets.set_groups(np.repeat(np.arange(len(chunk)), ngen))
+                    ids, nrows = engine.setcover_filter(
+                        ctx, probes, targets, self.mismatches, self.lcf_thres,
+                        self.island_of_exact_match, self.cover_extension,
+                        len(strs), None, universe_p, self.scan_mode)
+                finally:
+                    probes.close()
+            finally:
+                targets.close()
+            ids = np.asarray(ids, dtype=np.int64)
+            grp = np.searchsorted(offsets, ids, side="right") - 1
+            for j, gi in enumerate(chunk):
+                selected[gi] = (ids[grp == j] - offsets[j]).tolist()
+            ms, nl = ctx.kernel_ms(engine.PHASE_SCAN)
+            timings["scan_ms"] += ms
+            timings["scan_launches"] += nl
+            timings["rows_ms"] += ctx.kernel_ms(engine.PHASE_ROWS)[0]
+            timings["rows"] += nrows
+            ms, nl = ctx.kernel_ms(engine.PHASE_GREEDY)
+            timings["greedy_ms"] += ms
+            timings["greedy_launches"] += nl
+            timings["picks"] += len(ids)
 
 
 _extra_ctxs = []

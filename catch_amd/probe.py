@@ -155,22 +155,34 @@ def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
             use_random = True
     if use_random:
         kk = k
-        pairs = set()
-        for idx, p in enumerate(probe_strs):
-            if kk > len(p):
-                raise ValueError("k is larger than the length of a probe")
-            n_kmers = len(p) - kk + 1
-            pi = first[p] if first is not None else idx
-            for pos in np.random.choice(n_kmers, size=num_kmers_per_probe,
-                                        replace=True):
-                pairs.add((pi, int(pos)))
-                if with_draws:
-                    draws.append((idx, int(pos)))
-        pairs = sorted(pairs)
-        ent_probe = np.fromiter((a for a, _ in pairs), dtype=np.int32,
-                                count=len(pairs))
-        ent_pos = np.fromiter((b for _, b in pairs), dtype=np.int32,
-                              count=len(pairs))
+        # np.random.choice(n, size=20, replace=True) per probe IS randint(0, n,
+        # size=20) (legacy RandomState.choice), and legacy randint fills its
+        # output element by element from the 32-bit stream, so one randint call
+        # over a run of probes with equal k-mer counts draws the same numbers
+        # and leaves the generator in the same state as the reference's
+        # per-probe calls (tests/test_host_logic.py checks this against the
+        # per-probe form)
+        nprobes = len(probe_strs)
+        lens = np.fromiter(map(len, probe_strs), dtype=np.int64, count=nprobes)
+        if (lens < kk).any():
+            raise ValueError("k is larger than the length of a probe")
+        n_kmers = lens - kk + 1
+        pos = np.empty((nprobes, num_kmers_per_probe), dtype=np.int64)
+        cuts = np.flatnonzero(np.diff(n_kmers)) + 1
+        for a, b in zip([0] + cuts.tolist(), cuts.tolist() + [nprobes]):
+            pos[a:b] = np.random.randint(0, int(n_kmers[a]),
+                                         size=(b - a, num_kmers_per_probe))
+        if first is not None:
+            pi = np.fromiter((first[p] for p in probe_strs), dtype=np.int64,
+                             count=nprobes)
+        else:
+            pi = np.arange(nprobes, dtype=np.int64)
+        keys = np.unique(((pi[:, None] << 32) | pos).ravel())
+        ent_probe = (keys >> 32).astype(np.int32)
+        ent_pos = (keys & 0xffffffff).astype(np.int32)
+        if with_draws:
+            draws = list(zip(np.repeat(np.arange(nprobes), num_kmers_per_probe).tolist(),
+                             pos.ravel().tolist()))
     else:
         per = L // kk
         ent_probe = np.repeat(np.arange(len(uniq), dtype=np.int32), per)

@@ -239,6 +239,18 @@ int catchhip_ndf_minhash(catchhip_ctx *ctx, const uint8_t *bytes,
                          const int64_t *ab, int32_t ntables, int32_t k,
                          double dist_thres, uint8_t *keep);
 
+/* The same filter for `ngroups` independent groups of probes in one pass (the
+ * clusters of --cluster-and-design-separately; BaseFilter.filter runs _filter
+ * once per group, catch/filter/base_filter.py:111-175): group g = probes
+ * [group_off[g], group_off[g+1]) in priority order, with its own hash functions
+ * ab[g][ntables][k][2]; no probe is compared with a probe of another group. */
+int catchhip_ndf_minhash_many(catchhip_ctx *ctx, const uint8_t *bytes,
+                              const int64_t *probe_off, int64_t n,
+                              const int64_t *group_off, int64_t ngroups,
+                              int32_t kmer_size, const int64_t *ab,
+                              int32_t ntables, int32_t k, double dist_thres,
+                              uint8_t *keep);
+
 /* ---- clustering pre-step (next row: catch/utils/cluster.py) --------------
  * MinHash signatures of sequences, replacing lsh.MinHashFamily(kmer_size, N)
  * .make_h() / h(s) (catch/utils/lsh.py:75-153) with the deterministic md5 inner
@@ -298,6 +310,22 @@ int catchhip_cover_scan_first_seen(catchhip_ctx *ctx, const catchhip_probes *pro
 /* first_key[nrows], aligned with catchhip_rows_fetch */
 int catchhip_rows_fetch_first_seen(catchhip_ctx *ctx, const catchhip_rows *rows,
                                    uint64_t *first_key);
+
+/* ---- independent instances in one scan ------------------------------------
+ * The groups of a design are independent set cover instances
+ * (catch/filter/set_cover_filter.py:816-846: _make_sets per group, one solve
+ * per group).  Many small groups (the clusters of
+ * --cluster-and-design-separately) can share one probes / targets pair: give
+ * every probe and every genome the number of its group; the scans then report
+ * a probe only inside genomes of its own group.  The rows of the groups are
+ * disjoint in sets and universes, so one greedy solve over all of them makes,
+ * restricted to a group, exactly that group's own sequence of picks (a set's
+ * gain depends only on its own group's universes; ties go to the lowest id).
+ * Pass null to remove the groups. */
+int catchhip_probes_set_groups(catchhip_ctx *ctx, catchhip_probes *probes,
+                               const int32_t *group_of_probe);
+int catchhip_targets_set_groups(catchhip_ctx *ctx, catchhip_targets *targets,
+                                const int32_t *group_of_genome);
 
 #ifdef __cplusplus
 }

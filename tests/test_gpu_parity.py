@@ -1105,3 +1105,52 @@ def test_config5_pipeline_large_profile_matches_oracle(ctx, oracle, tmp_path, ca
     want = set(kept[i][j] for i, ids in enumerate(exp) for j in ids)
     got = set(seq_io.read_fasta(str(out)).values())
     assert got == want and len(pb.final_probes) == len(want) > 10
+
+
+def test_ndf_minhash_many_groups_equals_per_group_calls(ctx, oracle):
+    """catchhip_ndf_minhash_many (all clusters in one pass, hash functions per
+    group) == one catchhip_ndf_minhash call per group == the oracle."""
+    from catch_amd.filter.near_duplicate_filter import NearDuplicateFilterWithMinHash
+    groups = []
+    for seed, n in ((1, 5), (2, 1), (3, 7), (4, 3)):
+        g = small_species(seed=seed, n=n, length=1500, d1=0.05, d2=0.02, with_n=(seed % 2 == 0))
+        groups.append(candidates(g, 100, 50, dedup=False))
+    groups.insert(2, [])                       # an empty cluster
+    groups.append(groups[0][:40])              # same probes in another group: no cross-talk
+    f = NearDuplicateFilterWithMinHash(0.6)
+    random.seed(77)
+    many = f._filter_strs_many(groups)
+    random.seed(77)
+    single = [f._filter_strs(g) for g in groups]
+    assert many == single
+    random.seed(77)
+    for g, got in zip(groups, many):
+        params = oracle.minhash_draw_params(oracle.minhash_num_tables(0.6), 3)
+        assert got == oracle.ndf_minhash(g, 0.6, params)
+    assert any(0 < len(k) < len(g) for k, g in zip(many, groups))
+
+
+@pytest.mark.parametrize("m,coverage,ext", [(2, 1.0, 50), (5, 1.0, 50), (3, 0.9, 0), (2, 1.0, 0)])
+def test_union_of_groups_equals_per_group(ctx, oracle, monkeypatch, m, coverage, ext):
+    """Many groups solved as one instance (catchhip_*_set_groups + one fused
+    call) == one call per group == the oracle per group, picks in the same
+    order; the groups are strains of the same species, so without the group
+    filter probes would also cover other groups' genomes."""
+    from catch_amd.filter.set_cover_filter import SetCoverFilter
+    from catch_amd.genome import Genome
+    sp = (small_species(seed=12, n=14, length=2200, d1=0.03, d2=0.01) +
+          small_species(seed=13, n=10, length=1700, d1=0.04, d2=0.01, with_n=False))
+    groups = [sp[i:i + 2] for i in range(0, len(sp), 2)]          # 12 groups of 2 genomes
+    cands = [candidates(g, 100, 50) for g in groups]
+    gens = [[Genome.from_one_seq(x[0]) for x in g] for g in groups]
+    f = SetCoverFilter(mismatches=m, lcf_thres=100, coverage=coverage, cover_extension=ext)
+    np.random.seed(31)
+    union = f._filter_strs(cands, gens, assume_unique=True)
+    monkeypatch.setenv("CATCHHIP_UNION_MIN_GROUPS", "999")
+    np.random.seed(31)
+    single = f._filter_strs(cands, gens, assume_unique=True)
+    assert union == single
+    np.random.seed(31)
+    want = oracle.set_cover_filter(cands, groups, m, 100, coverage=coverage, cover_extension=ext)
+    assert [sorted(u) for u in union] == [sorted(w) for w in want]
+    assert sum(map(len, union)) > 50

@@ -55,11 +55,22 @@ def test_anchor_table_matches_reference_rows_inputs(oracle):
         strs += strs[:5]          # duplicates
         np.random.seed(42)
         k1, uniq, owner, ep, eo = probe.anchor_table(strs, m, thres, min_k, min_k)
+        state_after = np.random.get_state()[2]
         np.random.seed(42)
         k2, entries = oracle.anchor_table(strs, m, thres, min_k, min_k)
+        assert np.random.get_state()[2] == state_after     # the generator was advanced identically
         u2, own2 = oracle._unique_last(strs)
         assert k1 == k2 and uniq == u2 and list(owner) == own2
         assert sorted(zip(ep.tolist(), eo.tolist())) == entries
+    # probes of different lengths (always random anchors), draw order included
+    mixed = ["".join(rng.choice("ACGT") for _ in range(rng.choice([40, 40, 55, 90]))) for _ in range(60)]
+    mixed += mixed[:4]
+    np.random.seed(7)
+    k1, uniq, owner, ep, eo, draws = probe.anchor_table(mixed, 2, 40, 20, 20, with_draws=True)
+    np.random.seed(7)
+    k2, entries, draws2 = oracle.anchor_table(mixed, 2, 40, 20, 20, with_draws=True)
+    assert k1 == k2 and list(zip(ep.tolist(), eo.tolist())) == entries and draws == draws2
+
 
 
 def test_pigeonhole_kmer_length_table():
