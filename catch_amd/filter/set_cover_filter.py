@@ -219,8 +219,12 @@ class SetCoverFilter(BaseFilter):
                        rows=0, scan_launches=0, greedy_launches=0)
         todo = [i for i, pp in enumerate(input_strs) if len(pp) > 0]
         width = max(1, int(os.environ.get("CATCHHIP_GROUPS_IN_FLIGHT", "4")))
+        # many SMALL groups go through one instance; large groups (thousands of
+        # candidates each) overlap better as separate instances in flight
         if (assume_unique and not self.identify and not self.avoided_genomes
                 and len(todo) >= int(os.environ.get("CATCHHIP_UNION_MIN_GROUPS", "8"))
+                and sum(len(input_strs[gi]) for gi in todo) <= len(todo) * int(
+                    os.environ.get("CATCHHIP_UNION_MAX_MEAN_CANDIDATES", "8192"))
                 and len({len(s) for gi in todo for s in input_strs[gi]}) == 1):
             self._filter_strs_union(input_strs, target_genomes_grouped, todo,
                                     selected, timings)
