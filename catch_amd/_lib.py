@@ -91,6 +91,14 @@ PROTOTYPES = {
         c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_int32, c_u32p, c_vpp, c_i64p]),
     "catchhip_rows_fetch_first_seen": (ctypes.c_int, [c_vp, c_vp, c_u64p]),
+    "catchhip_candidates_create": (ctypes.c_int, [
+        c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, c_vpp,
+        c_i64p, c_i64p]),
+    "catchhip_candidates_destroy": (None, [c_vp]),
+    "catchhip_candidates_fetch": (ctypes.c_int, [
+        c_vp, c_vp, c_i64p, ctypes.c_int64, c_i64p]),
+    "catchhip_probes_from_candidates": (ctypes.c_int, [
+        c_vp, c_vp, c_i32p, c_i32p, ctypes.c_int64, ctypes.c_int32, c_vpp]),
     "catchhip_probes_set_groups": (ctypes.c_int, [c_vp, c_vp, c_i32p]),
     "catchhip_targets_set_groups": (ctypes.c_int, [c_vp, c_vp, c_i32p]),
 }

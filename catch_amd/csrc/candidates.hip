@@ -1,0 +1,477 @@
+// Candidate probes and their exact de-duplication on the device.
+//
+// Replaces, for the usual filter list [DuplicateFilter, SetCoverFilter]:
+//   * candidate_probes.make_candidate_probes_from_sequences
+//     (catch/filter/candidate_probes.py:21-182): per sequence the windows of
+//     probe_length every probe_stride bases, a last window flush with the end
+//     when the length is not a multiple of the stride, windows holding two or
+//     more consecutive N dropped (:63-70), and for every maximal run of >= 2 N
+//     the windows just left and right of it (:104-122) -- in exactly that
+//     order, sequences in genome order;
+//   * DuplicateFilter (catch/filter/duplicate_filter.py:16-26): first
+//     occurrences, order kept -- the position in that list is the candidate's
+//     set id, which the greedy solver's tie-break depends on.
+// The unique candidates never become strings: catchhip_probes_from_candidates
+// gathers them from the targets' characters into a probes object, and only the
+// selected ones are looked up again by the host (catchhip_candidates_fetch).
+//
+// Kernels (all streaming integer work, HBM-bound):
+//   cand_flags_kernel    per base: "an NN pair starts here", "a run of >= 2 N starts here"
+//   (two prefix sums)    pairs before a position (window validity in O(1)), runs before a position
+//   cand_seq_kernel      per sequence: windows, runs -> slots
+//   cand_regular_kernel  one thread per stride window (+ the tail window)
+//   cand_flank_kernel    one thread per N run: its two flanking windows
+//   (compaction)         valid slots -> candidate list in reference order
+//   cand_hash_kernel     64-bit hash of every candidate's characters
+//   (radix sort)         equal hashes adjacent, candidate order kept inside a run
+//   cand_dup_kernel      compare with the run's first candidate byte by byte;
+//                        a hash collision of different strings (never seen)
+//                        falls back to a walk over the run
+//   (compaction)         first occurrences in candidate order
+#include <algorithm>
+
+#include "internal.h"
+
+struct catchhip_candidates {
+    catchhip_ctx *ctx = nullptr;
+    const catchhip_targets *T = nullptr;   // borrowed: must outlive this object
+    i32 L = 0;
+    i64 ncand = 0, nuniq = 0;
+    DevBuf<u32> upos;   // global start of every unique candidate, first-occurrence order
+};
+
+#define CAND_NONE 0xffffffffu
+
+__device__ __forceinline__ u32 cand_find_segment(const u32 *__restrict__ off, u32 n, u32 x) {
+    u32 lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (off[mid] <= x) lo = mid; else hi = mid;
+    }
+    while (lo + 1 < n && off[lo + 1] <= x) ++lo;
+    return lo;
+}
+
+__global__ void __launch_bounds__(256)
+cand_flags_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ seq_off, u32 nseq, u32 total,
+                  u32 *__restrict__ pair, u32 *__restrict__ rstart) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > total) return;
+    u32 pr = 0, rs = 0;
+    if (g < total && bytes[g] == 'N') {
+        const u32 sq = cand_find_segment(seq_off, nseq, g);
+        const u32 lo = seq_off[sq], hi = seq_off[sq + 1];
+        pr = (g + 1 < hi && bytes[g + 1] == 'N') ? 1u : 0u;
+        rs = (pr && (g == lo || bytes[g - 1] != 'N')) ? 1u : 0u;
+    }
+    pair[g] = pr;      // entry `total` is the sentinel of the prefix sums
+    rstart[g] = rs;
+}
+
+// a window [s, s+L) holds two consecutive N iff an NN pair starts in [s, s+L-2]
+__device__ __forceinline__ bool cand_window_ok(const u32 *__restrict__ pairs_before, u32 s, u32 L) {
+    return pairs_before[s + L - 1] == pairs_before[s];
+}
+
+__global__ void __launch_bounds__(256)
+cand_seq_kernel(const u32 *__restrict__ seq_off, u32 nseq, u32 L, u32 stride, i64 skip_len,
+                const u32 *__restrict__ runs_before, u32 *__restrict__ nwin, u32 *__restrict__ nslot) {
+    const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nseq) return;
+    u32 w = 0, sl = 0;
+    if (q < nseq) {
+        const u32 lo = seq_off[q], hi = seq_off[q + 1], n = hi - lo;
+        if (!(skip_len >= 0 && (i64)n <= skip_len) && n >= L) {
+            w = (n - L) / stride + 1 + 1;                       // stride windows + the tail slot
+            sl = w + 2 * (runs_before[hi] - runs_before[lo]);   // + two flanks per run
+        }
+    }
+    nwin[q] = w;
+    nslot[q] = sl;
+}
+
+__global__ void __launch_bounds__(256)
+cand_regular_kernel(const u32 *__restrict__ seq_off, u32 nseq, u32 L, u32 stride, const u32 *__restrict__ win_off,
+                    const u32 *__restrict__ slot_off, const u32 *__restrict__ pairs_before, u32 nwin_total,
+                    u32 *__restrict__ slots) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nwin_total) return;
+    const u32 q = cand_find_segment(win_off, nseq, t);
+    const u32 w = t - win_off[q], nw = win_off[q + 1] - win_off[q];
+    const u32 lo = seq_off[q], hi = seq_off[q + 1], n = hi - lo;
+    u32 s = CAND_NONE;
+    if (w + 1 < nw) s = lo + w * stride;
+    else if (n % stride != 0) s = hi - L;                       // candidate_probes.py:99-102
+    if (s != CAND_NONE && !cand_window_ok(pairs_before, s, L)) s = CAND_NONE;
+    slots[slot_off[q] + w] = s;
+}
+
+__global__ void __launch_bounds__(256)
+cand_flank_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ seq_off, u32 nseq, u32 total, u32 L,
+                  const u32 *__restrict__ rstart, const u32 *__restrict__ runs_before,
+                  const u32 *__restrict__ win_off, const u32 *__restrict__ slot_off,
+                  const u32 *__restrict__ pairs_before, u32 *__restrict__ slots) {
+    const u32 a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= total || !rstart[a]) return;
+    const u32 q = cand_find_segment(seq_off, nseq, a);
+    const u32 nw = win_off[q + 1] - win_off[q];
+    if (nw == 0) return;                                        // skipped sequence
+    const u32 lo = seq_off[q], hi = seq_off[q + 1];
+    u32 b = a;
+    while (b < hi && bytes[b] == 'N') ++b;
+    const u32 r = runs_before[a] - runs_before[lo];
+    const u32 at = slot_off[q] + nw + 2 * r;
+    u32 left = CAND_NONE, right = CAND_NONE;
+    if (a - lo >= L && cand_window_ok(pairs_before, a - L, L)) left = a - L;      // :108-114
+    if (b + L <= hi && cand_window_ok(pairs_before, b, L)) right = b;              // :115-121
+    slots[at] = left;
+    slots[at + 1] = right;
+}
+
+__global__ void __launch_bounds__(256)
+cand_valid_kernel(const u32 *__restrict__ slots, u32 n, u32 *__restrict__ flag) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= n) flag[t] = (t < n && slots[t] != CAND_NONE) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256)
+cand_compact_kernel(const u32 *__restrict__ src, const u32 *__restrict__ flag, const u32 *__restrict__ at, u32 n,
+                    u32 *__restrict__ dst) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n && flag[t]) dst[at[t]] = src[t];
+}
+
+__global__ void __launch_bounds__(256)
+cand_hash_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ cpos, u32 n, u32 L, u64 *__restrict__ keys,
+                 u32 *__restrict__ vals) {
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const u8 *p = bytes + cpos[c];
+    u64 h = 0x9e3779b97f4a7c15ull ^ (u64)L;
+    u32 j = 0;
+    for (; j + 8 <= L; j += 8) {
+        u64 w = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) w |= (u64)p[j + t] << (8 * t);
+        h = (h ^ w) * 0xff51afd7ed558ccdull;
+        h ^= h >> 29;
+    }
+    u64 w = 0;
+    for (u32 t = 0; j + t < L; ++t) w |= (u64)p[j + t] << (8 * t);
+    h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 32;
+    keys[c] = h;
+    vals[c] = c;
+}
+
+__global__ void __launch_bounds__(256)
+cand_runstart_kernel(const u64 *__restrict__ keys, u32 n, u32 *__restrict__ flag) {
+    const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x <= n) flag[x] = (x < n && (x == 0 || keys[x] != keys[x - 1])) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256)
+cand_runhead_kernel(const u32 *__restrict__ flag, const u32 *__restrict__ runid, u32 n, u32 *__restrict__ head) {
+    const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n && flag[x]) head[runid[x]] = x;
+}
+
+__device__ __forceinline__ bool cand_same(const u8 *__restrict__ bytes, u32 a, u32 b, u32 L) {
+    for (u32 j = 0; j < L; ++j)
+        if (bytes[a + j] != bytes[b + j]) return false;
+    return true;
+}
+
+// keep[c] = 1 iff no earlier candidate has the same characters.  Inside a run of
+// equal hashes the stable sort keeps candidates in ascending order, so the run's
+// first element is the earliest.
+__global__ void __launch_bounds__(256)
+cand_dup_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ cpos, const u32 *__restrict__ vals,
+                const u32 *__restrict__ flag, const u32 *__restrict__ runid, const u32 *__restrict__ head, u32 n,
+                u32 L, u32 *__restrict__ keep) {
+    const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x > n) return;
+    if (x == n) { keep[n] = 0; return; }
+    const u32 c = vals[x];
+    // runid is an exclusive sum of the start flags: a run's own start counts for its later elements only
+    const u32 h = flag[x] ? x : head[runid[x] - 1];
+    u32 k = 1;
+    if (x != h) {
+        if (cand_same(bytes, cpos[c], cpos[vals[h]], L)) k = 0;
+        else
+            for (u32 y = x; y-- > h + 1;)   // different strings under one hash: look at the others
+                if (cand_same(bytes, cpos[c], cpos[vals[y]], L)) { k = 0; break; }
+    }
+    keep[c] = k;
+}
+
+__global__ void __launch_bounds__(256)
+cand_gather_kernel(const u8 *__restrict__ tbytes, const u32 *__restrict__ upos, u32 n, u32 L, u8 *__restrict__ out,
+                   u32 *__restrict__ probe_off, i32 *__restrict__ set_id, u32 *__restrict__ bucket_of,
+                   i32 *__restrict__ bucket_set) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 nb = (u64)n * L;
+    if (t < nb) {
+        const u32 i = (u32)(t / L), j = (u32)(t - (u64)i * L);
+        out[t] = tbytes[upos[i] + j];
+    }
+    if (t <= n) {
+        probe_off[t] = (u32)(t * L);
+        if (t < n) { set_id[t] = (i32)t; bucket_of[t] = (u32)t; bucket_set[t] = (i32)t; }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cand_pigeon_kernel(u32 n, u32 nanch, u32 k, i32 *__restrict__ ent_probe, i32 *__restrict__ ent_pos,
+                   u32 *__restrict__ sent_probe, u32 *__restrict__ sent_pos, u32 *__restrict__ ent_ptr) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 ne = (u64)n * nanch;
+    if (t < ne) {
+        const u32 p = (u32)(t / nanch), a = (u32)(t - (u64)p * nanch) * k;
+        ent_probe[t] = (i32)p; ent_pos[t] = (i32)a;
+        sent_probe[t] = p; sent_pos[t] = a;
+    }
+    if (t <= n) ent_ptr[t] = (u32)(t * nanch);
+}
+
+static int cand_scan(catchhip_ctx *ctx, DevBuf<u32> &flag, DevBuf<u32> &out, i64 n_plus_1, DevBuf<u32> &tmp) {
+    TRY(out.reserve((size_t)n_plus_1));
+    return chip_exclusive_scan_u32(ctx, flag.p, out.p, n_plus_1, tmp);
+}
+
+static int cand_read_u32(catchhip_ctx *ctx, const u32 *d, u32 *out) {
+    HIP_TRY(hipMemcpyAsync(ctx->h_pin, d, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = *(volatile u32 *)ctx->h_pin;
+    return 0;
+}
+
+static int candidates_build(catchhip_ctx *ctx, const catchhip_targets *T, u32 L, u32 stride, i64 skip_len,
+                            catchhip_candidates *C) {
+    hipStream_t s = ctx->stream;
+    const u32 total = (u32)T->total, nseq = (u32)T->nseq;
+    DevBuf<u32> pair, rstart, pairs_before, runs_before, nwin, nslot, win_off, slot_off, slots, flag, at, cpos, tmp;
+    PhaseTimer tm(ctx, PHASE_NDF);
+    TRY(pair.alloc((size_t)total + 1));
+    TRY(rstart.alloc((size_t)total + 1));
+    hipLaunchKernelGGL(cand_flags_kernel, dim3((unsigned)div_up((i64)total + 1, 256)), dim3(256), 0, s,
+                       (const u8 *)T->bytes.p, (const u32 *)T->seq_off.p, nseq, total, pair.p, rstart.p);
+    TRY(cand_scan(ctx, pair, pairs_before, (i64)total + 1, tmp));
+    TRY(cand_scan(ctx, rstart, runs_before, (i64)total + 1, tmp));
+    TRY(nwin.alloc((size_t)nseq + 1));
+    TRY(nslot.alloc((size_t)nseq + 1));
+    hipLaunchKernelGGL(cand_seq_kernel, dim3((unsigned)div_up((i64)nseq + 1, 256)), dim3(256), 0, s,
+                       (const u32 *)T->seq_off.p, nseq, L, stride, skip_len, (const u32 *)runs_before.p, nwin.p, nslot.p);
+    TRY(cand_scan(ctx, nwin, win_off, (i64)nseq + 1, tmp));
+    TRY(cand_scan(ctx, nslot, slot_off, (i64)nseq + 1, tmp));
+    u32 nwin_total = 0, nslot_total = 0;
+    TRY(cand_read_u32(ctx, win_off.p + nseq, &nwin_total));
+    TRY(cand_read_u32(ctx, slot_off.p + nseq, &nslot_total));
+    tm.launch(12);
+    C->ncand = 0;
+    C->nuniq = 0;
+    if (nslot_total == 0) { tm.finish(); return 0; }
+    TRY(slots.alloc((size_t)nslot_total + 1));
+    HIP_TRY(hipMemsetAsync(slots.p, 0xff, sizeof(u32) * ((size_t)nslot_total + 1), s));
+    hipLaunchKernelGGL(cand_regular_kernel, dim3((unsigned)div_up((i64)nwin_total, 256)), dim3(256), 0, s,
+                       (const u32 *)T->seq_off.p, nseq, L, stride, (const u32 *)win_off.p, (const u32 *)slot_off.p,
+                       (const u32 *)pairs_before.p, nwin_total, slots.p);
+    hipLaunchKernelGGL(cand_flank_kernel, dim3((unsigned)div_up((i64)total, 256)), dim3(256), 0, s,
+                       (const u8 *)T->bytes.p, (const u32 *)T->seq_off.p, nseq, total, L, (const u32 *)rstart.p,
+                       (const u32 *)runs_before.p, (const u32 *)win_off.p, (const u32 *)slot_off.p,
+                       (const u32 *)pairs_before.p, slots.p);
+    TRY(flag.alloc((size_t)nslot_total + 1));
+    hipLaunchKernelGGL(cand_valid_kernel, dim3((unsigned)div_up((i64)nslot_total + 1, 256)), dim3(256), 0, s,
+                       (const u32 *)slots.p, nslot_total, flag.p);
+    TRY(cand_scan(ctx, flag, at, (i64)nslot_total + 1, tmp));
+    u32 ncand = 0;
+    TRY(cand_read_u32(ctx, at.p + nslot_total, &ncand));
+    tm.launch(6);
+    C->ncand = ncand;
+    if (ncand == 0) { tm.finish(); return 0; }
+    TRY(cpos.alloc(ncand));
+    hipLaunchKernelGGL(cand_compact_kernel, dim3((unsigned)div_up((i64)nslot_total, 256)), dim3(256), 0, s,
+                       (const u32 *)slots.p, (const u32 *)flag.p, (const u32 *)at.p, nslot_total, cpos.p);
+    // the big per-base arrays are not needed any more
+    pair.release(); rstart.release(); pairs_before.release(); runs_before.release(); slots.release();
+    // exact de-duplication
+    DevBuf<u64> keys, keys_alt;
+    DevBuf<u32> vals, vals_alt, rflag, runid, head, keep, kat;
+    TRY(keys.alloc(ncand));
+    TRY(vals.alloc(ncand));
+    hipLaunchKernelGGL(cand_hash_kernel, dim3((unsigned)div_up((i64)ncand, 256)), dim3(256), 0, s,
+                       (const u8 *)T->bytes.p, (const u32 *)cpos.p, ncand, L, keys.p, vals.p);
+    TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, ncand, 64));
+    TRY(rflag.alloc((size_t)ncand + 1));
+    hipLaunchKernelGGL(cand_runstart_kernel, dim3((unsigned)div_up((i64)ncand + 1, 256)), dim3(256), 0, s,
+                       (const u64 *)keys.p, ncand, rflag.p);
+    TRY(cand_scan(ctx, rflag, runid, (i64)ncand + 1, tmp));
+    TRY(head.alloc((size_t)ncand + 1));
+    // runid (exclusive) of a run start = index of its run
+    hipLaunchKernelGGL(cand_runhead_kernel, dim3((unsigned)div_up((i64)ncand, 256)), dim3(256), 0, s,
+                       (const u32 *)rflag.p, (const u32 *)runid.p, ncand, head.p);
+    TRY(keep.alloc((size_t)ncand + 1));
+    hipLaunchKernelGGL(cand_dup_kernel, dim3((unsigned)div_up((i64)ncand + 1, 256)), dim3(256), 0, s,
+                       (const u8 *)T->bytes.p, (const u32 *)cpos.p, (const u32 *)vals.p, (const u32 *)rflag.p,
+                       (const u32 *)runid.p, (const u32 *)head.p, ncand, L, keep.p);
+    TRY(cand_scan(ctx, keep, kat, (i64)ncand + 1, tmp));
+    u32 nuniq = 0;
+    TRY(cand_read_u32(ctx, kat.p + ncand, &nuniq));
+    C->nuniq = nuniq;
+    TRY(C->upos.alloc((size_t)nuniq + 1));
+    hipLaunchKernelGGL(cand_compact_kernel, dim3((unsigned)div_up((i64)ncand, 256)), dim3(256), 0, s,
+                       (const u32 *)cpos.p, (const u32 *)keep.p, (const u32 *)kat.p, ncand, C->upos.p);
+    tm.launch(40);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    tm.finish();
+    return 0;
+}
+
+extern "C" int catchhip_candidates_create(catchhip_ctx *ctx, const catchhip_targets *T, i32 probe_length,
+                                          i32 probe_stride, i64 seq_length_to_skip, catchhip_candidates **out,
+                                          i64 *ncandidates, i64 *nunique) {
+    ARG_CHECK(ctx && T && T->ctx == ctx && out && probe_length >= 2 && probe_stride >= 1);
+    PoolScope pool_scope(ctx);
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // candidate_probes.py:37-50: a sequence shorter than the probe is an error
+    // (or a probe of its own with --small-seq-min: the host's string path)
+    for (i64 q = 0; q < T->nseq; ++q) {
+        const i64 n = T->h_seq_off[(size_t)q + 1] - T->h_seq_off[(size_t)q];
+        if (seq_length_to_skip >= 0 && n <= seq_length_to_skip) continue;
+        if (n < probe_length) {
+            chip_set_error("candidates: sequence %lld is shorter than the probe length %d", (long long)q,
+                           (int)probe_length);
+            return CATCHHIP_EINVAL;
+        }
+    }
+    catchhip_candidates *C = new catchhip_candidates();
+    C->ctx = ctx;
+    C->T = T;
+    C->L = probe_length;
+    int rc = T->total ? candidates_build(ctx, T, (u32)probe_length, (u32)probe_stride, seq_length_to_skip, C) : 0;
+    if (rc) { delete C; return rc; }
+    if (ncandidates) *ncandidates = C->ncand;
+    if (nunique) *nunique = C->nuniq;
+    *out = C;
+    return 0;
+}
+
+extern "C" void catchhip_candidates_destroy(catchhip_candidates *C) {
+    if (!C) return;
+    PoolScope pool_scope(C->ctx);
+    delete C;
+}
+
+extern "C" int catchhip_candidates_fetch(catchhip_ctx *ctx, const catchhip_candidates *C, const i64 *ids, i64 n,
+                                         i64 *global_start) {
+    ARG_CHECK(ctx && C && C->ctx == ctx && n >= 0);
+    if (n == 0) return 0;
+    ARG_CHECK(global_start);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<u32> h((size_t)C->nuniq);
+    if (C->nuniq) {
+        HIP_TRY(hipMemcpyAsync(h.data(), C->upos.p, sizeof(u32) * (size_t)C->nuniq, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    for (i64 i = 0; i < n; ++i) {
+        const i64 id = ids ? ids[i] : i;
+        if (id < 0 || id >= C->nuniq) { chip_set_error("candidates_fetch: id out of range"); return CATCHHIP_ERANK; }
+        global_start[i] = h[(size_t)id];
+    }
+    return 0;
+}
+
+extern "C" int catchhip_probes_from_candidates(catchhip_ctx *ctx, const catchhip_candidates *C, const i32 *ent_probe,
+                                               const i32 *ent_pos, i64 nent, i32 k, catchhip_probes **out) {
+    ARG_CHECK(ctx && C && C->ctx == ctx && out && k > 0 && k <= C->L);
+    ARG_CHECK((ent_probe == nullptr) == (ent_pos == nullptr));
+    PoolScope pool_scope(ctx);
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const i64 n = C->nuniq, L = C->L;
+    ARG_CHECK(n * L < ((i64)1 << 31));
+    const bool pigeon = ent_probe == nullptr;
+    if (pigeon) {
+        ARG_CHECK(L % k == 0);
+        nent = n * (L / k);
+    } else {
+        ARG_CHECK(nent >= 0);
+        for (i64 e = 0; e < nent; ++e) {
+            ARG_CHECK(ent_probe[e] >= 0 && ent_probe[e] < n && ent_pos[e] >= 0 && ent_pos[e] + k <= L);
+            if (e && (ent_probe[e] < ent_probe[e - 1] ||
+                      (ent_probe[e] == ent_probe[e - 1] && ent_pos[e] <= ent_pos[e - 1]))) {
+                chip_set_error("probes_from_candidates: anchors must be sorted by (probe, position), no duplicates");
+                return CATCHHIP_EINVAL;
+            }
+        }
+    }
+    catchhip_probes *p = new catchhip_probes();
+    p->ctx = ctx;
+    p->nprobes = n;
+    p->total = n * L;
+    p->nent = nent;
+    p->k = k;
+    p->L = n ? (i32)L : 0;
+    p->max_set_id = n ? n - 1 : 0;
+    p->nbuckets = n;
+    p->dna5 = C->T->dna5;       // windows of the targets: a subset of their alphabet
+    p->has_n = C->T->has_n;
+    p->sorted_unique = true;
+    hipStream_t s = ctx->stream;
+    int rc = 0;
+    do {
+        if ((rc = p->bytes.alloc((size_t)p->total + 256)) || (rc = p->probe_off.alloc((size_t)n + 1)) ||
+            (rc = p->set_id.alloc((size_t)n + 1)) || (rc = p->bucket_of.alloc((size_t)n + 1)) ||
+            (rc = p->bucket_set.alloc((size_t)n + 1)) || (rc = p->ent_probe.alloc((size_t)nent + 1)) ||
+            (rc = p->ent_pos.alloc((size_t)nent + 1)) || (rc = p->sent_probe.alloc((size_t)nent + 1)) ||
+            (rc = p->sent_pos.alloc((size_t)nent + 1)) || (rc = p->ent_ptr.alloc((size_t)n + 1)))
+            break;
+        if (hipMemsetAsync(p->bytes.p, 0, (size_t)p->total + 256, s) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
+        hipLaunchKernelGGL(cand_gather_kernel, dim3((unsigned)div_up(std::max<i64>(p->total, n + 1), 256)), dim3(256), 0,
+                           s, (const u8 *)C->T->bytes.p, (const u32 *)C->upos.p, (u32)n, (u32)L, p->bytes.p,
+                           p->probe_off.p, p->set_id.p, p->bucket_of.p, p->bucket_set.p);
+        if (pigeon) {
+            const u32 nanch = (u32)(L / k);
+            p->pigeonhole = n > 0;
+            hipLaunchKernelGGL(cand_pigeon_kernel, dim3((unsigned)div_up(std::max<i64>(nent, n + 1), 256)), dim3(256), 0,
+                               s, (u32)n, nanch, (u32)k, p->ent_probe.p, p->ent_pos.p, p->sent_probe.p, p->sent_pos.p,
+                               p->ent_ptr.p);
+        } else {
+            // given sorted by (probe, position): the sorted table is the table
+            std::vector<u32> ptr((size_t)n + 1, 0);
+            bool pg = n > 0 && L % k == 0 && nent == n * (L / k);
+            for (i64 e = 0; e < nent; ++e) {
+                ptr[(size_t)ent_probe[e] + 1]++;
+                if (pg && ent_pos[e] != (i32)((e % (L / k)) * k)) pg = false;
+            }
+            for (i64 i = 0; i < n; ++i) {
+                if (pg && ptr[(size_t)i + 1] != (u32)(L / k)) pg = false;
+                ptr[(size_t)i + 1] += ptr[(size_t)i];
+            }
+            p->pigeonhole = pg;
+            if (nent && (hipMemcpyAsync(p->ent_probe.p, ent_probe, sizeof(i32) * nent, hipMemcpyHostToDevice, s) != hipSuccess ||
+                         hipMemcpyAsync(p->ent_pos.p, ent_pos, sizeof(i32) * nent, hipMemcpyHostToDevice, s) != hipSuccess ||
+                         hipMemcpyAsync(p->sent_probe.p, ent_probe, sizeof(i32) * nent, hipMemcpyHostToDevice, s) != hipSuccess ||
+                         hipMemcpyAsync(p->sent_pos.p, ent_pos, sizeof(i32) * nent, hipMemcpyHostToDevice, s) != hipSuccess)) {
+                rc = CATCHHIP_EHIP;
+                break;
+            }
+            if (hipMemcpyAsync(p->ent_ptr.p, ptr.data(), sizeof(u32) * ((size_t)n + 1), hipMemcpyHostToDevice, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess) {
+                rc = CATCHHIP_EHIP;
+                break;
+            }
+        }
+        if ((rc = chip_probes_pack_planes(p))) break;
+        if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
+            chip_set_error("probes_from_candidates failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = CATCHHIP_EHIP;
+            break;
+        }
+    } while (0);
+    if (rc) { delete p; return rc; }
+    *out = p;
+    return 0;
+}

@@ -362,6 +362,28 @@ extern "C" int catchhip_targets_destroy(catchhip_targets *t) {
     return 0;
 }
 
+// packed image of equal-length DNA probes (planes + word 0), from p->bytes / p->probe_off
+int chip_probes_pack_planes(catchhip_probes *p) {
+    hipStream_t s = p->ctx->stream;
+    const i64 nprobes = p->nprobes;
+    if (!(p->dna5 && p->L > 0 && p->L <= 256)) return 0;
+    p->pwords = (p->L + 31) / 32;
+    size_t nw = (size_t)nprobes * p->pwords * 4;
+    TRY(p->planes.alloc(nw + 1024));
+    HIP_TRY(hipMemsetAsync(p->planes.p, 0, sizeof(u32) * (nw + 1024), s));
+    unsigned blocks = (unsigned)div_up(nprobes, 4);
+    if (nprobes)
+        hipLaunchKernelGGL(pack_probes_kernel, dim3(blocks), dim3(256), 0, s, p->bytes.p, p->probe_off.p, nprobes,
+                           p->pwords, p->planes.p);
+    TRY(p->w0.alloc((size_t)nprobes + 64));
+    HIP_TRY(hipMemsetAsync(p->w0.p, 0, sizeof(uint2) * (nprobes + 64), s));
+    const u32 mask0 = (p->pwords == 1 && (p->L & 31)) ? ((1u << (p->L & 31)) - 1u) : 0xffffffffu;
+    if (nprobes)
+        hipLaunchKernelGGL(probe_w0_kernel, dim3((unsigned)div_up(nprobes, 256)), dim3(256), 0, s, p->planes.p,
+                           nprobes, p->pwords, mask0, p->w0.p);
+    return 0;
+}
+
 extern "C" int catchhip_probes_create(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off,
                                       i64 nprobes, const i32 *set_id, const i32 *ent_probe,
                                       const i32 *ent_pos, i64 nent, i32 k, catchhip_probes **out) {
@@ -473,20 +495,7 @@ extern "C" int catchhip_probes_create(catchhip_ctx *ctx, const u8 *bytes, const 
                 break;
             }
         }
-        if (p->dna5 && p->L > 0 && p->L <= 256) {
-            p->pwords = (p->L + 31) / 32;
-            size_t nw = (size_t)nprobes * p->pwords * 4;
-            if ((rc = p->planes.alloc(nw + 1024))) break;
-            if (hipMemsetAsync(p->planes.p, 0, sizeof(u32) * (nw + 1024), s) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
-            unsigned blocks = (unsigned)div_up(nprobes, 4);
-            hipLaunchKernelGGL(pack_probes_kernel, dim3(blocks), dim3(256), 0, s, p->bytes.p, p->probe_off.p,
-                               nprobes, p->pwords, p->planes.p);
-            if ((rc = p->w0.alloc((size_t)nprobes + 64))) break;
-            if (hipMemsetAsync(p->w0.p, 0, sizeof(uint2) * (nprobes + 64), s) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
-            const u32 mask0 = (p->pwords == 1 && (p->L & 31)) ? ((1u << (p->L & 31)) - 1u) : 0xffffffffu;
-            hipLaunchKernelGGL(probe_w0_kernel, dim3((unsigned)div_up(nprobes, 256)), dim3(256), 0, s, p->planes.p,
-                               nprobes, p->pwords, mask0, p->w0.p);
-        }
+        if ((rc = chip_probes_pack_planes(p))) break;
         if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
             chip_set_error("probes pack failed");
             rc = CATCHHIP_EHIP;

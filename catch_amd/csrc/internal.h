@@ -183,6 +183,9 @@ struct catchhip_probes {
     DevBuf<uint2> w0;        // [probe] word 0 of planes 0/1 (the scan's 32-base filter), masked to L
 };
 
+// planes + word-0 image of equal-length DNA probes from p->bytes / p->probe_off (core.hip)
+int chip_probes_pack_planes(catchhip_probes *p);
+
 // rows: cover intervals in GLOBAL coordinates of a targets object
 struct catchhip_rows {
     catchhip_ctx *ctx = nullptr;

@@ -165,6 +165,7 @@ class Targets:
         self.nseq = len(seqs)
         self.ngenomes = len(genomes)
         self.total = int(off[-1])
+        self.seq_off = off      # global start of every sequence (+ total)
         self._h = ctypes.c_void_p()
         check(ctx._L.catchhip_targets_create(
             ctx._h, _ptr(buf, c_u8p), _ptr(off, c_i64p), _ptr(sgn, c_i32p),
@@ -225,6 +226,69 @@ class Probes:
     def close(self):
         if self._h:
             self.ctx._L.catchhip_probes_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Candidates:
+    """Unique candidate probes of a Targets object, on the device
+    (catchhip_candidates): sliding windows + exact de-duplication."""
+
+    def __init__(self, ctx, targets, probe_length, probe_stride,
+                 seq_length_to_skip=None):
+        self.ctx = ctx
+        self.targets = targets          # keeps the targets alive
+        self.L = int(probe_length)
+        self._h = ctypes.c_void_p()
+        nc, nu = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(ctx._L.catchhip_candidates_create(
+            ctx._h, targets._h, self.L, int(probe_stride),
+            -1 if seq_length_to_skip is None else int(seq_length_to_skip),
+            ctypes.byref(self._h), ctypes.byref(nc), ctypes.byref(nu)))
+        self.ncandidates, self.n = nc.value, nu.value
+
+    def positions(self, ids=None):
+        """Global start (concatenated target coordinate) of unique candidates
+        `ids` (default: all)."""
+        if ids is None:
+            n, idp = self.n, None
+        else:
+            ids = np.ascontiguousarray(ids, dtype=np.int64)
+            n, idp = int(ids.size), _ptr(ids, c_i64p)
+        out = np.zeros(max(n, 1), dtype=np.int64)
+        check(self.ctx._L.catchhip_candidates_fetch(
+            self.ctx._h, self._h, idp, n, _ptr(out, c_i64p)))
+        return out[:n]
+
+    def probes(self, k, ent_probe=None, ent_pos=None):
+        """Probes object of the unique candidates; anchors given (sorted by
+        (probe, position), unique) or the pigeonhole table when omitted."""
+        p = Probes.__new__(Probes)
+        p.ctx, p.n = self.ctx, self.n
+        p._h = ctypes.c_void_p()
+        if ent_probe is None:
+            check(self.ctx._L.catchhip_probes_from_candidates(
+                self.ctx._h, self._h, None, None, 0, int(k), ctypes.byref(p._h)))
+        else:
+            ep = np.ascontiguousarray(ent_probe, dtype=np.int32)
+            eo = np.ascontiguousarray(ent_pos, dtype=np.int32)
+            nent = int(ep.size)
+            if nent == 0:
+                ep = np.zeros(1, np.int32)
+                eo = np.zeros(1, np.int32)
+            check(self.ctx._L.catchhip_probes_from_candidates(
+                self.ctx._h, self._h, _ptr(ep, c_i32p), _ptr(eo, c_i32p), nent,
+                int(k), ctypes.byref(p._h)))
+        return p
+
+    def close(self):
+        if self._h:
+            self.ctx._L.catchhip_candidates_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):

@@ -327,6 +327,39 @@ int catchhip_probes_set_groups(catchhip_ctx *ctx, catchhip_probes *probes,
 int catchhip_targets_set_groups(catchhip_ctx *ctx, catchhip_targets *targets,
                                 const int32_t *group_of_genome);
 
+/* ---- candidate probes on the device (front end, next row #1) ---------------
+ * candidate_probes.make_candidate_probes_from_sequences over all sequences of a
+ * targets object, genome by genome (catch/filter/candidate_probes.py:21-182 as
+ * ProbeDesigner calls it, catch/filter/probe_designer.py:250-262: windows of
+ * probe_length every probe_stride bases, the window flush with the sequence end
+ * when the length is not a multiple of the stride, no window holding two or
+ * more consecutive 'N', and the windows flanking every run of >= 2 'N'),
+ * followed by DuplicateFilter (catch/filter/duplicate_filter.py:16-26: first
+ * occurrences, order kept).  The unique candidates stay on the device as
+ * positions in the targets; their index in first-occurrence order is the set id
+ * the set cover works with.  seq_length_to_skip < 0 = none; a sequence shorter
+ * than probe_length that is not skipped is an error, as in the reference
+ * (--small-seq-min is handled by the host's string path).  `targets` must
+ * outlive the candidates object. */
+typedef struct catchhip_candidates catchhip_candidates;
+int catchhip_candidates_create(catchhip_ctx *ctx, const catchhip_targets *targets,
+                               int32_t probe_length, int32_t probe_stride,
+                               int64_t seq_length_to_skip,
+                               catchhip_candidates **out, int64_t *ncandidates,
+                               int64_t *nunique);
+void catchhip_candidates_destroy(catchhip_candidates *cands);
+/* global_start[i] = position (in the targets' concatenated coordinate) of the
+ * first occurrence of unique candidate ids[i] (ids == NULL: candidates 0..n-1) */
+int catchhip_candidates_fetch(catchhip_ctx *ctx, const catchhip_candidates *cands,
+                              const int64_t *ids, int64_t n, int64_t *global_start);
+/* A probes object of the unique candidates (set id = candidate index), as
+ * catchhip_probes_create would build from their strings.  Anchors: sorted by
+ * (probe, position) without duplicates, or ent_probe = ent_pos = NULL for the
+ * pigeonhole table {0, k, 2k, ..} of every probe (k must divide probe_length). */
+int catchhip_probes_from_candidates(catchhip_ctx *ctx, const catchhip_candidates *cands,
+                                    const int32_t *ent_probe, const int32_t *ent_pos,
+                                    int64_t nent, int32_t k, catchhip_probes **out);
+
 #ifdef __cplusplus
 }
 #endif

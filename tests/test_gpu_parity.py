@@ -1154,3 +1154,93 @@ def test_union_of_groups_equals_per_group(ctx, oracle, monkeypatch, m, coverage,
     want = oracle.set_cover_filter(cands, groups, m, 100, coverage=coverage, cover_extension=ext)
     assert [sorted(u) for u in union] == [sorted(w) for w in want]
     assert sum(map(len, union)) > 50
+
+
+# ---------------------------------------------------------------- device front end
+def _rand_seq_with_n_runs(rnd, n):
+    s = [rnd.choice("ACGT") for _ in range(n)]
+    for _ in range(rnd.choice([0, 0, 1, 2, 5])):
+        a = rnd.randrange(0, n)
+        ln = rnd.choice([1, 1, 2, 3, 7, 40])
+        s[a:a + ln] = "N" * min(ln, n - a)
+    if rnd.random() < 0.2:
+        s[:3] = "NNN"
+    if rnd.random() < 0.2:
+        s[-2:] = "NN"
+    return "".join(s)
+
+
+@pytest.mark.parametrize("L,stride", [(100, 50), (75, 25), (60, 60), (80, 33), (20, 7)])
+def test_device_candidates_match_host_front_end(ctx, L, stride):
+    """catchhip_candidates_create == candidate_strings_from_sequences over the
+    genomes + dict.fromkeys (the reference's candidate order and duplicate
+    filter), incl. N runs, tails, flanking windows and repeated genomes."""
+    from catch_amd.filter import candidate_probes
+    engine = _engine()
+    rnd = random.Random(L * 1000 + stride)
+    g = load_golden("candidate_probes")
+    genomes = [[s] for s in g[0]["seqs"]]
+    for _ in range(25):
+        n = rnd.randrange(L, 900)
+        genomes.append([_rand_seq_with_n_runs(rnd, n) for _ in range(rnd.choice([1, 1, 2]))])
+    genomes.append(list(genomes[3]))           # a genome given twice: all its windows are duplicates
+    genomes.append(["ACGT" * 60])              # internal repeats
+    genomes.append(["N" * (L + 5)])            # nothing but N
+    genomes.append(["A" * L])                  # exactly one window
+    t = engine.Targets(ctx, genomes)
+    c = engine.Candidates(ctx, t, L, stride)
+    want_all = []
+    for gen in genomes:
+        want_all += candidate_probes.candidate_strings_from_sequences(list(gen), L, stride)
+    want = list(dict.fromkeys(want_all))
+    assert c.ncandidates == len(want_all) and c.n == len(want)
+    pos = c.positions()
+    flat = "".join(s for gen in genomes for s in gen)
+    assert [flat[p:p + L] for p in pos.tolist()] == want
+    sub = np.array([0, c.n - 1, c.n // 2], dtype=np.int64)
+    assert c.positions(sub).tolist() == pos[sub].tolist()
+    c.close()
+    # --small-seq-skip
+    skip = 300
+    c2 = engine.Candidates(ctx, t, L, stride, seq_length_to_skip=skip)
+    want2 = []
+    for gen in genomes:
+        if any(len(s) > skip for s in gen):
+            want2 += candidate_probes.candidate_strings_from_sequences(list(gen), L, stride,
+                                                                        seq_length_to_skip=skip)
+    assert c2.n == len(dict.fromkeys(want2)) and c2.ncandidates == len(want2)
+    c2.close()
+    t.close()
+    t3 = engine.Targets(ctx, [["ACGT" * 50], ["ACG"]])
+    with pytest.raises(ValueError):
+        engine.Candidates(ctx, t3, L, stride)
+    t3.close()
+
+
+@pytest.mark.parametrize("m,thres", [(2, 100), (5, 100), (3, 80)])
+def test_probes_from_device_candidates_scan_like_string_probes(ctx, m, thres):
+    """A probes object gathered from the device's candidates behaves exactly
+    like one built from the candidate strings (pigeonhole and given anchors)."""
+    engine, probe = _engine(), _probe_mod()
+    genomes = small_species(seed=21, n=5, length=2400, d1=0.04, d2=0.01)
+    t = engine.Targets(ctx, genomes)
+    c = engine.Candidates(ctx, t, 100, 50)
+    strs = candidates(genomes, 100, 50)
+    assert c.n == len(strs)
+    np.random.seed(2)
+    k, uniq, owner, ep, eo = probe.anchor_table(strs, m, thres, assume_unique=True)
+    p_str = engine.Probes(ctx, uniq, owner, ep, eo, k)
+    if m == 2:
+        p_dev = c.probes(k)                    # pigeonhole table generated on the device
+    else:
+        p_dev = c.probes(k, ep, eo)
+    outs = []
+    for p in (p_str, p_dev):
+        rows = engine.Rows.scan(ctx, p, t, m, thres, 0, 30)
+        outs.append(rows_as_tuples(*rows.fetch()))
+        rows.close()
+    assert outs[0] == outs[1] and len(outs[0]) > 100
+    ids0, _ = engine.setcover_filter(ctx, p_str, t, m, thres, 0, 30, len(strs))
+    ids1, _ = engine.setcover_filter(ctx, p_dev, t, m, thres, 0, 30, len(strs))
+    assert list(ids0) == list(ids1)
+    p_str.close(); p_dev.close(); c.close(); t.close()
