@@ -121,6 +121,13 @@ class ProbeDesigner:
         candidate (a design over 8,000 genomes spent 0.85 of its 1.0 s building
         them); only the selected probes become objects."""
         first, scf = filters
+        if self._device_front_end_ok(genomes, first, scf):
+            self._candidate_strs = None
+            self._candidate_genomes = genomes
+            chosen = scf._filter_genomes_device(
+                genomes, self.probe_length, self.probe_stride,
+                self.seq_length_to_skip)
+            return [[probe.Probe.from_str(s) for s in grp] for grp in chosen]
         cand = []
         for genomes_from_group in genomes:
             c = []
@@ -145,6 +152,38 @@ class ProbeDesigner:
         chosen = [[u[i] for i in sel] for u, sel in zip(uniq, ids)]
         return [[probe.Probe.from_str(s) for s in grp] for grp in chosen]
 
+    def _device_front_end_ok(self, genomes, first, scf):
+        """Candidates and the duplicate filter on the device: the default filter
+        pair without ranks, no --small-seq-min, every sequence a str at least a
+        probe long (or skipped), and groups that are few or large -- many small
+        groups (clusters) go through one instance on the string path."""
+        import os
+        if os.environ.get("CATCHHIP_HOST_FRONT_END"):
+            return False
+        if type(first) is not DuplicateFilter or self.allow_small_seqs:
+            return False
+        if scf.identify or scf.avoided_genomes:
+            return False
+        skip, L = self.seq_length_to_skip, self.probe_length
+        total, ngroups = 0, 0
+        for grp in genomes:
+            if len(grp) == 0:
+                continue
+            ngroups += 1
+            for g in grp:
+                for s in g.seqs:
+                    if not isinstance(s, str):
+                        return False
+                    n = len(s)
+                    if skip is not None and n <= skip:
+                        continue
+                    if n < L:
+                        return False      # the host path raises the reference's error
+                    total += n
+        if ngroups == 0:
+            return False
+        return ngroups < 8 or total >= 200000 * ngroups
+
     @staticmethod
     def _strings_path_ok(filters):
         return (len(filters) >= 2 and type(filters[0]) in (
@@ -154,6 +193,15 @@ class ProbeDesigner:
 
     @property
     def candidate_probes(self):
+        if (self._candidates is None and self._candidate_strs is None
+                and getattr(self, "_candidate_genomes", None) is not None):
+            # the device front end never built them: do it now, on request
+            self._candidate_strs = [
+                [s for g in grp for s in candidate_probes.candidate_strings_from_sequences(
+                    list(g.seqs), probe_length=self.probe_length,
+                    probe_stride=self.probe_stride,
+                    seq_length_to_skip=self.seq_length_to_skip)]
+                for grp in self._candidate_genomes]
         if self._candidates is None and self._candidate_strs is not None:
             self._candidates = [probe.Probe.from_str(s) for s in
                                 itertools.chain(*self._candidate_strs)]

@@ -285,6 +285,75 @@ class SetCoverFilter(BaseFilter):
         return selected
 
 
+    def _filter_genomes_device(self, target_genomes_grouped, probe_length,
+                               probe_stride, seq_length_to_skip=None):
+        """[DuplicateFilter, SetCoverFilter] with the front end on the device:
+        per group the candidate windows of its genomes are enumerated and
+        de-duplicated on the GPU (catchhip_candidates_create), gathered into a
+        probes object and solved; only the selected candidates are looked up
+        again, as slices of the host's sequence strings.  Returns the selected
+        probe strings per group, in pick order.  No ranks (identify / avoided
+        genomes need every candidate's string)."""
+        import os
+        assert not self.identify and not self.avoided_genomes
+        out = [[] for _ in target_genomes_grouped]
+        timings = dict(scan_ms=0.0, rows_ms=0.0, greedy_ms=0.0, picks=0,
+                       rows=0, scan_launches=0, greedy_launches=0,
+                       candidates=0, unique_candidates=0)
+        todo = [i for i, g in enumerate(target_genomes_grouped) if len(g) > 0]
+        width = max(1, int(os.environ.get("CATCHHIP_GROUPS_IN_FLIGHT", "4")))
+        for c0 in range(0, len(todo), width):
+            chunk = todo[c0:c0 + width]
+            ctxs = _contexts(len(chunk))
+            specs, held, cands_of = [], [], []
+            try:
+                for ctx, gi in zip(ctxs, chunk):
+                    target_genomes = target_genomes_grouped[gi]
+                    targets = engine.Targets(ctx, [g.seqs for g in target_genomes])
+                    held.append(targets)
+                    cands = engine.Candidates(ctx, targets, probe_length,
+                                              probe_stride, seq_length_to_skip)
+                    held.append(cands)
+                    cands_of.append((cands, targets, target_genomes))
+                    if cands.n == 0:
+                        logger.warning("There are no candidate probes for a "
+                                       "grouping of genomes")
+                    k, ep, eo = probe.anchor_entries_equal_length(
+                        cands.n, probe_length, self.mismatches, self.lcf_thres,
+                        min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
+                    probes = cands.probes(k, ep, eo)
+                    held.append(probes)
+                    timings["candidates"] += cands.ncandidates
+                    timings["unique_candidates"] += cands.n
+                    specs.append((ctx, probes, targets, cands.n, None,
+                                  self._make_universe_p(target_genomes)))
+                results = engine.setcover_filter_many(
+                    specs, self.mismatches, self.lcf_thres,
+                    self.island_of_exact_match, self.cover_extension,
+                    self.scan_mode)
+                for ctx, gi, (cands, targets, target_genomes), (ids, nrows) in zip(
+                        ctxs, chunk, cands_of, results):
+                    seqs = [s for g in target_genomes for s in g.seqs]
+                    pos = cands.positions(np.asarray(ids, dtype=np.int64))
+                    which = np.searchsorted(targets.seq_off, pos, side="right") - 1
+                    local = pos - targets.seq_off[which]
+                    out[gi] = [seqs[q][o:o + probe_length]
+                               for q, o in zip(which.tolist(), local.tolist())]
+                    ms, nl = ctx.kernel_ms(engine.PHASE_SCAN)
+                    timings["scan_ms"] += ms
+                    timings["scan_launches"] += nl
+                    timings["rows_ms"] += ctx.kernel_ms(engine.PHASE_ROWS)[0]
+                    timings["rows"] += nrows
+                    ms, nl = ctx.kernel_ms(engine.PHASE_GREEDY)
+                    timings["greedy_ms"] += ms
+                    timings["greedy_launches"] += nl
+                    timings["picks"] += len(ids)
+            finally:
+                for h in reversed(held):
+                    h.close()
+        self.last_timings = timings
+        return out
+
     def _filter_strs_union(self, input_strs, target_genomes_grouped, todo,
                            selected, timings, max_bases=1 << 30,
                            max_candidates=1 << 24):

@@ -193,3 +193,26 @@ def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
     if with_draws:
         return kk, uniq, owner, ent_probe, ent_pos, draws
     return kk, uniq, owner, ent_probe, ent_pos
+
+
+def anchor_entries_equal_length(nprobes, probe_length, mismatches, lcf_thres,
+                                min_k=20, k=20, num_kmers_per_probe=20):
+    """anchor_table for `nprobes` DISTINCT probes of one length without looking
+    at their strings (the device front end never materialises them): returns
+    (k, ent_probe, ent_pos) with ent_* = None for the pigeonhole table
+    {0, k, 2k, ..} of every probe.  Same rule and the same np.random draws as
+    anchor_table(strs, ..., assume_unique=True)."""
+    L = probe_length
+    use_random = (mismatches is None or lcf_thres is None or lcf_thres < L)
+    if not use_random:
+        kk = pigeonhole_kmer_length(L, mismatches)
+        if kk >= min_k:
+            return kk, None, None
+    if k > L:
+        raise ValueError("k is larger than the length of a probe")
+    if nprobes == 0:
+        return k, np.zeros(0, np.int32), np.zeros(0, np.int32)
+    pos = np.random.randint(0, L - k + 1, size=(nprobes, num_kmers_per_probe))
+    pi = np.arange(nprobes, dtype=np.int64)
+    keys = np.unique(((pi[:, None] << 32) | pos).ravel())
+    return k, (keys >> 32).astype(np.int32), (keys & 0xffffffff).astype(np.int32)
