@@ -12,6 +12,9 @@ from collections import OrderedDict
 from catch_amd import genome
 
 _DEGENERATE = re.compile("[YRWSMKBDHV]")
+# the same substitutions as one C-level pass per line (str.translate)
+_DEG_TO_N = str.maketrans("YRWSMKBDHV", "N" * 10)
+_DEG_TO_N_NO_GAPS = str.maketrans("YRWSMKBDHV", "N" * 10, "-")
 
 
 def _open(fn):
@@ -37,9 +40,11 @@ def read_fasta(fn, replace_degenerate=True, skip_gaps=True,
             else:
                 if make_uppercase:
                     line = line.upper()
-                if replace_degenerate:
-                    line = _DEGENERATE.sub("N", line)
-                if skip_gaps:
+                if replace_degenerate and skip_gaps:
+                    line = line.translate(_DEG_TO_N_NO_GAPS)
+                elif replace_degenerate:
+                    line = line.translate(_DEG_TO_N)
+                elif skip_gaps:
                     line = line.replace("-", "")
                 m[curr].append(line)
     return OrderedDict((k, "".join(v)) for k, v in m.items())
@@ -64,7 +69,7 @@ def iterate_fasta(fn, replace_degenerate=True):
                 parts = []
             else:
                 if replace_degenerate:
-                    line = _DEGENERATE.sub("N", line)
+                    line = line.translate(_DEG_TO_N)
                 if line:
                     parts.append(line)
         if parts:
