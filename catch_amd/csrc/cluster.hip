@@ -218,24 +218,19 @@ __global__ void sig_transpose_kernel(const u32 *__restrict__ sig, u32 nseq, u32 
     }
 }
 
-// common values met by the N-step merge walk of two ascending N-value lists
+// common values met by the N-step merge walk of two ascending N-value lists.
+// Branch-free: the three-way comparison of a divergent wavefront would run all
+// three paths every step (measured: 28-33 us per row of 6,000 walks, one
+// wavefront per CU, whether the values came from L2 or from LDS).
 template <typename FA, typename FB> __device__ __forceinline__ u32 walk_common(u32 N, FA a_at, FB b_at) {
     u32 ia = 0, ib = 0, common = 0;
-    u32 a = a_at(0), b = b_at(0);
     for (u32 step = 0; step < N; ++step) {
-        if (a < b) {
-            if (++ia == N) break;
-            a = a_at(ia);
-        } else if (a > b) {
-            if (++ib == N) break;
-            b = b_at(ib);
-        } else {
-            ++common;
-            ++ia; ++ib;
-            if (ia == N || ib == N) break;
-            a = a_at(ia);
-            b = b_at(ib);
-        }
+        const u32 act = (ia < N) & (ib < N);           // the reference's loop condition
+        const u32 a = a_at(min(ia, N - 1)), b = b_at(min(ib, N - 1));
+        const u32 lt = act & (a < b), gt = act & (a > b), eq = act & (a == b);
+        ia += lt | eq;
+        ib += gt | eq;
+        common += eq;
     }
     return common;
 }
@@ -249,6 +244,24 @@ __global__ __launch_bounds__(256) void sig_row_kernel(const u32 *__restrict__ si
     if (kq >= nseq) return;
     common[kq] = (uint16_t)walk_common(
         N, [&](u32 i) { return s_a[i]; }, [&](u32 i) { return sigT[(size_t)i * nseq + kq]; });
+}
+
+// The same with every thread's own signature staged in LDS first: the walk is a
+// chain of ~N dependent reads, 0.3 us each from L2 (28 us per row at N = 100)
+// against tens of ns from LDS; the staging loads are independent and coalesced
+// ([value][sequence] layout).  64 threads per workgroup, 64 * N * 4 bytes of LDS.
+__global__ __launch_bounds__(64) void sig_row_lds_kernel(const u32 *__restrict__ sig, const u32 *__restrict__ sigT,
+                                                         u32 nseq, u32 N, u32 j, uint16_t *__restrict__ common) {
+    extern __shared__ u32 s_mem[];
+    u32 *s_a = s_mem, *s_b = s_mem + N;   // s_b[i * 64 + lane]
+    for (u32 t = threadIdx.x; t < N; t += 64) s_a[t] = sig[(size_t)j * N + t];
+    const u32 kq = blockIdx.x * 64 + threadIdx.x;
+    const u32 kc = kq < nseq ? kq : nseq - 1;
+    for (u32 i = 0; i < N; ++i) s_b[i * 64 + threadIdx.x] = sigT[(size_t)i * nseq + kc];
+    __syncthreads();
+    if (kq >= nseq) return;
+    common[kq] = (uint16_t)walk_common(
+        N, [&](u32 i) { return s_a[i]; }, [&](u32 i) { return s_b[i * 64 + threadIdx.x]; });
 }
 
 __global__ __launch_bounds__(256) void sig_pairs_kernel(const u32 *__restrict__ sig, u32 nseq, u32 N, u32 T,
@@ -383,8 +396,12 @@ extern "C" int catchhip_sigs_common_row(catchhip_ctx *ctx, const catchhip_sigs *
     TRY(d.alloc(S->nseq));
     TRY(chip_pinned_reserve(ctx, sizeof(uint16_t) * (size_t)S->nseq));
     PhaseTimer tm(ctx, PHASE_NDF);
-    hipLaunchKernelGGL(sig_row_kernel, dim3((S->nseq + 255) / 256), dim3(256), sizeof(u32) * S->N, st,
-                       (const u32 *)S->sig.p, (const u32 *)S->sigT.p, S->nseq, S->N, j, d.p);
+    if (S->N <= 176)   // 65 * N * 4 bytes of LDS <= 45 KB
+        hipLaunchKernelGGL(sig_row_lds_kernel, dim3((S->nseq + 63) / 64), dim3(64), sizeof(u32) * 65 * (size_t)S->N, st,
+                           (const u32 *)S->sig.p, (const u32 *)S->sigT.p, S->nseq, S->N, j, d.p);
+    else
+        hipLaunchKernelGGL(sig_row_kernel, dim3((S->nseq + 255) / 256), dim3(256), sizeof(u32) * S->N, st,
+                           (const u32 *)S->sig.p, (const u32 *)S->sigT.p, S->nseq, S->N, j, d.p);
     tm.launch(1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ctx->h_big, d.p, sizeof(uint16_t) * (size_t)S->nseq, hipMemcpyDeviceToHost, st));

@@ -14,7 +14,14 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python /root/repo/bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+# the kernels outside the bench's hot path: clustering pre-step and the device front end
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cluster -- python /root/repo/tools/cluster_bench.py --scale 0.25 --cpu-sample 0 > $out/cluster_bench.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_frontend -- python /root/repo/tools/e2e_profile.py S4 0.5 > $out/frontend_e2e.txt 2>&1
 cd /root/repo
+for t in cluster frontend; do
+  f=$(ls -t $out/trace_$t/*/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && cp "$f" $out/${t}_kernel_stats.csv
+done
 OUT=$out python - <<'PY'
 import csv, glob, json, collections, shutil, os
 out = os.environ["OUT"]
