@@ -177,21 +177,34 @@ seed_init_kernel(unsigned long long *__restrict__ keys, u32 *__restrict__ cnt, u
 }
 
 // table build 2/3: give every used slot a contiguous range of ents[]
-// (one cursor atomic per 1024-slot workgroup: same-address atomics cost ~10 ns each)
-__global__ void __launch_bounds__(1024)
+// (one cursor atomic per 1024 slots: same-address atomics cost ~10 ns each).
+// 256 threads x 4 slots, not 1024 x 1: with other groups' kernels resident a
+// 16-wave workgroup waits for a whole CU's worth of free wave slots, and this
+// kernel then took milliseconds (S4, four groups in flight: 3.5 ms on average,
+// 33 ms at worst, 16 % of all kernel time).
+#define SA_SLOTS 1024
+__global__ void __launch_bounds__(256)
 seed_alloc_kernel(SeedTable t, u32 *__restrict__ cursor) {
-    __shared__ u32 s_part[16], s_base;
-    const u32 s = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u32 n = s <= t.mask ? t.cnt[s] : 0u;
+    __shared__ u32 s_part[4], s_base;
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 s0 = blockIdx.x * SA_SLOTS + threadIdx.x * 4;
+    uint4 n = make_uint4(0, 0, 0, 0);
+    if (s0 + 3 <= t.mask) n = *(const uint4 *)(t.cnt + s0);   // the table size is a multiple of 1024
+    const u32 mine = n.x + n.y + n.z + n.w;
     u32 total;
-    const u32 ex = wave_excl_scan(n, &total);
+    const u32 ex = wave_excl_scan(mine, &total);
     if (lane == 0) s_part[wave] = total;
     __syncthreads();
     u32 woff = 0, tot = 0;
-    for (int w = 0; w < 16; ++w) { if (w < (int)wave) woff += s_part[w]; tot += s_part[w]; }
+    for (int w = 0; w < 4; ++w) { if (w < (int)wave) woff += s_part[w]; tot += s_part[w]; }
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(cursor, tot) : 0u;
     __syncthreads();
-    if (s <= t.mask) t.range[s] = make_uint2(s_base + woff + ex, n);
+    if (s0 + 3 <= t.mask) {
+        const u32 b = s_base + woff + ex;
+        uint4 *r = (uint4 *)(t.range + s0);
+        r[0] = make_uint4(b, n.x, b + n.x, n.y);
+        r[1] = make_uint4(b + n.x + n.y, n.z, b + n.x + n.y + n.z, n.w);
+    }
 }
 
 // table build 3/3: drop the entries into their slot's range
@@ -700,7 +713,7 @@ static int seed_table_lookup_async(catchhip_ctx *ctx, const catchhip_probes *P, 
     hipLaunchKernelGGL(seed_count_kernel, eb, tb, 0, ctx->stream, (const uint4 *)P->planes.p,
                        (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p, nent, pos_limit,
                        P->pigeonhole ? (int)(P->L / k) : 0, k, (int)P->pwords, kb, t, S.slot_of.p);
-    hipLaunchKernelGGL(seed_alloc_kernel, dim3(capacity / 1024), dim3(1024), 0, ctx->stream, t, S.ctr.p);
+    hipLaunchKernelGGL(seed_alloc_kernel, dim3(capacity / SA_SLOTS), dim3(256), 0, ctx->stream, t, S.ctr.p);
     hipLaunchKernelGGL(seed_fill_kernel, eb, tb, 0, ctx->stream, nent, t, (const u32 *)S.slot_of.p);
     hipLaunchKernelGGL(seed_lookup_kernel, dim3((unsigned)div_up(T->total, SL_TILE)), dim3(SL_THREADS), 0, ctx->stream,
                        (const u32 *)T->planes.p, T->nwords, (u32)T->total, (const u32 *)T->seq_off.p,
