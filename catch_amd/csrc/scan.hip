@@ -903,7 +903,7 @@ static int bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, cons
                                   3 * BK_BIG * (int)sizeof(u32));
         big_attr_set = true;
     }
-    hipLaunchKernelGGL(bucket_merge_big_kernel, dim3((unsigned)ctx->num_cus), dim3(1024), 3 * BK_BIG * sizeof(u32), s,
+    hipLaunchKernelGGL(bucket_merge_big_kernel, dim3((unsigned)ctx->num_cus), dim3(BKB_THREADS), 3 * BK_BIG * sizeof(u32), s,
                        (const u32 *)B.bstart.p, B.nb, B.S.p, B.mcnt.p, B.blmax.p, bsum,
                        B.res.p + 1, dedupe ? 1 : 0);
     tm.launch(3);
