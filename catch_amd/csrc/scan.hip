@@ -865,7 +865,8 @@ static int bucket_scan(catchhip_ctx *ctx, BucketBuild &B, const u32 *in, u32 *ou
                        const u32 *aux, u32 *auxmax_out, PhaseTimer &tm) {
     hipStream_t s = ctx->stream;
     if (n <= 16384) {
-        hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, s, in, out, n, total_out, (u32 *)nullptr, aux,
+        static const int s1t = getenv("CATCHHIP_SCAN1_THREADS") ? atoi(getenv("CATCHHIP_SCAN1_THREADS")) : 1024;
+        hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(s1t), 0, s, in, out, n, total_out, (u32 *)nullptr, aux,
                            auxmax_out);
         tm.launch(1);
         return 0;
