@@ -82,7 +82,7 @@ __device__ __forceinline__ u32 md5_block_mod_p(const u32 (&M)[16]) {
     a += 0x67452301u; b += 0xefcdab89u; c += 0x98badcfeu; d += 0x10325476u;
     const u64 wa = __builtin_bswap32(a), wb = __builtin_bswap32(b), wc = __builtin_bswap32(c),
               wd = __builtin_bswap32(d);
-    return (u32)((8 * wa + 4 * wb + 2 * wc + wd) % MD5_P);
+    return mod_mersenne31(8 * wa + 4 * wb + 2 * wc + wd);
 }
 
 __global__ __launch_bounds__(KM_THREADS) void kmer_md5_kernel(const u32 *__restrict__ words, u64 total, int k,
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(KM_THREADS) void kmer_md5_kernel(const u32 *__restr
         M[14] = (u32)k * 8u;
         M[15] = 0;
         const u64 x = md5_block_mod_p(M);
-        H[g] = (u32)(((u64)am * x + b) % MD5_P);
+        H[g] = mod_mersenne31((u64)am * x + b);
     }
 }
 

@@ -258,6 +258,15 @@ int chip_exclusive_scan_u32(catchhip_ctx *ctx, const u32 *in, u32 *out, i64 n,
 int chip_radix_sort_pairs(catchhip_ctx *ctx, DevBuf<u64> &keys, DevBuf<u64> &keys_alt,
                           DevBuf<u32> &vals, DevBuf<u32> &vals_alt, i64 n, int key_bits);
 
+// v mod (2^31 - 1) for v < 2^63 without a 64-bit division: 2^31 = 1 (mod p),
+// so the 31-bit digits of v add up (two folds leave at most p + 1)
+__host__ __device__ static inline u32 mod_mersenne31(u64 v) {
+    const u64 P = 0x7fffffffull;
+    u64 t = (v & P) + (v >> 31);      // < 2^33
+    t = (t & P) + (t >> 31);          // <= p + 3
+    return (u32)(t >= P ? t - P : t);
+}
+
 static inline int ceil_log2_u64(u64 x) {
     int b = 0;
     while (b < 64 && ((u64)1 << b) < x) ++b;
