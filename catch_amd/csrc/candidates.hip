@@ -38,6 +38,8 @@ struct catchhip_candidates {
     i32 L = 0;
     i64 ncand = 0, nuniq = 0;
     DevBuf<u32> upos;   // global start of every unique candidate, first-occurrence order
+    DevBuf<u32> mult;   // how many candidates equal each unique one (valid until a near-duplicate filter ran)
+    bool filtered = false;   // a near-duplicate filter replaced the list (multiplicity order, kept ones only)
 };
 
 #define CAND_NONE 0xffffffffu
@@ -188,21 +190,22 @@ __device__ __forceinline__ bool cand_same(const u8 *__restrict__ bytes, u32 a, u
 __global__ void __launch_bounds__(256)
 cand_dup_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ cpos, const u32 *__restrict__ vals,
                 const u32 *__restrict__ flag, const u32 *__restrict__ runid, const u32 *__restrict__ head, u32 n,
-                u32 L, u32 *__restrict__ keep) {
+                u32 L, u32 *__restrict__ keep, u32 *__restrict__ mult) {
     const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x > n) return;
     if (x == n) { keep[n] = 0; return; }
     const u32 c = vals[x];
     // runid is an exclusive sum of the start flags: a run's own start counts for its later elements only
     const u32 h = flag[x] ? x : head[runid[x] - 1];
-    u32 k = 1;
+    u32 k = 1, rep = c;   // rep: the earliest candidate with these characters
     if (x != h) {
-        if (cand_same(bytes, cpos[c], cpos[vals[h]], L)) k = 0;
+        if (cand_same(bytes, cpos[c], cpos[vals[h]], L)) { k = 0; rep = vals[h]; }
         else
-            for (u32 y = x; y-- > h + 1;)   // different strings under one hash: look at the others
-                if (cand_same(bytes, cpos[c], cpos[vals[y]], L)) { k = 0; break; }
+            for (u32 y = h + 1; y < x; ++y)   // different strings under one hash: look at the others, earliest first
+                if (cand_same(bytes, cpos[c], cpos[vals[y]], L)) { k = 0; rep = vals[y]; break; }
     }
     keep[c] = k;
+    atomicAdd(&mult[rep], 1u);   // multiplicity of the unique candidate (the near-duplicate filters' priority)
 }
 
 __global__ void __launch_bounds__(256)
@@ -310,18 +313,24 @@ static int candidates_build(catchhip_ctx *ctx, const catchhip_targets *T, u32 L,
     // runid (exclusive) of a run start = index of its run
     hipLaunchKernelGGL(cand_runhead_kernel, dim3((unsigned)div_up((i64)ncand, 256)), dim3(256), 0, s,
                        (const u32 *)rflag.p, (const u32 *)runid.p, ncand, head.p);
+    DevBuf<u32> cmult;
     TRY(keep.alloc((size_t)ncand + 1));
+    TRY(cmult.alloc((size_t)ncand + 1));
+    HIP_TRY(hipMemsetAsync(cmult.p, 0, sizeof(u32) * ((size_t)ncand + 1), s));
     hipLaunchKernelGGL(cand_dup_kernel, dim3((unsigned)div_up((i64)ncand + 1, 256)), dim3(256), 0, s,
                        (const u8 *)T->bytes.p, (const u32 *)cpos.p, (const u32 *)vals.p, (const u32 *)rflag.p,
-                       (const u32 *)runid.p, (const u32 *)head.p, ncand, L, keep.p);
+                       (const u32 *)runid.p, (const u32 *)head.p, ncand, L, keep.p, cmult.p);
     TRY(cand_scan(ctx, keep, kat, (i64)ncand + 1, tmp));
     u32 nuniq = 0;
     TRY(cand_read_u32(ctx, kat.p + ncand, &nuniq));
     C->nuniq = nuniq;
     TRY(C->upos.alloc((size_t)nuniq + 1));
+    TRY(C->mult.alloc((size_t)nuniq + 1));
     hipLaunchKernelGGL(cand_compact_kernel, dim3((unsigned)div_up((i64)ncand, 256)), dim3(256), 0, s,
                        (const u32 *)cpos.p, (const u32 *)keep.p, (const u32 *)kat.p, ncand, C->upos.p);
-    tm.launch(40);
+    hipLaunchKernelGGL(cand_compact_kernel, dim3((unsigned)div_up((i64)ncand, 256)), dim3(256), 0, s,
+                       (const u32 *)cmult.p, (const u32 *)keep.p, (const u32 *)kat.p, ncand, C->mult.p);
+    tm.launch(41);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     tm.finish();
@@ -381,6 +390,111 @@ extern "C" int catchhip_candidates_fetch(catchhip_ctx *ctx, const catchhip_candi
         global_start[i] = h[(size_t)id];
     }
     return 0;
+}
+
+// ---- near-duplicate filters on the device's candidates ------------------------
+__global__ void __launch_bounds__(256)
+cand_multkey_kernel(const u32 *__restrict__ mult, u32 n, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = (u64)(0xffffffffu - mult[i]);   // ascending = multiplicity descending; the sort is stable
+    vals[i] = i;
+}
+
+__global__ void __launch_bounds__(256)
+cand_permute_kernel(const u32 *__restrict__ upos, const u32 *__restrict__ order, u32 n, u32 *__restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = upos[order[i]];
+}
+
+__global__ void __launch_bounds__(256)
+cand_rows_kernel(const u8 *__restrict__ tbytes, const u32 *__restrict__ pos, u32 n, u32 L, u8 *__restrict__ out) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (u64)n * L) return;
+    const u32 i = (u32)(t / L), j = (u32)(t - (u64)i * L);
+    out[t] = tbytes[pos[i] + j];
+}
+
+// the unique candidates in the near-duplicate filters' priority order (multiplicity
+// descending, ties in first-occurrence order: near_duplicate_filter.py:60-66) and
+// their characters as rows
+static int cand_priority_rows(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<u32> &opos, DevBuf<u8> &rows) {
+    hipStream_t s = ctx->stream;
+    const u32 n = (u32)C->nuniq, L = (u32)C->L;
+    DevBuf<u64> keys, keys_alt;
+    DevBuf<u32> vals, vals_alt;
+    TRY(keys.alloc(n));
+    TRY(vals.alloc(n));
+    hipLaunchKernelGGL(cand_multkey_kernel, dim3((unsigned)div_up((i64)n, 256)), dim3(256), 0, s,
+                       (const u32 *)C->mult.p, n, keys.p, vals.p);
+    TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, 32));
+    TRY(opos.alloc((size_t)n + 1));
+    hipLaunchKernelGGL(cand_permute_kernel, dim3((unsigned)div_up((i64)n, 256)), dim3(256), 0, s,
+                       (const u32 *)C->upos.p, (const u32 *)vals.p, n, opos.p);
+    TRY(rows.alloc((size_t)n * L + 64));
+    HIP_TRY(hipMemsetAsync(rows.p + (size_t)n * L, 0, 64, s));
+    hipLaunchKernelGGL(cand_rows_kernel, dim3((unsigned)div_up((i64)n * L, 256)), dim3(256), 0, s,
+                       (const u8 *)C->T->bytes.p, (const u32 *)opos.p, n, L, rows.p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// keep[] (host) -> the candidate list becomes the kept ones, in priority order
+static int cand_apply_keep(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<u32> &opos, const std::vector<u8> &keep,
+                           i64 *nkept) {
+    hipStream_t s = ctx->stream;
+    const u32 n = (u32)C->nuniq;
+    std::vector<u32> h((size_t)n + 1, 0);
+    for (u32 i = 0; i < n; ++i) h[i] = keep[i] ? 1u : 0u;
+    DevBuf<u32> flag, at, tmp, out;
+    TRY(flag.alloc((size_t)n + 1));
+    HIP_TRY(hipMemcpyAsync(flag.p, h.data(), sizeof(u32) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
+    TRY(cand_scan(ctx, flag, at, (i64)n + 1, tmp));
+    u32 nk = 0;
+    TRY(cand_read_u32(ctx, at.p + n, &nk));
+    TRY(out.alloc((size_t)nk + 1));
+    hipLaunchKernelGGL(cand_compact_kernel, dim3((unsigned)div_up((i64)n, 256)), dim3(256), 0, s,
+                       (const u32 *)opos.p, (const u32 *)flag.p, (const u32 *)at.p, n, out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    C->upos.swap(out);
+    C->nuniq = nk;
+    C->filtered = true;
+    if (nkept) *nkept = nk;
+    return 0;
+}
+
+extern "C" int catchhip_candidates_ndf_hamming(catchhip_ctx *ctx, catchhip_candidates *C, const i32 *positions,
+                                               i32 ntables, i32 k, i32 dist_thres, i64 *nkept) {
+    ARG_CHECK(ctx && C && C->ctx == ctx && positions && ntables >= 1 && k >= 1);
+    PoolScope pool_scope(ctx);
+    if (C->filtered) { chip_set_error("candidates: a near-duplicate filter was already applied"); return CATCHHIP_EINVAL; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (C->nuniq == 0) { C->filtered = true; if (nkept) *nkept = 0; return 0; }
+    DevBuf<u32> opos;
+    DevBuf<u8> rows;
+    TRY(cand_priority_rows(ctx, C, opos, rows));
+    std::vector<u8> keep((size_t)C->nuniq, 0);
+    TRY(chip_ndf_hamming_device(ctx, rows.p, C->nuniq, C->L, positions, ntables, k, dist_thres, keep.data()));
+    return cand_apply_keep(ctx, C, opos, keep, nkept);
+}
+
+extern "C" int catchhip_candidates_ndf_minhash(catchhip_ctx *ctx, catchhip_candidates *C, i32 kmer_size,
+                                               const i64 *ab, i32 ntables, i32 k, double dist_thres, i64 *nkept) {
+    ARG_CHECK(ctx && C && C->ctx == ctx && ab && ntables >= 1 && k >= 1);
+    PoolScope pool_scope(ctx);
+    if (C->filtered) { chip_set_error("candidates: a near-duplicate filter was already applied"); return CATCHHIP_EINVAL; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (C->nuniq == 0) { C->filtered = true; if (nkept) *nkept = 0; return 0; }
+    DevBuf<u32> opos;
+    DevBuf<u8> rows;
+    TRY(cand_priority_rows(ctx, C, opos, rows));
+    std::vector<i64> off((size_t)C->nuniq + 1);
+    for (i64 i = 0; i <= C->nuniq; ++i) off[(size_t)i] = i * C->L;
+    std::vector<u8> keep((size_t)C->nuniq, 0);
+    TRY(chip_ndf_minhash_device(ctx, rows.p, off.data(), C->nuniq, kmer_size, ab, ntables, k, dist_thres,
+                                keep.data()));
+    return cand_apply_keep(ctx, C, opos, keep, nkept);
 }
 
 extern "C" int catchhip_probes_from_candidates(catchhip_ctx *ctx, const catchhip_candidates *C, const i32 *ent_probe,

@@ -186,6 +186,14 @@ struct catchhip_probes {
 // planes + word-0 image of equal-length DNA probes from p->bytes / p->probe_off (core.hip)
 int chip_probes_pack_planes(catchhip_probes *p);
 
+// near-duplicate filters on probes already on the device (ndf.hip): n rows of L
+// characters / rows at probe_off[] (>= 16 bytes of slack after the last one);
+// keep[] is a host array
+int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, const i32 *positions, i32 ntables,
+                            i32 k, i32 dist_thres, u8 *keep);
+int chip_ndf_minhash_device(catchhip_ctx *ctx, const u8 *d_rows, const i64 *probe_off, i64 n, i32 kmer_size,
+                            const i64 *ab, i32 ntables, i32 k, double dist_thres, u8 *keep);
+
 // rows: cover intervals in GLOBAL coordinates of a targets object
 struct catchhip_rows {
     catchhip_ctx *ctx = nullptr;

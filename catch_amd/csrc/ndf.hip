@@ -139,38 +139,36 @@ static int ndf_resolve(catchhip_ctx *ctx, u32 nn, u32 ne, DevBuf<u32> &e_i, DevB
     return 0;
 }
 
-extern "C" int catchhip_ndf_hamming(catchhip_ctx *ctx, const u8 *bytes, i64 n, i32 L, const i32 *positions,
-                                    i32 ntables, i32 k, i32 dist_thres, u8 *keep) {
+// the filter on probes whose characters are already on the device (n rows of L)
+int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, const i32 *positions, i32 ntables,
+                            i32 k, i32 dist_thres, u8 *keep) {
     ARG_CHECK(ctx && n >= 0 && L > 0 && ntables >= 1 && k >= 1 && positions);
-    PoolScope pool_scope(ctx);
     if (n == 0) return 0;
-    ARG_CHECK(bytes && keep);
+    ARG_CHECK(d_rows && keep);
     ARG_CHECK(n < ((i64)1 << 31) && n * (i64)L < ((i64)1 << 40));
     for (i64 t = 0; t < (i64)ntables * k; ++t) ARG_CHECK(positions[t] >= 0 && positions[t] < L);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const u32 nn = (u32)n;
-    DevBuf<u8> d_bytes;
+    struct { const u8 *p; } d_bytes = {d_rows};
     DevBuf<i32> d_pos;
     DevBuf<u64> keys, keys_alt;
     DevBuf<u32> vals, vals_alt, e_i, e_j, count, status, flags;
-    TRY(d_bytes.alloc((size_t)n * L));
     TRY(d_pos.alloc((size_t)ntables * k));
     TRY(keys.alloc(nn));
     TRY(vals.alloc(nn));
     TRY(count.alloc(2));
     TRY(status.alloc(nn));
     TRY(flags.alloc(nn));
-    HIP_TRY(hipMemcpyAsync(d_bytes.p, bytes, (size_t)n * L, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_pos.p, positions, sizeof(i32) * ntables * k, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(count.p, 0, 2 * sizeof(u32), s));
+    HIP_TRY(hipMemsetAsync(status.p, 0, sizeof(u32) * nn, s));
+    HIP_TRY(hipMemsetAsync(flags.p, 0, sizeof(u32) * nn, s));
     const int W = (L + 7) / 8;
     DevBuf<u64> padded;
     TRY(padded.alloc((size_t)n * W));
     hipLaunchKernelGGL(ndf_pad_kernel, dim3((unsigned)div_up((i64)n * W * 8, 256)), dim3(256), 0, s,
                        (const u8 *)d_bytes.p, (u32)n, (int)L, W * 8, (u8 *)padded.p);
-    HIP_TRY(hipMemcpyAsync(d_pos.p, positions, sizeof(i32) * ntables * k, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(count.p, 0, 2 * sizeof(u32), s));
-    HIP_TRY(hipMemsetAsync(status.p, 0, sizeof(u32) * nn, s));
-    HIP_TRY(hipMemsetAsync(flags.p, 0, sizeof(u32) * nn, s));
 
     PhaseTimer tm(ctx, PHASE_NDF);
     const unsigned nb = (unsigned)div_up(nn, 256);
@@ -198,6 +196,19 @@ extern "C" int catchhip_ndf_hamming(catchhip_ctx *ctx, const u8 *bytes, i64 n, i
         cap = ne;
     }
     return ndf_resolve(ctx, nn, ne, e_i, e_j, count, status, flags, tm, keep);
+}
+
+extern "C" int catchhip_ndf_hamming(catchhip_ctx *ctx, const u8 *bytes, i64 n, i32 L, const i32 *positions,
+                                    i32 ntables, i32 k, i32 dist_thres, u8 *keep) {
+    ARG_CHECK(ctx && n >= 0 && L > 0);
+    PoolScope pool_scope(ctx);
+    if (n == 0) return 0;
+    ARG_CHECK(bytes && keep && n * (i64)L < ((i64)1 << 40));
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf<u8> d_bytes;
+    TRY(d_bytes.alloc((size_t)n * L));
+    HIP_TRY(hipMemcpyAsync(d_bytes.p, bytes, (size_t)n * L, hipMemcpyHostToDevice, ctx->stream));
+    return chip_ndf_hamming_device(ctx, d_bytes.p, n, L, positions, ntables, k, dist_thres, keep);
 }
 
 // ------------------------------------------------------------------------
@@ -405,9 +416,10 @@ mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
     }
 }
 
+// bytes_on_device: `bytes` already lives on the device (>= probe_off[n] + 16 bytes allocated)
 static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off, i64 n, const i64 *group_off,
                             i64 ngroups, i32 kmer_size, const i64 *ab, i32 ntables, i32 k, double dist_thres,
-                            u8 *keep) {
+                            u8 *keep, bool bytes_on_device = false) {
     ARG_CHECK(ctx && n >= 0 && kmer_size >= 1 && kmer_size <= 16 && ntables >= 1 && k >= 1 && k <= 16 && ab);
     PoolScope pool_scope(ctx);
     if (n == 0) return 0;
@@ -440,10 +452,11 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
     hipStream_t s = ctx->stream;
     const u32 nn = (u32)n;
     const size_t total = (size_t)probe_off[n], nkm = h_koff[n];
-    DevBuf<u8> d_bytes;
+    DevBuf<u8> d_bytes_own;
     DevBuf<u64> d_ab, keys, keys_alt, id_hi, id_lo;
     DevBuf<u32> d_off, d_koff, xs, nuniq, sig, vals, vals_alt, e_i, e_j, count, status, flags, d_grp;
-    TRY(d_bytes.alloc(total + 16));
+    if (!bytes_on_device) TRY(d_bytes_own.alloc(total + 16));
+    struct { const u8 *p; } d_bytes = {bytes_on_device ? bytes : (const u8 *)d_bytes_own.p};
     TRY(d_ab.alloc((size_t)ngroups * ntables * k * 2));
     if (group_off) TRY(d_grp.alloc((size_t)n));
     TRY(d_off.alloc((size_t)n + 1));
@@ -462,7 +475,7 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
     TRY(count.alloc(2));
     TRY(status.alloc(nn));
     TRY(flags.alloc(nn));
-    HIP_TRY(hipMemcpyAsync(d_bytes.p, bytes, total, hipMemcpyHostToDevice, s));
+    if (!bytes_on_device) HIP_TRY(hipMemcpyAsync(d_bytes_own.p, bytes, total, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_ab.p, ab, sizeof(i64) * (size_t)ngroups * ntables * k * 2, hipMemcpyHostToDevice, s));
     if (group_off) HIP_TRY(hipMemcpyAsync(d_grp.p, h_grp.data(), sizeof(u32) * (size_t)n, hipMemcpyHostToDevice, s));
     const u32 *grp = group_off ? (const u32 *)d_grp.p : (const u32 *)nullptr;
@@ -523,4 +536,10 @@ extern "C" int catchhip_ndf_minhash_many(catchhip_ctx *ctx, const u8 *bytes, con
     ARG_CHECK(group_off && ngroups >= 1);
     return ndf_minhash_impl(ctx, bytes, probe_off, n, group_off, ngroups, kmer_size, ab, ntables, k, dist_thres,
                             keep);
+}
+
+// the MinHash filter on probes whose characters are already on the device
+int chip_ndf_minhash_device(catchhip_ctx *ctx, const u8 *d_rows, const i64 *probe_off, i64 n, i32 kmer_size,
+                            const i64 *ab, i32 ntables, i32 k, double dist_thres, u8 *keep) {
+    return ndf_minhash_impl(ctx, d_rows, probe_off, n, nullptr, 1, kmer_size, ab, ntables, k, dist_thres, keep, true);
 }

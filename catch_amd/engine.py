@@ -265,6 +265,25 @@ class Candidates:
             self.ctx._h, self._h, idp, n, _ptr(out, c_i64p)))
         return out[:n]
 
+    def ndf_hamming(self, positions, dist_thres):
+        """catchhip_candidates_ndf_hamming: the list becomes the candidates the
+        Hamming near-duplicate filter keeps, in its priority order."""
+        pos = np.ascontiguousarray(positions, dtype=np.int32)
+        nk = ctypes.c_int64(0)
+        check(self.ctx._L.catchhip_candidates_ndf_hamming(
+            self.ctx._h, self._h, _ptr(pos, c_i32p), pos.shape[0], pos.shape[1],
+            int(dist_thres), ctypes.byref(nk)))
+        self.n = nk.value
+
+    def ndf_minhash(self, kmer_size, params, dist_thres):
+        """catchhip_candidates_ndf_minhash; params[table][fn] = (a, b)."""
+        ab = np.ascontiguousarray(params, dtype=np.int64)
+        nk = ctypes.c_int64(0)
+        check(self.ctx._L.catchhip_candidates_ndf_minhash(
+            self.ctx._h, self._h, int(kmer_size), _ptr(ab, c_i64p), ab.shape[0],
+            ab.shape[1], float(dist_thres), ctypes.byref(nk)))
+        self.n = nk.value
+
     def probes(self, k, ent_probe=None, ent_pos=None):
         """Probes object of the unique candidates; anchors given (sorted by
         (probe, position), unique) or the pigeonhole table when omitted."""

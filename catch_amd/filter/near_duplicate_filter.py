@@ -90,6 +90,16 @@ class NearDuplicateFilterWithHammingDistance(NearDuplicateFilter):
                                                     self.dist_thres)
         return [s for s, kp in zip(order, keep) if kp]
 
+    def _apply_to_candidates(self, cands):
+        """The filter on an engine.Candidates object (device front end):
+        multiplicity order, filter and compaction all stay on the device."""
+        positions = self._draw_positions()
+        if cands.n == 0:
+            return
+        if cands.L != self.dim:
+            raise ValueError("Sequences must be of same length")
+        cands.ndf_hamming(positions, self.dist_thres)
+
 
 class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
     """catch/filter/near_duplicate_filter.py:159-190: MinHash family over
@@ -149,6 +159,16 @@ class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
         keep = engine.default_context().ndf_minhash(order, self.kmer_size, params,
                                                     self.dist_thres)
         return [s for s, kp in zip(order, keep) if kp]
+
+    def _apply_to_candidates(self, cands):
+        """The filter on an engine.Candidates object (device front end):
+        multiplicity order, filter and compaction all stay on the device."""
+        params = self._draw_params()
+        if cands.n == 0:
+            return
+        if cands.L < self.kmer_size:
+            raise AssertionError("k-mer size exceeds a sequence's length")
+        cands.ndf_minhash(self.kmer_size, params, self.dist_thres)
 
     def _filter_strs_many(self, groups):
         """_filter_strs for every group (the clusters of a clustered design),

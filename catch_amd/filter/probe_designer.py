@@ -126,7 +126,8 @@ class ProbeDesigner:
             self._candidate_genomes = genomes
             chosen = scf._filter_genomes_device(
                 genomes, self.probe_length, self.probe_stride,
-                self.seq_length_to_skip)
+                self.seq_length_to_skip,
+                None if type(first) is DuplicateFilter else first)
             return [[probe.Probe.from_str(s) for s in grp] for grp in chosen]
         cand = []
         for genomes_from_group in genomes:
@@ -153,14 +154,22 @@ class ProbeDesigner:
         return [[probe.Probe.from_str(s) for s in grp] for grp in chosen]
 
     def _device_front_end_ok(self, genomes, first, scf):
-        """Candidates and the duplicate filter on the device: the default filter
-        pair without ranks, no --small-seq-min, every sequence a str at least a
+        """Candidates and the duplicate (or near-duplicate) filter on the device:
+        one of the usual filter pairs without ranks, no --small-seq-min, every sequence a str at least a
         probe long (or skipped), and groups that are few or large -- many small
         groups (clusters) go through one instance on the string path."""
         import os
         if os.environ.get("CATCHHIP_HOST_FRONT_END"):
             return False
-        if type(first) is not DuplicateFilter or self.allow_small_seqs:
+        if self.allow_small_seqs:
+            return False
+        if type(first) is NearDuplicateFilterWithHammingDistance:
+            if first.dim != self.probe_length:
+                return False              # the host path raises the reference's error
+        elif type(first) is NearDuplicateFilterWithMinHash:
+            if not (first.kmer_size <= self.probe_length <= first.kmer_size + 255):
+                return False
+        elif type(first) is not DuplicateFilter:
             return False
         if scf.identify or scf.avoided_genomes:
             return False

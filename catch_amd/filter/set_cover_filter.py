@@ -286,8 +286,12 @@ class SetCoverFilter(BaseFilter):
 
 
     def _filter_genomes_device(self, target_genomes_grouped, probe_length,
-                               probe_stride, seq_length_to_skip=None):
-        """[DuplicateFilter, SetCoverFilter] with the front end on the device:
+                               probe_stride, seq_length_to_skip=None,
+                               near_duplicate_filter=None):
+        """[DuplicateFilter | near-duplicate filter, SetCoverFilter] with the
+        front end on the device (near_duplicate_filter: an LSH filter object to
+        apply to the unique candidates, in their multiplicity order, before the
+        set cover):
         per group the candidate windows of its genomes are enumerated and
         de-duplicated on the GPU (catchhip_candidates_create), gathered into a
         probes object and solved; only the selected candidates are looked up
@@ -314,6 +318,10 @@ class SetCoverFilter(BaseFilter):
                     cands = engine.Candidates(ctx, targets, probe_length,
                                               probe_stride, seq_length_to_skip)
                     held.append(cands)
+                    timings["candidates"] += cands.ncandidates
+                    timings["unique_candidates"] += cands.n
+                    if near_duplicate_filter is not None:
+                        near_duplicate_filter._apply_to_candidates(cands)
                     cands_of.append((cands, targets, target_genomes))
                     if cands.n == 0:
                         logger.warning("There are no candidate probes for a "
@@ -323,8 +331,6 @@ class SetCoverFilter(BaseFilter):
                         min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
                     probes = cands.probes(k, ep, eo)
                     held.append(probes)
-                    timings["candidates"] += cands.ncandidates
-                    timings["unique_candidates"] += cands.n
                     specs.append((ctx, probes, targets, cands.n, None,
                                   self._make_universe_p(target_genomes)))
                 results = engine.setcover_filter_many(

@@ -352,6 +352,20 @@ void catchhip_candidates_destroy(catchhip_candidates *cands);
  * first occurrence of unique candidate ids[i] (ids == NULL: candidates 0..n-1) */
 int catchhip_candidates_fetch(catchhip_ctx *ctx, const catchhip_candidates *cands,
                               const int64_t *ids, int64_t n, int64_t *global_start);
+/* NearDuplicateFilter._filter on the candidates (catch/filter/
+ * near_duplicate_filter.py:47-103; arguments as catchhip_ndf_hamming /
+ * catchhip_ndf_minhash): the unique candidates are taken in the filters'
+ * priority order -- multiplicity among ALL candidates descending, ties in
+ * first-occurrence order (:60-66) -- and the object's list becomes the kept
+ * ones in that order, which is the order the set cover filter then numbers
+ * them in.  At most one such call per candidates object. */
+int catchhip_candidates_ndf_hamming(catchhip_ctx *ctx, catchhip_candidates *cands,
+                                    const int32_t *positions, int32_t ntables,
+                                    int32_t k, int32_t dist_thres, int64_t *nkept);
+int catchhip_candidates_ndf_minhash(catchhip_ctx *ctx, catchhip_candidates *cands,
+                                    int32_t kmer_size, const int64_t *ab,
+                                    int32_t ntables, int32_t k, double dist_thres,
+                                    int64_t *nkept);
 /* A probes object of the unique candidates (set id = candidate index), as
  * catchhip_probes_create would build from their strings.  Anchors: sorted by
  * (probe, position) without duplicates, or ent_probe = ent_pos = NULL for the
