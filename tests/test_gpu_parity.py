@@ -1244,3 +1244,39 @@ def test_probes_from_device_candidates_scan_like_string_probes(ctx, m, thres):
     ids1, _ = engine.setcover_filter(ctx, p_dev, t, m, thres, 0, 30, len(strs))
     assert list(ids0) == list(ids1)
     p_str.close(); p_dev.close(); c.close(); t.close()
+
+
+@pytest.mark.parametrize("kind", ["hamming", "minhash"])
+def test_device_candidates_near_duplicate_filter_matches_string_path(ctx, oracle, kind):
+    """catchhip_candidates_ndf_* (multiplicities from the device's
+    de-duplication, priority order, filter on device-resident rows) == the
+    filter on the candidate strings == the oracle, kept candidates in the same
+    order; genomes repeated so that multiplicities differ."""
+    from catch_amd.filter import near_duplicate_filter as ndf
+    engine = _engine()
+    base = small_species(seed=31, n=6, length=2000, d1=0.04, d2=0.01)
+    genomes = base + [base[1], base[1], base[4]] + small_species(seed=32, n=2, length=900, d1=0.0, d2=0.02)
+    L, stride = 100, 25
+    strs = candidates(genomes, L, stride, dedup=False)
+    f = (ndf.NearDuplicateFilterWithHammingDistance(2, L) if kind == "hamming"
+         else ndf.NearDuplicateFilterWithMinHash(0.5))
+    random.seed(11)
+    want = f._filter_strs(strs)
+    t = engine.Targets(ctx, genomes)
+    c = engine.Candidates(ctx, t, L, stride)
+    random.seed(11)
+    f._apply_to_candidates(c)
+    pos = c.positions()
+    flat = "".join(s for g in genomes for s in g)
+    got = [flat[p:p + L] for p in pos.tolist()]
+    assert got == want and 0 < len(want) < len(set(strs))
+    random.seed(11)
+    if kind == "hamming":
+        positions = oracle.lsh_draw_positions(oracle.lsh_num_tables(2, L, 20), 20, L)
+        assert want == oracle.ndf_hamming(strs, 2, positions)
+    else:
+        params = oracle.minhash_draw_params(oracle.minhash_num_tables(0.5), 3)
+        assert want == oracle.ndf_minhash(strs, 0.5, params)
+    with pytest.raises(ValueError):
+        c.ndf_hamming([[0] * 20], 2)       # a second filter on the same candidates
+    c.close(); t.close()
