@@ -39,6 +39,9 @@ struct catchhip_candidates {
     i64 ncand = 0, nuniq = 0;
     DevBuf<u32> upos;   // global start of every unique candidate, first-occurrence order
     DevBuf<u32> mult;   // how many candidates equal each unique one (valid until a near-duplicate filter ran)
+    bool grouped = false;   // the targets carry groups: duplicates are only removed inside a group
+    i32 ngroups = 0;
+    DevBuf<u32> ugrp;   // group of every unique candidate (non-decreasing)
     bool filtered = false;   // a near-duplicate filter replaced the list (multiplicity order, kept ones only)
 };
 
@@ -145,11 +148,17 @@ cand_compact_kernel(const u32 *__restrict__ src, const u32 *__restrict__ flag, c
 
 __global__ void __launch_bounds__(256)
 cand_hash_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ cpos, u32 n, u32 L, u64 *__restrict__ keys,
-                 u32 *__restrict__ vals) {
+                 u32 *__restrict__ vals, const u32 *__restrict__ seq_off, u32 nseq, const i32 *__restrict__ seq_group,
+                 u32 *__restrict__ cgrp) {
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     const u8 *p = bytes + cpos[c];
     u64 h = 0x9e3779b97f4a7c15ull ^ (u64)L;
+    if (seq_group) {   // independent groups: equal windows of different groups are different candidates
+        const u32 g = (u32)seq_group[cand_find_segment(seq_off, nseq, cpos[c])];
+        cgrp[c] = g;
+        h = (h ^ (u64)g) * 0xff51afd7ed558ccdull;
+    }
     u32 j = 0;
     for (; j + 8 <= L; j += 8) {
         u64 w = 0;
@@ -190,7 +199,7 @@ __device__ __forceinline__ bool cand_same(const u8 *__restrict__ bytes, u32 a, u
 __global__ void __launch_bounds__(256)
 cand_dup_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ cpos, const u32 *__restrict__ vals,
                 const u32 *__restrict__ flag, const u32 *__restrict__ runid, const u32 *__restrict__ head, u32 n,
-                u32 L, u32 *__restrict__ keep, u32 *__restrict__ mult) {
+                u32 L, u32 *__restrict__ keep, u32 *__restrict__ mult, const u32 *__restrict__ cgrp) {
     const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x > n) return;
     if (x == n) { keep[n] = 0; return; }
@@ -199,10 +208,11 @@ cand_dup_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ cpos, cons
     const u32 h = flag[x] ? x : head[runid[x] - 1];
     u32 k = 1, rep = c;   // rep: the earliest candidate with these characters
     if (x != h) {
-        if (cand_same(bytes, cpos[c], cpos[vals[h]], L)) { k = 0; rep = vals[h]; }
+        const u32 g = cgrp ? cgrp[c] : 0u;
+        if ((!cgrp || cgrp[vals[h]] == g) && cand_same(bytes, cpos[c], cpos[vals[h]], L)) { k = 0; rep = vals[h]; }
         else
             for (u32 y = h + 1; y < x; ++y)   // different strings under one hash: look at the others, earliest first
-                if (cand_same(bytes, cpos[c], cpos[vals[y]], L)) { k = 0; rep = vals[y]; break; }
+                if ((!cgrp || cgrp[vals[y]] == g) && cand_same(bytes, cpos[c], cpos[vals[y]], L)) { k = 0; rep = vals[y]; break; }
     }
     keep[c] = k;
     atomicAdd(&mult[rep], 1u);   // multiplicity of the unique candidate (the near-duplicate filters' priority)
@@ -300,10 +310,15 @@ static int candidates_build(catchhip_ctx *ctx, const catchhip_targets *T, u32 L,
     // exact de-duplication
     DevBuf<u64> keys, keys_alt;
     DevBuf<u32> vals, vals_alt, rflag, runid, head, keep, kat;
+    DevBuf<u32> cgrp;
     TRY(keys.alloc(ncand));
     TRY(vals.alloc(ncand));
+    if (C->grouped) TRY(cgrp.alloc((size_t)ncand + 1));
+    const u32 *cg = C->grouped ? (const u32 *)cgrp.p : (const u32 *)nullptr;
     hipLaunchKernelGGL(cand_hash_kernel, dim3((unsigned)div_up((i64)ncand, 256)), dim3(256), 0, s,
-                       (const u8 *)T->bytes.p, (const u32 *)cpos.p, ncand, L, keys.p, vals.p);
+                       (const u8 *)T->bytes.p, (const u32 *)cpos.p, ncand, L, keys.p, vals.p,
+                       (const u32 *)T->seq_off.p, nseq, C->grouped ? (const i32 *)T->seq_group.p : (const i32 *)nullptr,
+                       cgrp.p);
     TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, ncand, 64));
     TRY(rflag.alloc((size_t)ncand + 1));
     hipLaunchKernelGGL(cand_runstart_kernel, dim3((unsigned)div_up((i64)ncand + 1, 256)), dim3(256), 0, s,
@@ -319,7 +334,7 @@ static int candidates_build(catchhip_ctx *ctx, const catchhip_targets *T, u32 L,
     HIP_TRY(hipMemsetAsync(cmult.p, 0, sizeof(u32) * ((size_t)ncand + 1), s));
     hipLaunchKernelGGL(cand_dup_kernel, dim3((unsigned)div_up((i64)ncand + 1, 256)), dim3(256), 0, s,
                        (const u8 *)T->bytes.p, (const u32 *)cpos.p, (const u32 *)vals.p, (const u32 *)rflag.p,
-                       (const u32 *)runid.p, (const u32 *)head.p, ncand, L, keep.p, cmult.p);
+                       (const u32 *)runid.p, (const u32 *)head.p, ncand, L, keep.p, cmult.p, cg);
     TRY(cand_scan(ctx, keep, kat, (i64)ncand + 1, tmp));
     u32 nuniq = 0;
     TRY(cand_read_u32(ctx, kat.p + ncand, &nuniq));
@@ -330,6 +345,11 @@ static int candidates_build(catchhip_ctx *ctx, const catchhip_targets *T, u32 L,
                        (const u32 *)cpos.p, (const u32 *)keep.p, (const u32 *)kat.p, ncand, C->upos.p);
     hipLaunchKernelGGL(cand_compact_kernel, dim3((unsigned)div_up((i64)ncand, 256)), dim3(256), 0, s,
                        (const u32 *)cmult.p, (const u32 *)keep.p, (const u32 *)kat.p, ncand, C->mult.p);
+    if (C->grouped) {
+        TRY(C->ugrp.alloc((size_t)nuniq + 1));
+        hipLaunchKernelGGL(cand_compact_kernel, dim3((unsigned)div_up((i64)ncand, 256)), dim3(256), 0, s,
+                           (const u32 *)cgrp.p, (const u32 *)keep.p, (const u32 *)kat.p, ncand, C->ugrp.p);
+    }
     tm.launch(41);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -359,6 +379,8 @@ extern "C" int catchhip_candidates_create(catchhip_ctx *ctx, const catchhip_targ
     C->ctx = ctx;
     C->T = T;
     C->L = probe_length;
+    C->grouped = T->has_groups;
+    C->ngroups = T->ngroups_set;
     int rc = T->total ? candidates_build(ctx, T, (u32)probe_length, (u32)probe_stride, seq_length_to_skip, C) : 0;
     if (rc) { delete C; return rc; }
     if (ncandidates) *ncandidates = C->ncand;
@@ -394,10 +416,12 @@ extern "C" int catchhip_candidates_fetch(catchhip_ctx *ctx, const catchhip_candi
 
 // ---- near-duplicate filters on the device's candidates ------------------------
 __global__ void __launch_bounds__(256)
-cand_multkey_kernel(const u32 *__restrict__ mult, u32 n, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+cand_multkey_kernel(const u32 *__restrict__ mult, const u32 *__restrict__ ugrp, u32 n, u64 *__restrict__ keys,
+                    u32 *__restrict__ vals) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    keys[i] = (u64)(0xffffffffu - mult[i]);   // ascending = multiplicity descending; the sort is stable
+    // ascending = (group,) multiplicity descending; the sort is stable
+    keys[i] = ((u64)(ugrp ? ugrp[i] : 0u) << 32) | (u64)(0xffffffffu - mult[i]);
     vals[i] = i;
 }
 
@@ -418,7 +442,8 @@ cand_rows_kernel(const u8 *__restrict__ tbytes, const u32 *__restrict__ pos, u32
 // the unique candidates in the near-duplicate filters' priority order (multiplicity
 // descending, ties in first-occurrence order: near_duplicate_filter.py:60-66) and
 // their characters as rows
-static int cand_priority_rows(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<u32> &opos, DevBuf<u8> &rows) {
+static int cand_priority_rows(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<u32> &opos, DevBuf<u8> &rows,
+                              DevBuf<u32> &ogrp) {
     hipStream_t s = ctx->stream;
     const u32 n = (u32)C->nuniq, L = (u32)C->L;
     DevBuf<u64> keys, keys_alt;
@@ -426,11 +451,17 @@ static int cand_priority_rows(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<
     TRY(keys.alloc(n));
     TRY(vals.alloc(n));
     hipLaunchKernelGGL(cand_multkey_kernel, dim3((unsigned)div_up((i64)n, 256)), dim3(256), 0, s,
-                       (const u32 *)C->mult.p, n, keys.p, vals.p);
-    TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, 32));
+                       (const u32 *)C->mult.p, C->grouped ? (const u32 *)C->ugrp.p : (const u32 *)nullptr, n, keys.p,
+                       vals.p);
+    TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, C->grouped ? 64 : 32));
     TRY(opos.alloc((size_t)n + 1));
     hipLaunchKernelGGL(cand_permute_kernel, dim3((unsigned)div_up((i64)n, 256)), dim3(256), 0, s,
                        (const u32 *)C->upos.p, (const u32 *)vals.p, n, opos.p);
+    if (C->grouped) {
+        TRY(ogrp.alloc((size_t)n + 1));
+        hipLaunchKernelGGL(cand_permute_kernel, dim3((unsigned)div_up((i64)n, 256)), dim3(256), 0, s,
+                           (const u32 *)C->ugrp.p, (const u32 *)vals.p, n, ogrp.p);
+    }
     TRY(rows.alloc((size_t)n * L + 64));
     HIP_TRY(hipMemsetAsync(rows.p + (size_t)n * L, 0, 64, s));
     hipLaunchKernelGGL(cand_rows_kernel, dim3((unsigned)div_up((i64)n * L, 256)), dim3(256), 0, s,
@@ -440,8 +471,8 @@ static int cand_priority_rows(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<
 }
 
 // keep[] (host) -> the candidate list becomes the kept ones, in priority order
-static int cand_apply_keep(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<u32> &opos, const std::vector<u8> &keep,
-                           i64 *nkept) {
+static int cand_apply_keep(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<u32> &opos, DevBuf<u32> &ogrp,
+                           const std::vector<u8> &keep, i64 *nkept) {
     hipStream_t s = ctx->stream;
     const u32 n = (u32)C->nuniq;
     std::vector<u32> h((size_t)n + 1, 0);
@@ -455,9 +486,16 @@ static int cand_apply_keep(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<u32
     TRY(out.alloc((size_t)nk + 1));
     hipLaunchKernelGGL(cand_compact_kernel, dim3((unsigned)div_up((i64)n, 256)), dim3(256), 0, s,
                        (const u32 *)opos.p, (const u32 *)flag.p, (const u32 *)at.p, n, out.p);
+    DevBuf<u32> gout;
+    if (C->grouped) {
+        TRY(gout.alloc((size_t)nk + 1));
+        hipLaunchKernelGGL(cand_compact_kernel, dim3((unsigned)div_up((i64)n, 256)), dim3(256), 0, s,
+                           (const u32 *)ogrp.p, (const u32 *)flag.p, (const u32 *)at.p, n, gout.p);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     C->upos.swap(out);
+    if (C->grouped) C->ugrp.swap(gout);
     C->nuniq = nk;
     C->filtered = true;
     if (nkept) *nkept = nk;
@@ -470,31 +508,77 @@ extern "C" int catchhip_candidates_ndf_hamming(catchhip_ctx *ctx, catchhip_candi
     PoolScope pool_scope(ctx);
     if (C->filtered) { chip_set_error("candidates: a near-duplicate filter was already applied"); return CATCHHIP_EINVAL; }
     HIP_TRY(hipSetDevice(ctx->device));
+    if (C->grouped) { chip_set_error("candidates_ndf_hamming: not available on grouped candidates"); return CATCHHIP_EINVAL; }
     if (C->nuniq == 0) { C->filtered = true; if (nkept) *nkept = 0; return 0; }
-    DevBuf<u32> opos;
+    DevBuf<u32> opos, ogrp;
     DevBuf<u8> rows;
-    TRY(cand_priority_rows(ctx, C, opos, rows));
+    TRY(cand_priority_rows(ctx, C, opos, rows, ogrp));
     std::vector<u8> keep((size_t)C->nuniq, 0);
     TRY(chip_ndf_hamming_device(ctx, rows.p, C->nuniq, C->L, positions, ntables, k, dist_thres, keep.data()));
-    return cand_apply_keep(ctx, C, opos, keep, nkept);
+    return cand_apply_keep(ctx, C, opos, ogrp, keep, nkept);
 }
 
-extern "C" int catchhip_candidates_ndf_minhash(catchhip_ctx *ctx, catchhip_candidates *C, i32 kmer_size,
-                                               const i64 *ab, i32 ntables, i32 k, double dist_thres, i64 *nkept) {
+static int cand_ndf_minhash(catchhip_ctx *ctx, catchhip_candidates *C, i32 kmer_size, const i64 *ab, i64 ngroups,
+                            i32 ntables, i32 k, double dist_thres, i64 *nkept) {
     ARG_CHECK(ctx && C && C->ctx == ctx && ab && ntables >= 1 && k >= 1);
     PoolScope pool_scope(ctx);
     if (C->filtered) { chip_set_error("candidates: a near-duplicate filter was already applied"); return CATCHHIP_EINVAL; }
     HIP_TRY(hipSetDevice(ctx->device));
     if (C->nuniq == 0) { C->filtered = true; if (nkept) *nkept = 0; return 0; }
-    DevBuf<u32> opos;
+    DevBuf<u32> opos, ogrp;
     DevBuf<u8> rows;
-    TRY(cand_priority_rows(ctx, C, opos, rows));
+    TRY(cand_priority_rows(ctx, C, opos, rows, ogrp));
     std::vector<i64> off((size_t)C->nuniq + 1);
     for (i64 i = 0; i <= C->nuniq; ++i) off[(size_t)i] = i * C->L;
+    std::vector<i64> goff;
+    if (C->grouped) {   // groups are runs of the priority order
+        std::vector<u32> hg((size_t)C->nuniq);
+        HIP_TRY(hipMemcpyAsync(hg.data(), ogrp.p, sizeof(u32) * (size_t)C->nuniq, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        goff.assign((size_t)ngroups + 1, 0);
+        for (i64 i = 0; i < C->nuniq; ++i) {
+            ARG_CHECK((i64)hg[(size_t)i] < ngroups);
+            goff[(size_t)hg[(size_t)i] + 1]++;
+        }
+        for (i64 g = 0; g < ngroups; ++g) goff[(size_t)g + 1] += goff[(size_t)g];
+    }
     std::vector<u8> keep((size_t)C->nuniq, 0);
-    TRY(chip_ndf_minhash_device(ctx, rows.p, off.data(), C->nuniq, kmer_size, ab, ntables, k, dist_thres,
-                                keep.data()));
-    return cand_apply_keep(ctx, C, opos, keep, nkept);
+    TRY(chip_ndf_minhash_device(ctx, rows.p, off.data(), C->nuniq, C->grouped ? goff.data() : nullptr,
+                                C->grouped ? ngroups : 1, kmer_size, ab, ntables, k, dist_thres, keep.data()));
+    return cand_apply_keep(ctx, C, opos, ogrp, keep, nkept);
+}
+
+extern "C" int catchhip_candidates_ndf_minhash(catchhip_ctx *ctx, catchhip_candidates *C, i32 kmer_size,
+                                               const i64 *ab, i32 ntables, i32 k, double dist_thres, i64 *nkept) {
+    ARG_CHECK(C);
+    if (C->grouped) {
+        chip_set_error("candidates_ndf_minhash: grouped candidates need one set of hash functions per group (..._many)");
+        return CATCHHIP_EINVAL;
+    }
+    return cand_ndf_minhash(ctx, C, kmer_size, ab, 1, ntables, k, dist_thres, nkept);
+}
+
+extern "C" int catchhip_candidates_ndf_minhash_many(catchhip_ctx *ctx, catchhip_candidates *C, i32 kmer_size,
+                                                    const i64 *ab, i64 ngroups, i32 ntables, i32 k,
+                                                    double dist_thres, i64 *nkept) {
+    ARG_CHECK(C);
+    if (!C->grouped || ngroups < C->ngroups) {
+        chip_set_error("candidates_ndf_minhash_many: the targets carry no groups, or more groups than hash function sets");
+        return CATCHHIP_EINVAL;
+    }
+    return cand_ndf_minhash(ctx, C, kmer_size, ab, ngroups, ntables, k, dist_thres, nkept);
+}
+
+extern "C" int catchhip_candidates_groups(catchhip_ctx *ctx, const catchhip_candidates *C, i32 *group_of_candidate) {
+    ARG_CHECK(ctx && C && C->ctx == ctx);
+    if (C->nuniq == 0) return 0;
+    ARG_CHECK(group_of_candidate);
+    if (!C->grouped) { memset(group_of_candidate, 0, sizeof(i32) * (size_t)C->nuniq); return 0; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(group_of_candidate, C->ugrp.p, sizeof(i32) * (size_t)C->nuniq, hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 extern "C" int catchhip_probes_from_candidates(catchhip_ctx *ctx, const catchhip_candidates *C, const i32 *ent_probe,
@@ -577,6 +661,14 @@ extern "C" int catchhip_probes_from_candidates(catchhip_ctx *ctx, const catchhip
                 rc = CATCHHIP_EHIP;
                 break;
             }
+        }
+        if (C->grouped) {   // the scans pair a probe only with its own group's genomes
+            if ((rc = p->group.alloc((size_t)n + 1))) break;
+            if (n && hipMemcpyAsync(p->group.p, C->ugrp.p, sizeof(u32) * (size_t)n, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                rc = CATCHHIP_EHIP;
+                break;
+            }
+            p->has_groups = true;
         }
         if ((rc = chip_probes_pack_planes(p))) break;
         if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {

@@ -539,6 +539,11 @@ extern "C" int catchhip_targets_set_groups(catchhip_ctx *ctx, catchhip_targets *
     if (!group_of_genome) { T->has_groups = false; return 0; }
     HIP_TRY(hipSetDevice(ctx->device));
     std::vector<i32> sg((size_t)T->nseq + 1, 0);
+    T->ngroups_set = 0;
+    for (i32 g = 0; g < T->ngenomes; ++g) {
+        ARG_CHECK(group_of_genome[g] >= 0);
+        T->ngroups_set = std::max(T->ngroups_set, group_of_genome[g] + 1);
+    }
     for (i64 s = 0; s < T->nseq; ++s) sg[(size_t)s] = group_of_genome[T->h_seq_genome[(size_t)s]];
     TRY(T->seq_group.alloc((size_t)T->nseq + 1));
     HIP_TRY(hipMemcpyAsync(T->seq_group.p, sg.data(), sizeof(i32) * ((size_t)T->nseq + 1), hipMemcpyHostToDevice,

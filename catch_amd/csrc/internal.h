@@ -145,6 +145,7 @@ struct catchhip_targets {
     DevBuf<i32> seq_genome;  // nseq
     bool has_groups = false;
     DevBuf<i32> seq_group;   // nseq: instance of the sequence's genome (catchhip_targets_set_groups)
+    i32 ngroups_set = 0;     // 1 + the largest group number
     DevBuf<u32> genome_off;  // ngenomes+1 global offset of each genome's first base
     i64 nwords = 0;          // 32-base words per plane (+ padding)
     DevBuf<u32> planes;      // 3 planes, SoA: plane b at planes + b*nwords
@@ -191,8 +192,9 @@ int chip_probes_pack_planes(catchhip_probes *p);
 // keep[] is a host array
 int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, const i32 *positions, i32 ntables,
                             i32 k, i32 dist_thres, u8 *keep);
-int chip_ndf_minhash_device(catchhip_ctx *ctx, const u8 *d_rows, const i64 *probe_off, i64 n, i32 kmer_size,
-                            const i64 *ab, i32 ntables, i32 k, double dist_thres, u8 *keep);
+int chip_ndf_minhash_device(catchhip_ctx *ctx, const u8 *d_rows, const i64 *probe_off, i64 n, const i64 *group_off,
+                            i64 ngroups, i32 kmer_size, const i64 *ab, i32 ntables, i32 k, double dist_thres,
+                            u8 *keep);
 
 // rows: cover intervals in GLOBAL coordinates of a targets object
 struct catchhip_rows {

@@ -558,7 +558,9 @@ extern "C" int catchhip_ndf_minhash_many(catchhip_ctx *ctx, const u8 *bytes, con
 }
 
 // the MinHash filter on probes whose characters are already on the device
-int chip_ndf_minhash_device(catchhip_ctx *ctx, const u8 *d_rows, const i64 *probe_off, i64 n, i32 kmer_size,
-                            const i64 *ab, i32 ntables, i32 k, double dist_thres, u8 *keep) {
-    return ndf_minhash_impl(ctx, d_rows, probe_off, n, nullptr, 1, kmer_size, ab, ntables, k, dist_thres, keep, true);
+int chip_ndf_minhash_device(catchhip_ctx *ctx, const u8 *d_rows, const i64 *probe_off, i64 n, const i64 *group_off,
+                            i64 ngroups, i32 kmer_size, const i64 *ab, i32 ntables, i32 k, double dist_thres,
+                            u8 *keep) {
+    return ndf_minhash_impl(ctx, d_rows, probe_off, n, group_off, ngroups, kmer_size, ab, ntables, k, dist_thres, keep,
+                            true);
 }

@@ -284,6 +284,24 @@ class Candidates:
             ab.shape[1], float(dist_thres), ctypes.byref(nk)))
         self.n = nk.value
 
+    def ndf_minhash_many(self, kmer_size, params, dist_thres):
+        """catchhip_candidates_ndf_minhash_many (grouped targets);
+        params[group][table][fn] = (a, b)."""
+        ab = np.ascontiguousarray(params, dtype=np.int64)
+        assert ab.ndim == 4
+        nk = ctypes.c_int64(0)
+        check(self.ctx._L.catchhip_candidates_ndf_minhash_many(
+            self.ctx._h, self._h, int(kmer_size), _ptr(ab, c_i64p), ab.shape[0],
+            ab.shape[1], ab.shape[2], float(dist_thres), ctypes.byref(nk)))
+        self.n = nk.value
+
+    def groups(self):
+        """Group of every unique candidate (zeros without grouped targets)."""
+        out = np.zeros(max(self.n, 1), dtype=np.int32)
+        check(self.ctx._L.catchhip_candidates_groups(self.ctx._h, self._h,
+                                                     _ptr(out, c_i32p)))
+        return out[:self.n]
+
     def probes(self, k, ent_probe=None, ent_pos=None):
         """Probes object of the unique candidates; anchors given (sorted by
         (probe, position), unique) or the pigeonhole table when omitted."""

@@ -121,13 +121,15 @@ class ProbeDesigner:
         candidate (a design over 8,000 genomes spent 0.85 of its 1.0 s building
         them); only the selected probes become objects."""
         first, scf = filters
-        if self._device_front_end_ok(genomes, first, scf):
+        mode = self._device_front_end_mode(genomes, first, scf)
+        if mode is not None:
             self._candidate_strs = None
             self._candidate_genomes = genomes
-            chosen = scf._filter_genomes_device(
-                genomes, self.probe_length, self.probe_stride,
-                self.seq_length_to_skip,
-                None if type(first) is DuplicateFilter else first)
+            run = (scf._filter_genomes_device if mode == "per group"
+                   else scf._filter_genomes_device_union)
+            chosen = run(genomes, self.probe_length, self.probe_stride,
+                         self.seq_length_to_skip,
+                         None if type(first) is DuplicateFilter else first)
             return [[probe.Probe.from_str(s) for s in grp] for grp in chosen]
         cand = []
         for genomes_from_group in genomes:
@@ -153,7 +155,7 @@ class ProbeDesigner:
         chosen = [[u[i] for i in sel] for u, sel in zip(uniq, ids)]
         return [[probe.Probe.from_str(s) for s in grp] for grp in chosen]
 
-    def _device_front_end_ok(self, genomes, first, scf):
+    def _device_front_end_mode(self, genomes, first, scf):
         """Candidates and the duplicate (or near-duplicate) filter on the device:
         one of the usual filter pairs without ranks, no --small-seq-min, every sequence a str at least a
         probe long (or skipped), and groups that are few or large -- many small
@@ -182,16 +184,20 @@ class ProbeDesigner:
             for g in grp:
                 for s in g.seqs:
                     if not isinstance(s, str):
-                        return False
+                        return None
                     n = len(s)
                     if skip is not None and n <= skip:
                         continue
                     if n < L:
-                        return False      # the host path raises the reference's error
+                        return None       # the host path raises the reference's error
                     total += n
         if ngroups == 0:
-            return False
-        return ngroups < 8 or total >= 200000 * ngroups
+            return None
+        if ngroups < 8 or total >= 200000 * ngroups:
+            return "per group"
+        if type(first) is NearDuplicateFilterWithHammingDistance:
+            return None
+        return "union"
 
     @staticmethod
     def _strings_path_ok(filters):

@@ -360,6 +360,93 @@ class SetCoverFilter(BaseFilter):
         self.last_timings = timings
         return out
 
+    def _filter_genomes_device_union(self, target_genomes_grouped, probe_length,
+                                     probe_stride, seq_length_to_skip=None,
+                                     near_duplicate_filter=None,
+                                     max_bases=1 << 30):
+        """_filter_genomes_device for many small groups (the clusters of a
+        clustered design): the groups of a chunk share one targets / candidates
+        / probes triple that carries group numbers -- duplicates are removed
+        inside a group only, the MinHash filter (if any) runs over all groups in
+        one pass with each group's own hash functions, the scan pairs a probe
+        with its own group's genomes only, and one greedy solve over the
+        disjoint union makes every group's own picks in its own order."""
+        assert not self.identify and not self.avoided_genomes
+        ngroups = len(target_genomes_grouped)
+        out = [[] for _ in range(ngroups)]
+        timings = dict(scan_ms=0.0, rows_ms=0.0, greedy_ms=0.0, picks=0,
+                       rows=0, scan_launches=0, greedy_launches=0,
+                       candidates=0, unique_candidates=0)
+        ctx = engine.default_context()
+        at = 0
+        while at < ngroups:
+            chunk, bases = [], 0
+            while at < ngroups:
+                b = sum(g.size() for g in target_genomes_grouped[at])
+                if chunk and bases + b > max_bases:
+                    break
+                chunk.append(at)
+                bases += b
+                at += 1
+            logger.info("Groups %d..%d of %d as one instance", chunk[0] + 1,
+                        chunk[-1] + 1, ngroups)
+            genomes = [g.seqs for gi in chunk for g in target_genomes_grouped[gi]]
+            ngen = [len(target_genomes_grouped[gi]) for gi in chunk]
+            seqs = [s for gs in genomes for s in gs]
+            universe_p = [p for gi in chunk
+                          for p in self._make_universe_p(target_genomes_grouped[gi])]
+            targets = engine.Targets(ctx, genomes)
+            cands = probes = None
+            try:
+                targets.set_groups(np.repeat(np.arange(len(chunk)), ngen))
+                cands = engine.Candidates(ctx, targets, probe_length,
+                                          probe_stride, seq_length_to_skip)
+                timings["candidates"] += cands.ncandidates
+                timings["unique_candidates"] += cands.n
+                if near_duplicate_filter is not None:
+                    # one set of hash functions per group, drawn in group order
+                    # as one _filter call per group would
+                    params = [near_duplicate_filter._draw_params()
+                              for _ in chunk]
+                    if cands.n:
+                        if cands.L < near_duplicate_filter.kmer_size:
+                            raise AssertionError(
+                                "k-mer size exceeds a sequence's length")
+                        cands.ndf_minhash_many(near_duplicate_filter.kmer_size,
+                                               params,
+                                               near_duplicate_filter.dist_thres)
+                k, ep, eo = probe.anchor_entries_equal_length(
+                    cands.n, probe_length, self.mismatches, self.lcf_thres,
+                    min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
+                probes = cands.probes(k, ep, eo)
+                ids, nrows = engine.setcover_filter(
+                    ctx, probes, targets, self.mismatches, self.lcf_thres,
+                    self.island_of_exact_match, self.cover_extension, cands.n,
+                    None, universe_p, self.scan_mode)
+                ids = np.asarray(ids, dtype=np.int64)
+                if ids.size:
+                    grp = cands.groups()[ids]
+                    pos = cands.positions(ids)
+                    which = np.searchsorted(targets.seq_off, pos, side="right") - 1
+                    local = pos - targets.seq_off[which]
+                    for g, q, o in zip(grp.tolist(), which.tolist(), local.tolist()):
+                        out[chunk[g]].append(seqs[q][o:o + probe_length])
+            finally:
+                for h in (probes, cands, targets):
+                    if h is not None:
+                        h.close()
+            ms, nl = ctx.kernel_ms(engine.PHASE_SCAN)
+            timings["scan_ms"] += ms
+            timings["scan_launches"] += nl
+            timings["rows_ms"] += ctx.kernel_ms(engine.PHASE_ROWS)[0]
+            timings["rows"] += nrows
+            ms, nl = ctx.kernel_ms(engine.PHASE_GREEDY)
+            timings["greedy_ms"] += ms
+            timings["greedy_launches"] += nl
+            timings["picks"] += int(ids.size)
+        self.last_timings = timings
+        return out
+
     def _filter_strs_union(self, input_strs, target_genomes_grouped, todo,
                            selected, timings, max_bases=1 << 30,
                            max_candidates=1 << 24):

@@ -366,6 +366,19 @@ int catchhip_candidates_ndf_minhash(catchhip_ctx *ctx, catchhip_candidates *cand
                                     int32_t kmer_size, const int64_t *ab,
                                     int32_t ntables, int32_t k, double dist_thres,
                                     int64_t *nkept);
+/* Grouped targets (catchhip_targets_set_groups before catchhip_candidates_create):
+ * duplicates are only removed inside a group, the candidates of a group stay
+ * together (groups in order), the priority order is per group, and
+ * catchhip_probes_from_candidates passes the groups on to the probes.  The
+ * MinHash filter then takes one set of hash functions per group,
+ * ab[ngroups][ntables][k][2] as catchhip_ndf_minhash_many;
+ * catchhip_candidates_groups returns the group of every unique candidate. */
+int catchhip_candidates_ndf_minhash_many(catchhip_ctx *ctx, catchhip_candidates *cands,
+                                         int32_t kmer_size, const int64_t *ab,
+                                         int64_t ngroups, int32_t ntables, int32_t k,
+                                         double dist_thres, int64_t *nkept);
+int catchhip_candidates_groups(catchhip_ctx *ctx, const catchhip_candidates *cands,
+                               int32_t *group_of_candidate);
 /* A probes object of the unique candidates (set id = candidate index), as
  * catchhip_probes_create would build from their strings.  Anchors: sorted by
  * (probe, position) without duplicates, or ent_probe = ent_pos = NULL for the

@@ -1280,3 +1280,35 @@ def test_device_candidates_near_duplicate_filter_matches_string_path(ctx, oracle
     with pytest.raises(ValueError):
         c.ndf_hamming([[0] * 20], 2)       # a second filter on the same candidates
     c.close(); t.close()
+
+
+@pytest.mark.parametrize("first_kind", ["dup", "minhash"])
+def test_union_device_front_end_equals_string_path(ctx, monkeypatch, first_kind):
+    """Many small groups with the front end on the device (grouped targets:
+    duplicates removed per group, MinHash filter over all groups in one pass,
+    union solve) == the string path.  The groups are strains of the same species
+    and one genome sits in two groups, so identical windows occur in different
+    groups and must stay separate candidates."""
+    from catch_amd.filter import duplicate_filter, near_duplicate_filter, probe_designer, set_cover_filter
+    from catch_amd.genome import Genome
+    sp = (small_species(seed=41, n=12, length=2100, d1=0.03, d2=0.01) +
+          small_species(seed=42, n=8, length=1500, d1=0.05, d2=0.01, with_n=False))
+    groups = [sp[i:i + 2] for i in range(0, len(sp), 2)]
+    groups[3] = groups[3] + [groups[0][0]]          # the same genome in two groups
+    genomes = [[Genome.from_one_seq(x[0]) for x in g] for g in groups]
+    results = []
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("CATCHHIP_HOST_FRONT_END", "1")
+        first = (duplicate_filter.DuplicateFilter() if first_kind == "dup"
+                 else near_duplicate_filter.NearDuplicateFilterWithMinHash(0.5))
+        scf = set_cover_filter.SetCoverFilter(mismatches=3, lcf_thres=100, coverage=1.0, cover_extension=20)
+        pd = probe_designer.ProbeDesigner(genomes, [first, scf], probe_length=100, probe_stride=50)
+        if not host:
+            assert pd._device_front_end_mode(genomes, first, scf) == "union"
+        random.seed(5)
+        np.random.seed(6)
+        grouped = pd._design_on_strings(genomes, [first, scf])
+        results.append([[p.seq_str for p in g] for g in grouped])
+    assert results[0] == results[1]
+    assert sum(map(len, results[0])) > 40 and all(len(g) > 0 for g in results[0])
