@@ -157,24 +157,27 @@ class ProbeDesigner:
 
     def _device_front_end_mode(self, genomes, first, scf):
         """Candidates and the duplicate (or near-duplicate) filter on the device:
-        one of the usual filter pairs without ranks, no --small-seq-min, every sequence a str at least a
-        probe long (or skipped), and groups that are few or large -- many small
-        groups (clusters) go through one instance on the string path."""
+        one of the usual filter pairs without ranks, no --small-seq-min, every
+        sequence a str at least a probe long (or skipped).  "per group": few or
+        large groups, each its own instance; "union": many small groups
+        (clusters) as one instance with group numbers (not with the Hamming
+        filter, whose kernels know no groups: those go through the string
+        path); None: host front end."""
         import os
         if os.environ.get("CATCHHIP_HOST_FRONT_END"):
-            return False
+            return None
         if self.allow_small_seqs:
-            return False
+            return None
         if type(first) is NearDuplicateFilterWithHammingDistance:
             if first.dim != self.probe_length:
-                return False              # the host path raises the reference's error
+                return None              # the host path raises the reference's error
         elif type(first) is NearDuplicateFilterWithMinHash:
             if not (first.kmer_size <= self.probe_length <= first.kmer_size + 255):
-                return False
+                return None
         elif type(first) is not DuplicateFilter:
-            return False
+            return None
         if scf.identify or scf.avoided_genomes:
-            return False
+            return None
         skip, L = self.seq_length_to_skip, self.probe_length
         total, ngroups = 0, 0
         for grp in genomes:

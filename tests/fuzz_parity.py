@@ -129,6 +129,34 @@ def one_case(seed, ctx):
             got_a = fa.filter([probe.Probe.from_str(s) for s in sub],
                               [[mk(gen) for gen in g] for g in groups])
             assert [p.seq_str for p in got_a] == want_a, (desc, "adapter filter", kmap)
+    # whole designs: front end on the device (per group or as one grouped
+    # instance) against the host front end, same random streams
+    from catch_amd.filter import duplicate_filter, probe_designer
+    kind = rnd.choice(["dup", "hamming", "minhash"])
+    hd = rnd.choice([1, 2])
+    gens = [[mk(gen) for gen in g] for g in groups]
+    if rnd.random() < 0.5:          # many small groups
+        gens = [[x] for grp in gens for x in grp] * 2
+        gens = gens[:max(8, len(gens))]
+    outs = []
+    for host in (False, True):
+        if host:
+            os.environ["CATCHHIP_HOST_FRONT_END"] = "1"
+        else:
+            os.environ.pop("CATCHHIP_HOST_FRONT_END", None)
+        first = (duplicate_filter.DuplicateFilter() if kind == "dup" else
+                 near_duplicate_filter.NearDuplicateFilterWithHammingDistance(hd, L)
+                 if kind == "hamming" else near_duplicate_filter.NearDuplicateFilterWithMinHash(0.5))
+        fs = SetCoverFilter(mismatches=m, lcf_thres=thres, island_of_exact_match=island,
+                            coverage=coverage, cover_extension=ext)
+        pd = probe_designer.ProbeDesigner(gens, [first, fs], probe_length=L, probe_stride=stride,
+                                          seq_length_to_skip=L - 1)
+        random.seed(seed)
+        np.random.seed(np_seed)
+        outs.append([[p.seq_str for p in g] for g in pd._design_on_strings(gens, [first, fs])])
+    os.environ.pop("CATCHHIP_HOST_FRONT_END", None)
+    rnd.random()   # keep the stream position independent of the branch above
+    assert outs[0] == outs[1], (desc, "front end", kind, len(gens))
     # clustering of all sequences (whole and fragmented), both methods
     from catch_amd.utils import cluster
     all_seqs = [s for g in groups for gen in g for s in gen if len(s) >= 12]
