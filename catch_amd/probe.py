@@ -177,9 +177,7 @@ def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
                              count=nprobes)
         else:
             pi = np.arange(nprobes, dtype=np.int64)
-        keys = np.unique(((pi[:, None] << 32) | pos).ravel())
-        ent_probe = (keys >> 32).astype(np.int32)
-        ent_pos = (keys & 0xffffffff).astype(np.int32)
+        ent_probe, ent_pos = _entries_from_draws(pi, pos)
         if with_draws:
             draws = list(zip(np.repeat(np.arange(nprobes), num_kmers_per_probe).tolist(),
                              pos.ravel().tolist()))
@@ -193,6 +191,21 @@ def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
     if with_draws:
         return kk, uniq, owner, ent_probe, ent_pos, draws
     return kk, uniq, owner, ent_probe, ent_pos
+
+
+def _entries_from_draws(pi, pos):
+    """Sorted unique (probe, position) anchors from the drawn positions
+    pos[probe_row][j]; pi[probe_row] = unique-probe index of each row."""
+    if pi.size and (pi.size == 1 or bool((np.diff(pi) > 0).all())):
+        # one row per probe, rows in probe order: sort inside the rows and drop
+        # repeated draws -- no global sort of nprobes * 20 keys
+        srt = np.sort(pos, axis=1)
+        keep = np.ones(srt.shape, dtype=bool)
+        keep[:, 1:] = srt[:, 1:] != srt[:, :-1]
+        ent_probe = np.repeat(pi, keep.sum(axis=1)).astype(np.int32)
+        return ent_probe, srt[keep].astype(np.int32)
+    keys = np.unique(((pi[:, None] << 32) | pos).ravel())
+    return (keys >> 32).astype(np.int32), (keys & 0xffffffff).astype(np.int32)
 
 
 def anchor_entries_equal_length(nprobes, probe_length, mismatches, lcf_thres,
@@ -213,6 +226,5 @@ def anchor_entries_equal_length(nprobes, probe_length, mismatches, lcf_thres,
     if nprobes == 0:
         return k, np.zeros(0, np.int32), np.zeros(0, np.int32)
     pos = np.random.randint(0, L - k + 1, size=(nprobes, num_kmers_per_probe))
-    pi = np.arange(nprobes, dtype=np.int64)
-    keys = np.unique(((pi[:, None] << 32) | pos).ravel())
-    return k, (keys >> 32).astype(np.int32), (keys & 0xffffffff).astype(np.int32)
+    ent_probe, ent_pos = _entries_from_draws(np.arange(nprobes, dtype=np.int64), pos)
+    return k, ent_probe, ent_pos

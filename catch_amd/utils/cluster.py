@@ -77,7 +77,7 @@ def _components(n, row_fn, threshold, early_stop_threshold):
     can depend on the order neighbours are examined in.  That order is the
     iteration order of `remaining - queued`; the same set operations are
     applied to the same sets in the same sequence here, so CPython produces
-    the same order.  row_fn(j, candidates) -> float64 distances."""
+    the same order.  row_fn(j, candidates as an int64 array) -> float64 distances."""
     remaining = set(range(n))
     done = set()
     components = []
@@ -92,14 +92,15 @@ def _components(n, row_fn, threshold, early_stop_threshold):
             if j in seen:
                 continue
             seen.add(j)
-            cand = list(remaining - queued)
-            if not cand:
+            diff = remaining - queued
+            if not diff:
                 continue
+            # the set's own iteration order, as an index array in one pass
+            cand = np.fromiter(diff, dtype=np.int64, count=len(diff))
             d = row_fn(j, cand)
             adjacent = np.nonzero(d <= threshold)[0]
             near = d[adjacent] <= early_stop_threshold
-            for pos, is_near in zip(adjacent.tolist(), near.tolist()):
-                k = cand[pos]
+            for k, is_near in zip(cand[adjacent].tolist(), near.tolist()):
                 if is_near:
                     seen.add(k)
                 else:
@@ -116,7 +117,7 @@ def find_connected_components(n, dist_fn, threshold,
                               early_stop_threshold=_jaccard_dist_from_mash_dist(0.02, 12)):
     """Components under an arbitrary Python distance function (:235-355)."""
     def row(j, cand):
-        return np.asarray([dist_fn(j, k) for k in cand], dtype=np.float64)
+        return np.asarray([dist_fn(j, k) for k in cand.tolist()], dtype=np.float64)
     return _components(n, row, threshold, early_stop_threshold)
 
 
@@ -127,7 +128,7 @@ def _components_of_signatures(sigs, threshold,
     def row(j, cand):
         common = sigs.common_row(j)
         # float(intersect_count) / union_count, 1.0 - similarity (lsh.py:212-215)
-        return 1.0 - common[np.asarray(cand, dtype=np.int64)].astype(np.float64) / N
+        return 1.0 - common[cand].astype(np.float64) / N
     return _components(sigs.n, row, threshold, early_stop_threshold)
 
 
