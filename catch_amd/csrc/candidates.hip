@@ -149,7 +149,7 @@ cand_compact_kernel(const u32 *__restrict__ src, const u32 *__restrict__ flag, c
 __global__ void __launch_bounds__(256)
 cand_hash_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ cpos, u32 n, u32 L, u64 *__restrict__ keys,
                  u32 *__restrict__ vals, const u32 *__restrict__ seq_off, u32 nseq, const i32 *__restrict__ seq_group,
-                 u32 *__restrict__ cgrp) {
+                 u32 *__restrict__ cgrp, u64 hash_mask) {
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     const u8 *p = bytes + cpos[c];
@@ -171,7 +171,7 @@ cand_hash_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ cpos, u32
     for (u32 t = 0; j + t < L; ++t) w |= (u64)p[j + t] << (8 * t);
     h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
     h ^= h >> 32;
-    keys[c] = h;
+    keys[c] = h & hash_mask;   // all ones, except in tests that provoke collisions
     vals[c] = c;
 }
 
@@ -311,6 +311,13 @@ static int candidates_build(catchhip_ctx *ctx, const catchhip_targets *T, u32 L,
     DevBuf<u64> keys, keys_alt;
     DevBuf<u32> vals, vals_alt, rflag, runid, head, keep, kat;
     DevBuf<u32> cgrp;
+    // CATCHHIP_CAND_HASH_BITS (tests): keep only that many bits of the hash, so that
+    // different windows collide and the byte-wise resolution is exercised
+    u64 hash_mask = ~0ull;
+    if (const char *e = getenv("CATCHHIP_CAND_HASH_BITS")) {
+        const int b = atoi(e);
+        if (b >= 0 && b < 64) hash_mask = ((u64)1 << b) - 1;
+    }
     TRY(keys.alloc(ncand));
     TRY(vals.alloc(ncand));
     if (C->grouped) TRY(cgrp.alloc((size_t)ncand + 1));
@@ -318,7 +325,7 @@ static int candidates_build(catchhip_ctx *ctx, const catchhip_targets *T, u32 L,
     hipLaunchKernelGGL(cand_hash_kernel, dim3((unsigned)div_up((i64)ncand, 256)), dim3(256), 0, s,
                        (const u8 *)T->bytes.p, (const u32 *)cpos.p, ncand, L, keys.p, vals.p,
                        (const u32 *)T->seq_off.p, nseq, C->grouped ? (const i32 *)T->seq_group.p : (const i32 *)nullptr,
-                       cgrp.p);
+                       cgrp.p, hash_mask);
     TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, ncand, 64));
     TRY(rflag.alloc((size_t)ncand + 1));
     hipLaunchKernelGGL(cand_runstart_kernel, dim3((unsigned)div_up((i64)ncand + 1, 256)), dim3(256), 0, s,

@@ -1170,6 +1170,42 @@ def _rand_seq_with_n_runs(rnd, n):
     return "".join(s)
 
 
+@pytest.mark.parametrize("bits", ["0", "3", "9"])
+def test_device_candidates_with_hash_collisions(ctx, monkeypatch, bits):
+    """The de-duplication stays exact when different windows share a hash
+    (CATCHHIP_CAND_HASH_BITS keeps 0 / 3 / 9 bits of it): unique list,
+    multiplicities (through the Hamming filter's priority order) and groups."""
+    from catch_amd.filter import candidate_probes, near_duplicate_filter as ndf
+    engine = _engine()
+    monkeypatch.setenv("CATCHHIP_CAND_HASH_BITS", bits)
+    base = small_species(seed=51, n=4, length=700, d1=0.03, d2=0.01)
+    genomes = base + [base[2], base[0]]
+    L, stride = 60, 20
+    strs = candidates(genomes, L, stride, dedup=False)
+    flat = "".join(s for g in genomes for s in g)
+    t = engine.Targets(ctx, genomes)
+    c = engine.Candidates(ctx, t, L, stride)
+    assert [flat[p:p + L] for p in c.positions().tolist()] == list(dict.fromkeys(strs))
+    f = ndf.NearDuplicateFilterWithHammingDistance(1, L)
+    random.seed(2)
+    want = f._filter_strs(strs)
+    random.seed(2)
+    f._apply_to_candidates(c)
+    assert [flat[p:p + L] for p in c.positions().tolist()] == want
+    c.close()
+    # grouped: the same genomes as three groups of two
+    t.set_groups([0, 0, 1, 1, 2, 2])
+    c = engine.Candidates(ctx, t, L, stride)
+    want_g, want_grp = [], []
+    for gi in range(3):
+        u = list(dict.fromkeys(candidates(genomes[2 * gi:2 * gi + 2], L, stride, dedup=False)))
+        want_g += u
+        want_grp += [gi] * len(u)
+    assert [flat[p:p + L] for p in c.positions().tolist()] == want_g
+    assert c.groups().tolist() == want_grp
+    c.close(); t.close()
+
+
 @pytest.mark.parametrize("L,stride", [(100, 50), (75, 25), (60, 60), (80, 33), (20, 7)])
 def test_device_candidates_match_host_front_end(ctx, L, stride):
     """catchhip_candidates_create == candidate_strings_from_sequences over the
