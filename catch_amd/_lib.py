@@ -103,6 +103,9 @@ PROTOTYPES = {
     "catchhip_candidates_ndf_minhash": (ctypes.c_int, [
         c_vp, c_vp, ctypes.c_int32, c_i64p, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_double, c_i64p]),
+    "catchhip_candidates_ndf_hamming_many": (ctypes.c_int, [
+        c_vp, c_vp, c_i32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+        ctypes.c_int32, c_i64p]),
     "catchhip_candidates_ndf_minhash_many": (ctypes.c_int, [
         c_vp, c_vp, ctypes.c_int32, c_i64p, ctypes.c_int64, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_double, c_i64p]),

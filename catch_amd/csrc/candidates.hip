@@ -509,20 +509,40 @@ static int cand_apply_keep(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<u32
     return 0;
 }
 
-extern "C" int catchhip_candidates_ndf_hamming(catchhip_ctx *ctx, catchhip_candidates *C, const i32 *positions,
-                                               i32 ntables, i32 k, i32 dist_thres, i64 *nkept) {
+static int cand_ndf_hamming(catchhip_ctx *ctx, catchhip_candidates *C, const i32 *positions, i64 ngroups,
+                            i32 ntables, i32 k, i32 dist_thres, i64 *nkept) {
     ARG_CHECK(ctx && C && C->ctx == ctx && positions && ntables >= 1 && k >= 1);
     PoolScope pool_scope(ctx);
     if (C->filtered) { chip_set_error("candidates: a near-duplicate filter was already applied"); return CATCHHIP_EINVAL; }
     HIP_TRY(hipSetDevice(ctx->device));
-    if (C->grouped) { chip_set_error("candidates_ndf_hamming: not available on grouped candidates"); return CATCHHIP_EINVAL; }
     if (C->nuniq == 0) { C->filtered = true; if (nkept) *nkept = 0; return 0; }
     DevBuf<u32> opos, ogrp;
     DevBuf<u8> rows;
     TRY(cand_priority_rows(ctx, C, opos, rows, ogrp));
     std::vector<u8> keep((size_t)C->nuniq, 0);
-    TRY(chip_ndf_hamming_device(ctx, rows.p, C->nuniq, C->L, positions, ntables, k, dist_thres, keep.data()));
+    TRY(chip_ndf_hamming_device(ctx, rows.p, C->nuniq, C->L, positions, ntables, k, dist_thres, keep.data(),
+                                C->grouped ? (const u32 *)ogrp.p : (const u32 *)nullptr, C->grouped ? ngroups : 1));
     return cand_apply_keep(ctx, C, opos, ogrp, keep, nkept);
+}
+
+extern "C" int catchhip_candidates_ndf_hamming(catchhip_ctx *ctx, catchhip_candidates *C, const i32 *positions,
+                                               i32 ntables, i32 k, i32 dist_thres, i64 *nkept) {
+    ARG_CHECK(C);
+    if (C->grouped) {
+        chip_set_error("candidates_ndf_hamming: grouped candidates need one set of sampled positions per group (..._many)");
+        return CATCHHIP_EINVAL;
+    }
+    return cand_ndf_hamming(ctx, C, positions, 1, ntables, k, dist_thres, nkept);
+}
+
+extern "C" int catchhip_candidates_ndf_hamming_many(catchhip_ctx *ctx, catchhip_candidates *C, const i32 *positions,
+                                                    i64 ngroups, i32 ntables, i32 k, i32 dist_thres, i64 *nkept) {
+    ARG_CHECK(C);
+    if (!C->grouped || ngroups < C->ngroups) {
+        chip_set_error("candidates_ndf_hamming_many: the targets carry no groups, or more groups than position sets");
+        return CATCHHIP_EINVAL;
+    }
+    return cand_ndf_hamming(ctx, C, positions, ngroups, ntables, k, dist_thres, nkept);
 }
 
 static int cand_ndf_minhash(catchhip_ctx *ctx, catchhip_candidates *C, i32 kmer_size, const i64 *ab, i64 ngroups,

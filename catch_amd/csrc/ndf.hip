@@ -24,11 +24,15 @@
 
 __global__ void __launch_bounds__(256)
 ndf_key_kernel(const u8 *__restrict__ bytes, u32 n, int L, const i32 *__restrict__ pos, int k,
-               u64 *__restrict__ keys, u32 *__restrict__ vals) {
+               u64 *__restrict__ keys, u32 *__restrict__ vals, const u32 *__restrict__ grp, size_t pos_group_stride) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u8 *p = bytes + (size_t)i * L;
     u64 h = 0xcbf29ce484222325ull;
+    if (grp) {   // independent groups: own sampled positions, and the group is part of the key
+        pos += (size_t)grp[i] * pos_group_stride;
+        h = (h ^ (u64)grp[i]) * 0x100000001b3ull;
+    }
     for (int j = 0; j < k; ++j) h = (h ^ (u64)p[pos[j]]) * 0x100000001b3ull;
     keys[i] = h;
     vals[i] = i;
@@ -68,15 +72,18 @@ __device__ __forceinline__ bool ndf_near(const u64 *__restrict__ a, const u64 *_
 __global__ void __launch_bounds__(256)
 ndf_edge_kernel(const u64 *__restrict__ padded, u32 n, int W, int d, const i32 *__restrict__ pos, int k,
                 const u64 *__restrict__ keys, const u32 *__restrict__ vals, u32 *__restrict__ e_i,
-                u32 *__restrict__ e_j, u32 *__restrict__ count, u32 cap) {
+                u32 *__restrict__ e_j, u32 *__restrict__ count, u32 cap, const u32 *__restrict__ grp,
+                size_t pos_group_stride) {
     u32 x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n) return;
     const u64 key = keys[x];
     const u32 i = vals[x];
     const u64 *a = padded + (size_t)i * W;
+    if (grp) pos += (size_t)grp[i] * pos_group_stride;
     for (u32 y = x; y-- > 0;) {
         if (keys[y] != key) break;
         const u32 j = vals[y];  // j < i: stable sort keeps indices ascending in a run
+        if (grp && grp[j] != grp[i]) continue;   // another group under the same key
         if (ndf_near(a, padded + (size_t)j * W, W, d, pos, k)) {
             u32 slot = atomicAdd(count, 1u);
             if (slot < cap) { e_i[slot] = i; e_j[slot] = j; }
@@ -140,13 +147,17 @@ static int ndf_resolve(catchhip_ctx *ctx, u32 nn, u32 ne, DevBuf<u32> &e_i, DevB
 }
 
 // the filter on probes whose characters are already on the device (n rows of L)
+// d_grp / ngroups: optional group of every row (device array); positions is then
+// [ngroups][ntables][k], every group with its own sampled positions
 int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, const i32 *positions, i32 ntables,
-                            i32 k, i32 dist_thres, u8 *keep) {
+                            i32 k, i32 dist_thres, u8 *keep, const u32 *d_grp, i64 ngroups) {
     ARG_CHECK(ctx && n >= 0 && L > 0 && ntables >= 1 && k >= 1 && positions);
     if (n == 0) return 0;
     ARG_CHECK(d_rows && keep);
     ARG_CHECK(n < ((i64)1 << 31) && n * (i64)L < ((i64)1 << 40));
-    for (i64 t = 0; t < (i64)ntables * k; ++t) ARG_CHECK(positions[t] >= 0 && positions[t] < L);
+    if (!d_grp) ngroups = 1;
+    ARG_CHECK(ngroups >= 1);
+    for (i64 t = 0; t < ngroups * ntables * k; ++t) ARG_CHECK(positions[t] >= 0 && positions[t] < L);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const u32 nn = (u32)n;
@@ -154,13 +165,14 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
     DevBuf<i32> d_pos;
     DevBuf<u64> keys, keys_alt;
     DevBuf<u32> vals, vals_alt, e_i, e_j, count, status, flags;
-    TRY(d_pos.alloc((size_t)ntables * k));
+    TRY(d_pos.alloc((size_t)ngroups * ntables * k));
     TRY(keys.alloc(nn));
     TRY(vals.alloc(nn));
     TRY(count.alloc(2));
     TRY(status.alloc(nn));
     TRY(flags.alloc(nn));
-    HIP_TRY(hipMemcpyAsync(d_pos.p, positions, sizeof(i32) * ntables * k, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_pos.p, positions, sizeof(i32) * (size_t)ngroups * ntables * k, hipMemcpyHostToDevice, s));
+    const size_t pstride = (size_t)ntables * k;
     HIP_TRY(hipMemsetAsync(count.p, 0, 2 * sizeof(u32), s));
     HIP_TRY(hipMemsetAsync(status.p, 0, sizeof(u32) * nn, s));
     HIP_TRY(hipMemsetAsync(flags.p, 0, sizeof(u32) * nn, s));
@@ -180,11 +192,11 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
         HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(u32), s));
         for (int t = 0; t < ntables; ++t) {
             hipLaunchKernelGGL(ndf_key_kernel, dim3(nb), dim3(256), 0, s, d_bytes.p, nn, (int)L,
-                               d_pos.p + (size_t)t * k, (int)k, keys.p, vals.p);
+                               d_pos.p + (size_t)t * k, (int)k, keys.p, vals.p, d_grp, pstride);
             TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nn, 64));
             hipLaunchKernelGGL(ndf_edge_kernel, dim3(nb), dim3(256), 0, s, (const u64 *)padded.p, nn, W,
                                (int)dist_thres, d_pos.p + (size_t)t * k, (int)k, keys.p, vals.p, e_i.p,
-                               e_j.p, count.p, cap);
+                               e_j.p, count.p, cap, d_grp, pstride);
             tm.launch(2 + 24);
         }
         HIP_TRY(hipGetLastError());
@@ -208,7 +220,7 @@ extern "C" int catchhip_ndf_hamming(catchhip_ctx *ctx, const u8 *bytes, i64 n, i
     DevBuf<u8> d_bytes;
     TRY(d_bytes.alloc((size_t)n * L));
     HIP_TRY(hipMemcpyAsync(d_bytes.p, bytes, (size_t)n * L, hipMemcpyHostToDevice, ctx->stream));
-    return chip_ndf_hamming_device(ctx, d_bytes.p, n, L, positions, ntables, k, dist_thres, keep);
+    return chip_ndf_hamming_device(ctx, d_bytes.p, n, L, positions, ntables, k, dist_thres, keep, nullptr, 1);
 }
 
 // ------------------------------------------------------------------------

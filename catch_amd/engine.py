@@ -284,6 +284,17 @@ class Candidates:
             ab.shape[1], float(dist_thres), ctypes.byref(nk)))
         self.n = nk.value
 
+    def ndf_hamming_many(self, positions, dist_thres):
+        """catchhip_candidates_ndf_hamming_many (grouped targets);
+        positions[group][table][j]."""
+        pos = np.ascontiguousarray(positions, dtype=np.int32)
+        assert pos.ndim == 3
+        nk = ctypes.c_int64(0)
+        check(self.ctx._L.catchhip_candidates_ndf_hamming_many(
+            self.ctx._h, self._h, _ptr(pos, c_i32p), pos.shape[0], pos.shape[1],
+            pos.shape[2], int(dist_thres), ctypes.byref(nk)))
+        self.n = nk.value
+
     def ndf_minhash_many(self, kmer_size, params, dist_thres):
         """catchhip_candidates_ndf_minhash_many (grouped targets);
         params[group][table][fn] = (a, b)."""

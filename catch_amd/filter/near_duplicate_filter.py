@@ -90,6 +90,16 @@ class NearDuplicateFilterWithHammingDistance(NearDuplicateFilter):
                                                     self.dist_thres)
         return [s for s, kp in zip(order, keep) if kp]
 
+    def _apply_to_grouped_candidates(self, cands, ngroups):
+        """The same on candidates of grouped targets: sampled positions drawn
+        per group in group order, as one _filter call per group would."""
+        positions = [self._draw_positions() for _ in range(ngroups)]
+        if cands.n == 0:
+            return
+        if cands.L != self.dim:
+            raise ValueError("Sequences must be of same length")
+        cands.ndf_hamming_many(positions, self.dist_thres)
+
     def _apply_to_candidates(self, cands):
         """The filter on an engine.Candidates object (device front end):
         multiplicity order, filter and compaction all stay on the device."""
@@ -159,6 +169,16 @@ class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
         keep = engine.default_context().ndf_minhash(order, self.kmer_size, params,
                                                     self.dist_thres)
         return [s for s, kp in zip(order, keep) if kp]
+
+    def _apply_to_grouped_candidates(self, cands, ngroups):
+        """The same on candidates of grouped targets: hash functions drawn per
+        group in group order, as one _filter call per group would."""
+        params = [self._draw_params() for _ in range(ngroups)]
+        if cands.n == 0:
+            return
+        if cands.L < self.kmer_size:
+            raise AssertionError("k-mer size exceeds a sequence's length")
+        cands.ndf_minhash_many(self.kmer_size, params, self.dist_thres)
 
     def _apply_to_candidates(self, cands):
         """The filter on an engine.Candidates object (device front end):

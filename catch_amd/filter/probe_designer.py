@@ -160,9 +160,7 @@ class ProbeDesigner:
         one of the usual filter pairs without ranks, no --small-seq-min, every
         sequence a str at least a probe long (or skipped).  "per group": few or
         large groups, each its own instance; "union": many small groups
-        (clusters) as one instance with group numbers (not with the Hamming
-        filter, whose kernels know no groups: those go through the string
-        path); None: host front end."""
+        (clusters) as one instance with group numbers; None: host front end."""
         import os
         if os.environ.get("CATCHHIP_HOST_FRONT_END"):
             return None
@@ -198,8 +196,6 @@ class ProbeDesigner:
             return None
         if ngroups < 8 or total >= 200000 * ngroups:
             return "per group"
-        if type(first) is NearDuplicateFilterWithHammingDistance:
-            return None
         return "union"
 
     @staticmethod

@@ -404,17 +404,8 @@ class SetCoverFilter(BaseFilter):
                 timings["candidates"] += cands.ncandidates
                 timings["unique_candidates"] += cands.n
                 if near_duplicate_filter is not None:
-                    # one set of hash functions per group, drawn in group order
-                    # as one _filter call per group would
-                    params = [near_duplicate_filter._draw_params()
-                              for _ in chunk]
-                    if cands.n:
-                        if cands.L < near_duplicate_filter.kmer_size:
-                            raise AssertionError(
-                                "k-mer size exceeds a sequence's length")
-                        cands.ndf_minhash_many(near_duplicate_filter.kmer_size,
-                                               params,
-                                               near_duplicate_filter.dist_thres)
+                    near_duplicate_filter._apply_to_grouped_candidates(
+                        cands, len(chunk))
                 k, ep, eo = probe.anchor_entries_equal_length(
                     cands.n, probe_length, self.mismatches, self.lcf_thres,
                     min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)

@@ -370,9 +370,13 @@ int catchhip_candidates_ndf_minhash(catchhip_ctx *ctx, catchhip_candidates *cand
  * duplicates are only removed inside a group, the candidates of a group stay
  * together (groups in order), the priority order is per group, and
  * catchhip_probes_from_candidates passes the groups on to the probes.  The
- * MinHash filter then takes one set of hash functions per group,
- * ab[ngroups][ntables][k][2] as catchhip_ndf_minhash_many;
+ * near-duplicate filters then take one set of sampled positions / hash
+ * functions per group (ab[ngroups][ntables][k][2] as catchhip_ndf_minhash_many);
  * catchhip_candidates_groups returns the group of every unique candidate. */
+int catchhip_candidates_ndf_hamming_many(catchhip_ctx *ctx, catchhip_candidates *cands,
+                                         const int32_t *positions /* [ngroups][ntables][k] */,
+                                         int64_t ngroups, int32_t ntables, int32_t k,
+                                         int32_t dist_thres, int64_t *nkept);
 int catchhip_candidates_ndf_minhash_many(catchhip_ctx *ctx, catchhip_candidates *cands,
                                          int32_t kmer_size, const int64_t *ab,
                                          int64_t ngroups, int32_t ntables, int32_t k,

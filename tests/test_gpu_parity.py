@@ -1318,7 +1318,7 @@ def test_device_candidates_near_duplicate_filter_matches_string_path(ctx, oracle
     c.close(); t.close()
 
 
-@pytest.mark.parametrize("first_kind", ["dup", "minhash"])
+@pytest.mark.parametrize("first_kind", ["dup", "minhash", "hamming"])
 def test_union_device_front_end_equals_string_path(ctx, monkeypatch, first_kind):
     """Many small groups with the front end on the device (grouped targets:
     duplicates removed per group, MinHash filter over all groups in one pass,
@@ -1337,7 +1337,8 @@ def test_union_device_front_end_equals_string_path(ctx, monkeypatch, first_kind)
         if host:
             monkeypatch.setenv("CATCHHIP_HOST_FRONT_END", "1")
         first = (duplicate_filter.DuplicateFilter() if first_kind == "dup"
-                 else near_duplicate_filter.NearDuplicateFilterWithMinHash(0.5))
+                 else near_duplicate_filter.NearDuplicateFilterWithMinHash(0.5) if first_kind == "minhash"
+                 else near_duplicate_filter.NearDuplicateFilterWithHammingDistance(2, 100))
         scf = set_cover_filter.SetCoverFilter(mismatches=3, lcf_thres=100, coverage=1.0, cover_extension=20)
         pd = probe_designer.ProbeDesigner(genomes, [first, scf], probe_length=100, probe_stride=50)
         if not host:
