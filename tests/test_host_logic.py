@@ -282,3 +282,25 @@ def test_genome_fragments():
     h = Genome.from_chrs(OrderedDict([("x", "AAAAAB"), ("y", "CC")]))
     f = h.break_into_fragments(3, include_full_end=True)
     assert list(f.chrs.items()) == [("x-0", "AAA"), ("x-1", "AAB"), ("y-0", "CC")]
+
+
+def test_anchor_entries_without_strings_match_anchor_table():
+    """probe.anchor_entries_equal_length (the device front end never sees the
+    candidate strings) == anchor_table on distinct strings of that length:
+    same rule, same entries, same np.random stream."""
+    from catch_amd import probe
+    rng = random.Random(9)
+    for L, m, thres, min_k in [(100, 2, 100, 20), (100, 5, 100, 20), (75, 2, 60, 20),
+                               (100, 0, 100, 20), (60, 3, 60, 10), (30, 1, 30, 20)]:
+        strs = list(dict.fromkeys("".join(rng.choice("ACGT") for _ in range(L)) for _ in range(70)))
+        np.random.seed(12)
+        k1, _u, _o, ep, eo = probe.anchor_table(strs, m, thres, min_k, min_k, assume_unique=True)
+        state1 = np.random.get_state()[2]
+        np.random.seed(12)
+        k2, ep2, eo2 = probe.anchor_entries_equal_length(len(strs), L, m, thres, min_k, min_k)
+        assert k1 == k2 and np.random.get_state()[2] == state1
+        if ep2 is None:      # pigeonhole table {0, k, 2k, ..}: generated on the device
+            assert eo.tolist() == list(range(0, L, k1)) * len(strs)
+        else:
+            assert np.array_equal(ep, ep2) and np.array_equal(eo, eo2)
+    assert probe.anchor_entries_equal_length(0, 100, 5, 100)[1].size == 0
