@@ -6,7 +6,10 @@ its reverse complement) that some probe covers,
 `probe.find_probe_covers_in_sequence(sequence, merge_overlapping=False)` per
 sequence (:183-280) -- is one catchhip_cover_ranges call per strand over all
 genomes at once (every sequence its own universe); the statistics the
-reference derives from those ranges (:282-427) are NumPy on the fetched rows.
+reference derives from those ranges (:282-335) are reduced on the device too (catchhip_rows_stats: bases
+covered, summed range lengths, sequences per probe), so a report over thousands
+of genomes never brings the row table to the host; `target_covers` and
+`sliding_coverage` (:337-411) are fetched / computed on first use.
 Same constructor, attributes (`target_covers`, `bp_covered`,
 `average_coverage`, `sliding_coverage`, `probe_map_counts`) and writers.
 
@@ -49,6 +52,10 @@ class Analyzer:
         self.cover_extension = cover_extension
         self.kmer_probe_map_k = kmer_probe_map_k
         self.rc_too = rc_too
+        self._covers = None
+        self._sliding = None
+        self._window = (50, 25)
+        self._scan_inputs = None
 
     def _iter_target_genomes(self):
         for i, genomes_from_group in enumerate(self.target_genomes):
@@ -58,52 +65,110 @@ class Analyzer:
                     yield i, j, gnm, True
 
     # ------------------------------------------------------------------
-    def _find_covers_in_target_genomes(self):
-        """self.target_covers[i][j][rc] = list of (start, end) in genome
-        coordinates (chromosomes offset by the lengths before them), one entry
-        per distinct range of every probe; self.probe_map_counts[p] = number
-        of sequences probe p maps to (forward strand only)."""
-        logger.info("Finding probe covers across target genomes")
-        self.target_covers = {}
-        self.probe_map_counts = Counter()
-        for i, j, _gnm, rc in self._iter_target_genomes():
-            self.target_covers.setdefault(i, {}).setdefault(
-                j, {False: None, True: None})
-        strs = [p.seq_str for p in self.probes]
-        flat = [(i, j, gnm) for i, grp in enumerate(self.target_genomes)
+    def _strand_targets(self, ctx, flat, rc):
+        """All sequences of all genomes as one targets object, every sequence
+        its own universe (ranges stay per sequence); plus, per sequence, the
+        genome it belongs to and its offset inside the genome."""
+        seqs, owner_of_seq, offset_of_seq = [], [], []
+        for g, (_i, _j, gnm) in enumerate(flat):
+            so_far = 0
+            for s in gnm.seqs:
+                seqs.append([s[::-1].translate(_RC) if rc else s])
+                owner_of_seq.append(g)
+                offset_of_seq.append(so_far)
+                so_far += len(s)
+        return (engine.Targets(ctx, seqs), np.asarray(owner_of_seq, dtype=np.int64),
+                np.asarray(offset_of_seq, dtype=np.int64))
+
+    def _scan(self, ctx, probes_dev, targets):
+        return engine.Rows.scan(ctx, probes_dev, targets, self.mismatches,
+                                self.lcf_thres, self.island_of_exact_match,
+                                self.cover_extension, engine.SCAN_AUTO, merge=False)
+
+    def _flat_genomes(self):
+        return [(i, j, gnm) for i, grp in enumerate(self.target_genomes)
                 for j, gnm in enumerate(grp)]
+
+    def _find_covers_in_target_genomes(self):
+        """One scan per strand over all genomes (every distinct range of every
+        probe, nothing merged: find_probe_covers_in_sequence(...,
+        merge_overlapping=False), :183-280).  The row table stays on the device;
+        what the report needs is reduced there (catchhip_rows_stats):
+          self.bp_covered[i][j][rc]   bases covered by at least one probe (:282-302)
+          self._total_covered[i][j][rc]  sum of the ranges' lengths (:318-320)
+          self.probe_map_counts[p]    sequences probe p maps to, forward strand (:255-258)
+        self.target_covers / self.sliding_coverage are fetched / computed on
+        first use (they need every range on the host)."""
+        logger.info("Finding probe covers across target genomes")
+        self.probe_map_counts = Counter()
+        self.bp_covered, self._total_covered = {}, {}
+        for i, j, _gnm, rc in self._iter_target_genomes():
+            for d in (self.bp_covered, self._total_covered):
+                d.setdefault(i, {}).setdefault(j, {False: None, True: None})[rc] = 0
+        self._covers = None
+        strs = [p.seq_str for p in self.probes]
+        flat = self._flat_genomes()
+        self._scan_inputs = None
         if not strs or not flat:
-            for i, j, _gnm, rc in self._iter_target_genomes():
-                self.target_covers[i][j][rc] = []
             return
         ctx = engine.default_context()
-        k, uniq, owner, ep, eo = probe.anchor_table(
+        self._scan_inputs = probe.anchor_table(
             strs, self.mismatches, self.lcf_thres,
             min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
+        k, uniq, owner, ep, eo = self._scan_inputs
         probes_dev = engine.Probes(ctx, uniq, owner, ep, eo, k)
         try:
             for rc in ((False, True) if self.rc_too else (False,)):
-                # every sequence is its own universe, so ranges stay per sequence
-                seqs, owner_of_seq, offset_of_seq = [], [], []
-                for g, (_i, _j, gnm) in enumerate(flat):
-                    so_far = 0
-                    for s in gnm.seqs:
-                        seqs.append([s[::-1].translate(_RC) if rc else s])
-                        owner_of_seq.append(g)
-                        offset_of_seq.append(so_far)
-                        so_far += len(s)
-                targets = engine.Targets(ctx, seqs)
+                targets, owner_of_seq, _off = self._strand_targets(ctx, flat, rc)
                 try:
-                    rows = engine.Rows.scan(
-                        ctx, probes_dev, targets, self.mismatches,
-                        self.lcf_thres, self.island_of_exact_match,
-                        self.cover_extension, engine.SCAN_AUTO, merge=False)
-                    sid, univ, st, en = rows.fetch()
+                    rows = self._scan(ctx, probes_dev, targets)
+                    total_len, union_len, per_probe = rows.stats(
+                        targets.ngenomes, len(strs) if not rc else 0)
                     rows.close()
                 finally:
                     targets.close()
-                owner_of_seq = np.asarray(owner_of_seq, dtype=np.int64)
-                offset_of_seq = np.asarray(offset_of_seq, dtype=np.int64)
+                tot = np.bincount(owner_of_seq, weights=total_len.astype(np.float64),
+                                  minlength=len(flat)).astype(np.int64)
+                uni = np.bincount(owner_of_seq, weights=union_len.astype(np.float64),
+                                  minlength=len(flat)).astype(np.int64)
+                for g, (i, j, _gnm) in enumerate(flat):
+                    self.bp_covered[i][j][rc] = int(uni[g])
+                    self._total_covered[i][j][rc] = int(tot[g])
+                if not rc:
+                    for pi in np.nonzero(per_probe)[0]:
+                        self.probe_map_counts[self.probes[pi]] += int(per_probe[pi])
+        finally:
+            probes_dev.close()
+
+    @property
+    def target_covers(self):
+        """target_covers[i][j][rc] = sorted list of (start, end) in genome
+        coordinates (chromosomes offset by the lengths before them), one entry
+        per distinct range of every probe.  Fetched from the device on first
+        use (a second scan: the report itself does not need them)."""
+        if self._covers is None:
+            self._covers = self._fetch_covers()
+        return self._covers
+
+    def _fetch_covers(self):
+        covers = {}
+        for i, j, _gnm, rc in self._iter_target_genomes():
+            covers.setdefault(i, {}).setdefault(j, {False: None, True: None})[rc] = []
+        flat = self._flat_genomes()
+        if self._scan_inputs is None:
+            return covers
+        ctx = engine.default_context()
+        k, uniq, owner, ep, eo = self._scan_inputs
+        probes_dev = engine.Probes(ctx, uniq, owner, ep, eo, k)
+        try:
+            for rc in ((False, True) if self.rc_too else (False,)):
+                targets, owner_of_seq, offset_of_seq = self._strand_targets(ctx, flat, rc)
+                try:
+                    rows = self._scan(ctx, probes_dev, targets)
+                    _sid, univ, st, en = rows.fetch()
+                    rows.close()
+                finally:
+                    targets.close()
                 gidx = owner_of_seq[univ] if univ.size else univ.astype(np.int64)
                 a = st + (offset_of_seq[univ] if univ.size else 0)
                 b = en + (offset_of_seq[univ] if univ.size else 0)
@@ -112,41 +177,18 @@ class Analyzer:
                 bounds = np.searchsorted(gidx, np.arange(len(flat) + 1))
                 for g, (i, j, _gnm) in enumerate(flat):
                     lo, hi = bounds[g], bounds[g + 1]
-                    self.target_covers[i][j][rc] = list(
-                        zip(a[lo:hi].tolist(), b[lo:hi].tolist()))
-                if not rc and sid.size:
-                    # sequences each probe maps to: distinct (probe, sequence)
-                    pairs = np.unique(sid.astype(np.int64) * len(seqs) + univ)
-                    cnt = np.bincount(pairs // len(seqs), minlength=len(strs))
-                    for pi in np.nonzero(cnt)[0]:
-                        self.probe_map_counts[self.probes[pi]] += int(cnt[pi])
+                    covers[i][j][rc] = list(zip(a[lo:hi].tolist(), b[lo:hi].tolist()))
         finally:
             probes_dev.close()
+        return covers
 
     def _compute_bp_covered_in_target_genomes(self):
-        self.bp_covered = {}
-        for i, j, _gnm, rc in self._iter_target_genomes():
-            covers = self.target_covers[i][j][rc]
-            total = 0
-            if covers:
-                arr = np.asarray(covers, dtype=np.int64)   # sorted by (start, end)
-                st, en = arr[:, 0], arr[:, 1]
-                reach = np.maximum.accumulate(en)
-                # a new merged interval starts where no earlier one reaches it
-                # (touching intervals merge, catch/utils/interval.py:25-44)
-                new = np.ones(len(st), dtype=bool)
-                new[1:] = st[1:] > reach[:-1]
-                starts = st[new]
-                ends = np.maximum.reduceat(en, np.nonzero(new)[0])
-                total = int((ends - starts).sum())
-            self.bp_covered.setdefault(i, {}).setdefault(
-                j, {False: None, True: None})[rc] = total
+        """Done on the device by _find_covers_in_target_genomes."""
 
     def _compute_average_coverage_in_target_genomes(self):
         self.average_coverage = {}
         for i, j, gnm, rc in self._iter_target_genomes():
-            covers = self.target_covers[i][j][rc]
-            total_covered = sum(c[1] - c[0] for c in covers)
+            total_covered = self._total_covered[i][j][rc]
             self.average_coverage.setdefault(i, {}).setdefault(
                 j, {False: None, True: None})[rc] = (
                 float(total_covered) / gnm.size(False),
@@ -154,28 +196,38 @@ class Analyzer:
 
     def _compute_sliding_coverage_in_target_genomes(self, window_length,
                                                     window_stride):
-        """:337-411: average depth in windows; keys are window middles."""
-        self.sliding_coverage = {}
-        for i, j, gnm, rc in self._iter_target_genomes():
-            covers = self.target_covers[i][j][rc]
-            n = gnm.size(False)
-            diff = np.zeros(n + 1, dtype=np.int64)
-            if covers:
-                arr = np.asarray(covers, dtype=np.int64)
-                np.add.at(diff, arr[:, 0], 1)
-                np.add.at(diff, arr[:, 1], -1)
-            # the reference stores the depth as uint16
-            counts = np.cumsum(diff[:n]).astype(np.uint16)
-            out = {}
-            for window_start in np.arange(0, n, window_stride):
-                window_end = window_start + window_length
-                if window_end > n:
-                    window_end = n
-                    window_start = window_end - window_length
-                middle = window_start + (window_length / 2)
-                out[middle] = np.average(counts[window_start:window_end])
-            self.sliding_coverage.setdefault(i, {}).setdefault(
-                j, {False: None, True: None})[rc] = out
+        """:337-411: average depth in windows; keys are window middles.
+        Needs every range on the host: computed on first use of
+        self.sliding_coverage."""
+        self._window = (window_length, window_stride)
+        self._sliding = None
+
+    @property
+    def sliding_coverage(self):
+        if self._sliding is None:
+            window_length, window_stride = self._window
+            self._sliding = {}
+            for i, j, gnm, rc in self._iter_target_genomes():
+                covers = self.target_covers[i][j][rc]
+                n = gnm.size(False)
+                diff = np.zeros(n + 1, dtype=np.int64)
+                if covers:
+                    arr = np.asarray(covers, dtype=np.int64)
+                    np.add.at(diff, arr[:, 0], 1)
+                    np.add.at(diff, arr[:, 1], -1)
+                # the reference stores the depth as uint16
+                counts = np.cumsum(diff[:n]).astype(np.uint16)
+                out = {}
+                for window_start in np.arange(0, n, window_stride):
+                    window_end = window_start + window_length
+                    if window_end > n:
+                        window_end = n
+                        window_start = window_end - window_length
+                    middle = window_start + (window_length / 2)
+                    out[middle] = np.average(counts[window_start:window_end])
+                self._sliding.setdefault(i, {}).setdefault(
+                    j, {False: None, True: None})[rc] = out
+        return self._sliding
 
     def run(self, window_length=50, window_stride=25):
         self._find_covers_in_target_genomes()

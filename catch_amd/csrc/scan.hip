@@ -1430,6 +1430,92 @@ extern "C" int catchhip_rows_fetch(catchhip_ctx *ctx, const catchhip_rows *R, i3
     return 0;
 }
 
+// ------------------------------------------------------------------------
+// per-universe / per-set statistics of a row table (coverage analysis at scale:
+// the rows never leave the device)
+// ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+rows_stats_kernel(const i32 *__restrict__ set_id, const i32 *__restrict__ univ, const u32 *__restrict__ gs,
+                  const u32 *__restrict__ ge, u32 n, unsigned long long *__restrict__ bm,
+                  unsigned long long *__restrict__ total_len, unsigned long long *__restrict__ per_set) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const u32 s = gs[r], e = ge[r];
+    atomicAdd(&total_len[univ[r]], (unsigned long long)(e - s));
+    // rows are sorted by (set, start) and universes are contiguous: the first row of a
+    // (set, universe) group counts one universe for its set
+    if (per_set && (r == 0 || set_id[r - 1] != set_id[r] || univ[r - 1] != univ[r]))
+        atomicAdd(&per_set[set_id[r]], 1ull);
+    if (e > s) {
+        const u32 w0 = s >> 6, w1 = (e - 1) >> 6;
+        for (u32 w = w0; w <= w1; ++w) {
+            u64 m = ~0ull;
+            if (w == w0) m &= ~0ull << (s & 63);
+            if (w == w1) m &= ~0ull >> (63 - ((e - 1) & 63));
+            if ((bm[w] & m) != m) atomicOr(&bm[w], m);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+rows_union_kernel(const unsigned long long *__restrict__ bm, const u32 *__restrict__ genome_off,
+                  unsigned long long *__restrict__ union_len) {
+    __shared__ u32 part[4];
+    const u32 u = blockIdx.x;
+    const u32 s = genome_off[u], e = genome_off[u + 1];
+    u32 c = 0;
+    if (e > s) {
+        const u32 w0 = s >> 6, w1 = (e - 1) >> 6;
+        for (u32 w = w0 + threadIdx.x; w <= w1; w += blockDim.x) {
+            u64 m = ~0ull;
+            if (w == w0) m &= ~0ull << (s & 63);
+            if (w == w1) m &= ~0ull >> (63 - ((e - 1) & 63));
+            c += (u32)__popcll(bm[w] & m);
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, WAVE);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) union_len[u] = (unsigned long long)part[0] + part[1] + part[2] + part[3];
+}
+
+extern "C" int catchhip_rows_stats(catchhip_ctx *ctx, const catchhip_rows *R, i64 *total_len, i64 *union_len,
+                                   i64 num_sets, i64 *universes_per_set) {
+    ARG_CHECK(ctx && R && R->ctx == ctx && !R->deferred && total_len && union_len);
+    ARG_CHECK(num_sets >= 0 && (num_sets == 0 || universes_per_set));
+    PoolScope pool_scope(ctx);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t ng = (size_t)R->ngenomes, nw = (size_t)(R->total >> 6) + 2;
+    if (ng == 0) return 0;
+    DevBuf<unsigned long long> bm, tl, ul, ps;
+    TRY(bm.alloc(nw));
+    TRY(tl.alloc(ng));
+    TRY(ul.alloc(ng));
+    TRY(ps.alloc((size_t)num_sets + 1));
+    HIP_TRY(hipMemsetAsync(bm.p, 0, sizeof(unsigned long long) * nw, s));
+    HIP_TRY(hipMemsetAsync(tl.p, 0, sizeof(unsigned long long) * ng, s));
+    HIP_TRY(hipMemsetAsync(ps.p, 0, sizeof(unsigned long long) * ((size_t)num_sets + 1), s));
+    PhaseTimer tm(ctx, PHASE_ROWS);
+    if (R->n) {
+        // every set id must index universes_per_set
+        hipLaunchKernelGGL(rows_stats_kernel, dim3((unsigned)div_up(R->n, 256)), dim3(256), 0, s,
+                           (const i32 *)R->set_id.p, (const i32 *)R->univ.p, (const u32 *)R->gs.p, (const u32 *)R->ge.p,
+                           (u32)R->n, bm.p, tl.p, num_sets ? ps.p : (unsigned long long *)nullptr);
+    }
+    hipLaunchKernelGGL(rows_union_kernel, dim3((unsigned)ng), dim3(256), 0, s, (const unsigned long long *)bm.p,
+                       (const u32 *)R->genome_off.p, ul.p);
+    tm.launch(2);
+    HIP_TRY(hipGetLastError());
+    static_assert(sizeof(i64) == sizeof(unsigned long long), "64-bit counters");
+    HIP_TRY(hipMemcpyAsync(total_len, tl.p, sizeof(i64) * ng, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(union_len, ul.p, sizeof(i64) * ng, hipMemcpyDeviceToHost, s));
+    if (num_sets) HIP_TRY(hipMemcpyAsync(universes_per_set, ps.p, sizeof(i64) * (size_t)num_sets, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    tm.finish();
+    return 0;
+}
+
 extern "C" int catchhip_rows_from_host(catchhip_ctx *ctx, const i32 *set_id, const i32 *universe,
                                        const i64 *start, const i64 *end, i64 nrows, const i64 *genome_len,
                                        i32 ngenomes, catchhip_rows **out) {

@@ -385,6 +385,17 @@ class Rows:
             ctypes.byref(h), ctypes.byref(n)))
         return Rows(ctx, h, n.value)
 
+    def stats(self, ngenomes, num_sets=0):
+        """catchhip_rows_stats -> (total_len[ngenomes], union_len[ngenomes],
+        universes_per_set[num_sets])."""
+        tl = np.zeros(max(ngenomes, 1), dtype=np.int64)
+        ul = np.zeros(max(ngenomes, 1), dtype=np.int64)
+        ps = np.zeros(max(num_sets, 1), dtype=np.int64)
+        check(self.ctx._L.catchhip_rows_stats(
+            self.ctx._h, self._h, _ptr(tl, c_i64p), _ptr(ul, c_i64p),
+            int(num_sets), _ptr(ps, c_i64p)))
+        return tl[:ngenomes], ul[:ngenomes], ps[:num_sets]
+
     def fetch_first_seen(self):
         """uint64[n]: (k-mer position in the universe << 32) | anchor order."""
         out = np.zeros(max(self.n, 1), dtype=np.uint64)

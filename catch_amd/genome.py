@@ -11,13 +11,17 @@ class Genome:
         self.seqs = seqs
         self.chrs = chrs
         self._size = None
+        self._size_unambig = None
 
     def divided_into_chrs(self):
         return len(self.seqs) > 1
 
     def size(self, only_unambig=False):
         if only_unambig:
-            return sum(seq.count(b) for seq in self.seqs for b in "ATCG")
+            if self._size_unambig is None:
+                self._size_unambig = sum(seq.count(b) for seq in self.seqs
+                                         for b in "ATCG")
+            return self._size_unambig
         if self._size is None:
             self._size = sum(len(seq) for seq in self.seqs)
         return self._size

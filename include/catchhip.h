@@ -391,6 +391,16 @@ int catchhip_probes_from_candidates(catchhip_ctx *ctx, const catchhip_candidates
                                     const int32_t *ent_probe, const int32_t *ent_pos,
                                     int64_t nent, int32_t k, catchhip_probes **out);
 
+/* Statistics of a row table without fetching it (coverage analysis of large
+ * designs, catch/coverage_analysis.py:282-335): per universe total_len = sum of
+ * (end - start) over its rows (:318-320) and union_len = bases covered by at
+ * least one row (:282-302); per set id < num_sets the number of universes it
+ * has rows in (probe_map_counts, :255-258, with one universe per sequence).
+ * Every set id in the table must be < num_sets when num_sets > 0. */
+int catchhip_rows_stats(catchhip_ctx *ctx, const catchhip_rows *rows,
+                        int64_t *total_len, int64_t *union_len,
+                        int64_t num_sets, int64_t *universes_per_set);
+
 #ifdef __cplusplus
 }
 #endif
