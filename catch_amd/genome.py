@@ -3,6 +3,9 @@
 from collections import OrderedDict
 
 
+_DROP_ATCG = str.maketrans("", "", "ATCG")
+
+
 class Genome:
     def __init__(self, seqs, chrs=None):
         if len(seqs) > 1 and chrs is None:
@@ -19,8 +22,10 @@ class Genome:
     def size(self, only_unambig=False):
         if only_unambig:
             if self._size_unambig is None:
-                self._size_unambig = sum(seq.count(b) for seq in self.seqs
-                                         for b in "ATCG")
+                # bases that are A, T, C or G (catch/genome.py:52-56), one pass
+                self._size_unambig = sum(
+                    len(seq) - len(seq.translate(_DROP_ATCG))
+                    for seq in self.seqs)
             return self._size_unambig
         if self._size is None:
             self._size = sum(len(seq) for seq in self.seqs)
