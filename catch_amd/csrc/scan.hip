@@ -1516,6 +1516,185 @@ extern "C" int catchhip_rows_stats(catchhip_ctx *ctx, const catchhip_rows *R, i6
     return 0;
 }
 
+// ------------------------------------------------------------------------
+// adapter votes (catch/filter/adapter_filter.py:191-361) on a row table with
+// first-discovery keys, one universe per sequence
+// ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+av_key1_kernel(const unsigned long long *__restrict__ first_key, u32 n, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) { keys[r] = first_key[r]; vals[r] = r; }
+}
+
+__global__ void __launch_bounds__(256)
+av_key2_kernel(const i32 *__restrict__ univ, const u32 *__restrict__ ge, const u32 *__restrict__ vals, u32 n,
+               u64 *__restrict__ keys) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const u32 r = vals[i]; keys[i] = ((u64)(u32)univ[r] << 32) | ge[r]; }
+}
+
+// first index whose key's universe is >= u (keys sorted by (universe, end))
+__device__ __forceinline__ u32 av_lower(const u64 *__restrict__ keys, u32 n, u32 u) {
+    u32 lo = 0, hi = n;
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if ((u32)(keys[mid] >> 32) < u) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// interval.schedule per sequence (catch/utils/interval.py:319-358): rows by end
+// (ties: first-discovery key), take a row when it starts at or after the last
+// taken end; a taken row marks its (probe, sequence) group
+__global__ void __launch_bounds__(64)
+av_schedule_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ perm, u32 n, u32 nuniv,
+                   const i32 *__restrict__ set_id, const i32 *__restrict__ univ, const u32 *__restrict__ gs,
+                   const u32 *__restrict__ ge, const u32 *__restrict__ genome_off, u32 *__restrict__ group_chosen) {
+    const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nuniv) return;
+    const u32 lo = av_lower(keys, n, u), hi = av_lower(keys, n, u + 1);
+    u32 last_end = 0;
+    bool any = false;
+    for (u32 i = lo; i < hi; ++i) {
+        const u32 r = perm[i];
+        const u32 s = gs[r];
+        if (!any || s >= last_end) {
+            any = true;
+            last_end = ge[r];
+            // first row of the (set, universe) group in the set-sorted table
+            const u32 head = rows_lower_bound(set_id, gs, n, set_id[r], genome_off[univ[r]]);
+            group_chosen[head] = 1u;
+        }
+    }
+}
+
+// group heads (one per (probe, sequence)) keyed by universe
+__global__ void __launch_bounds__(256)
+av_heads_kernel(const i32 *__restrict__ set_id, const i32 *__restrict__ univ, u32 n, u32 *__restrict__ flag) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= n) flag[r] = (r < n && (r == 0 || set_id[r - 1] != set_id[r] || univ[r - 1] != univ[r])) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256)
+av_headkeys_kernel(const u32 *__restrict__ flag, const u32 *__restrict__ at, const i32 *__restrict__ univ, u32 n,
+                   u64 *__restrict__ keys, u32 *__restrict__ vals) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && flag[r]) { keys[at[r]] = (u64)(u32)univ[r]; vals[at[r]] = r; }
+}
+
+// The running totals over the sequences, in order (:330-358): one workgroup;
+// per sequence every voter's vote is added plain or swapped, whichever gives
+// the larger sum of per-probe majorities (swapped only if strictly larger).
+__global__ void __launch_bounds__(1024)
+av_tally_kernel(const u64 *__restrict__ hkeys, const u32 *__restrict__ heads, u32 nheads, u32 nuniv,
+                const i32 *__restrict__ set_id, const u32 *__restrict__ group_chosen, const i64 *__restrict__ mult,
+                i64 *__restrict__ cum_a, i64 *__restrict__ cum_b) {
+    __shared__ long long s_plain[16], s_swap[16];
+    __shared__ int s_flip;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 lo = 0;
+    while (lo < nheads) {
+        const u32 u = (u32)hkeys[lo];            // uniform
+        u32 hi = lo;                            // end of this universe's voters
+        {
+            u32 a = lo, b = nheads;
+            while (a < b) { const u32 mid = (a + b) >> 1; if ((u32)hkeys[mid] <= u) a = mid + 1; else b = mid; }
+            hi = a;
+        }
+        long long plain = 0, swp = 0;
+        for (u32 i = lo + tid; i < hi; i += 1024) {
+            const u32 h = heads[i];
+            const i32 p = set_id[h];
+            const long long a = group_chosen[h] ? 1 : 0, b = 1 - a, ca = cum_a[p], cb = cum_b[p], w = mult[p];
+            const long long base = ca > cb ? ca : cb;
+            const long long m1 = (ca + a > cb + b ? ca + a : cb + b), m2 = (ca + b > cb + a ? ca + b : cb + a);
+            plain += w * (m1 - base);
+            swp += w * (m2 - base);
+        }
+        for (int d = 32; d > 0; d >>= 1) { plain += __shfl_down(plain, d, WAVE); swp += __shfl_down(swp, d, WAVE); }
+        if (lane == 0) { s_plain[wave] = plain; s_swap[wave] = swp; }
+        __syncthreads();
+        if (tid == 0) {
+            long long P = 0, S = 0;
+            for (int w = 0; w < 16; ++w) { P += s_plain[w]; S += s_swap[w]; }
+            s_flip = S > P ? 1 : 0;
+        }
+        __syncthreads();
+        const int flip = s_flip;
+        for (u32 i = lo + tid; i < hi; i += 1024) {
+            const u32 h = heads[i];
+            const i32 p = set_id[h];
+            const long long a = group_chosen[h] ? 1 : 0, b = 1 - a;
+            cum_a[p] += flip ? b : a;
+            cum_b[p] += flip ? a : b;
+        }
+        __syncthreads();
+        lo = hi;
+    }
+}
+
+extern "C" int catchhip_adapter_votes(catchhip_ctx *ctx, const catchhip_rows *R, i64 num_sets, const i64 *multiplicity,
+                                      i64 *votes_a, i64 *votes_b) {
+    ARG_CHECK(ctx && R && R->ctx == ctx && !R->deferred && num_sets >= 0);
+    if (num_sets == 0) return 0;
+    ARG_CHECK(votes_a && votes_b && multiplicity);
+    PoolScope pool_scope(ctx);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    memset(votes_a, 0, sizeof(i64) * (size_t)num_sets);
+    memset(votes_b, 0, sizeof(i64) * (size_t)num_sets);
+    if (R->n == 0) return 0;
+    if (!R->first_key.p) {
+        chip_set_error("adapter_votes: these rows do not come from catchhip_cover_scan_first_seen");
+        return CATCHHIP_EINVAL;
+    }
+    const u32 n = (u32)R->n, nuniv = (u32)R->ngenomes;
+    DevBuf<u64> keys, keys_alt, hkeys, hkeys_alt;
+    DevBuf<u32> perm, perm_alt, chosen, flag, at, tmp, heads, heads_alt;
+    DevBuf<i64> d_mult, cum_a, cum_b;
+    TRY(keys.alloc(n));
+    TRY(perm.alloc(n));
+    TRY(chosen.alloc((size_t)n + 1));
+    TRY(flag.alloc((size_t)n + 1));
+    TRY(at.alloc((size_t)n + 1));
+    TRY(d_mult.alloc((size_t)num_sets));
+    TRY(cum_a.alloc((size_t)num_sets));
+    TRY(cum_b.alloc((size_t)num_sets));
+    HIP_TRY(hipMemcpyAsync(d_mult.p, multiplicity, sizeof(i64) * (size_t)num_sets, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(cum_a.p, 0, sizeof(i64) * (size_t)num_sets, s));
+    HIP_TRY(hipMemsetAsync(cum_b.p, 0, sizeof(i64) * (size_t)num_sets, s));
+    HIP_TRY(hipMemsetAsync(chosen.p, 0, sizeof(u32) * ((size_t)n + 1), s));
+    PhaseTimer tm(ctx, PHASE_ROWS);
+    const unsigned nb = (unsigned)div_up((i64)n, 256);
+    // rows by (universe, end, first-discovery key): two stable sorts, least significant key first
+    hipLaunchKernelGGL(av_key1_kernel, dim3(nb), dim3(256), 0, s, (const unsigned long long *)R->first_key.p, n, keys.p, perm.p);
+    TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, perm, perm_alt, n, 64));
+    hipLaunchKernelGGL(av_key2_kernel, dim3(nb), dim3(256), 0, s, (const i32 *)R->univ.p, (const u32 *)R->ge.p,
+                       (const u32 *)perm.p, n, keys.p);
+    TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, perm, perm_alt, n, 64));
+    hipLaunchKernelGGL(av_schedule_kernel, dim3((unsigned)div_up((i64)nuniv, 64)), dim3(64), 0, s, (const u64 *)keys.p,
+                       (const u32 *)perm.p, n, nuniv, (const i32 *)R->set_id.p, (const i32 *)R->univ.p,
+                       (const u32 *)R->gs.p, (const u32 *)R->ge.p, (const u32 *)R->genome_off.p, chosen.p);
+    // voters: one per (set, universe) group, grouped by universe
+    hipLaunchKernelGGL(av_heads_kernel, dim3((unsigned)div_up((i64)n + 1, 256)), dim3(256), 0, s, (const i32 *)R->set_id.p,
+                       (const i32 *)R->univ.p, n, flag.p);
+    TRY(chip_exclusive_scan_u32(ctx, flag.p, at.p, (i64)n + 1, tmp));
+    HIP_TRY(hipMemcpyAsync(ctx->h_pin, at.p + n, sizeof(u32), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const u32 nheads = *(volatile u32 *)ctx->h_pin;
+    TRY(hkeys.alloc(nheads));
+    TRY(heads.alloc(nheads));
+    hipLaunchKernelGGL(av_headkeys_kernel, dim3(nb), dim3(256), 0, s, (const u32 *)flag.p, (const u32 *)at.p,
+                       (const i32 *)R->univ.p, n, hkeys.p, heads.p);
+    TRY(chip_radix_sort_pairs(ctx, hkeys, hkeys_alt, heads, heads_alt, nheads, 32));
+    hipLaunchKernelGGL(av_tally_kernel, dim3(1), dim3(1024), 0, s, (const u64 *)hkeys.p, (const u32 *)heads.p, nheads,
+                       nuniv, (const i32 *)R->set_id.p, (const u32 *)chosen.p, (const i64 *)d_mult.p, cum_a.p, cum_b.p);
+    tm.launch(60);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(votes_a, cum_a.p, sizeof(i64) * (size_t)num_sets, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(votes_b, cum_b.p, sizeof(i64) * (size_t)num_sets, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    tm.finish();
+    return 0;
+}
+
 extern "C" int catchhip_rows_from_host(catchhip_ctx *ctx, const i32 *set_id, const i32 *universe,
                                        const i64 *start, const i64 *end, i64 nrows, const i64 *genome_len,
                                        i32 ngenomes, catchhip_rows **out) {

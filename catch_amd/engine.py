@@ -385,6 +385,17 @@ class Rows:
             ctypes.byref(h), ctypes.byref(n)))
         return Rows(ctx, h, n.value)
 
+    def adapter_votes(self, multiplicity):
+        """catchhip_adapter_votes -> (A votes, B votes) per set id."""
+        mult = np.ascontiguousarray(multiplicity, dtype=np.int64)
+        n = int(mult.size)
+        a = np.zeros(max(n, 1), dtype=np.int64)
+        b = np.zeros(max(n, 1), dtype=np.int64)
+        check(self.ctx._L.catchhip_adapter_votes(
+            self.ctx._h, self._h, n, _ptr(mult, c_i64p), _ptr(a, c_i64p),
+            _ptr(b, c_i64p)))
+        return a[:n], b[:n]
+
     def stats(self, ngenomes, num_sets=0):
         """catchhip_rows_stats -> (total_len[ngenomes], union_len[ngenomes],
         universes_per_set[num_sets])."""

@@ -15,8 +15,11 @@ stable sort breaks ties between ranges with equal ends.  At one k-mer position
 the reference lists the k-mer's entries by iterating a Python set of
 (Probe, position) tuples; the same sets are built here from the caller's probe
 objects in the same insertion order, so the interpreter yields the same order
-(whatever its string-hash seed is).  On the host: the sequential parts
-(scheduling inside a sequence, the running vote totals across sequences).
+(whatever its string-hash seed is).  The sequential parts run on the device
+as well (catchhip_adapter_votes): the rows are sorted by (sequence, end,
+first-seen key), one thread per sequence makes the schedule, and one workgroup
+walks the sequences in order keeping the running vote totals -- the row table
+(hundreds of millions of rows for a large design) never comes to the host.
 """
 import logging
 
@@ -93,47 +96,14 @@ class AdapterFilter(BaseFilter):
                 rows = engine.Rows.scan_first_seen(
                     ctx, dev, targets, self.mismatches, self.lcf_thres,
                     self.island_of_exact_match, 0, engine.SCAN_AUTO, order)
-                sid, univ, st, en = rows.fetch()
-                key = rows.fetch_first_seen()
+                # scheduling inside every sequence and the running totals over
+                # the sequences, on the device (catchhip_adapter_votes)
+                cum_a, cum_b = rows.adapter_votes(mult)
                 rows.close()
             finally:
                 dev.close()
                 targets.close()
-            self._tally(sid, univ, st, en, key, mult, cum_a, cum_b)
         return list(zip(cum_a[which].tolist(), cum_b[which].tolist()))
-
-    @staticmethod
-    def _tally(sid, univ, st, en, key, mult, cum_a, cum_b):
-        """Per sequence, in order: schedule (stable sort by end over the dict
-        order = (first-seen key, start)), votes, swap if that raises the sum of
-        majorities (:191-240, :330-358)."""
-        if sid.size == 0:
-            return
-        by = np.lexsort((st, key, en, univ))
-        sid, univ, st, en = sid[by], univ[by], st[by].tolist(), en[by].tolist()
-        n = len(st)
-        chosen = np.zeros(n, dtype=np.int64)
-        bounds = np.flatnonzero(np.diff(univ)) + 1
-        starts = [0] + bounds.tolist()
-        ends = bounds.tolist() + [n]
-        for lo, hi in zip(starts, ends):
-            last_end = -1
-            for i in range(lo, hi):
-                if st[i] >= last_end:
-                    chosen[i] = 1
-                    last_end = en[i]
-            voters, inv = np.unique(sid[lo:hi], return_inverse=True)
-            a = np.zeros(len(voters), dtype=np.int64)
-            np.maximum.at(a, inv, chosen[lo:hi])
-            b = 1 - a
-            ca, cb, w = cum_a[voters], cum_b[voters], mult[voters]
-            base = np.maximum(ca, cb)
-            plain = int((w * (np.maximum(ca + a, cb + b) - base)).sum())
-            swapped = int((w * (np.maximum(ca + b, cb + a) - base)).sum())
-            if swapped > plain:
-                a, b = b, a
-            cum_a[voters] += a
-            cum_b[voters] += b
 
     def _filter(self, input, target_genomes):
         input = list(input)

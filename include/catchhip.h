@@ -401,6 +401,19 @@ int catchhip_rows_stats(catchhip_ctx *ctx, const catchhip_rows *rows,
                         int64_t *total_len, int64_t *union_len,
                         int64_t num_sets, int64_t *universes_per_set);
 
+/* AdapterFilter._make_votes_across_target_genomes (catch/filter/adapter_filter.py
+ * :299-361) on rows from catchhip_cover_scan_first_seen with one universe per
+ * sequence: per sequence, in order, the greedy interval schedule over its
+ * ranges sorted by end (ties by first-discovery key; catch/utils/interval.py
+ * :319-358) gives the scheduled probes an 'A' vote and the other hybridizing
+ * probes a 'B' vote, and the sequence's votes are swapped when that makes the
+ * sum over all probes of max(A, B) strictly larger; multiplicity[set id] = how
+ * many input probes equal that probe (each counts in the sums).  Returns the
+ * totals per set id (num_sets must exceed every set id of the table). */
+int catchhip_adapter_votes(catchhip_ctx *ctx, const catchhip_rows *rows,
+                           int64_t num_sets, const int64_t *multiplicity,
+                           int64_t *votes_a, int64_t *votes_b);
+
 #ifdef __cplusplus
 }
 #endif
