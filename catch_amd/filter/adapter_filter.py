@@ -49,6 +49,29 @@ class AdapterFilter(BaseFilter):
         self.lcf_thres = lcf_thres
         self.island_of_exact_match = island_of_exact_match
         self.kmer_probe_map_k = kmer_probe_map_k
+        # the targets object of the last call: the designer calls the filter
+        # once per group of probes with the SAME target genomes
+        self._cached_targets = None
+
+    def _targets_for(self, ctx, target_genomes, seqs):
+        key = (id(target_genomes), len(seqs), sum(map(len, seqs)))
+        if self._cached_targets is not None and self._cached_targets[0] == key:
+            return self._cached_targets[1]
+        self._drop_cached_targets()
+        targets = engine.Targets(ctx, [[s] for s in seqs])
+        self._cached_targets = (key, targets, target_genomes)   # keeps the list (and its id) alive
+        return targets
+
+    def _drop_cached_targets(self):
+        if self._cached_targets is not None:
+            self._cached_targets[1].close()
+            self._cached_targets = None
+
+    def __del__(self):
+        try:
+            self._drop_cached_targets()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------
     def _anchor_order(self, probes, strs, uniq, ep, eo, draws, k):
@@ -89,7 +112,7 @@ class AdapterFilter(BaseFilter):
         cum_b = np.zeros(len(uniq), dtype=np.int64)
         if seqs:
             ctx = engine.default_context()
-            targets = engine.Targets(ctx, [[s] for s in seqs])
+            targets = self._targets_for(ctx, target_genomes, seqs)
             dev = engine.Probes(ctx, uniq,
                                 np.arange(len(uniq), dtype=np.int32), ep, eo, k)
             try:
@@ -102,7 +125,6 @@ class AdapterFilter(BaseFilter):
                 rows.close()
             finally:
                 dev.close()
-                targets.close()
         return list(zip(cum_a[which].tolist(), cum_b[which].tolist()))
 
     def _filter(self, input, target_genomes):
