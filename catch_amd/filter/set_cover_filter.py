@@ -507,13 +507,42 @@ class SetCoverFilter(BaseFilter):
             timings["picks"] += len(ids)
 
 
-_extra_ctxs = []
+_extra_ctxs = {}
+
+
+def _devices():
+    """Devices the groups in flight are spread over.  Default: the default
+    context's device only (one process per GPU, as torchrun launches the
+    bench).  CATCHHIP_DEVICES=all or a comma-separated list lets ONE process
+    use several GPUs for independent groups (first row: whole
+    groups to GPUs, no collective): every context has its own device, stream
+    and allocator partition, and catchhip_setcover_filter_many already runs
+    one host thread per context."""
+    import os
+    first = engine.default_context().device
+    spec = os.environ.get("CATCHHIP_DEVICES", "")
+    if not spec:
+        return [first]
+    if spec == "all":
+        devs = list(range(engine.device_count()))
+    else:
+        devs = [int(x) for x in spec.split(",") if x.strip() != ""]
+    devs = [d for d in devs if 0 <= d < engine.device_count()]
+    if first in devs:                      # the default context keeps slot 0
+        devs.remove(first)
+    return [first] + devs
 
 
 def _contexts(n):
-    """The default context plus cached extra ones on the same device, one per
-    group in flight."""
+    """The default context plus cached extra ones, one per group in flight,
+    round-robin over _devices()."""
     first = engine.default_context()
-    while len(_extra_ctxs) < n - 1:
-        _extra_ctxs.append(engine.Context(first.device))
-    return [first] + _extra_ctxs[:n - 1]
+    devs = _devices()
+    out = [first]
+    for i in range(1, n):
+        dev = devs[i % len(devs)]
+        key = (dev, i // len(devs))
+        if key not in _extra_ctxs:
+            _extra_ctxs[key] = engine.Context(dev)
+        out.append(_extra_ctxs[key])
+    return out
