@@ -1,5 +1,5 @@
 """Randomised differential test of the HIP path against the CPU oracle (GPU box).
-    python tools/fuzz_parity.py [seconds] [seed]
+    python tests/fuzz_parity.py [seconds] [seed]
 Random groups of genomes (several chromosomes, N runs, repeats, short
 sequences), random -pl/-ps/-m/-l/-e/-c/island/identify settings, with and
 without duplicate candidates; compares the cover rows and the selected probe

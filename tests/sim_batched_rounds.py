@@ -1,7 +1,7 @@
 """Design aid (not product code): simulate the batched greedy round structure
 on the CPU to see how many rounds different candidate rules need.
 
-    python tools/sim_batched_rounds.py [dataset] [group]
+    python tests/sim_batched_rounds.py [dataset] [group]
 
 Rule "full": every live set is a candidate (theoretical minimum of rounds for
 the word-granular ownership test).  Rule "topT": per-thread top-T keys over
