@@ -460,20 +460,12 @@ seed_join_kernel(const u8 *__restrict__ tbytes, u32 total, const u32 *__restrict
 #define MAX_MM 32
 // one lane per seed hit: the reference's cover function on the aligned window
 // (catch/probe.py:1070-1108 + :1328-1344 + longest_common_substring.py:59-159)
-__global__ void __launch_bounds__(256)
-extend_kernel(const u8 *__restrict__ tbytes, const u32 *__restrict__ seq_off, u32 nseq,
-              const u8 *__restrict__ pbytes, const u32 *__restrict__ probe_off,
-              const i32 *__restrict__ ent_probe, const i32 *__restrict__ ent_pos, int k,
-              int mm, int lcf_thres, int island, const u32 *__restrict__ seed_ent,
-              const u32 *__restrict__ seed_pos, u32 nseeds, HitBuf out) {
-    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nseeds) return;
-    const u32 e = seed_ent[t], gi = seed_pos[t];
-    const i32 p = ent_probe[e];
-    const i64 a = ent_pos[e];
+__device__ __forceinline__ void extend_bytes(const u8 *__restrict__ tbytes, const u32 *__restrict__ seq_off, u32 s,
+                                             const u8 *__restrict__ pbytes, const u32 *__restrict__ probe_off,
+                                             i32 p, i64 a, int k, int mm, int lcf_thres, int island, u32 e, u32 gi,
+                                             const HitBuf &out) {
     const u8 *pf = pbytes + probe_off[p];
     const i64 L = (i64)(probe_off[p + 1] - probe_off[p]);
-    const u32 s = find_segment(seq_off, nseq, gi);
     const i64 lo = seq_off[s], G = (i64)seq_off[s + 1] - lo;
     const i64 i = (i64)gi - lo;
     const i64 off = i - a;
@@ -517,6 +509,217 @@ extend_kernel(const u8 *__restrict__ tbytes, const u32 *__restrict__ seq_off, u3
         out.a[slot] = (u32)p; out.b[slot] = gs; out.c[slot] = gs + (u32)best_len;
         if (out.d) { out.d[slot] = gi; out.e[slot] = e; }
     }
+}
+
+__global__ void __launch_bounds__(256)
+extend_kernel(const u8 *__restrict__ tbytes, const u32 *__restrict__ seq_off, u32 nseq,
+              const u8 *__restrict__ pbytes, const u32 *__restrict__ probe_off,
+              const i32 *__restrict__ ent_probe, const i32 *__restrict__ ent_pos, int k,
+              int mm, int lcf_thres, int island, const u32 *__restrict__ seed_ent,
+              const u32 *__restrict__ seed_pos, u32 nseeds, HitBuf out) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseeds) return;
+    const u32 e = seed_ent[t], gi = seed_pos[t];
+    extend_bytes(tbytes, seq_off, find_segment(seq_off, nseq, gi), pbytes, probe_off, ent_probe[e], (i64)ent_pos[e], k,
+                 mm, lcf_thres, island, e, gi, out);
+}
+
+// highest set bit of the NW-word mask below position `below`, or -1
+template <int NW>
+__device__ __forceinline__ int mask_prev(const u32 (&mw)[NW], int below) {
+#pragma unroll
+    for (int j = NW - 1; j >= 0; --j) {
+        const int lim = below - 32 * j;
+        if (lim <= 0) continue;
+        const u32 w = lim >= 32 ? mw[j] : (mw[j] & ((1u << lim) - 1u));
+        if (w) return 32 * j + 31 - __clz((int)w);
+    }
+    return -1;
+}
+// lowest set bit at or above position `from`, or -1 (bits beyond the probe are zero)
+template <int NW>
+__device__ __forceinline__ int mask_next(const u32 (&mw)[NW], int from) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int lo = from - 32 * j;
+        if (lo >= 32) continue;
+        const u32 w = lo <= 0 ? mw[j] : (mw[j] & ~((1u << lo) - 1u));
+        if (w) return 32 * j + __ffs((int)w) - 1;
+    }
+    return -1;
+}
+
+// The same cover function on the packed images (equal-length DNA probes): the
+// mismatch mask of the whole window in NW words, then the <= mm+1 mismatches on
+// either side of the anchor by bit scans instead of up to L byte comparisons.
+// Windows cut by a sequence end (rare) take the byte routine.
+struct ExtHit { u32 p, gs, ge, gi, e; };
+template <int NW>
+__device__ __forceinline__ bool extend_planes_one(u32 t, const u32 *__restrict__ tplanes, i64 nwords,
+                                                  const u32 *__restrict__ seq_off, const uint4 *__restrict__ pplanes,
+                                                  const i32 *__restrict__ ent_probe, const i32 *__restrict__ ent_pos,
+                                                  int L, int k, int mm, int lcf_thres, int island, u32 tailmask,
+                                                  int use_n, const u32 *__restrict__ seed_ent,
+                                                  const u32 *__restrict__ seed_pos, const u32 *__restrict__ seed_seq,
+                                                  u32 *__restrict__ cut, u32 cut_cap, ExtHit &hit) {
+    const u32 e = seed_ent[t], gi = seed_pos[t], sq = seed_seq[t];
+    const i32 p = ent_probe[e];
+    const int a = ent_pos[e];
+    const u32 lo = seq_off[sq], hi = seq_off[sq + 1];
+    // a window cut by a sequence end goes on a list for the byte routine (its
+    // local arrays would give THIS kernel a scratch frame, and with it a fraction of
+    // the wavefronts in flight: 15 ms instead of 2 for the seeds of S4 x 0.1)
+    const bool is_cut = gi < lo + (u32)a || gi - (u32)a + (u32)L > hi;
+    if (is_cut) {
+        const u32 at = atomicAdd(&cut[0], 1u);
+        if (at < cut_cap) cut[1 + at] = t;
+    }
+    bool ok = !is_cut && mm >= 0;
+    u32 gs = 0, glen = 0;
+    if (ok) {
+        const u32 o = gi - (u32)a;
+        const u32 wi = o >> 5, sh = o & 31;
+        const u32 *p0 = tplanes + wi, *p1 = tplanes + nwords + wi, *p2 = tplanes + 2 * nwords + wi;
+        const uint4 *pq = pplanes + (size_t)p * NW;
+        u32 mw[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const uint4 q = pq[j];
+            u32 x = (__builtin_amdgcn_alignbit(p0[j + 1], p0[j], sh) ^ q.x) |
+                    (__builtin_amdgcn_alignbit(p1[j + 1], p1[j], sh) ^ q.y);
+            if (use_n) x |= (__builtin_amdgcn_alignbit(p2[j + 1], p2[j], sh) ^ q.z);
+            if (j == NW - 1) x &= tailmask;
+            mw[j] = x;
+        }
+        // the seed is a k-mer equality in the reference (dict lookup)
+        ok = mask_range_zero<NW>(mw, a, k);
+        if (ok) {
+            const int ks = a, ke = a + k;
+            // right side: up to mm+1 mismatches; `rcur` = the na-th of them
+            int na = 0, rcur = -1;
+            for (int pos = ke; na <= mm;) {
+                const int b = mask_next<NW>(mw, pos);
+                if (b < 0) break;
+                rcur = b; ++na; pos = b + 1;
+            }
+            // budget q on the left, mm - q on the right (longest_common_substring.py:133-157):
+            // the left pointer walks outwards, the right one back in; the first maximum wins
+            int best_len = -1, best_start = -1, lcur = ks;
+            bool lmore = true;
+            for (int q = 0; q <= mm; ++q) {
+                int bl = ks;
+                if (lmore) {
+                    const int b = mask_prev<NW>(mw, lcur);
+                    if (b < 0) lmore = false;
+                    else { bl = (ks - 1) - b; lcur = b; }
+                }
+                const int jr = mm - q;                 // index of the right mismatch that stops the run
+                int al = L - ke;
+                if (jr < na) al = rcur - ke;       // rcur stands on right mismatch number jr
+                const int len = bl + k + al;
+                if (len > best_len) { best_len = len; best_start = ks - bl; }
+                // the next iteration needs right mismatch number jr - 1: the one before rcur
+                if (jr < na && jr >= 1) rcur = mask_prev<NW>(mw, rcur);
+            }
+            i64 thr = lcf_thres;
+            if (L < thr) thr = L;
+            if ((i64)(hi - lo) < thr) thr = (i64)(hi - lo);
+            ok = best_len >= thr;
+            if (ok && island > 0) {
+                const int b0 = mask_prev<NW>(mw, ks), a0 = mask_next<NW>(mw, ke);
+                int exact = (b0 >= 0 ? (ks - 1) - b0 : ks) + k + (a0 >= 0 ? a0 - ke : (L - ke));
+                if (mm == 0) exact = best_len;
+                ok = exact >= island;
+            }
+            gs = o + (u32)best_start;
+            glen = (u32)best_len;
+        }
+    }
+    hit.p = (u32)p; hit.gs = gs; hit.ge = gs + glen; hit.gi = gi; hit.e = e;
+    return ok;
+}
+
+// SE_PPT seeds per thread and ONE counter update per workgroup: the hit counter
+// is a single address, ~10 ns per atomic -- one per wavefront (what the compiler
+// makes of a per-hit atomicAdd) was 1.8 M atomics = 15-20 ms for the 114 M seeds
+// of S4 x 0.1, whatever the rest of the kernel did.
+#define SE_PPT 4
+template <int NW>
+__global__ void __launch_bounds__(256)
+extend_planes_kernel(const u32 *__restrict__ tplanes, i64 nwords, const u8 *__restrict__ tbytes,
+                     const u32 *__restrict__ seq_off, const uint4 *__restrict__ pplanes,
+                     const u8 *__restrict__ pbytes, const u32 *__restrict__ probe_off,
+                     const i32 *__restrict__ ent_probe, const i32 *__restrict__ ent_pos, int L, int k, int mm,
+                     int lcf_thres, int island, u32 tailmask, int use_n, const u32 *__restrict__ seed_ent,
+                     const u32 *__restrict__ seed_pos, const u32 *__restrict__ seed_seq, u32 nseeds, HitBuf out,
+                     u32 *__restrict__ cut, u32 cut_cap) {
+    __shared__ u32 s_part[4], s_base;
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 t0 = blockIdx.x * (256 * SE_PPT);
+    ExtHit h[SE_PPT];
+    u32 okmask = 0, mine = 0;
+#pragma unroll
+    for (int q = 0; q < SE_PPT; ++q) {
+        const u32 t = t0 + q * 256 + threadIdx.x;   // consecutive lanes, consecutive seeds
+        bool ok = false;
+        if (t < nseeds)
+            ok = extend_planes_one<NW>(t, tplanes, nwords, seq_off, pplanes, ent_probe, ent_pos, L, k, mm, lcf_thres,
+                                       island, tailmask, use_n, seed_ent, seed_pos, seed_seq, cut, cut_cap, h[q]);
+        okmask |= ok ? (1u << q) : 0u;
+        mine += ok ? 1u : 0u;
+    }
+    u32 wtotal;
+    const u32 ex = wave_excl_scan(mine, &wtotal);
+    if (lane == 0) s_part[wave] = wtotal;
+    __syncthreads();
+    u32 woff = 0, tot = 0;
+    for (int w = 0; w < 4; ++w) { if (w < (int)wave) woff += s_part[w]; tot += s_part[w]; }
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(out.count, tot) : 0u;
+    __syncthreads();
+    u32 slot = s_base + woff + ex;
+#pragma unroll
+    for (int q = 0; q < SE_PPT; ++q) {
+        if (!(okmask & (1u << q))) continue;
+        if (slot < out.cap) {
+            out.a[slot] = h[q].p; out.b[slot] = h[q].gs; out.c[slot] = h[q].ge;
+            if (out.d) { out.d[slot] = h[q].gi; out.e[slot] = h[q].e; }
+        }
+        ++slot;
+    }
+    (void)tbytes; (void)pbytes; (void)probe_off;
+}
+
+// the listed seeds through the byte routine
+__global__ void __launch_bounds__(256)
+extend_cut_kernel(const u32 *__restrict__ cut, u32 cut_cap, const u8 *__restrict__ tbytes,
+                  const u32 *__restrict__ seq_off, const u8 *__restrict__ pbytes, const u32 *__restrict__ probe_off,
+                  const i32 *__restrict__ ent_probe, const i32 *__restrict__ ent_pos, int k, int mm, int lcf_thres,
+                  int island, const u32 *__restrict__ seed_ent, const u32 *__restrict__ seed_pos,
+                  const u32 *__restrict__ seed_seq, HitBuf out) {
+    const u32 n = min(cut[0], cut_cap);
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const u32 t = cut[1 + i];
+        const u32 e = seed_ent[t];
+        extend_bytes(tbytes, seq_off, seed_seq[t], pbytes, probe_off, ent_probe[e], (i64)ent_pos[e], k, mm, lcf_thres,
+                     island, e, seed_pos[t], out);
+    }
+}
+
+typedef void (*extend_planes_fn)(const u32 *, i64, const u8 *, const u32 *, const uint4 *, const u8 *, const u32 *,
+                                 const i32 *, const i32 *, int, int, int, int, int, u32, int, const u32 *, const u32 *,
+                                 const u32 *, u32, HitBuf, u32 *, u32);
+static extend_planes_fn pick_extend_planes(int nw) {
+    switch (nw) {
+    case 1: return extend_planes_kernel<1>;
+    case 2: return extend_planes_kernel<2>;
+    case 3: return extend_planes_kernel<3>;
+    case 4: return extend_planes_kernel<4>;
+    case 5: return extend_planes_kernel<5>;
+    case 6: return extend_planes_kernel<6>;
+    case 7: return extend_planes_kernel<7>;
+    case 8: return extend_planes_kernel<8>;
+    }
+    return nullptr;
 }
 
 // ------------------------------------------------------------------------
@@ -820,9 +1023,37 @@ static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchh
     }
     HitBuf ob = {H.a.p, H.b.p, H.c.p, H.count.p, nseeds, H.want_seed ? H.d.p : nullptr,
                  H.want_seed ? H.e.p : nullptr};
-    hipLaunchKernelGGL(extend_kernel, dim3((unsigned)div_up(nseeds, 256)), dim3(256), 0, ctx->stream, T->bytes.p,
-                       T->seq_off.p, (u32)T->nseq, P->bytes.p, P->probe_off.p, e_probe, e_pos,
-                       (int)P->k, mm, lcf_thres, island, seed_ent, seed_pos, nseeds, ob);
+    extend_planes_fn planes = table && !getenv("CATCHHIP_EXTEND_BYTES") ? pick_extend_planes((int)P->pwords) : nullptr;
+    DevBuf<u32> cut;
+    const u32 cut_cap = 1u << 22;
+    if (planes) {
+        // packed images: the window's mismatch mask in a few words, bit scans around the anchor
+        TRY(cut.alloc((size_t)cut_cap + 1));
+        HIP_TRY(hipMemsetAsync(cut.p, 0, sizeof(u32), ctx->stream));
+        const u32 tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
+        hipLaunchKernelGGL(planes, dim3((unsigned)div_up(nseeds, 256 * SE_PPT)), dim3(256), 0, ctx->stream,
+                           (const u32 *)T->planes.p, T->nwords, (const u8 *)T->bytes.p, (const u32 *)T->seq_off.p,
+                           (const uint4 *)P->planes.p, (const u8 *)P->bytes.p, (const u32 *)P->probe_off.p, e_probe,
+                           e_pos, (int)P->L, (int)P->k, mm, lcf_thres, island, tailmask,
+                           (P->has_n || T->has_n) ? 1 : 0, seed_ent, seed_pos, (const u32 *)S.sseq.p, nseeds, ob,
+                           cut.p, cut_cap);
+        hipLaunchKernelGGL(extend_cut_kernel, dim3(256), dim3(256), 0, ctx->stream, (const u32 *)cut.p, cut_cap,
+                           (const u8 *)T->bytes.p, (const u32 *)T->seq_off.p, (const u8 *)P->bytes.p,
+                           (const u32 *)P->probe_off.p, e_probe, e_pos, (int)P->k, mm, lcf_thres, island, seed_ent,
+                           seed_pos, (const u32 *)S.sseq.p, ob);
+        tm.launch();
+        u32 ncut = 0;
+        TRY(read_count(ctx, cut.p, &ncut));
+        if (ncut > cut_cap) {   // never seen: more cut windows than the list holds -> everything by bytes
+            HIP_TRY(hipMemsetAsync(H.count.p, 0, sizeof(u32), ctx->stream));
+            planes = nullptr;
+        }
+    }
+    if (!planes) {
+        hipLaunchKernelGGL(extend_kernel, dim3((unsigned)div_up(nseeds, 256)), dim3(256), 0, ctx->stream, T->bytes.p,
+                           T->seq_off.p, (u32)T->nseq, P->bytes.p, P->probe_off.p, e_probe, e_pos,
+                           (int)P->k, mm, lcf_thres, island, seed_ent, seed_pos, nseeds, ob);
+    }
     tm.launch();
     HIP_TRY(hipGetLastError());
     TRY(read_count(ctx, H.count.p, &H.n));
