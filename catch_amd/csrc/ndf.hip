@@ -22,6 +22,16 @@
 
 #include "internal.h"
 
+// The edge list is written through ONE counter per shard: a single counter is a
+// single address (~10 ns per atomic, however the compiler aggregates them), and
+// the walks below append edges from inside their loops, once per iteration in
+// which some lane found one.  Shard s owns e_i/e_j[s * segcap ..) and the
+// counter count[s * ES_STRIDE] (128 bytes apart); wavefronts pick their shard
+// round-robin.  count[ES_SHARDS * ES_STRIDE] counts the undecided nodes of a round.
+#define ES_SHARDS 64
+#define ES_STRIDE 32
+#define ES_WORDS (ES_SHARDS * ES_STRIDE + 1)
+
 __global__ void __launch_bounds__(256)
 ndf_key_kernel(const u8 *__restrict__ bytes, u32 n, int L, const i32 *__restrict__ pos, int k,
                u64 *__restrict__ keys, u32 *__restrict__ vals, const u32 *__restrict__ grp, size_t pos_group_stride) {
@@ -85,8 +95,9 @@ ndf_edge_kernel(const u64 *__restrict__ padded, u32 n, int W, int d, const i32 *
         const u32 j = vals[y];  // j < i: stable sort keeps indices ascending in a run
         if (grp && grp[j] != grp[i]) continue;   // another group under the same key
         if (ndf_near(a, padded + (size_t)j * W, W, d, pos, k)) {
-            u32 slot = atomicAdd(count, 1u);
-            if (slot < cap) { e_i[slot] = i; e_j[slot] = j; }
+            const u32 shard = (x >> 6) & (ES_SHARDS - 1);
+            const u32 slot = atomicAdd(&count[shard * ES_STRIDE], 1u);
+            if (slot < cap) { e_i[(size_t)shard * cap + slot] = i; e_j[(size_t)shard * cap + slot] = j; }
         }
     }
 }
@@ -94,10 +105,13 @@ ndf_edge_kernel(const u64 *__restrict__ padded, u32 n, int W, int d, const i32 *
 // status: 0 undecided, 1 kept, 2 dropped.  flags: bit0 = has kept higher
 // neighbour, bit1 = has undecided higher neighbour
 __global__ void __launch_bounds__(256)
-ndf_edge_round_kernel(const u32 *__restrict__ e_i, const u32 *__restrict__ e_j, u32 ne,
-                      const u32 *__restrict__ status, u32 *__restrict__ flags) {
-    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ne) return;
+ndf_edge_round_kernel(const u32 *__restrict__ e_i, const u32 *__restrict__ e_j, u32 segcap,
+                      const u32 *__restrict__ count, const u32 *__restrict__ status, u32 *__restrict__ flags) {
+    const u64 t64 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 shard = (u32)(t64 / segcap);
+    if (shard >= ES_SHARDS) return;
+    if ((u32)(t64 - (u64)shard * segcap) >= min(count[shard * ES_STRIDE], segcap)) return;
+    const size_t t = (size_t)t64;
     u32 i = e_i[t];
     if (status[i] != 0) return;
     u32 sj = status[e_j[t]];
@@ -119,18 +133,32 @@ ndf_node_round_kernel(u32 *__restrict__ status, u32 *__restrict__ flags, u32 n, 
 
 // greedy resolution rounds over the edge list + read-back (shared by the two
 // LSH families)
-static int ndf_resolve(catchhip_ctx *ctx, u32 nn, u32 ne, DevBuf<u32> &e_i, DevBuf<u32> &e_j, DevBuf<u32> &count,
-                       DevBuf<u32> &status, DevBuf<u32> &flags, PhaseTimer &tm, u8 *keep) {
+// edges in the fullest shard
+static int ndf_fullest_shard(catchhip_ctx *ctx, const u32 *count, u32 *out) {
+    TRY(chip_pinned_reserve(ctx, sizeof(u32) * ES_WORDS));
+    HIP_TRY(hipMemcpyAsync(ctx->h_big, count, sizeof(u32) * ES_WORDS, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    u32 m = 0;
+    for (int sh = 0; sh < ES_SHARDS; ++sh) { const u32 v = ((const volatile u32 *)ctx->h_big)[sh * ES_STRIDE]; if (v > m) m = v; }
+    *out = m;
+    return 0;
+}
+
+// segused: edges in the fullest shard (the round kernel only looks at that many slots per shard)
+static int ndf_resolve(catchhip_ctx *ctx, u32 nn, u32 segused, u32 segcap, DevBuf<u32> &e_i, DevBuf<u32> &e_j,
+                       DevBuf<u32> &count, DevBuf<u32> &status, DevBuf<u32> &flags, PhaseTimer &tm, u8 *keep) {
     hipStream_t s = ctx->stream;
     const unsigned nb = (unsigned)div_up(nn, 256);
+    u32 *undecided = count.p + ES_SHARDS * ES_STRIDE;
+    (void)segused;
     for (u32 round = 0; round <= nn + 1; ++round) {
-        HIP_TRY(hipMemsetAsync(count.p + 1, 0, sizeof(u32), s));
-        if (ne)
-            hipLaunchKernelGGL(ndf_edge_round_kernel, dim3((unsigned)div_up(ne, 256)), dim3(256), 0, s, e_i.p,
-                               e_j.p, ne, status.p, flags.p);
-        hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, count.p + 1);
+        HIP_TRY(hipMemsetAsync(undecided, 0, sizeof(u32), s));
+        if (segused)
+            hipLaunchKernelGGL(ndf_edge_round_kernel, dim3((unsigned)div_up((i64)ES_SHARDS * segcap, 256)), dim3(256), 0,
+                               s, e_i.p, e_j.p, segcap, (const u32 *)count.p, status.p, flags.p);
+        hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, undecided);
         tm.launch(2);
-        HIP_TRY(hipMemcpyAsync(ctx->h_pin, count.p + 1, sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, sizeof(u32), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (*(volatile u32 *)ctx->h_pin == 0) break;
     }
@@ -168,12 +196,12 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
     TRY(d_pos.alloc((size_t)ngroups * ntables * k));
     TRY(keys.alloc(nn));
     TRY(vals.alloc(nn));
-    TRY(count.alloc(2));
+    TRY(count.alloc(ES_WORDS));
     TRY(status.alloc(nn));
     TRY(flags.alloc(nn));
     HIP_TRY(hipMemcpyAsync(d_pos.p, positions, sizeof(i32) * (size_t)ngroups * ntables * k, hipMemcpyHostToDevice, s));
     const size_t pstride = (size_t)ntables * k;
-    HIP_TRY(hipMemsetAsync(count.p, 0, 2 * sizeof(u32), s));
+    HIP_TRY(hipMemsetAsync(count.p, 0, ES_WORDS * sizeof(u32), s));
     HIP_TRY(hipMemsetAsync(status.p, 0, sizeof(u32) * nn, s));
     HIP_TRY(hipMemsetAsync(flags.p, 0, sizeof(u32) * nn, s));
     const int W = (L + 7) / 8;
@@ -184,12 +212,12 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
 
     PhaseTimer tm(ctx, PHASE_NDF);
     const unsigned nb = (unsigned)div_up(nn, 256);
-    u32 cap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(n * 16, (i64)1 << 28));
+    u32 cap = (u32)std::max<i64>((i64)1 << 14, std::min<i64>(n * 16, (i64)1 << 28) / ES_SHARDS);   // per shard
     u32 ne = 0;
     for (int attempt = 0;; ++attempt) {
-        TRY(e_i.reserve(cap));
-        TRY(e_j.reserve(cap));
-        HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(u32), s));
+        TRY(e_i.reserve((size_t)cap * ES_SHARDS));
+        TRY(e_j.reserve((size_t)cap * ES_SHARDS));
+        HIP_TRY(hipMemsetAsync(count.p, 0, ES_WORDS * sizeof(u32), s));
         for (int t = 0; t < ntables; ++t) {
             hipLaunchKernelGGL(ndf_key_kernel, dim3(nb), dim3(256), 0, s, d_bytes.p, nn, (int)L,
                                d_pos.p + (size_t)t * k, (int)k, keys.p, vals.p, d_grp, pstride);
@@ -200,14 +228,12 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
             tm.launch(2 + 24);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(ctx->h_pin, count.p, sizeof(u32), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        ne = *(volatile u32 *)ctx->h_pin;
+        TRY(ndf_fullest_shard(ctx, count.p, &ne));
         if (ne <= cap) break;
         if (attempt >= 2) { chip_set_error("ndf: edge buffer overflow"); return CATCHHIP_ENOMEM; }
         cap = ne;
     }
-    return ndf_resolve(ctx, nn, ne, e_i, e_j, count, status, flags, tm, keep);
+    return ndf_resolve(ctx, nn, ne, cap, e_i, e_j, count, status, flags, tm, keep);
 }
 
 extern "C" int catchhip_ndf_hamming(catchhip_ctx *ctx, const u8 *bytes, i64 n, i32 L, const i32 *positions,
@@ -441,8 +467,9 @@ mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
         for (int f = 0; f < k; ++f) same = same && sig[(size_t)i * k + f] == sig[(size_t)j * k + f];
         if (same && mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j],
                             thres)) {
-            const u32 slot = atomicAdd(count, 1u);
-            if (slot < cap) { e_i[slot] = i; e_j[slot] = j; }
+            const u32 shard = (x >> 6) & (ES_SHARDS - 1);
+            const u32 slot = atomicAdd(&count[shard * ES_STRIDE], 1u);
+            if (slot < cap) { e_i[(size_t)shard * cap + slot] = i; e_j[(size_t)shard * cap + slot] = j; }
         }
     }
 }
@@ -503,7 +530,7 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
     TRY(keys_all.alloc((size_t)tchunk * nn));
     TRY(keys.alloc(nn));
     TRY(vals.alloc(nn));
-    TRY(count.alloc(2));
+    TRY(count.alloc(ES_WORDS));
     TRY(status.alloc(nn));
     TRY(flags.alloc(nn));
     if (!bytes_on_device) HIP_TRY(hipMemcpyAsync(d_bytes_own.p, bytes, total, hipMemcpyHostToDevice, s));
@@ -512,7 +539,7 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
     const u32 *grp = group_off ? (const u32 *)d_grp.p : (const u32 *)nullptr;
     HIP_TRY(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_koff.p, h_koff.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(count.p, 0, 2 * sizeof(u32), s));
+    HIP_TRY(hipMemsetAsync(count.p, 0, ES_WORDS * sizeof(u32), s));
     HIP_TRY(hipMemsetAsync(status.p, 0, sizeof(u32) * nn, s));
     HIP_TRY(hipMemsetAsync(flags.p, 0, sizeof(u32) * nn, s));
 
@@ -522,12 +549,12 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
                        (const u8 *)d_bytes.p, (const u32 *)d_off.p, (const u32 *)d_koff.p, nn, (int)kmer_size, xs.p,
                        id_hi.p, id_lo.p, nuniq.p);
     tm.launch(1);
-    u32 cap = (u32)std::max<i64>((i64)1 << 20, std::min<i64>(n * 16, (i64)1 << 28));
+    u32 cap = (u32)std::max<i64>((i64)1 << 14, std::min<i64>(n * 16, (i64)1 << 28) / ES_SHARDS);   // per shard
     u32 ne = 0;
     for (int attempt = 0;; ++attempt) {
-        TRY(e_i.reserve(cap));
-        TRY(e_j.reserve(cap));
-        HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(u32), s));
+        TRY(e_i.reserve((size_t)cap * ES_SHARDS));
+        TRY(e_j.reserve((size_t)cap * ES_SHARDS));
+        HIP_TRY(hipMemsetAsync(count.p, 0, ES_WORDS * sizeof(u32), s));
         for (int t = 0; t < ntables; ++t) {
             const int tc = t % tchunk;
             if (tc == 0) {
@@ -546,14 +573,12 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
             tm.launch(2 + 24);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(ctx->h_pin, count.p, sizeof(u32), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        ne = *(volatile u32 *)ctx->h_pin;
+        TRY(ndf_fullest_shard(ctx, count.p, &ne));
         if (ne <= cap) break;
         if (attempt >= 2) { chip_set_error("ndf: edge buffer overflow"); return CATCHHIP_ENOMEM; }
         cap = ne;
     }
-    return ndf_resolve(ctx, nn, ne, e_i, e_j, count, status, flags, tm, keep);
+    return ndf_resolve(ctx, nn, ne, cap, e_i, e_j, count, status, flags, tm, keep);
 }
 
 extern "C" int catchhip_ndf_minhash(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off, i64 n, i32 kmer_size,
