@@ -233,6 +233,10 @@ seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const
     __shared__ u32 s_off[SL_TILE + 1], s_rx[SL_TILE], s_sq[SL_TILE], s_part[SL_THREADS / 64], s_base;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 tile0 = blockIdx.x * SL_TILE;
+    // the tile's first sequence, found once (the same addresses for every lane); a
+    // seeded position then walks on from there -- a tile rarely spans more than one
+    // or two sequence ends -- instead of a binary search of its own
+    const u32 sq0 = find_segment(seq_off, nseq, min(tile0, total - 1));
     u32 cnt[SL_PPT], mine = 0;
 #pragma unroll
     for (int j = 0; j < SL_PPT; ++j) {
@@ -249,7 +253,8 @@ seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const
             }
         }
         if (r.y) {
-            const u32 sq = find_segment(seq_off, nseq, i);
+            u32 sq = sq0;
+            while (sq + 1 < nseq && seq_off[sq + 1] <= i) ++sq;
             s_sq[q] = sq;
             if (i + (u32)k > seq_off[sq + 1]) r.y = 0;   // the k-mer must lie inside one sequence
         }
