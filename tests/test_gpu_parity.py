@@ -1349,3 +1349,36 @@ def test_union_device_front_end_equals_string_path(ctx, monkeypatch, first_kind)
         results.append([[p.seq_str for p in g] for g in grouped])
     assert results[0] == results[1]
     assert sum(map(len, results[0])) > 40 and all(len(g) > 0 for g in results[0])
+
+
+def test_rows_stats_match_fetched_rows(ctx):
+    """catchhip_rows_stats (coverage report without fetching the rows): summed
+    range lengths, bases covered (union) per universe and universes per set ==
+    the same numbers from the fetched table."""
+    engine, probe = _engine(), _probe_mod()
+    genomes = small_species(seed=61, n=7, length=1800, d1=0.04, d2=0.01)
+    genomes.append(["ACGT" * 100, "T" * 150])          # two sequences: one universe each below
+    seqs = [[s] for g in genomes for s in g]
+    strs = candidates(genomes[:4], 100, 25)[::3]
+    np.random.seed(3)
+    k, uniq, owner, ep, eo = probe.anchor_table(strs, 3, 100, min_k=10, k=10)
+    t = engine.Targets(ctx, seqs)
+    p = engine.Probes(ctx, uniq, owner, ep, eo, k)
+    for merge in (False, True):
+        rows = engine.Rows.scan(ctx, p, t, 3, 100, 0, 15, engine.SCAN_AUTO, merge)
+        sid, univ, st, en = rows.fetch()
+        total, union, per_set = rows.stats(len(seqs), len(strs))
+        rows.close()
+        want_total = np.bincount(univ, weights=(en - st).astype(np.float64), minlength=len(seqs)).astype(np.int64)
+        want_union = np.zeros(len(seqs), dtype=np.int64)
+        for u in range(len(seqs)):
+            cov = np.zeros(len(seqs[u][0]) + 1, dtype=np.int64)
+            for a, b in zip(st[univ == u].tolist(), en[univ == u].tolist()):
+                cov[a] += 1; cov[b] -= 1
+            want_union[u] = int((np.cumsum(cov)[:-1] > 0).sum())
+        pairs = np.unique(sid.astype(np.int64) * len(seqs) + univ)
+        want_sets = np.bincount(pairs // len(seqs), minlength=len(strs))
+        assert total.tolist() == want_total.tolist()
+        assert union.tolist() == want_union.tolist()
+        assert per_set.tolist() == want_sets.tolist() and per_set.sum() > 10
+    p.close(); t.close()
