@@ -304,3 +304,35 @@ def test_anchor_entries_without_strings_match_anchor_table():
         else:
             assert np.array_equal(ep, ep2) and np.array_equal(eo, eo2)
     assert probe.anchor_entries_equal_length(0, 100, 5, 100)[1].size == 0
+
+
+def test_probe_designer_object_pipeline_without_gpu():
+    """Filter lists other than [duplicate / near-duplicate filter, set cover]
+    run as objects through BaseFilter.filter: contrived inputs in the style of
+    the reference's designer tests (probe length 100 / stride 50; short
+    sequences with allow_small_seqs)."""
+    from catch_amd import genome
+    from catch_amd.filter import duplicate_filter, probe_designer
+    seqs = [[genome.Genome.from_one_seq("A" * 100 + "C" * 100 + "A" * 100)]]
+    pd = probe_designer.ProbeDesigner(seqs, [duplicate_filter.DuplicateFilter()],
+                                      probe_length=100, probe_stride=50)
+    pd.design()
+    assert [p.seq_str for p in pd.candidate_probes] == [
+        "A" * 100, "A" * 50 + "C" * 50, "C" * 100, "C" * 50 + "A" * 50, "A" * 100]
+    assert sorted(p.seq_str for p in pd.final_probes) == sorted(
+        ["A" * 100, "A" * 50 + "C" * 50, "C" * 100, "C" * 50 + "A" * 50])
+    two = [[genome.Genome.from_one_seq("A" * 200), genome.Genome.from_one_seq("G" * 150)],
+           [genome.Genome.from_one_seq("C" * 300)]]
+    pd = probe_designer.ProbeDesigner(two, [duplicate_filter.DuplicateFilter()],
+                                      probe_length=100, probe_stride=50)
+    pd.design()
+    assert len(pd.candidate_probes) == 10
+    assert sorted(p.seq_str for p in pd.final_probes) == ["A" * 100, "C" * 100, "G" * 100]
+    small = [[genome.Genome.from_one_seq("ACGTTGCAACGGTA"), genome.Genome.from_one_seq("TTGAC")]]
+    pd = probe_designer.ProbeDesigner(small, [duplicate_filter.DuplicateFilter()], probe_length=6,
+                                      probe_stride=3, allow_small_seqs=5)
+    pd.design()
+    assert [p.seq_str for p in pd.final_probes] == ["ACGTTG", "TTGCAA", "CAACGG", "ACGGTA", "TTGAC"]
+    with pytest.raises(ValueError):
+        probe_designer.ProbeDesigner(small, [duplicate_filter.DuplicateFilter()], probe_length=6,
+                                     probe_stride=3).design()
