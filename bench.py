@@ -2,24 +2,33 @@
 """Benchmark of the SetCoverFilter hot path (K1 coverage scan + row build +
 K2 greedy set cover) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S4|S2|S3]
 
-A step = one full pass of the hot path over the workload with the packed
-inputs already resident in HBM: one catchhip_setcover_filter_many call = for
-every group (each on its own stream) the hash-seeded coverage scan, the
-bucketed row build and the frontier set-cover solver.
-Workload at N=1: BASELINE.json configs[1] -- ~100 Ebola+Lassa-like genomes,
-`design.py -pl 100 -ps 50 -m 2 -e 50` -- as the seeded synthetic set S2
-(catch_amd/utils/synthetic.py; the reference ships no input at this scale).
-For N>1 (launched by torch.distributed.run, one rank per GPU) every rank
-processes its own S2-shaped dataset (seed 2+rank): groups are independent
-set-cover instances, so they shard with no data-path collective (weak
-scaling).  `--shard probes` instead runs ONE dataset on all ranks with the
-candidate sets sharded and one RCCL all-reduce(MAX) per greedy pick.
+Workload (default S4 = BASELINE.json configs[3], the largest configuration
+that fits one GPU and the "V-All-scale" input the metric is quoted on): the
+seeded synthetic pool of 20 species / 20 groups (catch_amd/utils/synthetic.py,
+SURVEY.md 8(d); the reference ships no input at this scale), `design.py
+-pl 100 -ps 50 -m 2 -e 50 -c 1.0`.  `--workload S2` is configs[1] (the round-1
+bench), `--workload S3` configs[2]'s genomes without the near-duplicate filter.
 
-Prints one JSON line on rank 0 (see README/DESIGN.md for the fields).
+A step = one full pass of the hot path over every group with the packed
+inputs already resident in HBM (targets as bit planes, de-duplicated
+candidates as packed probe images + anchors): per group one fused
+catchhip_setcover_filter call = hash-seeded coverage scan, bucketed row build,
+frontier set-cover solver, selected ids back on the host.  Groups are
+independent instances: the large ones run one after the other, largest first
+(each fills the GPU), the small ones `--groups-in-flight` (default 4) at a
+time on their own HIP streams.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): ONE dataset,
+strong scaling -- see shard_plan() in catch_amd/parallel.py: whole groups go
+to ranks longest-first with no data-path collective.
+
+Prints one JSON line on rank 0 (fields: README / DESIGN.md section 6).
 """
 import argparse
+import concurrent.futures
+import hashlib
 import json
 import os
 import sys
@@ -30,94 +39,136 @@ sys.path.insert(0, REPO)
 
 import numpy as np  # noqa: E402
 
-from catch_amd import engine, probe  # noqa: E402
-from catch_amd.filter import candidate_probes  # noqa: E402
+from catch_amd import engine, parallel, probe  # noqa: E402
 from catch_amd.utils import synthetic  # noqa: E402
 
 PROBE_LEN, STRIDE, MISMATCHES, EXT = 100, 50, 2, 50
 SCAN_MODE = int(os.environ.get("CATCHHIP_SCAN_MODE", "0"))   # 0 auto, 1 general, 2 fast
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
-
-
-def make_workload(name, seed, scale):
-    groups = synthetic.dataset(name, seed=seed, scale=scale)
-    cands = []
-    for genomes in groups:
-        c = []
-        for g in genomes:
-            c += [p.seq_str for p in
-                  candidate_probes.make_candidate_probes_from_sequences(
-                      list(g), probe_length=PROBE_LEN, probe_stride=STRIDE)]
-        cands.append(list(dict.fromkeys(c)))     # DuplicateFilter
-    return groups, cands
+CONFIG_OF = {"S1": 0, "S2": 1, "S3": 2, "S4": 3}
 
 
 class ResidentGroup:
-    def __init__(self, ctx, genomes, cand):
-        self.ctx = ctx
-        self.n_sets = len(cand)
-        self.G = sum(len(s) for g in genomes for s in g)
-        k, uniq, owner, ep, eo = probe.anchor_table(cand, MISMATCHES, PROBE_LEN)
+    """One group's packed inputs in HBM: targets (bytes + bit planes), unique
+    candidates (device front end = candidate windows + DuplicateFilter) and the
+    probes object (packed images + pigeonhole anchors)."""
+
+    def __init__(self, ctx, index, genomes):
+        self.ctx, self.index = ctx, index
         self.targets = engine.Targets(ctx, genomes)
-        self.probes = engine.Probes(ctx, uniq, owner, ep, eo, k)
-        self.n_unique = len(uniq)
+        self.cands = engine.Candidates(ctx, self.targets, PROBE_LEN, STRIDE)
+        k, ep, eo = probe.anchor_entries_equal_length(
+            self.cands.n, PROBE_LEN, MISMATCHES, PROBE_LEN)
+        self.probes = self.cands.probes(k, ep, eo)
+        self.n_sets = self.cands.n
+        self.G = self.targets.total
+        self.n_genomes = len(genomes)
 
     def close(self):
         self.probes.close()
+        self.cands.close()
         self.targets.close()
 
 
-def one_step(ctx, groups, stats=None, in_flight=0):
-    """One pass of the hot path over every group.  in_flight = 0: all groups
-    at once (catchhip_setcover_filter_many: one stream + host thread per
-    group); 1: one group after the other (catchhip_setcover_filter)."""
-    if ctx.has_comm:
-        # probe-sharded RCCL solver: separate scan / solve calls on one context
-        res = []
-        for g in groups:
-            rows = engine.Rows.scan(ctx, g.probes, g.targets, MISMATCHES,
-                                    PROBE_LEN, 0, EXT, SCAN_MODE)
-            res.append((rows.greedy(g.n_sets), rows.n))
-            rows.close()
-    else:
-        specs = [(g.ctx, g.probes, g.targets, g.n_sets, None, None)
-                 for g in groups]
-        if in_flight == 1:
-            res = [engine.setcover_filter(*sp[:3], MISMATCHES, PROBE_LEN, 0, EXT,
-                                          sp[3], mode=SCAN_MODE) for sp in specs]
-        else:
+class Stepper:
+    """Runs the groups of this rank.  Large groups (>= BIG_BASES bases) fill
+    the GPU on their own and run one after the other, largest first, on the
+    default context; the small ones run `width` at a time, each lane (worker
+    thread + context = HIP stream) owning the groups lpt_assign gave it --
+    kernels of large groups only get in each other's way (seed_lookup went
+    from 0.6-8 ms to 12 ms per launch with four S4 groups in flight)."""
+    BIG_BASES = int(os.environ.get("CATCHHIP_BENCH_BIG_BASES", str(8_000_000)))
+
+    def __init__(self, device, groups, indices, width):
+        sizes = {i: sum(len(s) for g in groups[i] for s in g) for i in indices}
+        big = sorted((i for i in indices if sizes[i] >= self.BIG_BASES),
+                     key=lambda i: (-sizes[i], i))
+        small = [i for i in indices if sizes[i] < self.BIG_BASES]
+        self.width = max(1, min(width, len(small))) if small else 1
+        self.ctxs = [engine.default_context() if w == 0 else engine.Context(device)
+                     for w in range(self.width)]
+        self.big = [ResidentGroup(self.ctxs[0], i, groups[i]) for i in big]
+        lanes = parallel.lpt_assign([sizes[i] for i in small], self.width)
+        self.lanes = [[ResidentGroup(self.ctxs[w], small[j], groups[small[j]])
+                       for j in lane] for w, lane in enumerate(lanes)]
+        for c in self.ctxs:
+            c.sync()
+        self.pool = (concurrent.futures.ThreadPoolExecutor(self.width)
+                     if self.width > 1 else None)
+        self.resident = self.big + [g for lane in self.lanes for g in lane]
+
+    def _run_lane(self, lane, stats):
+        out = []
+        for g in lane:
+            ids, nrows = engine.setcover_filter(
+                g.ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN, 0, EXT,
+                g.n_sets, mode=SCAN_MODE)
+            if stats is not None:
+                self._collect(g, ids, nrows, stats)
+            out.append((g.index, ids))
+        return out
+
+    def step(self, stats=None):
+        """One pass over every group of this rank -> {group index: pick ids}."""
+        out = dict(self._run_lane(self.big, stats))
+        small = [g for lane in self.lanes for g in lane]
+        if len(small) > 1 and len(small) <= self.width:
+            # one group per lane: the C side's persistent helper threads
+            specs = [(g.ctx, g.probes, g.targets, g.n_sets, None, None)
+                     for g in small]
             res = engine.setcover_filter_many(specs, MISMATCHES, PROBE_LEN, 0,
                                               EXT, SCAN_MODE)
-    if stats is not None:
-        for g, (ids, nrows) in zip(groups, res):
-            c = g.ctx
-            ms, nl = c.kernel_ms(engine.PHASE_SCAN)
-            stats["scan_ms"] += ms
-            stats["scan_launches"] += nl
-            stats["rows_ms"] += c.kernel_ms(engine.PHASE_ROWS)[0]
-            stats["rows"] += nrows
-            ms, nl = c.kernel_ms(engine.PHASE_GREEDY)
-            stats["greedy_ms"] += ms
-            stats["greedy_launches"] += nl
-            rms, rnl = c.kernel_ms(engine.PHASE_GREEDY_ROUNDS)
-            stats["rounds_ms"] = stats.get("rounds_ms", 0.0) + rms
-            stats["rounds_launches"] = stats.get("rounds_launches", 0) + rnl
-            stats["picks"] += len(ids)
-            cn = c.counters()
-            for k in ("raw_hits", "seed_hits", "winner_rows", "rows_recounted",
-                      "bitmap_words_read", "greedy_iters"):
-                stats[k] = stats.get(k, 0) + cn[k]
-    return [ids for ids, _ in res]
+            for g, (ids, nrows) in zip(small, res):
+                out[g.index] = ids
+                if stats is not None:
+                    self._collect(g, ids, nrows, stats)
+            return out
+        if self.pool is None:
+            parts = [self._run_lane(lane, stats) for lane in self.lanes]
+        else:
+            per = [[] if stats is not None else None for _ in self.lanes]
+            futs = [self.pool.submit(self._run_lane, lane, st)
+                    for lane, st in zip(self.lanes, per)]
+            parts = [f.result() for f in futs]
+            if stats is not None:
+                for st in per:
+                    stats.extend(st)
+        out.update({i: ids for part in parts for i, ids in part})
+        return out
+
+    def _collect(self, g, ids, nrows, stats):
+        c = g.ctx
+        st = dict(rows=nrows, picks=len(ids))
+        for name, ph in (("scan_ms", engine.PHASE_SCAN),
+                         ("verify_ms", engine.PHASE_VERIFY),
+                         ("rows_ms", engine.PHASE_ROWS),
+                         ("greedy_ms", engine.PHASE_GREEDY),
+                         ("rounds_ms", engine.PHASE_GREEDY_ROUNDS)):
+            ms, nl = c.kernel_ms(ph)
+            st[name] = ms
+            st[name.replace("_ms", "_launches")] = nl
+        st.update(c.counters())
+        stats.append(st)
+
+    def sync(self):
+        for c in self.ctxs:
+            c.sync()
+
+    def close(self):
+        for g in self.resident:
+            g.close()
+        if self.pool is not None:
+            self.pool.shutdown()
 
 
 def pmc_traffic(unit, workload, scale):
-    """HBM bytes per launch of `unit` (a kernel, or the pair of kernels of a
-    solver round) from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in
-    separate runs of this same command; FETCH_SIZE doubled for gfx950 as
-    MI355X_MICROARCH.md prescribes).  None when no matching record exists:
-    counters cannot be collected from inside the timed run."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    """HBM bytes per launch of `unit` from the committed rocprofv3 PMC passes of
+    this same command (profiles/r02_pmc_traffic_<workload>.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, tools/collect_profiles.sh;
+    FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes).  None
+    when no matching record exists: counters cannot be collected from inside
+    the timed run."""
+    path = os.path.join(REPO, "profiles", "r02_pmc_traffic_%s.json" % workload)
     try:
         with open(path) as f:
             rec = json.load(f)
@@ -130,42 +181,75 @@ def pmc_traffic(unit, workload, scale):
         return None
 
 
-def cpu_baseline(groups, cands, budget_s=12.0):
-    """The CPU oracle (oracle/, plain C, 1 thread) timed on the same
-    workload; reported beside the GPU number, never part of it."""
+def digest(ids):
+    a = np.sort(np.asarray(ids, dtype=np.int64))
+    return hashlib.sha256(a.astype("<i8").tobytes()).hexdigest()
+
+
+def golden_digests(workload, scale):
+    """tests/golden/full_size_picks.json (made in the authoring container by
+    tests/golden/make_full_size.py with the pinned CPU oracle)."""
+    key = workload if scale == 1.0 else "%s:%g" % (workload, scale)
+    try:
+        with open(os.path.join(REPO, "tests", "golden", "full_size_picks.json")) as f:
+            return {g["group"]: g for g in json.load(f)[key]["groups"]}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def cpu_baseline(groups, sample, budget_s=20.0):
+    """The CPU oracle (oracle/, plain C) timed on a bounded sample of the
+    workload's groups: per group the threaded per-sequence scans (all host
+    cores, like the reference's process pool) and then the line-by-line greedy
+    restatement (one core, like the reference's one process per instance).
+    Reported beside the GPU number, never part of it."""
+    from catch_amd.filter import candidate_probes
     from oracle import oracle as orc
     orc.build()
-    units = sum(len(c) * sum(len(s) for g in grp for s in g)
-                for c, grp in zip(cands, groups))
+    cores = orc.set_threads(orc.hw_threads())
+    sel, units, cand_s = {}, 0, 0.0
     t0 = time.perf_counter()
     reps = 0
-    sel = None
     while True:
-        sel = orc.set_cover_filter(cands, groups, MISMATCHES, PROBE_LEN,
-                                   coverage=1.0, cover_extension=EXT)
+        for gi in sample:
+            genomes = groups[gi]
+            tc = time.perf_counter()
+            seqs = [s for g in genomes for s in g]
+            cands = list(dict.fromkeys(
+                candidate_probes.candidate_strings_from_sequences(
+                    seqs, PROBE_LEN, STRIDE)))
+            cand_s += time.perf_counter() - tc
+            ids = orc.set_cover_filter([cands], [genomes], MISMATCHES, PROBE_LEN,
+                                       coverage=1.0, cover_extension=EXT)[0]
+            sel[gi] = ids
+            units += len(cands) * sum(len(s) for s in seqs)
         reps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 50:
+        el = time.perf_counter() - t0 - cand_s
+        if el >= budget_s / 2 or reps >= 50:
             break
-    return dict(value=units * reps / el, unit="probe*bp/s", cores=1,
-                kind="port", seconds_per_pass=el / reps,
-                sample="%d full passes of the bench workload through the "
-                       "plain-C oracle (seed-and-extend scan + interval-set "
-                       "greedy), single thread" % reps), sel
+    orc.set_threads(1)
+    el = time.perf_counter() - t0 - cand_s
+    return dict(value=units / el, unit="probe*bp/s", cores=cores, kind="port",
+                seconds=el, passes=reps,
+                sample="groups %s of the bench workload (the smallest by bases, "
+                       "%d of %d groups), %d pass%s through the plain-C oracle: "
+                       "seed-and-extend scan on %d OpenMP threads, interval-set "
+                       "greedy on 1 (as the reference: pool for the scans, one "
+                       "process per instance for the solve)"
+                       % (sample, len(sample), len(groups), reps,
+                          "" if reps == 1 else "es", cores)), sel
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="S2")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="S4")
     ap.add_argument("--scale", type=float, default=1.0)
-    ap.add_argument("--shard", choices=["groups", "probes"], default="groups")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--groups-in-flight", type=int, default=0,
-                    help="0 = all groups of the batch at once (one stream "
-                         "each), 1 = one after the other")
+    ap.add_argument("--groups-in-flight", type=int, default=4,
+                    help="groups running at once per GPU, each on its own stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -189,124 +273,124 @@ def main():
             os.close(saved)
 
     ndev = max(1, engine.device_count())
-    ctx = engine.Context(local_rank % ndev)   # one rank per GPU on a real node
-    seed = 2 + (rank if args.shard == "groups" else 0)
-    groups, cands = make_workload(args.workload, seed, args.scale)
-    if args.shard == "probes":
-        ids = [engine.Context.comm_unique_id() if rank == 0 else None]
-        if dist is not None:
-            dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(ids[0], world, rank)
+    device = local_rank % ndev
+    os.environ["CATCHHIP_DEVICE"] = str(device)   # engine.default_context()
+
+    t_gen = time.perf_counter()
+    groups = synthetic.dataset(args.workload, scale=args.scale)
+    gen_s = time.perf_counter() - t_gen
+    bases = [sum(len(s) for g in grp for s in g) for grp in groups]
+    plan = parallel.shard_plan(bases, world)          # whole groups, longest first
+    mine = plan[rank]
 
     t_up0 = time.perf_counter()
-    # one context (= one HIP stream) per group, so that independent groups can
-    # be in flight together; the probe-sharded mode keeps everything on ctx
-    ctx.has_comm = args.shard == "probes"
-    gctx = [ctx if (i == 0 or ctx.has_comm) else engine.Context(ctx.device)
-            for i in range(len(groups))]
-    resident = [ResidentGroup(c, g, cd) for c, g, cd in zip(gctx, groups, cands)]
-    for c in gctx:
-        c.sync()
+    stepper = Stepper(device, groups, mine, args.groups_in_flight)
+    stepper.sync()
     upload_s = time.perf_counter() - t_up0
-    units = sum(r.n_sets * r.G for r in resident)
+    units = sum(g.n_sets * g.G for g in stepper.resident)
+    n_cands = sum(g.n_sets for g in stepper.resident)
 
     def barrier():
-        for c in gctx:
-            c.sync()
+        stepper.sync()
         if dist is not None:
             dist.barrier()
 
     for _ in range(args.warmup):
-        one_step(ctx, resident, None, args.groups_in_flight)
-    stats = dict(scan_ms=0.0, rows_ms=0.0, greedy_ms=0.0, scan_launches=0,
-                 greedy_launches=0, picks=0, rows=0)
+        stepper.step()
+    stats = []
     barrier()
+    pool0 = engine.pool_stats()
     t0 = time.perf_counter()
     picks = None
+    step_s = []
     for _ in range(args.steps):
-        picks = one_step(ctx, resident, stats, args.groups_in_flight)
-    for c in gctx:
-        c.sync()
+        ts = time.perf_counter()
+        picks = stepper.step(stats)
+        step_s.append(time.perf_counter() - ts)
+    stepper.sync()
     elapsed = time.perf_counter() - t0
+    pool1 = engine.pool_stats()
+    my_elapsed = elapsed
+
+    # identical picks whatever N: every group against the committed digests
+    gold = golden_digests(args.workload, args.scale)
+    gold_ok, gold_n = True, 0
+    if gold is not None:
+        for gi, ids in picks.items():
+            if gi in gold:
+                gold_n += 1
+                gold_ok = gold_ok and (len(ids) == gold[gi]["n_picks"] and
+                                       digest(ids) == gold[gi]["picks_sha256"])
+    total_units, all_elapsed = float(units), [elapsed]
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-        u = torch.tensor([float(units)], dtype=torch.float64)
-        if args.shard == "groups":
-            dist.all_reduce(u, op=dist.ReduceOp.SUM)
-        total_units = float(u[0])
+        u = torch.tensor([float(units), float(gold_n), 0.0 if gold_ok else 1.0,
+                          float(n_cands)], dtype=torch.float64)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        total_units, gold_n, gold_ok = float(u[0]), int(u[1]), float(u[2]) == 0.0
+        n_cands = int(u[3])
+        gathered = [None] * world
+        dist.all_gather_object(gathered, my_elapsed)
+        all_elapsed = gathered
         dist.barrier()
-    else:
-        total_units = float(units)
 
     if rank == 0:
         K = args.steps
-        P = sum(r.n_sets for r in resident)
-        G = sum(r.G for r in resident)
-        rows_per_step = stats["rows"] / K
-        # Algorithmic bytes per step (DESIGN.md "Roofline accounting"):
-        #  K1 seed scan: 2 planes of the targets (0.25 B/base) + one hash-table
-        #    probe per position (8 B key + 8 B range) + per seed: work-list
-        #    write+read (24 B), the target window (3 planes x 5 words = 60 B),
-        #    the probe image (64 B) and the hit record (20 B)
-        #  rows: per hit 20 B record read + 12 B scatter + 12 B sort read; per
-        #    merged row 12 B write + 12 B read + 16 B final row
-        #  K2 round: per re-counted row 8 B record + 1 B flag, per bitmap word
-        #    8 B read + 8 B owner word, per set and round 12 B of state
-        seeds_step = stats.get("seed_hits", 0) / K
-        hits_step = stats.get("raw_hits", 0) / K
-        k1_bytes = 16.25 * G + 168.0 * seeds_step
-        rows_bytes = 44.0 * hits_step + 40.0 * rows_per_step
-        k1_ms = stats["scan_ms"] / K
-        rows_ms = stats["rows_ms"] / K
-        k1_launch_ms = stats["scan_ms"] / max(stats["scan_launches"], 1)
-        k1_gbs = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-        rows_gbs = rows_bytes / (rows_ms * 1e-3) / 1e9 if rows_ms > 0 else 0.0
-        picks_per_step = stats["picks"] / K
-        k2_ms = stats["greedy_ms"] / K
-        rounds_step = stats.get("greedy_iters", 0) / K
-        k2_bytes_step = (9.0 * stats.get("rows_recounted", 0)
-                         + 16.0 * stats.get("bitmap_words_read", 0)) / K \
-            + 12.0 * P * rounds_step
-        k2_rounds_ms = stats.get("rounds_ms", 0.0) / K     # the round launches only
-        k2_launches = stats.get("rounds_launches", 0)
-        k2_gbs = k2_bytes_step / (k2_rounds_ms * 1e-3) / 1e9 if k2_rounds_ms > 0 else 0.0
-        # dominant kernel = the unit with the most device time per step.  A
-        # solver round is one unit: gf_count_claim_kernel + gf_check_apply_kernel
-        # (two dependent launches; HIP events bracket the whole batch of rounds)
-        phases = {"k1_seed_scan": k1_ms, "rows_build": rows_ms,
-                  "k2_solver_rounds": k2_rounds_ms}
-        dominant = max(phases, key=phases.get)
-        if dominant == "k2_solver_rounds":
-            pair_ms = stats.get("rounds_ms", 0.0) / max(k2_launches // 2, 1)
-            roof = dict(bound="hbm",
-                        kernel="gf_count_claim_kernel+gf_check_apply_kernel",
-                        achieved=k2_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=k2_gbs / HBM_PEAK_GBS,
-                        traffic=pmc_traffic("solver_round", args.workload, args.scale),
-                        algorithmic_bytes_per_launch=(
-                            k2_bytes_step * K / max(k2_launches // 2, 1)),
-                        avg_launch_ms=pair_ms,
-                        launches_are="pairs (count+claim, check+apply), "
-                                     "including the no-op pairs after the last round",
-                        us_per_pick=k2_rounds_ms * 1e3 / max(picks_per_step, 1),
-                        rounds_per_step=rounds_step)
-        elif dominant == "k1_seed_scan":
-            roof = dict(bound="hbm", kernel="seed scan (6 launches)",
-                        achieved=k1_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=k1_gbs / HBM_PEAK_GBS,
-                        traffic=pmc_traffic("seed_scan", args.workload, args.scale),
-                        algorithmic_bytes_per_launch=k1_bytes * K / max(stats["scan_launches"], 1),
-                        avg_launch_ms=k1_launch_ms)
-        else:
-            roof = dict(bound="hbm", kernel="bucketed row build",
-                        achieved=rows_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=rows_gbs / HBM_PEAK_GBS,
-                        traffic=pmc_traffic("rows_build", args.workload, args.scale),
-                        algorithmic_bytes_per_launch=rows_bytes / 6.0,
-                        avg_launch_ms=rows_ms / 6.0)
+        P_all = n_cands
+        P = sum(g.n_sets for g in stepper.resident)
+        G = sum(g.G for g in stepper.resident)
+        tot = {}
+        for st in stats:
+            for k, v in st.items():
+                tot[k] = tot.get(k, 0) + v
+        per = {k: v / K for k, v in tot.items()}        # per step, this rank
+        seeds, hits, rows = per.get("seed_hits", 0), per.get("raw_hits", 0), per.get("rows", 0)
+        # ---- bytes per step ("Roofline accounting") ----
+        # seed_verify, per seed: 12 B work item + 0.375 B/base of a (L+32)-base
+        #   target window and of the L-base probe + 4 B rank; per hit a 16 B record
+        verify_bytes = seeds * (12 + 0.375 * (PROBE_LEN + 32) + 0.375 * PROBE_LEN + 4) + 16.0 * hits
+        # SURVEY 8(d) K1 (brute-force tiles, T_p = 1024) for the same groups
+        survey_k1 = sum(0.375 * g.G * -(-g.n_sets // 1024) + 0.375 * PROBE_LEN * g.n_sets
+                        for g in stepper.resident) + 16.0 * rows
+        # whole seed scan as implemented: planes 0/1 + a 16 B table probe per
+        # position, per seed 24 B list + 60 B window + 64 B probe image + 20 B record
+        k1_impl = 16.25 * G + 168.0 * seeds
+        rows_bytes = 44.0 * hits + 40.0 * rows
+        # 12 B per (set, universe, interval) row re-counted + 8 B
+        #   per bitmap word read for the popcounts
+        k2_bytes = 12.0 * per.get("rows_recounted", 0) + 8.0 * per.get("bitmap_words_read", 0)
+        ms = {k: per.get(k, 0.0) for k in ("scan_ms", "verify_ms", "rows_ms", "greedy_ms", "rounds_ms")}
+        nlaunch = {k: tot.get(k, 0) for k in ("verify_launches", "rounds_launches", "scan_launches")}
+
+        def gbs(b, t_ms):
+            return b / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+        units_roof = {
+            "seed_verify": dict(kernel="seed_verify_kernel<%d>" % -(-PROBE_LEN // 32),
+                                ms=ms["verify_ms"], bytes=verify_bytes,
+                                launches=nlaunch["verify_launches"] / K, pmc="seed_verify"),
+            "solver_rounds": dict(kernel="gf_count_claim_kernel+gf_check_apply_kernel",
+                                  ms=ms["rounds_ms"], bytes=k2_bytes,
+                                  launches=max(nlaunch["rounds_launches"] // 2, 1) / K,
+                                  pmc="solver_round"),
+            "rows_build": dict(kernel="bucketed row build (6 launches per group)",
+                               ms=ms["rows_ms"], bytes=rows_bytes,
+                               launches=6.0 * len(stepper.resident), pmc="rows_build"),
+        }
+        dom = max(units_roof, key=lambda k: units_roof[k]["ms"])
+        d = units_roof[dom]
+        avg_ms = d["ms"] / max(d["launches"], 1)
+        roof = dict(bound="hbm", kernel=d["kernel"], achieved=gbs(d["bytes"], d["ms"]),
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs(d["bytes"], d["ms"]) / HBM_PEAK_GBS,
+                    traffic=pmc_traffic(d["pmc"], args.workload, args.scale),
+                    algorithmic_bytes_per_launch=d["bytes"] / max(d["launches"], 1),
+                    avg_launch_ms=avg_ms, launches_per_step=d["launches"],
+                    device_ms_per_step=d["ms"])
+        if dom == "solver_rounds":
+            roof["launches_are"] = ("pairs (count+claim, check+apply), including "
+                                    "the no-op pairs after the last round")
         out = {
             "metric": "candidate-probe x target-bp / s through SetCoverFilter "
                       "(K1 scan + K2 greedy)",
@@ -315,60 +399,82 @@ def main():
             "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak" if args.shard == "groups" else "strong",
+            "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "u32 bit-planes / u64 bitmap (integer)",
             "data": "synthetic",
             "config": {"workload": "%s (BASELINE configs[%d]%s): %d genomes in "
                                    "%d groups, G=%d bp, P=%d candidates, "
                                    "-pl 100 -ps 50 -m 2 -e 50 -c 1.0"
-                                   % (args.workload,
-                                      {"S1": 0, "S2": 1, "S3": 2, "S4": 3}.get(args.workload, 1),
+                                   % (args.workload, CONFIG_OF.get(args.workload, 1),
                                       "" if args.scale == 1.0 else " scaled x%g" % args.scale,
-                                      sum(len(g) for g in groups),
-                                      len(groups), G, P),
-                       "per_rank": True, "shard": args.shard,
-                       "groups_in_flight": (len(groups) if args.groups_in_flight == 0
-                                            else args.groups_in_flight),
-                       "scale": args.scale},
+                                      sum(len(g) for g in groups), len(groups),
+                                      sum(bases), P_all),
+                       "shard": "whole groups to ranks, longest first (no collective)",
+                       "groups_on_rank0": [g.index for g in stepper.resident],
+                       "groups_in_flight": stepper.width, "scale": args.scale},
             "setcoverfilter_ms": elapsed / K * 1e3,
-            "picks": picks_per_step, "rows": rows_per_step,
-            "kernel_ms_per_step": {"k1_scan": k1_ms,
-                                   "rows_build": rows_ms,
-                                   "k2_greedy": k2_ms,
-                                   "k2_greedy_rounds_only": k2_rounds_ms},
-            "k1_probe_bp_per_s": (sum(r.n_unique * r.G for r in resident)
-                                  / (k1_ms * 1e-3)) if k1_ms > 0 else None,
+            "picks": per.get("picks", 0), "rows": rows,
+            "kernel_ms_per_step": {"k1_scan": ms["scan_ms"], "k1_seed_verify": ms["verify_ms"],
+                                   "rows_build": ms["rows_ms"], "k2_greedy": ms["greedy_ms"],
+                                   "k2_greedy_rounds_only": ms["rounds_ms"],
+                                   "note": "HIP-event device time summed over the groups of rank 0; "
+                                           "groups in flight overlap, so the sum can exceed ms_per_step"},
             "roofline": roof,
-            "roofline_k1": dict(bound="hbm", achieved=k1_gbs,
-                                peak=HBM_PEAK_GBS, unit="GB/s",
-                                frac=k1_gbs / HBM_PEAK_GBS,
-                                avg_launch_ms=k1_launch_ms),
-            "roofline_rows": dict(bound="hbm", achieved=rows_gbs,
+            "roofline_k1_verify": dict(bound="hbm", achieved=gbs(verify_bytes, ms["verify_ms"]),
+                                       peak=HBM_PEAK_GBS, unit="GB/s",
+                                       frac=gbs(verify_bytes, ms["verify_ms"]) / HBM_PEAK_GBS,
+                                       traffic=pmc_traffic("seed_verify", args.workload, args.scale)),
+            "roofline_k1_scan": dict(bound="hbm", implementation_bytes=k1_impl,
+                                     achieved_implementation=gbs(k1_impl, ms["scan_ms"]),
+                                     survey_8d_formula_bytes=survey_k1,
+                                     achieved_survey_formula=gbs(survey_k1, ms["scan_ms"]),
+                                     peak=HBM_PEAK_GBS, unit="GB/s",
+                                     note="SURVEY 8(d)'s K1 bytes price a brute-force tiled scan "
+                                          "(every probe tile re-reads the targets); the seeded scan "
+                                          "does not do that work, so that figure is an upper "
+                                          "courtesy, not an achievement"),
+            "roofline_rows": dict(bound="hbm", achieved=gbs(rows_bytes, ms["rows_ms"]),
                                   peak=HBM_PEAK_GBS, unit="GB/s",
-                                  frac=rows_gbs / HBM_PEAK_GBS),
-            "roofline_k2": dict(bound="hbm", achieved=k2_gbs,
+                                  frac=gbs(rows_bytes, ms["rows_ms"]) / HBM_PEAK_GBS,
+                                  traffic=pmc_traffic("rows_build", args.workload, args.scale)),
+            "roofline_k2": dict(bound="hbm", achieved=gbs(k2_bytes, ms["rounds_ms"]),
                                 peak=HBM_PEAK_GBS, unit="GB/s",
-                                frac=k2_gbs / HBM_PEAK_GBS,
-                                us_per_pick=k2_rounds_ms * 1e3 / max(picks_per_step, 1),
-                                rounds_per_step=rounds_step),
-            "work_per_step": {"seeds": seeds_step, "hits": hits_step,
-                              "rows": rows_per_step,
-                              "rows_recounted": stats.get("rows_recounted", 0) / K,
-                              "bitmap_words_read": stats.get("bitmap_words_read", 0) / K},
-            "h2d_upload_s": upload_s,
+                                frac=gbs(k2_bytes, ms["rounds_ms"]) / HBM_PEAK_GBS,
+                                traffic=pmc_traffic("solver_round", args.workload, args.scale),
+                                us_per_pick=ms["rounds_ms"] * 1e3 / max(per.get("picks", 0), 1),
+                                rounds_per_step=per.get("greedy_iters", 0)),
+            "work_per_step": {"seeds": seeds, "hits": hits, "rows": rows,
+                              "rows_recounted": per.get("rows_recounted", 0),
+                              "bitmap_words_read": per.get("bitmap_words_read", 0)},
+            "dataset_generation_s": gen_s,
+            "pack_h2d_s": upload_s,
+            "m2_setcoverfilter_wall_s": upload_s + elapsed / K,
             "value_incl_h2d": total_units / (elapsed / K + upload_s),
+            "rank_seconds": all_elapsed,
+            "step_seconds_rank0": step_s,
+            "device_memory": dict(pool1, hipmalloc_calls_in_timed_region=(
+                pool1["hipmalloc_calls"] - pool0["hipmalloc_calls"])),
+            "parity_vs_golden_digests": (gold_ok if gold_n else None),
+            "groups_checked_against_digests": gold_n,
         }
         if world == 1 and not args.no_cpu_baseline:
-            base, sel = cpu_baseline(groups, cands)
+            order = sorted(range(len(groups)), key=lambda i: bases[i])
+            sample, acc = [], 0
+            for i in order:
+                if sample and acc + bases[i] > 13_000_000:
+                    break
+                sample.append(i)
+                acc += bases[i]
+            base, sel = cpu_baseline(groups, sample)
             out["cpu_baseline"] = base
             # the timed GPU result must equal the oracle's (parity guard)
-            out["parity_vs_oracle"] = [sorted(a) for a in picks] == \
-                [sorted(b) for b in sel]
+            out["parity_vs_oracle"] = all(sorted(picks[gi]) == sorted(sel[gi])
+                                          for gi in sample)
             out["speedup_vs_cpu_oracle"] = out["value"] / base["value"]
+            out["speedup_vs_cpu_oracle_incl_h2d"] = out["value_incl_h2d"] / base["value"]
         print(json.dumps(out))
-    for r in resident:
-        r.close()
+    stepper.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -29,6 +29,16 @@ std::multimap<std::pair<const void *, size_t>, void *> g_pool_free;
 struct PoolLive { const void *owner; size_t cls; };
 std::unordered_map<void *, PoolLive> g_pool_live;
 thread_local const void *g_pool_owner = nullptr;
+// [0] hipMalloc calls, [1] bytes obtained from the driver and still held,
+// [2] bytes cached (free), [3] hipMalloc retries after freeing the cache
+long long g_pool_stats[4] = {0, 0, 0, 0};
+
+// Blocks above 64 MiB are few and large: an exact-class cache would keep one
+// set per group size (S4: 20 groups, each with its own 64 MiB-granule sizes),
+// so a request takes the smallest cached block of its owner that is large
+// enough (at most twice the request); the request sequence of a step repeats,
+// so the assignment settles after the first pass.
+const size_t POOL_BIG = (size_t)1 << 26;
 
 size_t pool_class(size_t b) {
     if (b < 512) return 512;
@@ -56,23 +66,36 @@ void *chip_pool_alloc(size_t bytes) {
         // exact size class only: a looser fit lets one request take the block the
         // next one needs and the steady state (no hipMalloc at all) is lost
         auto it = g_pool_free.find(std::make_pair(owner, cls));
+        if (it == g_pool_free.end() && cls > POOL_BIG) {
+            it = g_pool_free.lower_bound(std::make_pair(owner, cls));
+            if (it != g_pool_free.end() && (it->first.first != owner || it->first.second > 2 * cls))
+                it = g_pool_free.end();
+        }
         if (it != g_pool_free.end()) {
             void *p = it->second;
+            const size_t got = it->first.second;
             g_pool_free.erase(it);
-            g_pool_live[p] = PoolLive{owner, cls};
+            g_pool_live[p] = PoolLive{owner, got};
+            g_pool_stats[2] -= (long long)got;
             return p;
         }
     }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, cls);
+    g_pool_stats[0]++;
     if (e != hipSuccess) {
+        g_pool_stats[3]++;
         // give this owner's cached blocks back to the driver and retry once
         // (other owners' blocks may still be referenced by queued work)
         {
             std::lock_guard<std::mutex> lk(g_pool_mu);
             for (auto it = g_pool_free.begin(); it != g_pool_free.end();) {
-                if (it->first.first == owner) { (void)hipFree(it->second); it = g_pool_free.erase(it); }
-                else ++it;
+                if (it->first.first == owner) {
+                    (void)hipFree(it->second);
+                    g_pool_stats[1] -= (long long)it->first.second;
+                    g_pool_stats[2] -= (long long)it->first.second;
+                    it = g_pool_free.erase(it);
+                } else ++it;
             }
         }
         e = hipMalloc(&p, cls);
@@ -83,6 +106,7 @@ void *chip_pool_alloc(size_t bytes) {
     }
     std::lock_guard<std::mutex> lk(g_pool_mu);
     g_pool_live[p] = PoolLive{owner, cls};
+    g_pool_stats[1] += (long long)cls;
     return p;
 }
 
@@ -92,6 +116,7 @@ void chip_pool_free(void *p) {
     auto it = g_pool_live.find(p);
     if (it == g_pool_live.end()) return;
     g_pool_free.insert(std::make_pair(std::make_pair(it->second.owner, it->second.cls), p));
+    g_pool_stats[2] += (long long)it->second.cls;
     g_pool_live.erase(it);
 }
 
@@ -99,9 +124,20 @@ void chip_pool_free(void *p) {
 void chip_pool_release_owner(const void *owner) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (auto it = g_pool_free.begin(); it != g_pool_free.end();) {
-        if (it->first.first == owner) { (void)hipFree(it->second); it = g_pool_free.erase(it); }
-        else ++it;
+        if (it->first.first == owner) {
+            (void)hipFree(it->second);
+            g_pool_stats[1] -= (long long)it->first.second;
+            g_pool_stats[2] -= (long long)it->first.second;
+            it = g_pool_free.erase(it);
+        } else ++it;
     }
+}
+
+extern "C" int catchhip_pool_stats(int64_t *out4) {
+    ARG_CHECK(out4 != nullptr);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (int i = 0; i < 4; ++i) out4[i] = g_pool_stats[i];
+    return 0;
 }
 
 extern "C" const char *catchhip_last_error(void) { return g_err; }
@@ -185,6 +221,7 @@ extern "C" int catchhip_ctx_sync(catchhip_ctx *c) {
 
 extern "C" int catchhip_ctx_last_kernel_ms(catchhip_ctx *c, int phase, double *ms, i64 *launches) {
     ARG_CHECK(c != nullptr && phase >= 0 && phase < NPHASE);
+    if (phase == PHASE_VERIFY && c->phase_launches[phase]) chip_phase_collect(c, phase);   // recorded inside the scan phase
     if (ms) *ms = c->phase_ms[phase];
     if (launches) *launches = c->phase_launches[phase];
     return 0;

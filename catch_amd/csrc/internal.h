@@ -97,7 +97,7 @@ template <typename T> struct DevBuf {
     }
 };
 
-enum { PHASE_SCAN = 0, PHASE_ROWS = 1, PHASE_GREEDY = 2, PHASE_NDF = 3, PHASE_GREEDY_ROUNDS = 4, NPHASE = 5 };
+enum { PHASE_SCAN = 0, PHASE_ROWS = 1, PHASE_GREEDY = 2, PHASE_NDF = 3, PHASE_GREEDY_ROUNDS = 4, PHASE_VERIFY = 5, NPHASE = 6 };
 
 struct catchhip_ctx {
     int device = 0;

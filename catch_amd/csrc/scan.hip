@@ -878,7 +878,9 @@ static int run_fast(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
 static u32 seed_capacity(const catchhip_probes *P, const catchhip_targets *T) {
     const double per_base = P->seed_ratio_hint > 0.0 ? std::max(1.0, 1.25 * P->seed_ratio_hint) : 6.0;
     const double want = per_base * (double)T->total;
-    return (u32)std::max<double>((double)((i64)1 << 20), std::min<double>(want, (double)((i64)1 << 30)));
+    // u32 indices; 32 B of work list + record per seed (a 288 GB part holds the
+    // 1.2e9 seeds of S4's largest group, 38 GB, without a second pass)
+    return (u32)std::max<double>((double)((i64)1 << 20), std::min<double>(want, 4.0e9));
 }
 
 // K1c host side: hash table of the anchor k-mers, one lookup per target
@@ -944,6 +946,8 @@ static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     if (!verify) { chip_set_error("seed scan: unsupported probe length"); return CATCHHIP_EINVAL; }
     TRY(seed_table_lookup_async(ctx, P, T, pos_limit, S, sink.bcnt, nb, res, tm));
     const u32 tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
+    // the verify launch alone is phase 5 (read lazily by catchhip_ctx_last_kernel_ms)
+    (void)hipEventRecord(ctx->ev[2 * PHASE_VERIFY], ctx->stream);
     hipLaunchKernelGGL(verify, dim3((unsigned)div_up((i64)S.scap, 256)), dim3(256), 0, ctx->stream,
                        (const u32 *)T->planes.p, T->nwords, (const u32 *)T->seq_off.p,
                        (const uint4 *)P->planes.p, (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p,
@@ -951,6 +955,8 @@ static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const cat
                        use_n ? 1 : 0,
                        (const u32 *)S.spos.p, (const u32 *)S.sent.p, (const u32 *)S.sseq.p,
                        (const u32 *)(S.ctr.p + 1), S.scap, sink);
+    (void)hipEventRecord(ctx->ev[2 * PHASE_VERIFY + 1], ctx->stream);
+    ctx->phase_launches[PHASE_VERIFY] = 1;
     tm.launch(1);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -13,6 +13,7 @@ from catch_amd._lib import (c_f32p, c_f64p, c_i32p, c_i64p, c_u16p, c_u32p,
 
 SCAN_AUTO, SCAN_GENERAL, SCAN_FAST, SCAN_SEED = 0, 1, 2, 3
 PHASE_SCAN, PHASE_ROWS, PHASE_GREEDY, PHASE_NDF, PHASE_GREEDY_ROUNDS = 0, 1, 2, 3, 4
+PHASE_VERIFY = 5
 
 
 def _ptr(a, t):
@@ -33,6 +34,14 @@ def device_count():
     n = ctypes.c_int(0)
     rc = _lib.lib().catchhip_device_count(ctypes.byref(n))
     return n.value if rc == 0 else 0
+
+
+def pool_stats():
+    """catchhip_pool_stats -> dict (device-memory cache of the library)."""
+    out = np.zeros(4, dtype=np.int64)
+    check(_lib.lib().catchhip_pool_stats(_ptr(out, c_i64p)))
+    return dict(zip(("hipmalloc_calls", "bytes_held", "bytes_cached_free",
+                     "oom_retries"), (int(x) for x in out)))
 
 
 class Context:

@@ -50,11 +50,18 @@ int catchhip_device_count(int *count);
 int catchhip_ctx_create(int device, catchhip_ctx **out);
 int catchhip_ctx_destroy(catchhip_ctx *ctx);
 int catchhip_ctx_sync(catchhip_ctx *ctx);
+/* Device-memory cache of the library (all contexts): out4 = {hipMalloc calls so
+ * far, bytes held from the driver, bytes of those currently free in the cache,
+ * hipMalloc failures answered by emptying the caller's cache}.  No reference
+ * counterpart (the reference keeps its working set in Python objects); the bench
+ * reports it so that a step that allocates is visible. */
+int catchhip_pool_stats(int64_t *out4);
 /* Elapsed GPU milliseconds spent in the kernels of the most recent call of
  * the named phase (HIP events on the context's stream).  phase: 0 = cover
  * scan kernels (K1 hit search), 1 = row build (sort/merge), 2 = greedy
  * set-cover kernels (set-up + solver), 3 = near-duplicate kernels, 4 = only the
- * (count+claim, check+apply) launch pairs of the frontier solver's rounds.
+ * (count+claim, check+apply) launch pairs of the frontier solver's rounds,
+ * 5 = only the seed-verify launch of the seed scan (part of phase 0).
  * *launches = kernel launches timed. */
 int catchhip_ctx_last_kernel_ms(catchhip_ctx *ctx, int phase, double *ms,
                                 int64_t *launches);

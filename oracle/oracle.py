@@ -45,6 +45,8 @@ def lib():
             build()
         L = ctypes.CDLL(_LIB_PATH)
         L.orc_free.argtypes = [ctypes.c_void_p]
+        L.orc_set_threads.argtypes = [ctypes.c_int]
+        L.orc_hw_threads.restype = ctypes.c_int
         L.orc_pyhash_seed0.argtypes = [_u8p, ctypes.c_int64]
         L.orc_pyhash_seed0.restype = ctypes.c_int64
         L.orc_minhash.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int64,
@@ -81,8 +83,24 @@ def lib():
             _i32p, _i32p, _i64p, _i64p, ctypes.c_int64, ctypes.c_int64,
             ctypes.c_int64, _f64p, _f64p, _i64p, _i64p]
         L.orc_approx_multiuniverse.restype = ctypes.c_int64
+        L.orc_lazy_greedy.argtypes = [
+            _i32p, _i32p, _i64p, _i64p, ctypes.c_int64, ctypes.c_int64,
+            ctypes.c_int64, _i64p, _f64p, _i64p, _i64p]
+        L.orc_lazy_greedy.restype = ctypes.c_int64
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    """OpenMP threads for the per-sequence scans of make_sets (default 1).
+    Returns the count in effect."""
+    n = max(1, int(n))
+    lib().orc_set_threads(n)
+    return n
+
+
+def hw_threads():
+    return int(lib().orc_hw_threads())
 
 
 def _bytes_arr(s):
@@ -303,6 +321,30 @@ def approx_multiuniverse(row_set, row_univ, row_start, row_end, num_sets,
     return [int(x) for x in out[:n]]
 
 
+def lazy_greedy(row_set, row_univ, row_start, row_end, num_sets, genome_len,
+                universe_p=None, ranks=None):
+    """orc_lazy_greedy: the same picks in the same order as
+    approx_multiuniverse with unit costs, by lazy evaluation over bitmaps (see
+    the C source).  genome_len[u] = length of universe u's coordinate space."""
+    rs = np.ascontiguousarray(row_set, dtype=np.int32)
+    ru = np.ascontiguousarray(row_univ, dtype=np.int32)
+    st = np.ascontiguousarray(row_start, dtype=np.int64)
+    en = np.ascontiguousarray(row_end, dtype=np.int64)
+    gl = np.ascontiguousarray(genome_len, dtype=np.int64)
+    P, U = int(num_sets), int(gl.size)
+    up = (np.ones(U, dtype=np.float64) if universe_p is None
+          else np.ascontiguousarray(universe_p, dtype=np.float64))
+    rk = (np.ones(P, dtype=np.int64) if ranks is None
+          else np.ascontiguousarray(ranks, dtype=np.int64))
+    out = np.zeros(max(P, 1), dtype=np.int64)
+    n = lib().orc_lazy_greedy(_p(rs, _i32p), _p(ru, _i32p), _p(st, _i64p),
+                              _p(en, _i64p), rs.size, P, U, _p(gl, _i64p),
+                              _p(up, _f64p), _p(rk, _i64p), _p(out, _i64p))
+    if n < 0:
+        raise IndexError("rank list exhausted (reference raises IndexError)")
+    return out[:n].tolist()
+
+
 # --------------------------------------------------------------------------
 # SetCoverFilter end to end: catch/filter/set_cover_filter.py:794-930
 # --------------------------------------------------------------------------
@@ -392,7 +434,7 @@ def set_cover_filter(probes_grouped, genomes_grouped, mismatches, lcf_thres,
                      lcf_thres_tolerant=None, island_tolerant=None,
                      identify=False, avoided_sequences=(), coverage=1.0,
                      cover_extension=0, kmer_probe_map_k=20,
-                     return_intermediate=False):
+                     return_intermediate=False, lazy=False):
     """SetCoverFilter.__init__ + _filter (catch/filter/set_cover_filter.py
     :199-357, :902-930).  probes_grouped: list of lists of probe strings;
     genomes_grouped: list (per group) of genomes, each a list of sequence
@@ -430,9 +472,14 @@ def set_cover_filter(probes_grouped, genomes_grouped, mismatches, lcf_thres,
         ranks = make_ranks(probe_strs, genomes_grouped, params,
                            list(avoided_sequences)) if P else []
         up = universe_p(coverage, [sum(len(s) for s in g) for g in genomes])
-        picks = approx_multiuniverse(rows[0], rows[1], rows[2], rows[3], P,
-                                     len(genomes), None, up,
-                                     ranks) if P else []
+        if lazy and P:
+            picks = lazy_greedy(rows[0], rows[1], rows[2], rows[3], P,
+                                [sum(len(s) for s in g) for g in genomes], up,
+                                ranks)
+        else:
+            picks = approx_multiuniverse(rows[0], rows[1], rows[2], rows[3], P,
+                                         len(genomes), None, up,
+                                         ranks) if P else []
         selected.append(sorted(picks))
         inter.append(dict(k=k, entries=entries, rows=rows, ranks=ranks,
                           universe_p=up, picks=picks))

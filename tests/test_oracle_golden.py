@@ -238,3 +238,83 @@ def test_adapter_filter_restatement_matches_reference(oracle):
                                          c["lcf_thres"], c.get("island", 0), c["kmer_probe_map_k"],
                                          hash_fn=oracle.pyhash_seed0) == c["out"]
     assert exact == len(recs) or not same_python
+
+
+def _random_instance(rng, nsets, nuniv, glen, partial, with_ranks):
+    rows = []
+    for s in range(nsets):
+        for u in sorted(rng.choice(nuniv, size=rng.integers(1, nuniv + 1), replace=False)):
+            iv, at = [], int(rng.integers(0, glen // 2))
+            for _ in range(int(rng.integers(1, 4))):
+                ln = int(rng.integers(1, 300))
+                if at + ln > glen:
+                    break
+                iv.append((s, int(u), at, at + ln))
+                at += ln + int(rng.integers(1, 200))
+            rows += iv
+    r = np.array(rows, dtype=np.int64).reshape(-1, 4)
+    p = [float(rng.choice([1.0, 0.9, 0.5, 0.25, 0.0])) if partial else 1.0
+         for _ in range(nuniv)]
+    ranks = ([int(x) for x in rng.integers(0, 3, size=nsets)] if with_ranks
+             else [0] * nsets)
+    return r, p, ranks
+
+
+def test_lazy_greedy_equals_restatement_on_reference_vectors(oracle):
+    """The lazy evaluation makes the reference's picks in the reference's order
+    on every unit-cost set cover instance recorded from its test suite."""
+    n = 0
+    for c in load_golden("setcover"):
+        if (c["costs"] is not None and any(x != 1 for x in c["costs"])) or not c["rows"]:
+            continue
+        r = np.array(c["rows"], dtype=np.int64).reshape(-1, 4)
+        glen = [int(r[r[:, 1] == u, 3].max()) if (r[:, 1] == u).any() else 0
+                for u in range(c["num_universes"])]
+        exp = oracle.approx_multiuniverse(r[:, 0], r[:, 1], r[:, 2], r[:, 3],
+                                          c["num_sets"], c["num_universes"],
+                                          c["costs"], c["universe_p"], c["ranks"])
+        got = oracle.lazy_greedy(r[:, 0], r[:, 1], r[:, 2], r[:, 3],
+                                 c["num_sets"], glen, c["universe_p"], c["ranks"])
+        assert got == exp, c
+        n += 1
+    assert n >= 10
+
+
+@pytest.mark.parametrize("partial,with_ranks", [(False, False), (True, False),
+                                                (False, True), (True, True)])
+def test_lazy_greedy_equals_restatement_random(oracle, partial, with_ranks):
+    rng = np.random.Generator(np.random.PCG64(11 + 2 * partial + with_ranks))
+    for it in range(40):
+        nsets, nuniv = int(rng.integers(2, 60)), int(rng.integers(1, 6))
+        glen = int(rng.integers(400, 3000))
+        r, p, ranks = _random_instance(rng, nsets, nuniv, glen, partial, with_ranks)
+        try:
+            exp = oracle.approx_multiuniverse(r[:, 0], r[:, 1], r[:, 2], r[:, 3],
+                                              nsets, nuniv, None, p, ranks)
+        except IndexError:
+            with pytest.raises(IndexError):
+                oracle.lazy_greedy(r[:, 0], r[:, 1], r[:, 2], r[:, 3], nsets,
+                                   [glen] * nuniv, p, ranks)
+            continue
+        got = oracle.lazy_greedy(r[:, 0], r[:, 1], r[:, 2], r[:, 3], nsets,
+                                 [glen] * nuniv, p, ranks)
+        assert got == exp, (it, partial, with_ranks)
+
+
+def test_lazy_greedy_and_threaded_scan_on_a_pipeline(oracle):
+    """Whole filter: threaded per-sequence scans + lazy greedy == the
+    single-threaded restatement (picks in pick order)."""
+    from tests.util import candidates, small_species
+    genomes = small_species(seed=5, n=12, length=2500)
+    cands = candidates(genomes, 100, 50)
+    _, a = oracle.set_cover_filter([cands], [genomes], 2, 100,
+                                   cover_extension=50, return_intermediate=True)
+    oracle.set_threads(4)
+    try:
+        _, b = oracle.set_cover_filter([cands], [genomes], 2, 100,
+                                       cover_extension=50, lazy=True,
+                                       return_intermediate=True)
+    finally:
+        oracle.set_threads(1)
+    assert rows_as_tuples(*a[0]["rows"]) == rows_as_tuples(*b[0]["rows"])
+    assert a[0]["picks"] == b[0]["picks"] and len(a[0]["picks"]) > 5

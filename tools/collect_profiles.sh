@@ -3,28 +3,31 @@
 # profiles/ for the current round: the bench JSON line, the rocprofv3
 # kernel-trace summary of the same command, and the HBM traffic counters
 # (FETCH_SIZE / WRITE_SIZE in separate passes, as MI355X_MICROARCH.md says).
-#   tools/collect_profiles.sh <tag>     -> gpurun_out/profiles_<tag>/
-tag=${1:-r01}
+#   tools/collect_profiles.sh <tag> [workload] [extra]   -> gpurun_out/profiles_<tag>/
+# extra = "all" also profiles the clustering pre-step and the device front end
+tag=${1:-r02}; wl=${2:-S4}; extra=${3:-}
 out=/root/repo/gpurun_out/profiles_$tag
 rm -rf $out
 mkdir -p $out
 cd /root/repo
-python bench.py > $out/bench.json 2> $out/bench.err
+python bench.py --workload $wl > $out/bench.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python /root/repo/bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-# the kernels outside the bench's hot path: clustering pre-step and the device front end
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cluster -- python /root/repo/tools/cluster_bench.py --scale 0.25 --cpu-sample 0 > $out/cluster_bench.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_frontend -- python /root/repo/tools/e2e_profile.py S4 0.5 > $out/frontend_e2e.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python /root/repo/bench.py --workload $wl --no-cpu-baseline > $out/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python /root/repo/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python /root/repo/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+if [ "$extra" = "all" ]; then
+  # the kernels outside the bench's hot path: clustering pre-step and the device front end
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cluster -- python /root/repo/tools/cluster_bench.py --scale 0.25 --cpu-sample 0 > $out/cluster_bench.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_frontend -- python /root/repo/tools/e2e_profile.py S4 0.5 > $out/frontend_e2e.txt 2>&1
+fi
 cd /root/repo
 for t in cluster frontend; do
   f=$(ls -t $out/trace_$t/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" $out/${t}_kernel_stats.csv
 done
-OUT=$out python - <<'PY'
+OUT=$out WL=$wl python - <<'PY'
 import csv, glob, json, collections, shutil, os
-out = os.environ["OUT"]
+out, wl = os.environ["OUT"], os.environ["WL"]
 ks = max(glob.glob(out + "/trace/*/*kernel_stats.csv"), key=os.path.getmtime)
 ds = sorted(glob.glob(out + "/trace/*/*domain_stats.csv"), key=os.path.getmtime)[-1:]
 shutil.copy(ks, out + "/bench_kernel_stats.csv")
@@ -47,20 +50,21 @@ def unit(names):
     return {"kernels": names,
             "FETCH_SIZE_KB_per_launch": sum(kern[n]["FETCH_SIZE_KB_per_launch"] for n in names if n in kern),
             "WRITE_SIZE_KB_per_launch": sum(kern[n]["WRITE_SIZE_KB_per_launch"] for n in names if n in kern)}
-seed = [k for k in kern if k.startswith("seed_")]
+seed = [k for k in kern if k.startswith("seed_") and not k.startswith("seed_verify")]
 rows = [k for k in kern if k.startswith(("scan1_", "bucket_", "rows_emit", "scan_tiles"))]
 rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
-               "'python bench.py --steps 5 --warmup 1 --no-cpu-baseline' (S2); KB per launch averaged over "
-               "the launches of the run; a unit sums the per-launch averages of its kernels (one launch of "
-               "each); on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md), "
-               "bench.py doubles it; other widths and WRITE_SIZE are uncalibrated",
-       "workload": "S2",
-       "units": {"solver_round": unit([k for k in kern if k.startswith(("gf_count_claim", "gf_check_apply"))]),
-                 "seed_scan": unit(seed), "rows_build": unit(rows)},
+               "'python bench.py --workload %s --steps 2 --warmup 1 --no-cpu-baseline'; KB per launch averaged over "
+               "the launches of the run (all groups, all rounds); a unit sums the per-launch averages of its kernels "
+               "(one launch of each); on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x "
+               "(MI355X_MICROARCH.md), bench.py doubles it; other widths and WRITE_SIZE are uncalibrated" % wl,
+       "workload": wl,
+       "units": {"solver_round": unit([k for k in kern if k.startswith(("gf_count_claim", "gf_check_apply", "gfx_"))]),
+                 "seed_verify": unit([k for k in kern if k.startswith("seed_verify")]),
+                 "seed_table_lookup": unit(seed), "rows_build": unit(rows)},
        "kernels": kern}
 json.dump(rec, open(out + "/pmc_traffic.json", "w"), indent=1)
 for i, r in enumerate(csv.DictReader(open(ks))):
-    if i < 14: print(r["Name"][:44].ljust(44), r["Calls"].rjust(5), r["TotalDurationNs"].rjust(11), r["AverageNs"][:10].rjust(11))
-print(open(out + "/bench.json").read()[:1500])
-print(json.dumps(rec["units"], indent=0)[:900])
+    if i < 16: print(r["Name"][:44].ljust(44), r["Calls"].rjust(6), r["TotalDurationNs"].rjust(12), r["AverageNs"][:10].rjust(11))
+print(open(out + "/bench.json").read()[:2500])
+print(json.dumps(rec["units"], indent=0)[:1200])
 PY
