@@ -244,7 +244,8 @@ __device__ __forceinline__ u32 dna_code(u8 c) {
 
 // targets: SoA planes (plane b at planes + b*nwords)
 __global__ void __launch_bounds__(256)
-pack_targets_kernel(const u8 *__restrict__ bytes, i64 n, u32 *__restrict__ planes, i64 nwords) {
+pack_targets_kernel(const u8 *__restrict__ bytes, i64 n, u32 *__restrict__ planes, i64 nwords,
+                    uint4 *__restrict__ tq) {
     const int lane = threadIdx.x & 63;
     const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
@@ -258,6 +259,12 @@ pack_targets_kernel(const u8 *__restrict__ bytes, i64 n, u32 *__restrict__ plane
             u32 w = (lane & 1) ? (u32)(b >> 32) : (u32)b;
             i64 wi = ch * 2 + (lane & 1);
             if (wi < nwords) planes[(size_t)(lane >> 1) * nwords + wi] = w;
+        }
+        if (lane < 2) {   // word-interleaved copy
+            const i64 wi = ch * 2 + lane;
+            if (wi < nwords)
+                tq[wi] = lane ? make_uint4((u32)(b0 >> 32), (u32)(b1 >> 32), (u32)(b2 >> 32), 0u)
+                              : make_uint4((u32)b0, (u32)b1, (u32)b2, 0u);
         }
     }
 }
@@ -376,11 +383,13 @@ extern "C" int catchhip_targets_create(catchhip_ctx *ctx, const u8 *bytes, const
             t->nwords = (total + 8192) / 32 + 64;
             if ((rc = t->planes.alloc((size_t)t->nwords * 3))) break;
             if (hipMemsetAsync(t->planes.p, 0, sizeof(u32) * t->nwords * 3, s) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
+            if ((rc = t->tq.alloc((size_t)t->nwords))) break;
+            if (hipMemsetAsync(t->tq.p, 0, sizeof(uint4) * t->nwords, s) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
             if (total) {
                 i64 chunks = (total + 63) / 64;
                 unsigned blocks = (unsigned)(chunks < 4 * 2048 ? div_up(chunks, 4) : 2048);
                 hipLaunchKernelGGL(pack_targets_kernel, dim3(blocks), dim3(256), 0, s, t->bytes.p, total,
-                                   t->planes.p, t->nwords);
+                                   t->planes.p, t->nwords, t->tq.p);
             }
         }
         if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {

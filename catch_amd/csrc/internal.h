@@ -149,6 +149,9 @@ struct catchhip_targets {
     DevBuf<u32> genome_off;  // ngenomes+1 global offset of each genome's first base
     i64 nwords = 0;          // 32-base words per plane (+ padding)
     DevBuf<u32> planes;      // 3 planes, SoA: plane b at planes + b*nwords
+    // the same bits word-interleaved, [word] = {plane0, plane1, plane2, 0}: a
+    // window of the seed-verify kernel is ONE run of 16-byte words (nwords entries)
+    DevBuf<uint4> tq;
     std::vector<i64> h_seq_off;
     std::vector<i32> h_seq_genome;
     std::vector<i64> h_genome_off;

@@ -357,6 +357,156 @@ seed_verify_kernel(const u32 *__restrict__ tplanes, i64 nwords, const u32 *__res
     else sink.rank[d] = BK_NONE;
 }
 
+// ---- cooperative verify: 4 lanes per seed ---------------------------------
+// seed_verify_kernel above gathers ~30 scattered dwords per lane (3 planes x
+// (NW+1) target words + the probe image): every wave-level load touches 64
+// different cache lines and the kernel is bound by the vector L1's line rate
+// (S4: 1.8e9 seeds x ~30 line look-ups / (256 CUs x 1 line per clock) = 87 ms,
+// measured 99).  Here a group of 4 lanes owns one seed: lane t loads words 2t
+// and 2t+1 of the window from the word-interleaved target image (two adjacent
+// 16-byte words: planes 0,1,2 of 32 bases each) and of the probe image, so a
+// wave-level load covers 16 seeds x one contiguous run of <= 128 bytes.  The
+// funnel shift takes the following word from the neighbouring lane (DPP
+// row_shl:1), the mismatch count is a 2-step DPP butterfly inside the quad,
+// the anchor tests are ballots against per-lane constant masks (pigeonhole
+// anchors sit at multiples of k whatever the seed).  A wavefront takes 64
+// consecutive seeds: it loads their work items coalesced, verifies them 16 at
+// a time and files the hits with all 64 lanes.  NW <= 7 (the window needs
+// NW + 1 <= 8 words).  (A first version with 8 lanes per seed and the masks
+// computed per seed was issue-bound: 99 -> 65 ms, ~24 instructions per seed.)
+__device__ __forceinline__ u32 dpp_row_shl1(u32 v) {   // lane i <- lane i + 1 (inside a row of 16)
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);
+}
+__device__ __forceinline__ u32 quad_sum(u32 v) {       // sum over the 4 lanes of a quad, in every lane
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    return v;
+}
+// bits [pos, pos+len) of a (NW x 32)-bit string restricted to word t
+__device__ __forceinline__ u32 word_range_mask(int t, int pos, int len) {
+    const int lo = max(pos - 32 * t, 0), hi = min(pos + len - 32 * t, 32);
+    if (hi <= lo) return 0u;
+    return (hi - lo >= 32 ? 0xffffffffu : ((1u << (hi - lo)) - 1u)) << lo;
+}
+#define SV_AMAX 4   // pigeonhole anchors with precomputed masks (more: masks on the fly)
+
+template <int NW>
+__global__ void __launch_bounds__(256)
+seed_verify4_kernel(const uint4 *__restrict__ tq, const u32 *__restrict__ seq_off,
+                    const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent_probe,
+                    const u32 *__restrict__ ent_pos, const u32 *__restrict__ ent_ptr, int nanch, int ntab, int L, int k,
+                    int mm, u32 tailmask, int use_n, const u32 *__restrict__ seed_pos,
+                    const u32 *__restrict__ seed_ent, const u32 *__restrict__ seed_seq,
+                    const u32 *__restrict__ seed_count, u32 seed_cap, HitSink sink) {
+    static_assert(NW >= 1 && NW <= 7, "the window needs NW + 1 <= 8 words");
+    const u32 nseeds = min(*seed_count, seed_cap);
+    const u32 lane = threadIdx.x & 63, sub = lane & 3, grp = lane >> 2;
+    const u32 d0 = (u32)((((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 6);
+    if (d0 >= nseeds) return;
+    // ---- A: this lane's own work item (coalesced) -------------------------
+    const u32 d = d0 + lane;
+    u32 i = 0, e = 0, sq = 0, p = 0, aidx = 0, apos = 0, lo = 0, hi = 0, o = 0, first_ent = 0;
+    bool pre = false;
+    if (d < nseeds) {
+        i = seed_pos[d]; e = seed_ent[d]; sq = seed_seq[d];
+        p = nanch ? e / (u32)nanch : ent_probe[e];
+        aidx = nanch ? e - p * (u32)nanch : 0u;          // index of the seeding anchor (pigeonhole)
+        apos = nanch ? aidx * (u32)k : ent_pos[e];
+        lo = seq_off[sq]; hi = seq_off[sq + 1];
+        pre = i >= lo + apos;
+        if (sink.probe_group) pre = pre && sink.probe_group[p] == sink.seq_group[sq];
+        o = i - apos;
+        pre = pre && o + (u32)L <= hi;
+        if (!nanch && pre) first_ent = ent_ptr[p];
+    }
+    const unsigned long long premask = __ballot(pre);
+    // per-lane constants: which of the window's words this lane owns, and the
+    // pigeonhole anchors' bit ranges inside them
+    const u32 wa = 2 * sub, wb = 2 * sub + 1;
+    const bool va = wa < (u32)NW, vb = wb < (u32)NW;
+    u32 ma[SV_AMAX], mb[SV_AMAX];
+#pragma unroll
+    for (int a = 0; a < SV_AMAX; ++a) {
+        ma[a] = (nanch && a < ntab) ? word_range_mask((int)wa, a * k, k) : 0u;
+        mb[a] = (nanch && a < ntab) ? word_range_mask((int)wb, a * k, k) : 0u;
+    }
+    unsigned long long verdict[4] = {0, 0, 0, 0};
+    // ---- B: 16 seeds at a time, 4 lanes each -----------------------------
+#pragma unroll
+    for (u32 it = 0; it < 4; ++it) {
+        if (((premask >> (it * 16)) & 0xffffull) == 0) continue;   // wave-uniform
+        const u32 src = it * 16 + grp;
+        const bool live = (premask >> src) & 1ull;                 // quad-uniform
+        const u32 go = __shfl(o, src), gp = __shfl(p, src), ga = __shfl(nanch ? aidx : apos, src);
+        u32 x0 = 0, x1 = 0;
+        if (live) {
+            const u32 wi = go >> 5, sh = go & 31;
+            const uint4 *tp = tq + (size_t)wi + wa;                // words wi .. wi+7 (the image has slack words)
+            const uint4 T0 = tp[0], T1 = tp[1];
+            uint4 Q0 = make_uint4(0, 0, 0, 0), Q1 = make_uint4(0, 0, 0, 0);
+            if (va) Q0 = pplanes[(size_t)gp * NW + wa];
+            if (vb) Q1 = pplanes[(size_t)gp * NW + wb];
+            const u32 nx = dpp_row_shl1(T0.x), ny = dpp_row_shl1(T0.y), nz = dpp_row_shl1(T0.z);
+            x0 = (__builtin_amdgcn_alignbit(T1.x, T0.x, sh) ^ Q0.x) | (__builtin_amdgcn_alignbit(T1.y, T0.y, sh) ^ Q0.y);
+            x1 = (__builtin_amdgcn_alignbit(nx, T1.x, sh) ^ Q1.x) | (__builtin_amdgcn_alignbit(ny, T1.y, sh) ^ Q1.y);
+            if (use_n) {
+                x0 |= __builtin_amdgcn_alignbit(T1.z, T0.z, sh) ^ Q0.z;
+                x1 |= __builtin_amdgcn_alignbit(nz, T1.z, sh) ^ Q1.z;
+            }
+            if (wa == (u32)NW - 1) x0 &= tailmask;
+            if (wb == (u32)NW - 1) x1 &= tailmask;
+            if (!va) x0 = 0;
+            if (!vb) x1 = 0;
+        }
+        const u32 cnt = quad_sum(__popc(x0) + __popc(x1));
+        bool ok = live && cnt <= (u32)mm;
+        // The seeding anchor must be exact on all planes (the key ignores plane 2
+        // and bases beyond 32), and the pair is reported from its lowest exact
+        // anchor only (lower anchors precede entry e).
+        if (nanch) {
+            // zbits: bit a = "anchor a has a mismatch in this window"
+            u32 zbits = 0;
+#pragma unroll
+            for (int a = 0; a < SV_AMAX; ++a) {
+                if (a < ntab) {
+                    const unsigned long long b = __ballot(((x0 & ma[a]) | (x1 & mb[a])) != 0);
+                    zbits |= ((b >> (grp * 4)) & 0xfull) ? (1u << a) : 0u;
+                }
+            }
+            for (int a = SV_AMAX; a < ntab; ++a) {   // tables with more anchors: masks on the fly
+                const unsigned long long b = __ballot(((x0 & word_range_mask((int)wa, a * k, k)) |
+                                                       (x1 & word_range_mask((int)wb, a * k, k))) != 0);
+                zbits |= ((b >> (grp * 4)) & 0xfull) ? (1u << a) : 0u;
+            }
+            // anchors below ga all broken, anchor ga exact
+            ok = ok && (zbits & ((2u << ga) - 1u)) == ((1u << ga) - 1u);
+        } else {
+            {
+                const unsigned long long b = __ballot(((x0 & word_range_mask((int)wa, (int)ga, k)) |
+                                                       (x1 & word_range_mask((int)wb, (int)ga, k))) != 0);
+                ok = ok && ((b >> (grp * 4)) & 0xfull) == 0;
+            }
+            const u32 ge = __shfl(e, src), gf = __shfl(first_ent, src);
+            u32 j = gf;
+            while (__ballot(ok && j < ge)) {
+                const int ap = (ok && j < ge) ? (int)ent_pos[j] : 0;
+                const unsigned long long b = __ballot(((x0 & word_range_mask((int)wa, ap, k)) |
+                                                       (x1 & word_range_mask((int)wb, ap, k))) != 0);
+                if (ok && j < ge && ((b >> (grp * 4)) & 0xfull) == 0) ok = false;
+                ++j;
+            }
+        }
+        verdict[it] = __ballot(ok);      // quad-uniform: bit 4*grp stands for seed it*16+grp
+    }
+    // ---- C: every lane files its own seed ----------------------------------
+    if (d < nseeds) {
+        const u32 q = lane >> 4;
+        const unsigned long long v = q == 0 ? verdict[0] : q == 1 ? verdict[1] : q == 2 ? verdict[2] : verdict[3];
+        if ((v >> ((lane & 15) * 4)) & 1ull) hit_record(sink, d, p, o, o + (u32)L, sq, lo, hi);
+        else sink.rank[d] = BK_NONE;
+    }
+}
+
 typedef void (*seed_verify_fn)(const u32 *, i64, const u32 *, const uint4 *, const u32 *, const u32 *, const u32 *,
                                int, int, int, int, u32, int, const u32 *, const u32 *, const u32 *, const u32 *, u32,
                                HitSink);
@@ -370,6 +520,22 @@ static seed_verify_fn pick_seed_verify(int nw) {
     case 6: return seed_verify_kernel<6>;
     case 7: return seed_verify_kernel<7>;
     case 8: return seed_verify_kernel<8>;
+    }
+    return nullptr;
+}
+
+typedef void (*seed_verify4_fn)(const uint4 *, const u32 *, const uint4 *, const u32 *, const u32 *, const u32 *, int, int,
+                                int, int, int, u32, int, const u32 *, const u32 *, const u32 *, const u32 *, u32,
+                                HitSink);
+static seed_verify4_fn pick_seed_verify4(int nw) {
+    switch (nw) {
+    case 1: return seed_verify4_kernel<1>;
+    case 2: return seed_verify4_kernel<2>;
+    case 3: return seed_verify4_kernel<3>;
+    case 4: return seed_verify4_kernel<4>;
+    case 5: return seed_verify4_kernel<5>;
+    case 6: return seed_verify4_kernel<6>;
+    case 7: return seed_verify4_kernel<7>;
     }
     return nullptr;
 }
@@ -948,6 +1114,19 @@ static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     const u32 tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
     // the verify launch alone is phase 5 (read lazily by catchhip_ctx_last_kernel_ms)
     (void)hipEventRecord(ctx->ev[2 * PHASE_VERIFY], ctx->stream);
+    seed_verify4_fn verify4 = getenv("CATCHHIP_VERIFY_V1") ? nullptr : pick_seed_verify4((int)P->pwords);
+    // anchors per probe in the table (pigeonhole: those below pos_limit), <= 31 for the bit set
+    const int nanch = P->pigeonhole ? (int)(P->L / k) : 0;
+    const int ntab = nanch ? (int)std::min<i64>(nanch, div_up((i64)pos_limit, k)) : 0;
+    if (ntab > 31) verify4 = nullptr;
+    if (verify4)
+        hipLaunchKernelGGL(verify4, dim3((unsigned)div_up((i64)S.scap, 256)), dim3(256), 0, ctx->stream,
+                           (const uint4 *)T->tq.p, (const u32 *)T->seq_off.p, (const uint4 *)P->planes.p,
+                           (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p, (const u32 *)P->ent_ptr.p,
+                           nanch, ntab, (int)P->L, k, mm, tailmask, use_n ? 1 : 0,
+                           (const u32 *)S.spos.p, (const u32 *)S.sent.p, (const u32 *)S.sseq.p,
+                           (const u32 *)(S.ctr.p + 1), S.scap, sink);
+    else
     hipLaunchKernelGGL(verify, dim3((unsigned)div_up((i64)S.scap, 256)), dim3(256), 0, ctx->stream,
                        (const u32 *)T->planes.p, T->nwords, (const u32 *)T->seq_off.p,
                        (const uint4 *)P->planes.p, (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p,
