@@ -13,8 +13,8 @@
 //
 // Three solvers, all exact (catchhip_setcover_greedy picks one):
 //
-// Frontier rounds (setcover_batched.inc; every universe fully covered, rows of
-// at most 257 bases -- the default): all locally-maximal sets are accepted per
+// Frontier rounds (setcover_batched.inc; every universe fully covered -- the
+// default): all locally-maximal sets are accepted per
 // round, two grid-wide launches each; the picks come back in the sequential
 // order.
 //
@@ -778,6 +778,9 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     // lanes per set (setcover_batched.inc): by the average rows per set, or --
     // when the row count is still on the device -- by the number of genomes
     const bool wide = d_info ? nuniv >= 256 : (i64)nrows >= 32 * (i64)nsets;
+    // rows of more than 5 bitmap words take the lane-per-word kernels (a deferred
+    // scan with such rows stops itself, info[5], and comes back through here)
+    const bool long_rows = (!d_info && R->lmax > 257) || getenv("CATCHHIP_GF_LONG") != nullptr;
     const u32 sets_per_wg = GF_THREADS / (wide ? 64 : 16);
     const unsigned gblocks = (unsigned)std::min<i64>(div_up(nsets, sets_per_wg), (i64)ctx->num_cus * 16);
     // arena: the zero-initialised part first
@@ -840,7 +843,15 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     PhaseTimer tr(ctx, PHASE_GREEDY_ROUNDS);   // the round launches only
     for (;;) {
         for (int r = 0; r < per_sync; ++r, ++rounds) {
-            if (wide) {
+            if (long_rows) {
+                if (wide) {
+                    hipLaunchKernelGGL(gfl_count_claim_kernel<64>, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
+                    hipLaunchKernelGGL(gfl_check_apply_kernel<64>, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
+                } else {
+                    hipLaunchKernelGGL(gfl_count_claim_kernel<16>, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
+                    hipLaunchKernelGGL(gfl_check_apply_kernel<16>, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
+                }
+            } else if (wide) {
                 hipLaunchKernelGGL(gf_count_claim_kernel<64>, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
                 hipLaunchKernelGGL(gf_check_apply_kernel<64>, dim3(gblocks), dim3(GF_THREADS), 0, s, fa, (u32)rounds);
             } else {
@@ -967,9 +978,9 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
                 return CATCHHIP_EINVAL;
             }
 
-    // every universe fully covered and rows <= 257 bases: batched rounds (many
-    // independent picks per round); otherwise one pick per iteration
-    bool batched = !distributed && R->lmax <= 257 && !getenv("CATCHHIP_GREEDY_SEQUENTIAL");
+    // every universe fully covered: batched rounds (many independent picks per
+    // round); otherwise one pick per iteration
+    bool batched = !distributed && !getenv("CATCHHIP_GREEDY_SEQUENTIAL");
     if (universe_p)
         for (u32 u = 0; u < nuniv && batched; ++u) batched = universe_p[u] == 1.0;
 

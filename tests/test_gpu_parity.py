@@ -336,6 +336,46 @@ def test_greedy_batched_rounds_restore_sequential_order(ctx, oracle):
         assert rounds < len(exp)      # really batched
 
 
+@pytest.mark.parametrize("force_long", [False, True])
+def test_greedy_long_rows_take_the_frontier_path(ctx, oracle, monkeypatch, force_long):
+    """Rows of more than 257 bases (up to 40 bitmap words) go through the
+    lane-per-word round kernels (gfl_*), in both set widths (16 lanes: few rows
+    per set, 64 lanes: many), still in rounds and still the oracle's order;
+    forced on short rows they must agree with the lane-per-row kernels."""
+    engine = _engine()
+    if force_long:
+        monkeypatch.setenv("CATCHHIP_GF_LONG", "1")
+    rng = np.random.Generator(np.random.PCG64(777 + force_long))
+    for trial in range(6):
+        P = int(rng.integers(200, 1500))
+        U = int(rng.integers(1, 5)) if trial % 2 else int(rng.integers(40, 90))
+        glen = rng.integers(4000, 12000, size=U)
+        maxlen = 250 if force_long else int(rng.choice([300, 600, 2500]))
+        rows = []
+        for s in range(P):
+            for u in range(U):
+                if rng.random() < (0.5 if U < 10 else 0.7):
+                    pos = int(rng.integers(0, glen[u] - maxlen - 1))
+                    for _ in range(int(rng.integers(1, 3))):
+                        ln = int(rng.integers(1, maxlen + 1))
+                        if pos + ln > glen[u]:
+                            break
+                        rows.append((s, u, pos, pos + ln))
+                        pos += ln + int(rng.integers(1, 200))
+        r = np.array(sorted(rows), dtype=np.int64)
+        ranks = rng.integers(0, 3, size=P) if trial % 3 == 0 else None
+        exp = oracle.lazy_greedy(r[:, 0], r[:, 1], r[:, 2], r[:, 3], P, glen,
+                                 None, ranks)
+        dev = engine.Rows.from_host(ctx, r[:, 0], r[:, 1], r[:, 2], r[:, 3], glen)
+        got = dev.greedy(P, ranks, None)
+        rounds = ctx.counters()["greedy_iters"]
+        dev.close()
+        assert got == exp, trial
+        assert rounds < len(exp), (rounds, len(exp))      # rounds, not one pick per iteration
+        if not force_long:
+            assert int((r[:, 3] - r[:, 2]).max()) > 257
+
+
 # ---------------------------------------------------------------- SCF
 def _run_filter(c):
     from catch_amd import genome, probe
@@ -626,8 +666,9 @@ def test_seed_work_list_overflow_retries(ctx, oracle, monkeypatch):
 
 def test_fused_filter_falls_back_when_rows_are_long(ctx, oracle):
     """cover_extension = 100 makes rows 300 bases long: the sync-free fused
-    path notices on the device that they exceed the frontier solver's 5-word
-    rows and the group is redone through the synchronous calls."""
+    path notices on the device that they exceed the 5-word rows of its round
+    kernels and the group is redone through the synchronous calls, which pick
+    the lane-per-word kernels."""
     engine, probe = _engine(), _probe_mod()
     genomes = small_species(seed=61, n=5)
     cand = candidates(genomes, 100, 50)
