@@ -77,6 +77,15 @@ PROTOTYPES = {
     "catchhip_comm_init": (ctypes.c_int, [
         c_vp, c_u8p, ctypes.c_int32, ctypes.c_int32]),
     "catchhip_comm_destroy": (ctypes.c_int, [c_vp]),
+    "catchhip_shard_create": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_i64p, c_vpp]),
+    "catchhip_shard_destroy": (ctypes.c_int, [c_vp]),
+    "catchhip_shard_count": (ctypes.c_int, [c_vp]),
+    "catchhip_shard_claim_check": (ctypes.c_int, [c_vp]),
+    "catchhip_shard_apply": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int32)]),
+    "catchhip_shard_buffers": (ctypes.c_int, [c_vp, c_vpp, c_i64p, c_vpp, c_i64p]),
+    "catchhip_shard_picks": (ctypes.c_int, [c_vp, c_i64p, c_i64p]),
+    "catchhip_shard_allreduce": (ctypes.c_int, [c_vp, ctypes.c_int32]),
+    "catchhip_shard_allreduce_local": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(c_vp), ctypes.c_int32]),
     "catchhip_ndf_hamming": (ctypes.c_int, [
         c_vp, c_u8p, ctypes.c_int64, ctypes.c_int32, c_i32p, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_int32, c_u8p]),

@@ -55,8 +55,10 @@ struct GreedyState {
     unsigned long long n_wrows, n_recount, n_words;  // work counters
 };
 
-#define ID_BITS 24
-#define ID_MASK 0xFFFFFFu
+// packed key = (gain << 32) | (0xFFFFFFFF - set id): gains are < 2^32 (a group's
+// coordinate space is < 2^32 bases), set ids are u32
+#define ID_BITS 32
+#define ID_MASK 0xFFFFFFFFu
 #define GAIN_BLOCK 256  // sets per block of the two-level max structure
 
 #define LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -961,7 +963,7 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     *n_out = 0;
     if (num_sets == 0 || R->n == 0) return 0;  // no universe has anything to cover
     ARG_CHECK(out_ids != nullptr);
-    if (num_sets >= (i64)ID_MASK) { chip_set_error("setcover: more than 2^24-1 sets not supported"); return CATCHHIP_EINVAL; }
+    if (num_sets >= (i64)ID_MASK) { chip_set_error("setcover: more than 2^32-2 sets not supported"); return CATCHHIP_EINVAL; }
     if (R->n >= ((i64)1 << 31)) { chip_set_error("setcover: too many rows"); return CATCHHIP_EINVAL; }
     HIP_TRY(hipSetDevice(ctx->device));
     const u32 nrows = (u32)R->n, nsets = (u32)num_sets, nuniv = (u32)R->ngenomes;
@@ -1158,3 +1160,5 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     *n_out = h_st.npicks;
     return 0;
 }
+
+#include "setcover_sharded.inc"

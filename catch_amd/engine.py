@@ -479,6 +479,64 @@ class Rows:
             pass
 
 
+class Shard:
+    """One rank's part of a universe-sharded set cover instance
+    (catchhip_shard): the frontier solver's state over this rank's cover
+    rows.  Driven round by round by catch_amd.parallel.sharded_solve."""
+
+    def __init__(self, rows, num_sets, ranks=None):
+        self.ctx = rows.ctx
+        self.rows = rows                     # keeps the rows alive
+        self.num_sets = int(num_sets)
+        rk = None if ranks is None else np.ascontiguousarray(ranks, np.int64)
+        self._h = ctypes.c_void_p()
+        check(self.ctx._L.catchhip_shard_create(
+            self.ctx._h, rows._h, self.num_sets,
+            None if rk is None else _ptr(rk, c_i64p), ctypes.byref(self._h)))
+
+    def count(self):
+        check(self.ctx._L.catchhip_shard_count(self._h))
+
+    def claim_check(self):
+        check(self.ctx._L.catchhip_shard_claim_check(self._h))
+
+    def apply(self):
+        """-> 1 finished, -1 ranks exhausted, 0 another round."""
+        done = ctypes.c_int32(0)
+        check(self.ctx._L.catchhip_shard_apply(self._h, ctypes.byref(done)))
+        return done.value
+
+    def allreduce(self, which):
+        """RCCL exchange on the context's communicator (0 gain, 1 lost)."""
+        check(self.ctx._L.catchhip_shard_allreduce(self._h, int(which)))
+
+    def picks(self):
+        out = np.zeros(max(self.num_sets, 1), dtype=np.int64)
+        n = ctypes.c_int64(0)
+        check(self.ctx._L.catchhip_shard_picks(self._h, _ptr(out, c_i64p),
+                                               ctypes.byref(n)))
+        return out[:n.value].tolist()
+
+    def close(self):
+        if self._h:
+            self.ctx._L.catchhip_shard_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shards_allreduce_local(shards, which):
+    """catchhip_shard_allreduce_local: the exchange between shards that live
+    in this process on one device."""
+    arr = (ctypes.c_void_p * len(shards))(*[s._h for s in shards])
+    check(shards[0].ctx._L.catchhip_shard_allreduce_local(len(shards), arr,
+                                                         int(which)))
+
+
 class Signatures:
     """Device-resident MinHash signatures of sequences (catchhip_sigs): the N
     smallest values of (a * md5(kmer) + b) mod (2^31 - 1) per sequence."""

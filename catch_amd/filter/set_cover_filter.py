@@ -440,7 +440,7 @@ class SetCoverFilter(BaseFilter):
 
     def _filter_strs_union(self, input_strs, target_genomes_grouped, todo,
                            selected, timings, max_bases=1 << 30,
-                           max_candidates=1 << 24):
+                           max_candidates=(1 << 24) - 2):
         """Many independent groups (the clusters of a clustered design) as ONE
         instance per chunk: the groups' candidates and genomes share a probes /
         targets pair with group numbers (catchhip_*_set_groups), so the scan

@@ -60,3 +60,57 @@ def merge_picks(picks, keys, ranks=None):
                  key=lambda i: ((ranks[picks[i]] if ranks is not None else 0),
                                 -keys[i]))
     return [picks[i] for i in idx]
+
+
+# ---------------------------------------------------------------------------
+# the round loop of a universe-sharded solve (include/catchhip.h,
+# catchhip_shard_*).  `shard` is anything with count() / claim_check() /
+# apply() / picks(); `exchange(which)` performs the all-reduce of the gain
+# (which = 0, SUM) or lost (which = 1, MAX) buffers of all shards of the
+# instance.  The same loop serves one process per GPU (RCCL), several shards in
+# one process (tests on one GPU) and the CPU stand-ins of the gloo tests.
+# ---------------------------------------------------------------------------
+def sharded_solve(shards, exchange):
+    """Runs the rounds of one instance over the shards THIS process holds
+    (normally one) and returns the picks in the sequential pick order.
+    Raises IndexError-like CatchHipError from picks() when the rank list is
+    exhausted, as the unsharded solver does."""
+    while True:
+        for sh in shards:
+            sh.count()
+        exchange(0)
+        for sh in shards:
+            sh.claim_check()
+        exchange(1)
+        done = [sh.apply() for sh in shards]
+        if any(d != done[0] for d in done):
+            raise RuntimeError("sharded solve: shards disagree on termination")
+        if done[0]:
+            break
+    out = [sh.picks() for sh in shards]
+    if any(o != out[0] for o in out):
+        raise RuntimeError("sharded solve: shards returned different picks")
+    return out[0]
+
+
+def plan_with_sharding(group_costs, world, min_cost=0):
+    """Two-level plan.  A group whose cost exceeds an even share of the total
+    (and min_cost) is SHARDED over all ranks (every rank takes 1/world of it);
+    the others go whole to ranks, longest first, onto the least loaded rank.
+    Returns (sharded: list of group indices, whole: world lists of indices)."""
+    costs = list(group_costs)
+    if world <= 1:
+        return [], [sorted(range(len(costs)), key=lambda i: (-costs[i], i))]
+    share = sum(costs) / float(world)
+    sharded = [i for i in range(len(costs))
+               if costs[i] > share and costs[i] >= min_cost]
+    rest = [i for i in range(len(costs)) if i not in set(sharded)]
+    order = sorted(rest, key=lambda i: (-costs[i], i))
+    base = sum(costs[i] for i in sharded) / float(world)
+    heap = [(base, b) for b in range(world)]
+    bins = [[] for _ in range(world)]
+    for i in order:
+        load, b = heapq.heappop(heap)
+        bins[b].append(i)
+        heapq.heappush(heap, (load + costs[i], b))
+    return sharded, bins

@@ -209,13 +209,56 @@ int catchhip_setcover_filter_many(int32_t n, catchhip_ctx *const *ctxs,
                                   int64_t *const *out_ids, int64_t *n_out,
                                   int64_t *nrows);
 
-/* Multi-GPU form: every rank holds the full rows; rank r evaluates the gains
- * of sets s with s % nranks == r and the per-pick winner is agreed with one
- * RCCL all-reduce(MAX) of a 64-bit key.  Requires catchhip_comm_init. */
+/* Multi-GPU, one process per GPU: an RCCL communicator attached to a context
+ * (the reference has no counterpart: it forks a process pool,
+ * catch/probe.py:727-743, catch/filter/set_cover_filter.py:848-900).  With a
+ * communicator catchhip_setcover_greedy takes the per-pick form: every rank
+ * holds the full rows, rank r evaluates the gains of sets s with s % nranks ==
+ * r and the winner is agreed by one all-reduce(MAX) of a 64-bit key per pick. */
 int catchhip_comm_unique_id(uint8_t *id128);
 int catchhip_comm_init(catchhip_ctx *ctx, const uint8_t *id128, int32_t nranks,
                        int32_t rank);
 int catchhip_comm_destroy(catchhip_ctx *ctx);
+
+/* ONE set cover instance with its UNIVERSES (target genomes) sharded over
+ * ranks -- set_cover.approx_multiuniverse (catch/utils/set_cover.py:147-615)
+ * for a group too large for one GPU's share of the work.  Every rank scans
+ * all candidate probes against its own contiguous range of the group's genomes
+ * (catchhip_cover_scan on a targets object holding just those) and creates a
+ * shard from its rows; num_sets and ranks are the same everywhere.  The
+ * frontier solver then runs in rounds, each of which the caller drives:
+ *     catchhip_shard_count        local gains           (enqueued)
+ *     all-reduce SUM of the gain buffer   (catchhip_shard_allreduce(S, 0), or
+ *                                          _allreduce_local for shards of one process)
+ *     catchhip_shard_claim_check  claims + local losses (enqueued)
+ *     all-reduce MAX of the lost buffer   (which = 1)
+ *     catchhip_shard_apply        accepted sets applied; synchronises; *done =
+ *                                 1 finished, -1 ranks exhausted, 0 next round
+ * and catchhip_shard_picks returns the picks in the sequential pick order --
+ * the same list on every rank, identical to the unsharded solver's.  Every
+ * universe must be fully covered (p == 1) and rows at most 257 bases; other
+ * instances are solved whole on one rank (catch_amd/parallel.py).
+ * catchhip_shard_buffers exposes the two exchange buffers (device pointers:
+ * uint32[gain_count], uint8[lost_count]) for callers with their own transport. */
+typedef struct catchhip_shard catchhip_shard;
+int catchhip_shard_create(catchhip_ctx *ctx, const catchhip_rows *rows,
+                          int64_t num_sets, const int64_t *ranks,
+                          catchhip_shard **out);
+int catchhip_shard_destroy(catchhip_shard *shard);
+int catchhip_shard_count(catchhip_shard *shard);
+int catchhip_shard_claim_check(catchhip_shard *shard);
+int catchhip_shard_apply(catchhip_shard *shard, int32_t *done);
+int catchhip_shard_buffers(catchhip_shard *shard, void **gain,
+                           int64_t *gain_count, void **lost,
+                           int64_t *lost_count);
+int catchhip_shard_picks(catchhip_shard *shard, int64_t *out_ids,
+                         int64_t *n_out);
+/* which: 0 = gain buffer (SUM), 1 = lost buffer (MAX).  _allreduce uses the
+ * context's RCCL communicator (stream-ordered); _allreduce_local reduces the
+ * buffers of n shards that live in this process on one device. */
+int catchhip_shard_allreduce(catchhip_shard *shard, int32_t which);
+int catchhip_shard_allreduce_local(int32_t n, catchhip_shard *const *shards,
+                                   int32_t which);
 
 /* ---- K3: near-duplicate filter (Hamming LSH) --------------------------- */
 /* Replaces NearDuplicateFilter._filter for NearDuplicateFilterWithHamming

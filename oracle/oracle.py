@@ -87,6 +87,10 @@ def lib():
             _i32p, _i32p, _i64p, _i64p, ctypes.c_int64, ctypes.c_int64,
             ctypes.c_int64, _i64p, _f64p, _i64p, _i64p]
         L.orc_lazy_greedy.restype = ctypes.c_int64
+        L.orc_ndf_hamming.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int64, _i32p,
+                                      ctypes.c_int64, ctypes.c_int64,
+                                      ctypes.c_int64, _u8p]
+        L.orc_ndf_hamming.restype = None
         _lib = L
     return _lib
 
@@ -541,6 +545,28 @@ def ndf_hamming(probe_strs, dist_thres, positions):
                 if int(np.count_nonzero(arr[p] != arr[q])) <= dist_thres:
                     exclude.add(q)
     return kept
+
+
+def ndf_hamming_c(probe_strs, dist_thres, positions):
+    """ndf_hamming with the bucket search and the sequential pass in C
+    (orc_ndf_hamming), for inputs of millions of probes.  Same result."""
+    occ = {}
+    for p in probe_strs:
+        occ[p] = occ.get(p, 0) + 1
+    order = [p for p, _ in sorted(occ.items(), key=lambda kv: kv[1],
+                                  reverse=True)]
+    if not order:
+        return []
+    L = len(order[0])
+    if any(len(p) != L for p in order):
+        raise ValueError("Sequences must be of same length")
+    buf = _bytes_arr("".join(order))
+    pos = np.ascontiguousarray(positions, dtype=np.int32)
+    keep = np.zeros(len(order), dtype=np.uint8)
+    lib().orc_ndf_hamming(_p(buf, _u8p), len(order), L, _p(pos, _i32p),
+                          pos.shape[0], pos.shape[1], int(dist_thres),
+                          _p(keep, _u8p))
+    return [p for p, k in zip(order, keep) if k]
 
 
 # --------------------------------------------------------------------------

@@ -59,6 +59,79 @@ def set_cover_groups(name, scale):
     return recs
 
 
+def config3(scale):
+    """configs[2]: S3 with --filter-with-lsh-hamming 2 in front of the set cover
+    (bin/design.py:296-340): candidate windows of all records -> Hamming
+    near-duplicate filter (random.seed(7) draws the sampled positions) ->
+    SetCoverFilter over the one group."""
+    import random
+    groups = synthetic.dataset("S3", scale=scale)
+    genomes = groups[0]
+    t0 = time.perf_counter()
+    seqs = [s for g in genomes for s in g]
+    strs = candidate_probes.candidate_strings_from_sequences(seqs, L, STRIDE)
+    random.seed(7)
+    pos = orc.lsh_draw_positions(orc.lsh_num_tables(2, L, 20), 20, L)
+    kept = orc.ndf_hamming_c(strs, 2, pos)
+    t1 = time.perf_counter()
+    k, entries = orc.anchor_table(kept, MISMATCHES, L)
+    rows = orc.make_sets(kept, entries, k, genomes, MISMATCHES, L, 0, EXT)
+    picks = orc.lazy_greedy(rows[0], rows[1], rows[2], rows[3], len(kept),
+                            [sum(len(s) for s in g) for g in genomes])
+    rec = dict(group=0, genomes=len(genomes), bases=sum(len(s) for s in seqs),
+               n_windows=len(strs), n_candidates=len(kept),
+               kept_sha256=hashlib.sha256("\n".join(kept).encode()).hexdigest(),
+               n_rows=int(rows[0].size), n_picks=len(picks),
+               picks_sha256=digest(picks))
+    sys.stderr.write("S3 x%g: %s (ndf %.0f s, total %.0f s)\n"
+                     % (scale, rec, t1 - t0, time.perf_counter() - t0))
+    return dict(flags="-pl 100 -ps 50 -m 2 -e 50 -c 1.0 --filter-with-lsh-hamming 2 "
+                      "(random.seed(7) before the filter is built); pick ids index "
+                      "the near-duplicate filter's output in its inclusion order",
+                seed="synthetic.dataset default", groups=[rec])
+
+
+def config5(scale):
+    """configs[4]: the design_large chain on S5 x scale, restated with the
+    oracle exactly as tests/test_gpu_parity.py::test_config5_pipeline_... does
+    for its toy input: 50-kb fragments -> MinHash-signature clustering at 0.15
+    -> per cluster candidates, MinHash near-duplicate filter 0.6, set cover
+    with -m 5 -e 50 (random anchors: np.random.seed(22); random.seed(21))."""
+    import random
+    groups = synthetic.dataset("S5", scale=scale)
+    genomes = groups[0]
+    t0 = time.perf_counter()
+    frags = [f for g in genomes for s in g for f in orc.fragments_of(s, 50000)]
+    random.seed(21)
+    np.random.seed(22)
+    clusters = orc.cluster_with_minhash_signatures(frags, threshold=0.15,
+                                                   cluster_method="simple")
+    t1 = time.perf_counter()
+    cl_genomes = [[[frags[i]] for i in c] for c in clusters]
+    kept = []
+    for g in cl_genomes:
+        seqs = [s for gg in g for s in gg]
+        cands = candidate_probes.candidate_strings_from_sequences(seqs, L, STRIDE)
+        params = orc.minhash_draw_params(orc.minhash_num_tables(0.6), 3)
+        kept.append(orc.ndf_minhash(cands, 0.6, params))
+    t2 = time.perf_counter()
+    exp = orc.set_cover_filter(kept, cl_genomes, 5, L, coverage=1.0,
+                               cover_extension=EXT, lazy=True)
+    want = sorted(set(kept[i][j] for i, ids in enumerate(exp) for j in ids))
+    rec = dict(genomes=len(genomes), bases=sum(len(s) for g in genomes for s in g),
+               fragments=len(frags), clusters=len(clusters),
+               n_candidates=sum(len(k) for k in kept), n_probes=len(want),
+               probes_sha256=hashlib.sha256("\n".join(want).encode()).hexdigest())
+    sys.stderr.write("S5 x%g: %s (cluster %.0f s, ndf %.0f s, total %.0f s)\n"
+                     % (scale, rec, t1 - t0, t2 - t1, time.perf_counter() - t0))
+    return dict(flags="design_large defaults (-m 5 -e 50, --cluster-and-design-separately "
+                      "0.15 simple, --cluster-from-fragments 50000, "
+                      "--filter-with-lsh-minhash 0.6); random.seed(21), "
+                      "np.random.seed(22); PYTHONHASHSEED=0; sha256 over the sorted "
+                      "distinct probe strings joined by newlines",
+                seed="synthetic.dataset default", design=rec)
+
+
 def main():
     orc.build()
     orc.set_threads(int(os.environ.get("ORC_THREADS", str(orc.hw_threads()))))
@@ -71,11 +144,16 @@ def main():
         name, _, sc = spec.partition(":")
         scale = float(sc) if sc else 1.0
         key = name if scale == 1.0 else "%s:%g" % (name, scale)
-        out[key] = dict(flags="-pl 100 -ps 50 -m 2 -e 50 -c 1.0, DuplicateFilter "
+        if name == "S3":
+            out[key] = config3(scale)
+        elif name == "S5":
+            out[key] = config5(scale)
+        else:
+            out[key] = dict(flags="-pl 100 -ps 50 -m 2 -e 50 -c 1.0, DuplicateFilter "
                               "then SetCoverFilter per group; pick ids index the "
-                              "group's de-duplicated candidates in first-occurrence "
-                              "order; sha256 over the sorted ids as little-endian int64",
-                        seed="synthetic.dataset default", groups=set_cover_groups(name, scale))
+                                  "group's de-duplicated candidates in first-occurrence "
+                                  "order; sha256 over the sorted ids as little-endian int64",
+                            seed="synthetic.dataset default", groups=set_cover_groups(name, scale))
         with open(OUT, "w") as f:
             json.dump(out, f, indent=1)
 

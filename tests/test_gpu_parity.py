@@ -547,6 +547,80 @@ def test_greedy_rccl_solver_single_rank_matches(oracle):
     c2.close()
 
 
+def _sharded_picks(engine, ctx, probes, genomes, bounds, n_sets, ranks, exchange_of):
+    """Universe-sharded solve: one targets / rows / shard triple per genome
+    range, driven by the product's round loop."""
+    from catch_amd import parallel
+    held, shards = [], []
+    try:
+        for v in range(len(bounds) - 1):
+            t = engine.Targets(ctx, genomes[bounds[v]:bounds[v + 1]])
+            held.append(t)
+            rows = engine.Rows.scan(ctx, probes, t, 2, 100, 0, 50)
+            held.append(rows)
+            shards.append(engine.Shard(rows, n_sets, ranks))
+        return parallel.sharded_solve(shards, exchange_of(shards))
+    finally:
+        for h in shards + held[::-1]:
+            h.close()
+
+
+@pytest.mark.parametrize("with_ranks", [False, True])
+def test_universe_sharded_solver_equals_unsharded(ctx, oracle, with_ranks):
+    """One group cut into 1, 2, 3 and 5 universe ranges (split_universes), each
+    scanned and held by its own shard, solved in rounds with the two
+    all-reduces per round (here: between shards of this process): the picks
+    and their order equal the unsharded solver's and the oracle's."""
+    from catch_amd import parallel
+    engine, probe = _engine(), _probe_mod()
+    rng = np.random.Generator(np.random.PCG64(99))
+    from catch_amd.utils import synthetic
+    genomes = synthetic.make_species(rng, [6000], 23, 3, 0.06, 0.012)
+    cand = candidates(genomes, 100, 50)
+    k, uniq, owner, ep, eo = probe.anchor_table(cand, 2, 100)
+    p = engine.Probes(ctx, uniq, owner, ep, eo, k)
+    t = engine.Targets(ctx, genomes)
+    rows = engine.Rows.scan(ctx, p, t, 2, 100, 0, 50)
+    ranks = rng.integers(0, 3, size=len(cand)) if with_ranks else None
+    want = rows.greedy(len(cand), ranks)
+    sid, un, st, en = rows.fetch()
+    exp = oracle.lazy_greedy(sid, un, st, en, len(cand), [len(g[0]) for g in genomes],
+                             None, ranks)
+    assert want == exp and len(want) > 20
+    rows.close(); t.close()
+    lens = [sum(len(s) for s in g) for g in genomes]
+    for world in (1, 2, 3, 5):
+        bounds = parallel.split_universes(lens, world)
+        assert bounds[0] == 0 and bounds[-1] == len(genomes) and len(bounds) == world + 1
+        got = _sharded_picks(engine, ctx, p, genomes, bounds, len(cand), ranks,
+                             lambda sh: (lambda w: engine.shards_allreduce_local(sh, w)))
+        assert got == want, world
+    # a rank without genomes (more ranks than genomes can feed) still takes part
+    got = _sharded_picks(engine, ctx, p, genomes, [0, 0, 10, 23, 23], len(cand), ranks,
+                         lambda sh: (lambda w: engine.shards_allreduce_local(sh, w)))
+    assert got == want
+    p.close()
+
+
+def test_universe_sharded_solver_over_rccl_single_rank(oracle):
+    """The same round loop with the exchanges going through RCCL
+    (catchhip_shard_allreduce) on a one-rank communicator."""
+    engine, probe = _engine(), _probe_mod()
+    c2 = engine.Context(0)
+    c2.comm_init(engine.Context.comm_unique_id(), 1, 0)
+    genomes = small_species(seed=17, n=9, length=4000)
+    cand = candidates(genomes, 100, 50)
+    k, uniq, owner, ep, eo = probe.anchor_table(cand, 2, 100)
+    p = engine.Probes(c2, uniq, owner, ep, eo, k)
+    sel = oracle.set_cover_filter([cand], [genomes], 2, 100, coverage=1.0,
+                                  cover_extension=50, return_intermediate=True)[1][0]["picks"]
+    got = _sharded_picks(engine, c2, p, genomes, [0, len(genomes)], len(cand), None,
+                         lambda sh: (lambda w: [s.allreduce(w) for s in sh]))
+    assert got == sel
+    p.close()
+    c2.close()
+
+
 # ---------------------------------------------------------------- other configs
 @pytest.mark.parametrize("name,scale", [("S3", 0.02), ("S4", 0.01)])
 def test_scaled_baseline_configs_match_oracle(ctx, oracle, name, scale):

@@ -318,3 +318,32 @@ def test_lazy_greedy_and_threaded_scan_on_a_pipeline(oracle):
         oracle.set_threads(1)
     assert rows_as_tuples(*a[0]["rows"]) == rows_as_tuples(*b[0]["rows"])
     assert a[0]["picks"] == b[0]["picks"] and len(a[0]["picks"]) > 5
+
+
+def test_ndf_hamming_c_equals_python(oracle):
+    """orc_ndf_hamming (C, for million-probe inputs) == oracle.ndf_hamming
+    (pinned to the reference's vectors above) on the recorded cases and on
+    near-duplicate-rich synthetic candidates."""
+    import random
+    from tests.util import candidates, small_species
+    n = 0
+    g = load_golden("ndf_hamming")
+    for c in g["from_reference_tests"] + g["synthetic"]:
+        kept = oracle.ndf_hamming_c(c["probes"], c["dist_thres"], c["positions"])
+        assert kept == oracle.ndf_hamming(c["probes"], c["dist_thres"], c["positions"])
+        assert sorted(kept) == c["out"]      # the reference's own answer
+        n += 1
+    for seed in (3, 4, 5):
+        genomes = small_species(seed=seed, n=25, length=1500, d1=0.03, d2=0.01)
+        strs = candidates(genomes, 100, 50, dedup=False)
+        random.seed(seed)
+        pos = oracle.lsh_draw_positions(oracle.lsh_num_tables(2, 100, 20), 20, 100)
+        a = oracle.ndf_hamming(strs, 2, pos)
+        oracle.set_threads(3)
+        try:
+            b = oracle.ndf_hamming_c(strs, 2, pos)
+        finally:
+            oracle.set_threads(1)
+        assert a == b and len(a) < len(set(strs))
+        n += 1
+    assert n >= 8
