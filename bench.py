@@ -21,8 +21,12 @@ independent instances: the large ones run one after the other, largest first
 time on their own HIP streams.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): ONE dataset,
-strong scaling -- see shard_plan() in catch_amd/parallel.py: whole groups go
-to ranks longest-first with no data-path collective.
+strong scaling (catch_amd/parallel.py): a group above an even share of the
+work is sharded over all ranks by universes -- every rank scans all candidates
+against its range of genomes and the frontier solver exchanges one SUM
+all-reduce of the per-candidate gains and one MAX all-reduce of the lost flags
+per round over RCCL; the other groups go whole to ranks, longest first, with
+no data-path collective.  The picks must equal the committed digests whatever N.
 
 Prints one JSON line on rank 0 (fields: README / DESIGN.md section 6).
 """
@@ -63,6 +67,60 @@ class ResidentGroup:
         self.n_sets = self.cands.n
         self.G = self.targets.total
         self.n_genomes = len(genomes)
+
+    def close(self):
+        self.probes.close()
+        self.cands.close()
+        self.targets.close()
+
+
+class ShardedGroup:
+    """One group sharded over all ranks by universes: every rank holds the
+    group's candidates (they come from all of its genomes) and the bit planes
+    of its own contiguous range of genomes; a step = local scan + row build +
+    the frontier rounds with two RCCL all-reduces each."""
+
+    def __init__(self, W, index, genomes):
+        self.W, self.index = W, index
+        ctx = self.ctx = W.comm_ctx
+        full = engine.Targets(ctx, genomes)
+        self.cands = engine.Candidates(ctx, full, PROBE_LEN, STRIDE)   # keeps `full` alive
+        k, ep, eo = probe.anchor_entries_equal_length(
+            self.cands.n, PROBE_LEN, MISMATCHES, PROBE_LEN)
+        self.probes = self.cands.probes(k, ep, eo)
+        self.n_sets = self.cands.n
+        b = parallel.split_universes([sum(len(s) for s in g) for g in genomes], W.size)
+        self.range = (b[W.rank], b[W.rank + 1])
+        self.targets = engine.Targets(ctx, genomes[b[W.rank]:b[W.rank + 1]])
+        self.G_local = self.targets.total
+        self.solve_ms = 0.0
+
+    def step(self, stats=None):
+        t0 = time.perf_counter()
+        rows = engine.Rows.scan(self.ctx, self.probes, self.targets, MISMATCHES,
+                                PROBE_LEN, 0, EXT, SCAN_MODE)
+        t1 = time.perf_counter()
+        shard = engine.Shard(rows, self.n_sets)
+        try:
+            ids = parallel.sharded_solve([shard], self.W.exchange_for([shard]))
+        finally:
+            shard.close()
+            nrows = rows.n
+            rows.close()
+        if stats is not None:
+            c = self.ctx
+            st = dict(rows=nrows, picks=len(ids) if self.W.rank == 0 else 0,
+                      sharded_scan_wall_ms=(t1 - t0) * 1e3,
+                      sharded_solve_wall_ms=(time.perf_counter() - t1) * 1e3)
+            for name, ph in (("scan_ms", engine.PHASE_SCAN), ("verify_ms", engine.PHASE_VERIFY),
+                             ("rows_ms", engine.PHASE_ROWS)):
+                ms, nl = c.kernel_ms(ph)
+                st[name] = ms
+                st[name.replace("_ms", "_launches")] = nl
+            cn = c.counters()
+            st.update(raw_hits=cn["raw_hits"], seed_hits=cn["seed_hits"], greedy_iters=cn["greedy_iters"])
+            stats.append(st)
+        return ids
 
     def close(self):
         self.probes.close()
@@ -252,43 +310,34 @@ def main():
                     help="groups running at once per GPU, each on its own stream")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist   # plumbing only: rendezvous/barrier
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # gloo announces its connections on stdout; rank 0 must print ONE line
-        import ctypes
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            dist.barrier()
-            ctypes.CDLL(None).fflush(None)
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
-
-    ndev = max(1, engine.device_count())
-    device = local_rank % ndev
-    os.environ["CATCHHIP_DEVICE"] = str(device)   # engine.default_context()
+    W = parallel.init_from_env()          # gloo plumbing + RCCL communicator when WORLD_SIZE > 1
+    rank, world, dist = W.rank, W.size, W.dist
+    device = engine.default_context().device
 
     t_gen = time.perf_counter()
     groups = synthetic.dataset(args.workload, scale=args.scale)
     gen_s = time.perf_counter() - t_gen
     bases = [sum(len(s) for g in grp for s in g) for grp in groups]
-    plan = parallel.shard_plan(bases, world)          # whole groups, longest first
+    # groups above an even share of the work are sharded over all ranks by
+    # universes (RCCL exchanges per solver round), the others go whole to ranks
+    sharded_idx, plan = parallel.plan_with_sharding(
+        bases, world, min_cost=int(os.environ.get("CATCHHIP_SHARD_MIN_BASES", "30000000")))
     mine = plan[rank]
 
     t_up0 = time.perf_counter()
     stepper = Stepper(device, groups, mine, args.groups_in_flight)
+    sharded = [ShardedGroup(W, i, groups[i]) for i in sharded_idx]
     stepper.sync()
     upload_s = time.perf_counter() - t_up0
-    units = sum(g.n_sets * g.G for g in stepper.resident)
-    n_cands = sum(g.n_sets for g in stepper.resident)
+    units = sum(g.n_sets * g.G for g in stepper.resident) + sum(g.n_sets * g.G_local for g in sharded)
+    n_cands = sum(g.n_sets for g in stepper.resident) + (sum(g.n_sets for g in sharded) if rank == 0 else 0)
+
+    def run_step(stats=None):
+        out = {}
+        for g in sharded:                 # all ranks together, in the same order
+            out[g.index] = g.step(stats)
+        out.update(stepper.step(stats))
+        return out
 
     def barrier():
         stepper.sync()
@@ -296,7 +345,7 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        stepper.step()
+        run_step()
     stats = []
     barrier()
     pool0 = engine.pool_stats()
@@ -305,7 +354,7 @@ def main():
     step_s = []
     for _ in range(args.steps):
         ts = time.perf_counter()
-        picks = stepper.step(stats)
+        picks = run_step(stats)
         step_s.append(time.perf_counter() - ts)
     stepper.sync()
     elapsed = time.perf_counter() - t0
@@ -317,6 +366,8 @@ def main():
     gold_ok, gold_n = True, 0
     if gold is not None:
         for gi, ids in picks.items():
+            if gi in sharded_idx and rank != 0:
+                continue                  # identical on every rank: counted once
             if gi in gold:
                 gold_n += 1
                 gold_ok = gold_ok and (len(ids) == gold[gi]["n_picks"] and
@@ -410,7 +461,10 @@ def main():
                                       "" if args.scale == 1.0 else " scaled x%g" % args.scale,
                                       sum(len(g) for g in groups), len(groups),
                                       sum(bases), P_all),
-                       "shard": "whole groups to ranks, longest first (no collective)",
+                       "shard": "groups above an even share of the bases are sharded over all ranks by "
+                                "universes (2 RCCL all-reduces per solver round), the others go whole to "
+                                "ranks, longest first (no collective)",
+                       "sharded_groups": list(sharded_idx),
                        "groups_on_rank0": [g.index for g in stepper.resident],
                        "groups_in_flight": stepper.width, "scale": args.scale},
             "setcoverfilter_ms": elapsed / K * 1e3,
@@ -474,6 +528,8 @@ def main():
             out["speedup_vs_cpu_oracle"] = out["value"] / base["value"]
             out["speedup_vs_cpu_oracle_incl_h2d"] = out["value_incl_h2d"] / base["value"]
         print(json.dumps(out))
+    for g in sharded:
+        g.close()
     stepper.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "catchhip_shard_buffers": (ctypes.c_int, [c_vp, c_vpp, c_i64p, c_vpp, c_i64p]),
     "catchhip_shard_picks": (ctypes.c_int, [c_vp, c_i64p, c_i64p]),
     "catchhip_shard_allreduce": (ctypes.c_int, [c_vp, ctypes.c_int32]),
+    "catchhip_shard_buffer_copy": (ctypes.c_int, [c_vp, ctypes.c_int32, c_vp, ctypes.c_int32]),
     "catchhip_shard_allreduce_local": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(c_vp), ctypes.c_int32]),
     "catchhip_ndf_hamming": (ctypes.c_int, [
         c_vp, c_u8p, ctypes.c_int64, ctypes.c_int32, c_i32p, ctypes.c_int32,

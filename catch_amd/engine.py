@@ -510,6 +510,20 @@ class Shard:
         """RCCL exchange on the context's communicator (0 gain, 1 lost)."""
         check(self.ctx._L.catchhip_shard_allreduce(self._h, int(which)))
 
+    def buffer_to_host(self, which):
+        """The gain (uint32[num_sets + 2]) or lost (uint8[num_sets]) buffer."""
+        out = (np.zeros(self.num_sets + 2, dtype=np.uint32) if which == 0
+               else np.zeros(self.num_sets, dtype=np.uint8))
+        check(self.ctx._L.catchhip_shard_buffer_copy(
+            self._h, int(which), out.ctypes.data_as(ctypes.c_void_p), 1))
+        return out
+
+    def buffer_from_host(self, which, arr):
+        a = np.ascontiguousarray(arr, dtype=np.uint32 if which == 0 else np.uint8)
+        assert a.size == (self.num_sets + 2 if which == 0 else self.num_sets)
+        check(self.ctx._L.catchhip_shard_buffer_copy(
+            self._h, int(which), a.ctypes.data_as(ctypes.c_void_p), 0))
+
     def picks(self):
         out = np.zeros(max(self.num_sets, 1), dtype=np.int64)
         n = ctypes.c_int64(0)

@@ -114,3 +114,107 @@ def plan_with_sharding(group_costs, world, min_cost=0):
         bins[b].append(i)
         heapq.heappush(heap, (load + costs[i], b))
     return sharded, bins
+
+
+# ---------------------------------------------------------------------------
+# run time: one process per GPU (torch.distributed.run / torchrun).  torch is
+# plumbing only -- rendezvous, barriers and small host objects over gloo; the
+# data path's exchanges are RCCL all-reduces on device buffers
+# (catchhip_shard_allreduce) over a communicator attached to a context of its
+# own (a context with a communicator switches catchhip_setcover_greedy to the
+# per-pick sharded form, which the whole-group solves must not take).
+# ---------------------------------------------------------------------------
+class World:
+    def __init__(self, rank=0, size=1, dist=None, comm_ctx=None, rccl=False):
+        self.rank, self.size, self.dist, self.comm_ctx = rank, size, dist, comm_ctx
+        self.rccl = rccl
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def allgather(self, obj):
+        """Every rank's host object, in rank order (gloo)."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.size
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def exchange_for(self, shards):
+        """The exchange callable sharded_solve wants: RCCL on the device buffers,
+        or -- CATCHHIP_EXCHANGE=gloo, for boxes where RCCL cannot span the ranks
+        (e.g. several ranks on ONE GPU) -- through the host over gloo."""
+        if self.rccl:
+            def exchange(which):
+                for sh in shards:
+                    sh.allreduce(which)
+            return exchange
+        return lambda which: host_exchange(self.dist, shards, which)
+
+
+_world = World()
+
+
+def world():
+    """The process's World (single process unless init_from_env ran)."""
+    return _world
+
+
+def init_from_env():
+    """Under torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*):
+    gloo process group for the plumbing and an RCCL communicator on a dedicated
+    context of this rank's GPU.  Idempotent; a no-op for WORLD_SIZE <= 1."""
+    global _world
+    import os
+    import sys
+    size = int(os.environ.get("WORLD_SIZE", "1"))
+    if size <= 1 or _world.size > 1:
+        return _world
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import ctypes
+    import torch.distributed as dist
+    from catch_amd import engine
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # gloo and RCCL announce themselves on stdout; callers print machine-readable lines
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", rank=rank, world_size=size)
+        dist.barrier()
+        ctypes.CDLL(None).fflush(None)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+    ndev = max(1, engine.device_count())
+    device = local_rank % ndev
+    os.environ.setdefault("CATCHHIP_DEVICE", str(device))   # engine.default_context()
+    ids = [engine.Context.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    comm_ctx = engine.Context(device)
+    rccl = os.environ.get("CATCHHIP_EXCHANGE", "rccl") != "gloo"
+    if rccl:
+        comm_ctx.comm_init(ids[0], size, rank)
+    _world = World(rank, size, dist, comm_ctx, rccl)
+    return _world
+
+
+def host_exchange(dist, shards, which):
+    """All-reduce of the shards' gain (SUM) or lost (MAX) buffers through host
+    memory: over the shards of this process first, then over the process group
+    (None: single process).  Fallback transport and the one the CPU tests use."""
+    import numpy as np
+    bufs = [sh.buffer_to_host(which) for sh in shards]
+    acc = bufs[0].astype(np.int64)
+    for b in bufs[1:]:
+        acc = acc + b if which == 0 else np.maximum(acc, b)
+    if dist is not None:
+        import torch
+        t = torch.from_numpy(acc)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if which == 0 else dist.ReduceOp.MAX)
+        acc = t.numpy()
+    for sh in shards:
+        sh.buffer_from_host(which, acc)

@@ -257,6 +257,10 @@ int catchhip_shard_picks(catchhip_shard *shard, int64_t *out_ids,
  * context's RCCL communicator (stream-ordered); _allreduce_local reduces the
  * buffers of n shards that live in this process on one device. */
 int catchhip_shard_allreduce(catchhip_shard *shard, int32_t which);
+/* Exchange buffer `which` to (to_host != 0) or from a host array of the
+ * buffer's size (synchronous): for a transport of the caller's own. */
+int catchhip_shard_buffer_copy(catchhip_shard *shard, int32_t which, void *host,
+                               int32_t to_host);
 int catchhip_shard_allreduce_local(int32_t n, catchhip_shard *const *shards,
                                    int32_t which);
 
