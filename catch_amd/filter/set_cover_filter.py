@@ -206,22 +206,47 @@ class SetCoverFilter(BaseFilter):
         return [[pp[i] for i in sel] for pp, sel in zip(input, ids)]
 
     def _filter_strs(self, input_strs, target_genomes_grouped,
-                     assume_unique=False):
+                     assume_unique=False, only=None, tables=None):
         """The filter on plain probe strings: per group the indices of the
         selected candidates, in pick order.  Groups are independent instances:
         up to CATCHHIP_GROUPS_IN_FLIGHT (default 4) of them run at once, each
         on its own context / HIP stream (catchhip_setcover_filter_many).
         assume_unique: the strings of a group are pairwise distinct (they come
-        out of the duplicate filter)."""
+        out of the duplicate filter).  only: restrict the work to these group
+        indices (the others come back empty; multi-rank runs).  With more than
+        one rank (catch_amd.parallel.init_from_env) the groups are spread over
+        the ranks and every rank returns the complete selection."""
         import os
+        from catch_amd import parallel
+        if only is None and parallel.world().size > 1:
+            return self._filter_strs_multirank(input_strs, target_genomes_grouped,
+                                               assume_unique, parallel.world())
         selected = [[] for _ in input_strs]
         timings = dict(scan_ms=0.0, rows_ms=0.0, greedy_ms=0.0, picks=0,
                        rows=0, scan_launches=0, greedy_launches=0)
-        todo = [i for i, pp in enumerate(input_strs) if len(pp) > 0]
+        nonempty = [i for i, pp in enumerate(input_strs) if len(pp) > 0]
+        todo = [i for i in nonempty if only is None or i in only]
+        # Random anchors (catch/probe.py:391-401) consume np.random once per
+        # probe, group after group in INPUT order: when groups are reordered or
+        # left to other ranks the tables of all groups are drawn up front, in
+        # that order, so that every rank and every schedule selects what the
+        # reference selects.
+        # (single rank: input order is kept whenever the anchors are random)
+        random_anchors = any(probe.anchors_use_random(
+            input_strs[i], self.mismatches, self.lcf_thres, self.kmer_probe_map_k)
+            for i in nonempty)
+        if only is not None and tables is None and random_anchors:
+            tables = self._anchor_tables_in_input_order(input_strs, nonempty,
+                                                        assume_unique)
+        # largest first, as the reference hands its instances to the pool
+        # (catch/filter/set_cover_filter.py:880-887)
+        if not random_anchors or tables is not None:
+            todo.sort(key=lambda i: (-len(input_strs[i]), i))
         width = max(1, int(os.environ.get("CATCHHIP_GROUPS_IN_FLIGHT", "4")))
         # many SMALL groups go through one instance; large groups (thousands of
         # candidates each) overlap better as separate instances in flight
-        if (assume_unique and not self.identify and not self.avoided_genomes
+        if (only is None and tables is None
+                and assume_unique and not self.identify and not self.avoided_genomes
                 and len(todo) >= int(os.environ.get("CATCHHIP_UNION_MIN_GROUPS", "8"))
                 and sum(len(input_strs[gi]) for gi in todo) <= len(todo) * int(
                     os.environ.get("CATCHHIP_UNION_MAX_MEAN_CANDIDATES", "8192"))
@@ -239,10 +264,12 @@ class SetCoverFilter(BaseFilter):
                         input_strs[gi], target_genomes_grouped[gi]
                     logger.info("Building set cover sets input (group %d of %d)",
                                 gi + 1, len(input_strs))
-                    k, uniq, owner, ep, eo = probe.anchor_table(
-                        strs, self.mismatches, self.lcf_thres,
-                        min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k,
-                        assume_unique=assume_unique)
+                    k, uniq, owner, ep, eo = (
+                        tables.pop(gi) if tables is not None else
+                        probe.anchor_table(
+                            strs, self.mismatches, self.lcf_thres,
+                            min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k,
+                            assume_unique=assume_unique))
                     targets = engine.Targets(ctx, [g.seqs for g in target_genomes])
                     held.append(targets)
                     probes = engine.Probes(ctx, uniq, owner, ep, eo, k)
@@ -284,6 +311,100 @@ class SetCoverFilter(BaseFilter):
         self.last_timings = timings
         return selected
 
+
+    def _anchor_tables_in_input_order(self, input_strs, nonempty, assume_unique):
+        """{group: anchor table} for all non-empty groups, drawn in input order,
+        when the anchors are random; None when they are the pigeonhole anchors
+        (no random numbers: tables are then built where they are used)."""
+        if not any(probe.anchors_use_random(input_strs[i], self.mismatches,
+                                            self.lcf_thres, self.kmer_probe_map_k)
+                   for i in nonempty):
+            return None
+        return {i: probe.anchor_table(input_strs[i], self.mismatches, self.lcf_thres,
+                                      min_k=self.kmer_probe_map_k,
+                                      k=self.kmer_probe_map_k,
+                                      assume_unique=assume_unique)
+                for i in nonempty}
+
+    def _filter_strs_multirank(self, input_strs, target_genomes_grouped,
+                               assume_unique, W):
+        """The filter over W.size ranks (one process per GPU).  Level 1: whole
+        groups go to ranks longest first (the reference's pool order,
+        catch/filter/set_cover_filter.py:880-887), no collective.  Level 2: a
+        group above an even share of the bases is sharded over ALL ranks by
+        universes: every rank scans the group's candidates against its own
+        range of genomes and the frontier solver's rounds exchange the
+        per-candidate gains (RCCL all-reduce, catch_amd/parallel.py).  Sharding
+        needs full coverage and no ranks (identify / avoided genomes); such
+        groups stay whole.  Every rank returns every group's selection."""
+        import os
+        from catch_amd import parallel
+        n = len(input_strs)
+        costs = [sum(g.size() for g in target_genomes_grouped[i]) if len(input_strs[i]) else 0
+                 for i in range(n)]
+        eligible = (not self.identify and not self.avoided_genomes
+                    and self.coverage == 1.0)
+        sharded, whole = parallel.plan_with_sharding(
+            costs, W.size,
+            min_cost=int(os.environ.get("CATCHHIP_SHARD_MIN_BASES", "30000000"))
+            if eligible else float("inf"))
+        selected = [[] for _ in range(n)]
+        timings = dict(scan_ms=0.0, rows_ms=0.0, greedy_ms=0.0, picks=0, rows=0,
+                       scan_launches=0, greedy_launches=0, sharded_groups=list(sharded))
+        ctx = W.comm_ctx
+        fallback = []
+        nonempty = [i for i in range(n) if len(input_strs[i]) > 0]
+        tables = self._anchor_tables_in_input_order(input_strs, nonempty, assume_unique)
+        for gi in sharded:                       # all ranks together, same order
+            strs, genomes = input_strs[gi], target_genomes_grouped[gi]
+            logger.info("Set cover of group %d of %d sharded over %d ranks",
+                        gi + 1, n, W.size)
+            k, uniq, owner, ep, eo = (
+                tables[gi] if tables is not None else
+                probe.anchor_table(
+                    strs, self.mismatches, self.lcf_thres,
+                    min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k,
+                    assume_unique=assume_unique))
+            b = parallel.split_universes([g.size() for g in genomes], W.size)
+            targets = engine.Targets(ctx, [g.seqs for g in genomes[b[W.rank]:b[W.rank + 1]]])
+            probes = engine.Probes(ctx, uniq, owner, ep, eo, k)
+            rows = shard = None
+            try:
+                rows = engine.Rows.scan(ctx, probes, targets, self.mismatches,
+                                        self.lcf_thres, self.island_of_exact_match,
+                                        self.cover_extension, self.scan_mode)
+                try:
+                    shard = engine.Shard(rows, len(strs))
+                except Exception:                 # rows too long for the sharded kernels
+                    shard = None
+                # every rank must take the same path
+                if all(W.allgather(shard is not None)):
+                    selected[gi] = parallel.sharded_solve([shard], W.exchange_for([shard]))
+                    timings["rows"] += rows.n
+                    timings["picks"] += len(selected[gi])
+                else:
+                    fallback.append(gi)
+            finally:
+                for h in (shard, rows, probes, targets):
+                    if h is not None:
+                        h.close()
+        # groups that could not be sharded after all go whole to the least loaded rank
+        loads = [sum(costs[i] for i in w) for w in whole]
+        for gi in fallback:
+            r = min(range(W.size), key=lambda q: (loads[q], q))
+            whole[r].append(gi)
+            loads[r] += costs[gi]
+        mine = self._filter_strs(input_strs, target_genomes_grouped, assume_unique,
+                                 only=set(whole[W.rank]), tables=tables)
+        for k_, v in self.last_timings.items():
+            if isinstance(v, (int, float)):
+                timings[k_] = timings.get(k_, 0) + v
+        parts = W.allgather({gi: mine[gi] for gi in whole[W.rank]})
+        for part in parts:
+            for gi, ids in part.items():
+                selected[gi] = ids
+        self.last_timings = timings
+        return selected
 
     def _filter_genomes_device(self, target_genomes_grouped, probe_length,
                                probe_stride, seq_length_to_skip=None,

@@ -103,7 +103,7 @@ def plan_with_sharding(group_costs, world, min_cost=0):
         return [], [sorted(range(len(costs)), key=lambda i: (-costs[i], i))]
     share = sum(costs) / float(world)
     sharded = [i for i in range(len(costs))
-               if costs[i] > share and costs[i] >= min_cost]
+               if costs[i] > share and costs[i] >= min_cost and costs[i] > 0]
     rest = [i for i in range(len(costs)) if i not in set(sharded)]
     order = sorted(rest, key=lambda i: (-costs[i], i))
     base = sum(costs[i] for i in sharded) / float(world)

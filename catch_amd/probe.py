@@ -193,6 +193,20 @@ def anchor_table(probe_strs, mismatches, lcf_thres, min_k=20, k=20,
     return kk, uniq, owner, ent_probe, ent_pos
 
 
+def anchors_use_random(probe_strs, mismatches, lcf_thres, min_k=20):
+    """Whether anchor_table would draw from np.random for these probes (the
+    rule of catch/probe.py:507-577): callers that skip or reorder groups must
+    then still build the tables in input order, or the stream -- and with it
+    the selected probes -- would differ from the reference's."""
+    if not probe_strs:
+        return False
+    L = len(probe_strs[0])
+    if (mismatches is None or lcf_thres is None or lcf_thres < L
+            or len(set(map(len, probe_strs))) > 1):
+        return True
+    return pigeonhole_kmer_length(L, mismatches) < min_k
+
+
 def _entries_from_draws(pi, pos):
     """Sorted unique (probe, position) anchors from the drawn positions
     pos[probe_row][j]; pi[probe_row] = unique-probe index of each row."""

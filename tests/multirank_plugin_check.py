@@ -1,0 +1,50 @@
+"""Run under torch.distributed.run by tests/test_gpu_parity.py: the SetCoverFilter
+plugin over several ranks (whole groups by LPT + one group sharded by
+universes) must select, on EVERY rank, exactly what the oracle selects --
+with the pigeonhole anchors and with random anchors (np.random stream)."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+
+from catch_amd import genome, parallel, probe  # noqa: E402
+from catch_amd.filter.set_cover_filter import SetCoverFilter  # noqa: E402
+from catch_amd.utils import synthetic  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from util import candidates  # noqa: E402
+
+
+def main():
+    W = parallel.init_from_env()
+    assert W.size > 1
+    orc.build()
+    rng = np.random.Generator(np.random.PCG64(5))
+    groups = [synthetic.make_species(rng, [2600], 4, 2, 0.05, 0.01),
+              synthetic.make_species(rng, [5200], 14, 3, 0.06, 0.012),     # the big one: sharded
+              synthetic.make_species(rng, [1800], 3, 1, 0.0, 0.02),
+              synthetic.make_species(rng, [2100], 5, 2, 0.04, 0.01)]
+    cands = [candidates(g, 100, 50) for g in groups]
+    gen = [[genome.Genome.from_one_seq(g[0]) for g in grp] for grp in groups]
+    ok = True
+    for m in (2, 5):
+        np.random.seed(31)
+        exp = orc.set_cover_filter(cands, groups, m, 100, coverage=1.0, cover_extension=50)
+        np.random.seed(31)
+        f = SetCoverFilter(mismatches=m, lcf_thres=100, coverage=1.0, cover_extension=50)
+        out = f.filter([[probe.Probe.from_str(s) for s in c] for c in cands], gen,
+                       input_is_grouped=True)
+        got = [sorted(p.seq_str for p in g) for g in out]
+        want = [sorted(c[i] for i in ids) for c, ids in zip(cands, exp)]
+        ok = ok and got == want and f.last_timings.get("sharded_groups") == [1]
+    res = W.allgather(ok)
+    if W.rank == 0:
+        print("MULTIRANK_PLUGIN_OK" if all(res) else "MULTIRANK_PLUGIN_MISMATCH %s" % res)
+    W.dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,9 @@
 """Parity of the HIP path (through the C ABI of libcatchhip.so) with the CPU
 oracle and with golden vectors recorded from the live reference.
 Bit-exact: everything here is integer/index work."""
+import os
 import random
+import sys
 
 import numpy as np
 import pytest
@@ -300,7 +302,6 @@ def test_greedy_batched_rounds_restore_sequential_order(ctx, oracle):
     """Larger full-coverage instances (many locally maximal sets per round,
     with and without ranks): the frontier solver must return the oracle's
     sequential pick order, and so must the one-pick-per-iteration solver."""
-    import os
     engine = _engine()
     rng = np.random.Generator(np.random.PCG64(321))
     for trial in range(6):
@@ -619,6 +620,28 @@ def test_universe_sharded_solver_over_rccl_single_rank(oracle):
     assert got == sel
     p.close()
     c2.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_plugin_over_several_ranks_selects_what_one_rank_selects(nranks):
+    """torch.distributed.run with 2 and 3 ranks (all on this box's one GPU, so
+    the exchanges go through gloo instead of RCCL): SetCoverFilter with one
+    group sharded by universes and the others spread whole, pigeonhole and
+    random anchors -- every rank returns the oracle's selection."""
+    import subprocess
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, CATCHHIP_EXCHANGE="gloo", CATCHHIP_SHARD_MIN_BASES="1",
+               MASTER_ADDR="127.0.0.1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(here, "multirank_plugin_check.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert "MULTIRANK_PLUGIN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 # ---------------------------------------------------------------- other configs

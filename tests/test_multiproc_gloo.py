@@ -1,10 +1,15 @@
-"""world_size-2 test of the multi-rank host logic on CPU (gloo).
+"""world_size-2 tests of the multi-rank host logic on CPU (gloo).
 
-The data path of the N>1 bench shards whole groups across ranks with no
-collective; what the ranks exchange is the timing/units reduction.  The probe-
-sharded variant's arithmetic (packed (gain, ~id) keys, MAX all-reduce, sets
-s % nranks == rank) is checked here with the oracle's gains standing in for
-the gain kernel (tests may use the oracle; the product never does)."""
+What runs here is the PRODUCT's multi-GPU host code (catch_amd/parallel.py):
+`plan_with_sharding` / `split_universes` (who gets what), `sharded_solve` (the
+round loop every rank drives) and `host_exchange` (the all-reduce of the
+per-set gain and lost buffers, here over a real gloo process group).  Only the
+device is missing, so the shard object behind the loop is a NumPy stand-in with
+the interface of engine.Shard (count / claim_check / apply / picks /
+buffer_to_host / buffer_from_host); its per-rank arithmetic restates what the
+gs_* kernels do on their local rows (test infrastructure, like the oracle).
+The result must equal the oracle's sequential greedy, on every rank.
+"""
 import os
 import socket
 import sys
@@ -15,7 +20,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ID_BITS, ID_MASK = 24, 0xFFFFFF
+ID_BITS, ID_MASK = 32, 0xFFFFFFFF
 
 
 def _free_port():
@@ -26,39 +31,121 @@ def _free_port():
     return p
 
 
-def _greedy_sharded(rank, world, rows, P, U, glen):
-    """Probe-sharded greedy with a MAX all-reduce of the packed key per pick."""
-    import torch
-    base = np.concatenate([[0], np.cumsum(glen)])
-    cov = np.zeros(int(base[-1]), dtype=bool)
-    for s, u, a, b in rows:
-        cov[base[u] + a:base[u] + b] = True
-    left = np.array([cov[base[u]:base[u + 1]].sum() for u in range(U)])
-    picked, picks = set(), []
-    while (left > 0).any():
-        best = 0
-        for s in range(rank, P, world):
-            if s in picked:
+class NumpyShard:
+    """One rank's universes of an instance, on the CPU.  rows: (set, universe,
+    start, end) in this rank's local universe numbering; ulen: their lengths.
+    Ownership is per 64-base word, as on the device."""
+
+    def __init__(self, rows, num_sets, ulen, ranks=None):
+        self.num_sets = num_sets
+        off = np.concatenate([[0], np.cumsum(ulen)]).astype(np.int64)
+        self.rows = [(int(s), int(off[u] + a), int(off[u] + b), int(u)) for s, u, a, b in rows]
+        self.cov = np.zeros(int(off[-1]) + 64, dtype=bool)
+        for _, a, b, _ in self.rows:
+            self.cov[a:b] = True
+        self.usize = np.array([int(self.cov[off[u]:off[u + 1]].sum()) for u in range(len(ulen))],
+                              dtype=np.int64)
+        self.uoff = off
+        self.rank = np.zeros(num_sets, dtype=np.int64) if ranks is None else np.asarray(ranks)
+        self.rank_vals = sorted(set(int(x) for x in self.rank))
+        self.cur = 0
+        self.picked = np.zeros(num_sets, dtype=bool)
+        self.gain = np.zeros(num_sets, dtype=np.int64)
+        self.gainbuf = np.zeros(num_sets + 2, dtype=np.uint32)
+        self.lostbuf = np.zeros(num_sets, dtype=np.uint8)
+        self.accepted = []          # (set, key)
+        self.done = 0
+
+    # -- the engine.Shard interface ------------------------------------
+    def count(self):
+        self.gainbuf[:] = 0
+        self.lostbuf[:] = 0
+        if self.done:
+            return
+        for s, a, b, _ in self.rows:
+            if not self.picked[s]:
+                self.gainbuf[s] += int(self.cov[a:b].sum())
+        self.gainbuf[self.num_sets] = int((self.usize > 0).sum())
+
+    def claim_check(self):
+        if self.done:
+            return
+        if self.gainbuf[self.num_sets] == 0:
+            self.done = 1
+            return
+        self.gain = np.where(self.picked, 0, self.gainbuf[:self.num_sets].astype(np.int64))
+        cur = self.rank_vals[self.cur]
+        self.claimants = [s for s in range(self.num_sets)
+                          if self.gain[s] > 0 and self.rank[s] == cur]
+        key = {s: (int(self.gain[s]) << ID_BITS) | (ID_MASK - s) for s in self.claimants}
+        owner = {}
+        mine = set(self.claimants)
+        for s, a, b, _ in self.rows:
+            if s in mine:
+                for w in range(a >> 6, ((b - 1) >> 6) + 1):
+                    lo, hi = max(a, w << 6), min(b, (w + 1) << 6)
+                    if self.cov[lo:hi].any():
+                        owner[w] = max(owner.get(w, 0), key[s])
+        for s, a, b, _ in self.rows:
+            if s in mine:
+                for w in range(a >> 6, ((b - 1) >> 6) + 1):
+                    lo, hi = max(a, w << 6), min(b, (w + 1) << 6)
+                    if self.cov[lo:hi].any() and owner[w] != key[s]:
+                        self.lostbuf[s] = 1
+
+    def apply(self):
+        if self.done:
+            return self.done
+        if not self.claimants:
+            self.cur += 1
+            if self.cur >= len(self.rank_vals):
+                self.done = -1
+            return self.done
+        for s in self.claimants:
+            if self.lostbuf[s]:
                 continue
-            g = 0
-            for u in range(U):
-                c = sum(int(cov[base[u] + a:base[u] + b].sum())
-                        for ss, uu, a, b in rows if ss == s and uu == u)
-                g += min(int(left[u]), c)
-            if g > 0:
-                best = max(best, (g << ID_BITS) | (ID_MASK - s))
-        t = torch.tensor([best], dtype=torch.int64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        key = int(t[0])
-        assert key >> ID_BITS > 0
-        s = ID_MASK - (key & ID_MASK)
-        picked.add(s)
-        picks.append(s)
-        for ss, u, a, b in rows:
-            if ss == s:
-                cov[base[u] + a:base[u] + b] = False
-        left = np.array([cov[base[u]:base[u + 1]].sum() for u in range(U)])
-    return picks
+            self.accepted.append((s, (int(self.gain[s]) << ID_BITS) | (ID_MASK - s)))
+            self.picked[s] = True
+            for ss, a, b, u in self.rows:
+                if ss == s:
+                    self.usize[u] -= int(self.cov[a:b].sum())
+                    self.cov[a:b] = False
+        return 0
+
+    def picks(self):
+        from catch_amd import parallel
+        if self.done == -1:
+            raise IndexError("ranks exhausted")
+        dense = {v: i for i, v in enumerate(self.rank_vals)}
+        return parallel.merge_picks([s for s, _ in self.accepted], [k for _, k in self.accepted],
+                                    [dense[int(r)] for r in self.rank])
+
+    def buffer_to_host(self, which):
+        return (self.gainbuf if which == 0 else self.lostbuf).copy()
+
+    def buffer_from_host(self, which, arr):
+        if which == 0:
+            self.gainbuf[:] = np.asarray(arr, dtype=np.uint32)
+        else:
+            self.lostbuf[:] = np.asarray(arr, dtype=np.uint8)
+
+
+def _instance(seed, P, U, with_ranks):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    glen = rng.integers(300, 1500, size=U)
+    rows = []
+    for s in range(P):
+        for u in range(U):
+            if rng.random() < 0.6:
+                pos = int(rng.integers(0, glen[u] - 260))
+                for _ in range(int(rng.integers(1, 3))):
+                    ln = int(rng.integers(1, 200))
+                    if pos + ln > glen[u]:
+                        break
+                    rows.append((s, u, pos, pos + ln))
+                    pos += ln + int(rng.integers(1, 100))
+    ranks = [int(x) for x in rng.integers(0, 3, size=P)] if with_ranks else None
+    return sorted(rows), [int(x) for x in glen], ranks
 
 
 def _worker(rank, world, port, q):
@@ -66,42 +153,74 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import torch
+    from catch_amd import parallel
     from oracle import oracle as orc
-    rng = np.random.Generator(np.random.PCG64(11))
-    P, U = 24, 3
-    glen = [120, 90, 150]
-    rows = []
-    for s in range(P):
-        for u in range(U):
-            if rng.random() < 0.5:
-                a = int(rng.integers(0, glen[u] - 30))
-                rows.append((s, u, a, a + int(rng.integers(5, 30))))
-    rows.sort()
-    picks = _greedy_sharded(rank, world, rows, P, U, glen)
-    r = np.array(rows)
-    exp = orc.approx_multiuniverse(r[:, 0], r[:, 1], r[:, 2], r[:, 3], P, U)
-    # weak-scaling bookkeeping of bench.py: max time over ranks, sum of units
-    t = torch.tensor([1.0 + rank], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    u = torch.tensor([10.0 * (rank + 1)], dtype=torch.float64)
-    dist.all_reduce(u, op=dist.ReduceOp.SUM)
-    dist.barrier()
-    q.put((rank, picks, exp, float(t[0]), float(u[0])))
+    orc.build()
+    ok = True
+    # ---- level 2: one instance, universes sharded over the ranks ----------
+    for seed, P, U, with_ranks in [(1, 40, 6, False), (2, 70, 9, True), (3, 25, 2, False),
+                                   (4, 60, 5, True)]:
+        rows, glen, ranks = _instance(seed, P, U, with_ranks)
+        r = np.array(rows, dtype=np.int64)
+        exp = orc.lazy_greedy(r[:, 0], r[:, 1], r[:, 2], r[:, 3], P, glen, None, ranks)
+        b = parallel.split_universes(glen, world)
+        g0, g1 = b[rank], b[rank + 1]
+        local = [(s, u - g0, a, e) for s, u, a, e in rows if g0 <= u < g1]
+        shard = NumpyShard(local, P, glen[g0:g1], ranks)
+        got = parallel.sharded_solve(
+            [shard], lambda which: parallel.host_exchange(dist, [shard], which))
+        ok = ok and got == exp and len(exp) > 3
+    # ---- level 1 + 2 together: a plan over several groups ------------------
+    costs = [900, 40, 35, 30, 20, 10]
+    sharded, whole = parallel.plan_with_sharding(costs, world)
+    ok = ok and sharded == [0] and sorted(i for w in whole for i in w) == [1, 2, 3, 4, 5]
+    loads = [sum(costs[i] for i in w) for w in whole]
+    ok = ok and max(loads) - min(loads) <= max(costs[1:])
+    mine = {}
+    for gi in whole[rank]:                           # my whole groups: solved alone
+        rows, glen, ranks = _instance(100 + gi, 30, 3, False)
+        r = np.array(rows, dtype=np.int64)
+        mine[gi] = orc.lazy_greedy(r[:, 0], r[:, 1], r[:, 2], r[:, 3], 30, glen)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    merged = {}
+    for part in gathered:
+        merged.update(part)
+    ok = ok and sorted(merged) == [1, 2, 3, 4, 5]
+    for gi in merged:                                # every rank now holds every group's picks
+        rows, glen, _ = _instance(100 + gi, 30, 3, False)
+        r = np.array(rows, dtype=np.int64)
+        ok = ok and merged[gi] == orc.lazy_greedy(r[:, 0], r[:, 1], r[:, 2], r[:, 3], 30, glen)
+    q.put((rank, ok))
     dist.destroy_process_group()
 
 
-def test_world_size_2_gloo():
+def test_two_rank_sharded_solve_and_plan_over_gloo():
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = sorted(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
-        assert p.exitcode == 0
-    for rank, picks, exp, tmax, usum in res:
-        assert picks == exp           # same picks, same order, on every rank
-        assert tmax == 2.0 and usum == 30.0
+    assert res == [(0, True), (1, True)]
+
+
+def test_plan_helpers_single_process():
+    sys.path.insert(0, REPO)
+    from catch_amd import parallel
+    assert parallel.lpt_assign([5, 9, 1, 7], 2) == [[1, 2], [3, 0]]
+    assert parallel.shard_plan([3, 3, 3], 1) == [[0, 1, 2]]
+    assert parallel.split_universes([10, 10, 10, 10], 2) == [0, 2, 4]
+    assert parallel.split_universes([100], 4) in ([0, 0, 0, 1, 1], [0, 0, 1, 1, 1], [0, 1, 1, 1, 1])
+    b = parallel.split_universes([5, 1, 1, 1, 20, 3, 3], 3)
+    assert b[0] == 0 and b[-1] == 7 and all(x <= y for x, y in zip(b, b[1:]))
+    sharded, whole = parallel.plan_with_sharding([10, 10, 10], 8)
+    assert sharded == [0, 1, 2] and all(w == [] for w in whole)
+    sharded, whole = parallel.plan_with_sharding([10, 10, 10], 1)
+    assert sharded == [] and whole == [[0, 1, 2]]
+    assert parallel.merge_picks([7, 3, 9], [50, 90, 70]) == [3, 9, 7]
+    assert parallel.merge_picks([7, 3, 9], [50, 90, 70], {7: 0, 3: 1, 9: 0}) == [9, 7, 3]
