@@ -687,6 +687,78 @@ def test_config3_pipeline_ndf_then_scf_matches_oracle(ctx, oracle):
     assert sorted(p.seq_str for p in out2[0]) == sorted(kept[i] for i in exp[0])
 
 
+# ---------------------------------------------------------------- full sizes
+def _full_size(key):
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                           "full_size_picks.json")) as f:
+        return json.load(f)[key]
+
+
+def _digest(ids):
+    import hashlib
+    a = np.sort(np.asarray(ids, dtype=np.int64))
+    return hashlib.sha256(a.astype("<i8").tobytes()).hexdigest()
+
+
+def test_full_size_config4_matches_oracle_digests(ctx):
+    """BASELINE configs[3] at FULL size (S4: 20,755 genomes in 20 groups, 592
+    Mbp, 8.9 M candidates, 519 M cover rows): per group the number of
+    candidates, the number of picks and the sha256 of the sorted pick ids equal
+    what the pinned CPU oracle computed in the authoring container
+    (tests/golden/make_full_size.py; the oracle needs ~20 minutes there)."""
+    from catch_amd import probe
+    from catch_amd.utils import synthetic
+    engine = _engine()
+    gold = {g["group"]: g for g in _full_size("S4")["groups"]}
+    groups = synthetic.dataset("S4")
+    assert len(groups) == len(gold) == 20
+    for gi, genomes in enumerate(groups):
+        t = engine.Targets(ctx, genomes)
+        c = engine.Candidates(ctx, t, 100, 50)
+        k, ep, eo = probe.anchor_entries_equal_length(c.n, 100, 2, 100)
+        p = c.probes(k, ep, eo)
+        ids, nrows = engine.setcover_filter(ctx, p, t, 2, 100, 0, 50, c.n)
+        p.close(); c.close(); t.close()
+        g = gold[gi]
+        assert (c.n, nrows, len(ids)) == (g["n_candidates"], g["n_rows"], g["n_picks"]), gi
+        assert _digest(ids) == g["picks_sha256"], gi
+
+
+def test_full_size_config3_matches_oracle_digests(ctx):
+    """BASELINE configs[2] at FULL size (S3: 40,000 influenza-like segment
+    records, 68 Mbp, --filter-with-lsh-hamming 2 then the set cover): the
+    near-duplicate filter keeps exactly the oracle's candidates (sha256 of the
+    kept strings in inclusion order) and the set cover picks the oracle's ids."""
+    import hashlib
+    from catch_amd import probe
+    from catch_amd.filter.near_duplicate_filter import NearDuplicateFilterWithHammingDistance
+    from catch_amd.utils import synthetic
+    engine = _engine()
+    g = _full_size("S3")["groups"][0]
+    genomes = synthetic.dataset("S3")[0]
+    t = engine.Targets(ctx, genomes)
+    c = engine.Candidates(ctx, t, 100, 50)
+    assert c.ncandidates == g["n_windows"]
+    random.seed(7)
+    ndf = NearDuplicateFilterWithHammingDistance(2, 100)
+    ndf._apply_to_candidates(c)
+    assert c.n == g["n_candidates"]
+    # the kept candidates, in the filter's inclusion order, as strings
+    pos = c.positions()
+    seqs = [s for gg in genomes for s in gg]
+    which = np.searchsorted(t.seq_off, pos, side="right") - 1
+    local = pos - t.seq_off[which]
+    kept = [seqs[q][o:o + 100] for q, o in zip(which.tolist(), local.tolist())]
+    assert hashlib.sha256("\n".join(kept).encode()).hexdigest() == g["kept_sha256"]
+    k, ep, eo = probe.anchor_entries_equal_length(c.n, 100, 2, 100)
+    p = c.probes(k, ep, eo)
+    ids, nrows = engine.setcover_filter(ctx, p, t, 2, 100, 0, 50, c.n)
+    p.close(); c.close(); t.close()
+    assert (nrows, len(ids)) == (g["n_rows"], g["n_picks"])
+    assert _digest(ids) == g["picks_sha256"]
+
+
 # ---------------------------------------------------------------- front end
 def test_design_cli_end_to_end(ctx, oracle, tmp_path, capsys):
     """python -m catch_amd.design on two FASTA datasets: the written probe set
