@@ -1,108 +1,118 @@
-"""Candidate probes by sliding window (catch/filter/candidate_probes.py
-:21-182): windows of probe_length every probe_stride bases, a last window
-flush with the end when the length is not a multiple of the stride, windows
-containing a run of >= min_n_string_length N dropped, and windows flanking
-every such run added."""
+"""Candidate probes by sliding window.
+
+Mirrors the interface of catch/filter/candidate_probes.py (:21-182): windows
+of probe_length every probe_stride bases, one more flush with the end when the
+length is not a multiple of the stride, windows holding a run of at least
+min_n_string_length N's dropped, and the windows flanking every such run
+added.  Here the windows are computed once, as (start, is_flank) pairs by
+interval arithmetic over the N runs (`window_starts`); the string and the
+Probe-object forms are thin layers over that list, and
+catch_amd/csrc/candidates.hip enumerates the same list on the device.
+"""
 import re
 
 from catch_amd import probe
 
 
-def make_candidate_probes_from_sequence(seq, probe_length, probe_stride,
-                                        min_n_string_length=2,
-                                        allow_small_seqs=None):
-    n_string_query = re.compile("(N{" + str(min_n_string_length) + ",})")
-    if len(seq) < probe_length:
-        if allow_small_seqs:
-            if len(seq) < allow_small_seqs:
-                raise ValueError(("Allowing sequences smaller than the probe "
-                                  "length (" + str(probe_length) + "), but "
-                                  "input sequence is smaller than minimum "
-                                  "allowed length"))
-            if n_string_query.search(seq):
-                raise Exception(("Only possible probe from input "
-                                 "sequence has too long a stretch of N's"))
-            return [probe.Probe.from_str(seq)]
-        raise ValueError(("An input sequence is smaller than the probe "
-                          "length (" + str(probe_length) + "); try "
-                          "setting --small-seq-skip"))
-    if not isinstance(seq, str):
-        seq = "".join(seq)
+def _n_runs(seq, min_n):
+    """[a, b) of every maximal run of at least min_n N's."""
+    if "N" * min_n not in seq:
+        return []
+    return [(m.start(), m.end()) for m in re.finditer("N{%d,}" % min_n, seq)]
 
-    probes = []
 
-    def add(start, end, flank=False):
-        sub = seq[start:end]
-        if not n_string_query.search(sub):
-            p = probe.Probe.from_str(sub)
-            p.is_flanking_n_string = flank
-            probes.append(p)
+def window_starts(seq, L, stride, min_n=2):
+    """(start, flanks_a_run) of every candidate window of a sequence of at
+    least L bases, in the reference's order: stride windows, the end-flush
+    window, then for every N run its left and right neighbour."""
+    n = len(seq)
+    runs = _n_runs(seq, min_n)
+    # a window [s, s+L) holds min_n consecutive N's of run [a, b)
+    # iff a + min_n - L <= s <= b - min_n
+    blocked = [(a + min_n - L, b - min_n) for a, b in runs]
 
-    for start in range(0, len(seq), probe_stride):
-        if start + probe_length > len(seq):
-            break
-        add(start, start + probe_length)
-    if len(seq) % probe_stride != 0:
-        add(len(seq) - probe_length, len(seq))
-    for match in n_string_query.finditer(seq):
-        if match.start() - probe_length >= 0:
-            add(match.start() - probe_length, match.start(), True)
-        if match.end() + probe_length <= len(seq):
-            add(match.end(), match.end() + probe_length, True)
-    return probes
+    def clean(s):
+        return not any(lo <= s <= hi for lo, hi in blocked)
+
+    starts = list(range(0, n - L + 1, stride))
+    if n % stride:
+        starts.append(n - L)
+    out = [(s, False) for s in starts if clean(s)] if blocked else \
+        [(s, False) for s in starts]
+    for a, b in runs:
+        for s in (a - L, b):
+            if 0 <= s <= n - L and clean(s):
+                out.append((s, True))
+    return out
+
+
+def _short_sequence(seq, L, min_n, allow_small_seqs):
+    """A sequence shorter than the probe length is its own single candidate
+    when --small-seq-min allows it (:64-83)."""
+    if not allow_small_seqs:
+        raise ValueError("sequence of %d bases is shorter than the probe length "
+                         "%d (--small-seq-skip leaves such sequences out)"
+                         % (len(seq), L))
+    if len(seq) < allow_small_seqs:
+        raise ValueError("sequence of %d bases is below the --small-seq-min "
+                         "of %d" % (len(seq), allow_small_seqs))
+    if _n_runs(seq, min_n):
+        raise Exception("the one candidate of a short sequence contains a run "
+                        "of N's")
+    return seq
+
+
+def _check_list(seqs):
+    if not isinstance(seqs, list):
+        raise TypeError("seqs must be a list of sequences")
+    if not seqs:
+        raise ValueError("seqs must have at least one sequence")
+    for seq in seqs:
+        if not isinstance(seq, str):
+            raise TypeError("seqs must be a list of Python strings")
 
 
 def candidate_strings_from_sequences(seqs, probe_length, probe_stride,
                                      min_n_string_length=2,
                                      allow_small_seqs=None,
                                      seq_length_to_skip=None):
-    """The sequences of make_candidate_probes_from_sequences(...) as plain
-    strings, same content and order, without building Probe objects.  A
-    sequence without a run of min_n_string_length N's (the usual case) is
-    sliced directly; one with such runs goes through the per-window code."""
-    if not isinstance(seqs, list):
-        raise TypeError("seqs must be a list of sequences")
-    if len(seqs) == 0:
-        raise ValueError("seqs must have at least one sequence")
-    n_run = "N" * min_n_string_length
-    n_query = re.compile("(N{" + str(min_n_string_length) + ",})")
+    """Candidate windows of all sequences as plain strings, in the order the
+    reference generates its Probe objects."""
+    _check_list(seqs)
     L, stride = probe_length, probe_stride
     out = []
     for seq in seqs:
-        if not isinstance(seq, str):
-            raise TypeError("seqs must be a list of Python strings")
-        if seq_length_to_skip is not None and len(seq) <= seq_length_to_skip:
-            continue
         n = len(seq)
-        if n >= L and n_run not in seq:
+        if seq_length_to_skip is not None and n <= seq_length_to_skip:
+            continue
+        if n < L:
+            out.append(_short_sequence(seq, L, min_n_string_length, allow_small_seqs))
+        elif "N" * min_n_string_length not in seq:
             out += [seq[i:i + L] for i in range(0, n - L + 1, stride)]
-            if n % stride != 0:
+            if n % stride:
                 out.append(seq[n - L:])
-        elif n >= L:
-            # runs of >= min_n N's: a window [s, s+L) holds min_n consecutive
-            # N's of the run [a, b) iff a + min_n - L <= s <= b - min_n
-            runs = [(m.start(), m.end()) for m in n_query.finditer(seq)]
-            bad = [(a + min_n_string_length - L, b - min_n_string_length)
-                   for a, b in runs]
-
-            def ok(s0):
-                for lo, hi in bad:
-                    if lo <= s0 <= hi:
-                        return False
-                return True
-            out += [seq[i:i + L] for i in range(0, n - L + 1, stride) if ok(i)]
-            if n % stride != 0 and ok(n - L):
-                out.append(seq[n - L:])
-            for a, b in runs:     # windows flanking every run
-                if a - L >= 0 and ok(a - L):
-                    out.append(seq[a - L:a])
-                if b + L <= n and ok(b):
-                    out.append(seq[b:b + L])
         else:
-            out += [p.seq_str for p in make_candidate_probes_from_sequence(
-                seq, probe_length=L, probe_stride=stride,
-                min_n_string_length=min_n_string_length,
-                allow_small_seqs=allow_small_seqs)]
+            out += [seq[s:s + L] for s, _ in
+                    window_starts(seq, L, stride, min_n_string_length)]
+    return out
+
+
+def make_candidate_probes_from_sequence(seq, probe_length, probe_stride,
+                                        min_n_string_length=2,
+                                        allow_small_seqs=None):
+    """Probe objects of one sequence (is_flanking_n_string set on the windows
+    next to an N run)."""
+    if not isinstance(seq, str):
+        seq = "".join(seq)
+    if len(seq) < probe_length:
+        return [probe.Probe.from_str(_short_sequence(
+            seq, probe_length, min_n_string_length, allow_small_seqs))]
+    out = []
+    for s, flank in window_starts(seq, probe_length, probe_stride,
+                                  min_n_string_length):
+        p = probe.Probe.from_str(seq[s:s + probe_length])
+        p.is_flanking_n_string = flank
+        out.append(p)
     return out
 
 
@@ -110,19 +120,12 @@ def make_candidate_probes_from_sequences(seqs, probe_length, probe_stride,
                                          min_n_string_length=2,
                                          allow_small_seqs=None,
                                          seq_length_to_skip=None):
-    if not isinstance(seqs, list):
-        raise TypeError("seqs must be a list of sequences")
-    if len(seqs) == 0:
-        raise ValueError("seqs must have at least one sequence")
-    for seq in seqs:
-        if not isinstance(seq, str):
-            raise TypeError("seqs must be a list of Python strings")
-    probes = []
+    _check_list(seqs)
+    out = []
     for seq in seqs:
         if seq_length_to_skip is not None and len(seq) <= seq_length_to_skip:
             continue
-        probes += make_candidate_probes_from_sequence(
-            seq, probe_length=probe_length, probe_stride=probe_stride,
-            min_n_string_length=min_n_string_length,
-            allow_small_seqs=allow_small_seqs)
-    return probes
+        out += make_candidate_probes_from_sequence(
+            seq, probe_length, probe_stride, min_n_string_length,
+            allow_small_seqs)
+    return out

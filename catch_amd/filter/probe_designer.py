@@ -36,82 +36,85 @@ class ProbeDesigner:
         self._candidate_strs = None
         self.final_probes = None
 
+    # -- clustering pre-step ------------------------------------------------
+    def _sequences_to_cluster(self):
+        """Every sequence of every genome of every group, cut into fragments
+        when asked to, short ones skipped -- in input order, which is the order
+        the clustering numbers them in."""
+        out = []
+        for grp in self.genomes:
+            for g in grp:
+                pieces = (g.seqs if self.cluster_fragment_length is None else
+                          g.break_into_fragments(self.cluster_fragment_length,
+                                                 include_full_end=True).seqs)
+                out += [s for s in pieces
+                        if self.seq_length_to_skip is None
+                        or len(s) > self.seq_length_to_skip]
+        return out
+
+    def _resolve_cluster_method(self):
+        """'choose' means connected components unless whole long genomes were
+        cut into fragments: their pieces would chain into one giant component,
+        which average linkage avoids (catch/filter/probe_designer.py:113-158)."""
+        if self.cluster_method != "choose":
+            return self.cluster_method
+        if self.cluster_fragment_length is None:
+            return "simple"
+        sizes = [(len(g.seqs), g.size()) for grp in self.genomes for g in grp]
+        nseq, total = sum(n for n, _ in sizes), sum(t for _, t in sizes)
+        long_genomes = nseq > 1 and total / nseq > self.cluster_fragment_length
+        return "hierarchical" if long_genomes else "simple"
+
     def _cluster_genomes(self):
-        """All sequences of all groups and genomes (optionally cut into
-        fragments), clustered by MinHash signature; returns one list of
-        single-sequence Genomes per cluster, largest cluster first
-        (probe_designer.py:78-184)."""
+        """One list of single-sequence Genomes per cluster of the MinHash
+        clustering, largest cluster first (probe_designer.py:78-184)."""
         if len(self.genomes) > 1:
-            logger.warning(("There are >1 groups of genomes in the input, but "
-                            "clustering these will override those groupings; "
-                            "differential identification or other tasks that "
-                            "rely on group separation may no longer work as "
-                            "intended"))
-        seqs = {}
-        for genomes_from_group in self.genomes:
-            for g in genomes_from_group:
-                if self.cluster_fragment_length is not None:
-                    g_seqs = g.break_into_fragments(
-                        self.cluster_fragment_length,
-                        include_full_end=True).seqs
-                else:
-                    g_seqs = g.seqs
-                for s in g_seqs:
-                    if (self.seq_length_to_skip is not None and
-                            len(s) <= self.seq_length_to_skip):
-                        continue
-                    seqs[len(seqs)] = s
-        method = self.cluster_method
-        if method == "choose":
-            # fragments of several long genomes chain into one giant connected
-            # component; average linkage does not (:113-158)
-            method = "simple"
-            if self.cluster_fragment_length is not None:
-                num_sequences = sum(len(g.seqs) for grp in self.genomes
-                                    for g in grp)
-                total_len = sum(g.size() for grp in self.genomes for g in grp)
-                if (num_sequences > 1 and total_len / num_sequences >
-                        self.cluster_fragment_length):
-                    method = "hierarchical"
-        logger.info(("Clustering %d sequences using MinHash signatures, at an "
-                     "average nucleotide dissimilarity threshold of %f"),
-                    len(seqs), self.cluster_threshold)
+            logger.warning("Clustering ignores the %d input groupings: anything that "
+                           "relies on them (e.g. --identify) no longer sees them",
+                           len(self.genomes))
+        seqs = self._sequences_to_cluster()
+        method = self._resolve_cluster_method()
+        logger.info("MinHash clustering of %d sequences (%s, threshold %f)",
+                    len(seqs), method, self.cluster_threshold)
         clusters = cluster.cluster_with_minhash_signatures(
-            seqs, threshold=self.cluster_threshold, cluster_method=method)
-        logger.info("Found %d clusters with sizes: %s", len(clusters),
-                    [len(c) for c in clusters])
-        return [[genome.Genome.from_one_seq(seqs[i]) for i in c]
-                for c in clusters]
+            dict(enumerate(seqs)), threshold=self.cluster_threshold,
+            cluster_method=method)
+        logger.info("%d clusters; sizes %s", len(clusters), [len(c) for c in clusters])
+        return [[genome.Genome.from_one_seq(seqs[i]) for i in members]
+                for members in clusters]
+
+    # -- object pipeline ----------------------------------------------------
+    @staticmethod
+    def _run_filters(filters, probes, genomes, grouped):
+        for f in filters:
+            logger.info("Filter %s", type(f).__name__)
+            probes = f.filter(probes, genomes, input_is_grouped=grouped)
+        return probes
 
     def _pass_through_filters_ungrouped(self, probes, genomes, filters):
-        for f in filters:
-            logger.info("Starting filter %s", f.__class__.__name__)
-            probes = f.filter(probes, genomes, input_is_grouped=False)
-        return probes
+        return self._run_filters(filters, probes, genomes, False)
 
     def _pass_through_filters(self, probes, genomes, filters):
-        assert len(probes) == len(genomes)
-        for f in filters:
-            logger.info("Starting filter %s", f.__class__.__name__)
-            probes = f.filter(probes, genomes, input_is_grouped=True)
-        return probes
+        if len(probes) != len(genomes):
+            raise ValueError("one list of probes per group of genomes")
+        return self._run_filters(filters, probes, genomes, True)
+
+    def _candidates_of_group(self, grp):
+        seqs = [s for g in grp for s in g.seqs]
+        if not seqs:
+            return []
+        return candidate_probes.make_candidate_probes_from_sequences(
+            seqs, self.probe_length, self.probe_stride,
+            allow_small_seqs=self.allow_small_seqs,
+            seq_length_to_skip=self.seq_length_to_skip)
 
     def _design_for_genomes(self, genomes, filters):
-        candidates = []
-        for genomes_from_group in genomes:
-            c = []
-            for g in genomes_from_group:
-                c += candidate_probes.make_candidate_probes_from_sequences(
-                    g.seqs, probe_length=self.probe_length,
-                    probe_stride=self.probe_stride,
-                    allow_small_seqs=self.allow_small_seqs,
-                    seq_length_to_skip=self.seq_length_to_skip)
-            if len(c) == 0:
-                logger.warning("There are no candidate probes for a grouping "
-                               "of genomes")
-            candidates.append(c)
-        return candidates, self._pass_through_filters(candidates, genomes,
-                                                      filters)
+        """(candidates per group, what the filters leave of them)."""
+        candidates = [self._candidates_of_group(grp) for grp in genomes]
+        for c in candidates:
+            if not c:
+                logger.warning("A group of genomes has no candidate probes")
+        return candidates, self._pass_through_filters(candidates, genomes, filters)
 
     def _design_on_strings(self, genomes, filters):
         """[DuplicateFilter | near-duplicate filter, SetCoverFilter] -- the
