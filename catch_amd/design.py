@@ -15,6 +15,7 @@ options run the coverage analysis of the designed probes (bin/design.py:417-442)
 """
 import argparse
 import logging
+import os
 import sys
 
 from catch_amd.filter import duplicate_filter, near_duplicate_filter
@@ -68,7 +69,7 @@ def parse_args(argv=None, args_type="basic"):
                         "near-duplicate filter")
     p.add_argument("--small-seq-skip", type=int)
     p.add_argument("--small-seq-min", type=int)
-    p.add_argument("--kmer-probe-map-k", type=int, default=20)
+    p.add_argument("--kmer-probe-map-k", type=int)
     p.add_argument("--print-analysis", action="store_true",
                    help="print coverage of the target genomes by the probes")
     p.add_argument("--write-analysis-to-tsv")
@@ -137,6 +138,21 @@ def main(args):
                          "add adapter sequences onto the ends of probes"))
     genomes_grouped = [seq_io.read_genomes_from_fasta(fn) for fn in args.dataset]
 
+    # bin/design.py:180-205, :232: argument checks and the k-mer length each
+    # consumer of the probe map uses (20 / 20 / 10 unless given)
+    if args.small_seq_skip is not None and args.small_seq_min is not None:
+        raise Exception("Both --small-seq-skip and --small-seq-min were given: "
+                        "one skips short sequences, the other designs on them")
+    if args.kmer_probe_map_k:
+        if args.kmer_probe_map_k > args.probe_length:
+            raise Exception("--kmer-probe-map-k (%d) exceeds the probe length (%d)"
+                            % (args.kmer_probe_map_k, args.probe_length))
+        k_scf = k_af = k_analyzer = args.kmer_probe_map_k
+    else:
+        if args.probe_length <= 20:
+            logger.warning("The probe length (%d) is small: consider a "
+                           "--kmer-probe-map-k below it", args.probe_length)
+        k_scf, k_af, k_analyzer = 20, 20, 10
     filters = []
     if (args.filter_with_lsh_hamming is not None and
             args.filter_with_lsh_minhash is not None):
@@ -167,7 +183,7 @@ def main(args):
         island_of_exact_match_tolerant=args.island_of_exact_match_tolerant,
         identify=args.identify, avoided_genomes=args.avoid_genomes,
         coverage=args.coverage, cover_extension=args.cover_extension,
-        kmer_probe_map_k=args.kmer_probe_map_k)
+        kmer_probe_map_k=k_scf)
     filters.append(scf)
     if args.add_adapters:      # bin/design.py:345-365 (default sequences :350, :354)
         from catch_amd.filter import adapter_filter
@@ -178,7 +194,7 @@ def main(args):
             ("AGGCCCTGGCTGCTGATATG", "GACCTTTTGGGACAGCGGTG"),
             mismatches=args.mismatches, lcf_thres=lcf_thres,
             island_of_exact_match=args.island_of_exact_match,
-            kmer_probe_map_k=args.kmer_probe_map_k))
+            kmer_probe_map_k=k_af))
 
     pb = probe_designer.ProbeDesigner(
         genomes_grouped, filters, probe_length=args.probe_length,
@@ -204,11 +220,10 @@ def main(args):
         from catch_amd import coverage_analysis
         analyzer = coverage_analysis.Analyzer(
             pb.final_probes, args.mismatches, lcf_thres, genomes_grouped,
-            target_genomes_names=args.dataset,
+            target_genomes_names=[os.path.basename(fn) for fn in args.dataset],
             island_of_exact_match=args.island_of_exact_match,
             cover_extension=args.cover_extension,
-            kmer_probe_map_k=(10 if args.kmer_probe_map_k == 20
-                              else args.kmer_probe_map_k),
+            kmer_probe_map_k=k_analyzer,
             rc_too=False)
         analyzer.run()
         if args.write_analysis_to_tsv:
@@ -220,7 +235,8 @@ def main(args):
             analyzer.write_probe_map_counts(args.write_probe_map_counts_to_tsv)
         if args.print_analysis:
             analyzer.print_analysis()
-    print(len(pb.final_probes))          # bin/design.py:445
+    else:
+        print(len(pb.final_probes))      # bin/design.py:443-445: only without an analysis
     return pb
 
 

@@ -10,9 +10,11 @@ multiplicity-ordered greedy pass (:60-103) on the GPU
 priority order; the reference returns them in CPython-set order, which callers
 never rely on (catch/filter/probe_designer.py:288,308).
 
-requires_probe_groupings is set so that grouped input is handled in-process
+grouped input is handled in-process by catch_amd's BaseFilter (HIP contexts
+do not survive the fork of the reference's BaseFilter)
 (HIP contexts do not survive the fork of catch/filter/base_filter.py:121-158).
 """
+import logging
 import math
 import operator
 import random
@@ -20,6 +22,9 @@ from collections import defaultdict
 
 from catch_amd import engine
 from catch_amd.filter.base_filter import BaseFilter
+
+
+logger = logging.getLogger(__name__)
 
 
 class NearDuplicateFilter(BaseFilter):
@@ -130,6 +135,26 @@ class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
         super().__init__(k=3)
         self.kmer_size = kmer_size
         self.dist_thres = dist_thres
+        self._warn_if_not_reproducible()
+
+    @staticmethod
+    def _warn_if_not_reproducible():
+        """The device computes the str hash of CPython <= 3.10 under
+        PYTHONHASHSEED=0 (SipHash-2-4, zero key).  Under any other interpreter
+        state the reference itself would bucket differently (and differently
+        from run to run with a random seed): the output is still a valid
+        near-duplicate filtering, but not bit-identical to a reference run in
+        THIS process -- say so instead of silently computing the 3.10 answer."""
+        import os
+        import sys
+        algo = getattr(sys.hash_info, "algorithm", "")
+        seed = os.environ.get("PYTHONHASHSEED", "random")
+        if algo != "siphash24" or seed != "0":
+            logger.warning(
+                "MinHash near-duplicate filter: this interpreter hashes str with %s and "
+                "PYTHONHASHSEED=%s; the GPU filter uses SipHash-2-4 with a zero key (CPython "
+                "<= 3.10 under PYTHONHASHSEED=0), so its buckets match a reference run only "
+                "under that setting", algo or "an unknown algorithm", seed)
 
     def num_tables(self):
         """lsh.py:268-276 with MinHashFamily.P1 = 1 - dist (:160-174)."""

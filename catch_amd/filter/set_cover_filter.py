@@ -62,6 +62,16 @@ class SetCoverFilter(BaseFilter):
                 or custom_cover_range_tolerant_fn is not None):
             raise NotImplementedError(
                 "custom hybridization functions cannot run on the GPU path")
+        # The seed scan (cover threshold == probe length, the default) takes any
+        # mismatch budget; the general path (-l below the probe length, island,
+        # unequal probes, other alphabets) keeps the nearest mismatches of each
+        # side in fixed arrays of 32 (csrc/scan.hip MAX_MM)
+        for name, val in (("mismatches", mismatches),
+                          ("mismatches_tolerant", mismatches_tolerant)):
+            if val is not None and val > 32 and lcf_thres is not None:
+                logger.warning("%s = %d: cover ranges below the full probe length "
+                               "(-l / --island-of-exact-match) support at most 32 "
+                               "mismatches on the GPU and will raise", name, val)
         self.mismatches = mismatches
         self.lcf_thres = lcf_thres
         self.island_of_exact_match = island_of_exact_match
