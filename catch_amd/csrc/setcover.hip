@@ -109,6 +109,17 @@ __device__ __forceinline__ u32 range_popcount_l2(const unsigned long long *bm, u
     return c + (u32)__popcll(LD(&bm[w1]) & m1);
 }
 
+// the RP_MAXW = 5 consecutive 64-bit words at p with two 16-byte loads and one
+// 8-byte load instead of five 8-byte ones: a lane's words are contiguous, but
+// lanes sit on different rows, so every wave-level load costs one cache-line
+// look-up per lane whatever its width (the round kernels are bound by that
+// rate).  p is 8-byte aligned; the arrays have >= 8 words of slack at the end.
+struct __attribute__((aligned(8))) u64x2 { unsigned long long a, b; };
+__device__ __forceinline__ void load_words5(const unsigned long long *p, unsigned long long (&v)[RP_MAXW]) {
+    const u64x2 q0 = *(const u64x2 *)p, q1 = *(const u64x2 *)(p + 2);
+    v[0] = q0.a; v[1] = q0.b; v[2] = q1.a; v[3] = q1.b; v[4] = p[4];
+}
+
 // ------------------------------------------------------------------------
 // set-up kernels (grid-wide)
 // ------------------------------------------------------------------------
@@ -637,6 +648,7 @@ greedy_wg_kernel(GreedyArgs a) {
 }
 
 #include "setcover_batched.inc"
+#include "setcover_flat.inc"
 
 // ------------------------------------------------------------------------
 // multi-launch solver (one gain launch + one apply launch per pick); used when
@@ -788,7 +800,7 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     // arena: the zero-initialised part first
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_bm = take(8 * nwords), o_ow0 = take(8 * (nwords + 8)), o_ow1 = take(8 * (nwords + 8)),
+    const size_t o_bm = take(8 * (nwords + 8)), o_ow0 = take(8 * (nwords + 8)), o_ow1 = take(8 * (nwords + 8)),
                  o_blk = take(16 * (size_t)gblocks), o_st = take(sizeof(GreedyState)),
                  o_picked = take(4 * (size_t)nsets), o_claimed = take(4 * (size_t)nsets),
                  o_rank = take(4 * (size_t)nsets);
@@ -987,6 +999,13 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         for (u32 u = 0; u < nuniv && batched; ++u) batched = universe_p[u] == 1.0;
 
     int no_retry = 0;
+    // large instances: the row-parallel, tile-ordered kernels (setcover_flat.inc).
+    // Measured on S4 (rows: fused vs flat rounds): 272 M: 65 vs 30 ms; 44 M: 9.9 vs
+    // 8.8; 19 M: 4.0 vs 4.6 (small tiles put dozens of concurrent claimants on
+    // every owner word); 4 M: 1.5 vs 1.5.
+    const i64 flat_min_rows = getenv("CATCHHIP_FLAT_MIN_ROWS") ? atoll(getenv("CATCHHIP_FLAT_MIN_ROWS")) : (i64)1 << 25;
+    if (batched && R->lmax <= 257 && (i64)nrows >= flat_min_rows)
+        return greedy_flat(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out);
     if (batched) return greedy_frontier(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out, &no_retry);
 
     DevBuf<u32> set_ptr, flag, idx, tmp, seg_row, seg_univ, seg_set, row_seg, set_seg_ptr, usize, can, left, rank,

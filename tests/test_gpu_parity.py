@@ -298,11 +298,15 @@ def test_greedy_random_instances_match_oracle(ctx, oracle):
         assert got == exp, trial
 
 
-def test_greedy_batched_rounds_restore_sequential_order(ctx, oracle):
+@pytest.mark.parametrize("flat", [False, True])
+def test_greedy_batched_rounds_restore_sequential_order(ctx, oracle, monkeypatch, flat):
     """Larger full-coverage instances (many locally maximal sets per round,
-    with and without ranks): the frontier solver must return the oracle's
-    sequential pick order, and so must the one-pick-per-iteration solver."""
+    with and without ranks): the frontier solver -- set-parallel fused kernels
+    and, forced here on these small instances, the row-parallel kernels large
+    instances take -- must return the oracle's sequential pick order, and so
+    must the one-pick-per-iteration solver."""
     engine = _engine()
+    monkeypatch.setenv("CATCHHIP_FLAT_MIN_ROWS", "0" if flat else str(1 << 40))
     rng = np.random.Generator(np.random.PCG64(321))
     for trial in range(6):
         P = int(rng.integers(300, 2500))
