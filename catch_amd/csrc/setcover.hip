@@ -1000,10 +1000,9 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
 
     int no_retry = 0;
     // large instances: the row-parallel, tile-ordered kernels (setcover_flat.inc).
-    // Measured on S4 (rows: fused vs flat rounds): 272 M: 65 vs 30 ms; 44 M: 9.9 vs
-    // 8.8; 19 M: 4.0 vs 4.6 (small tiles put dozens of concurrent claimants on
-    // every owner word); 4 M: 1.5 vs 1.5.
-    const i64 flat_min_rows = getenv("CATCHHIP_FLAT_MIN_ROWS") ? atoll(getenv("CATCHHIP_FLAT_MIN_ROWS")) : (i64)1 << 25;
+    // Measured on S4 (rows: rounds of the fused vs the flat kernels): 272 M: 65 vs
+    // 30 ms; 44 M: 9.9 vs 6.7; 29 M: 6.6 vs 4.5; 19 M: 4.0 vs 3.4; 4 M: 1.5 vs 1.5.
+    const i64 flat_min_rows = getenv("CATCHHIP_FLAT_MIN_ROWS") ? atoll(getenv("CATCHHIP_FLAT_MIN_ROWS")) : (i64)1 << 22;
     if (batched && R->lmax <= 257 && (i64)nrows >= flat_min_rows)
         return greedy_flat(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out);
     if (batched) return greedy_frontier(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out, &no_retry);

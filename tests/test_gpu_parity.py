@@ -763,6 +763,39 @@ def test_full_size_config3_matches_oracle_digests(ctx):
     assert _digest(ids) == g["picks_sha256"]
 
 
+def test_full_size_config5_design_large_matches_oracle_digest(ctx, tmp_path, capsys):
+    """BASELINE configs[4] at a real scale (S5 x 0.01: 2,132 genomes, 48 Mbp,
+    2,598 fragments -> 1,130 clusters, 826 k candidates after the MinHash
+    near-duplicate filter): `design_large` defaults end to end (-m 5 random
+    anchors, -e 50, cluster 0.15 from 50-kb fragments, MinHash filter 0.6, set
+    cover per cluster) writes exactly the probes the oracle's chain of the same
+    steps selects (tests/golden/make_full_size.py S5:0.01, 12 minutes of CPU)."""
+    import hashlib
+    from catch_amd import design
+    from catch_amd.utils import synthetic, seq_io
+    g = _full_size("S5:0.01")["design"]
+    genomes = synthetic.dataset("S5", scale=0.01)[0]
+    assert len(genomes) == g["genomes"]
+    fn = tmp_path / "s5.fasta"
+    with open(fn, "w") as f:
+        for i, gen in enumerate(genomes):
+            for j, s in enumerate(gen):
+                f.write(">g%d_%d\n%s\n" % (i, j, s))
+    out = tmp_path / "probes.fasta"
+    args = design.parse_args([str(fn), "-o", str(out),
+                              "--cluster-and-design-separately-method", "simple"],
+                             args_type="large")
+    assert (args.mismatches, args.cover_extension, args.filter_with_lsh_minhash,
+            args.cluster_and_design_separately, args.cluster_from_fragments) == (5, 50, 0.6, 0.15, 50000)
+    random.seed(21)
+    np.random.seed(22)
+    pb = design.main(args)
+    capsys.readouterr()
+    got = sorted(set(seq_io.read_fasta(str(out)).values()))
+    assert len(got) == g["n_probes"] == len(pb.final_probes)
+    assert hashlib.sha256("\n".join(got).encode()).hexdigest() == g["probes_sha256"]
+
+
 def test_selection_equals_live_reference_runs(ctx):
     """The inputs the LIVE reference was run on in the authoring container
     (tools/time_reference.py: S1, S2 in full, S3 and S4 scaled down to what the
