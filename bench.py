@@ -419,16 +419,17 @@ def main():
         def gbs(b, t_ms):
             return b / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
         units_roof = {
-            "seed_verify": dict(kernel="seed_verify_kernel<%d>" % -(-PROBE_LEN // 32),
+            "seed_verify": dict(kernel="seed_verify4_kernel<%d>" % -(-PROBE_LEN // 32),
                                 ms=ms["verify_ms"], bytes=verify_bytes,
                                 launches=nlaunch["verify_launches"] / K, pmc="seed_verify"),
-            "solver_rounds": dict(kernel="gf_count_claim_kernel+gf_check_apply_kernel",
+            "solver_rounds": dict(kernel="frontier solver round: gr_count+gr_claim+gr_check+gr_apply (flat, >= 4 M "
+                                         "rows) / gf_count_claim+gf_check_apply (fused)",
                                   ms=ms["rounds_ms"], bytes=k2_bytes,
                                   launches=max(nlaunch["rounds_launches"] // 2, 1) / K,
                                   pmc="solver_round"),
-            "rows_build": dict(kernel="bucketed row build (6 launches per group)",
+            "rows_build": dict(kernel="bucketed row build (per group: scatter, merge, scans, emit)",
                                ms=ms["rows_ms"], bytes=rows_bytes,
-                               launches=6.0 * len(stepper.resident), pmc="rows_build"),
+                               launches=float(len(stepper.resident)), pmc="rows_build"),
         }
         dom = max(units_roof, key=lambda k: units_roof[k]["ms"])
         d = units_roof[dom]
@@ -440,8 +441,8 @@ def main():
                     avg_launch_ms=avg_ms, launches_per_step=d["launches"],
                     device_ms_per_step=d["ms"])
         if dom == "solver_rounds":
-            roof["launches_are"] = ("pairs (count+claim, check+apply), including "
-                                    "the no-op pairs after the last round")
+            roof["launches_are"] = ("rounds (one count launch with its claim / check / apply "
+                                    "launches), including the no-op rounds queued after the last one")
         out = {
             "metric": "candidate-probe x target-bp / s through SetCoverFilter "
                       "(K1 scan + K2 greedy)",

@@ -236,24 +236,12 @@ class SetCoverFilter(BaseFilter):
                        rows=0, scan_launches=0, greedy_launches=0)
         nonempty = [i for i, pp in enumerate(input_strs) if len(pp) > 0]
         todo = [i for i in nonempty if only is None or i in only]
-        # Random anchors (catch/probe.py:391-401) consume np.random once per
-        # probe, group after group in INPUT order: when groups are reordered or
-        # left to other ranks the tables of all groups are drawn up front, in
-        # that order, so that every rank and every schedule selects what the
-        # reference selects.
-        # (single rank: input order is kept whenever the anchors are random)
         random_anchors = any(probe.anchors_use_random(
             input_strs[i], self.mismatches, self.lcf_thres, self.kmer_probe_map_k)
             for i in nonempty)
-        if only is not None and tables is None and random_anchors:
-            tables = self._anchor_tables_in_input_order(input_strs, nonempty,
-                                                        assume_unique)
-        # largest first, as the reference hands its instances to the pool
-        # (catch/filter/set_cover_filter.py:880-887)
-        if not random_anchors or tables is not None:
-            todo.sort(key=lambda i: (-len(input_strs[i]), i))
         width = max(1, int(os.environ.get("CATCHHIP_GROUPS_IN_FLIGHT", "4")))
-        # many SMALL groups go through one instance; large groups (thousands of
+        # many SMALL groups go through one instance (its anchors are the groups'
+        # anchors drawn back to back, in input order); large groups (thousands of
         # candidates each) overlap better as separate instances in flight
         if (only is None and tables is None
                 and assume_unique and not self.identify and not self.avoided_genomes
@@ -264,8 +252,28 @@ class SetCoverFilter(BaseFilter):
             self._filter_strs_union(input_strs, target_genomes_grouped, todo,
                                     selected, timings)
             todo = []
-        for c0 in range(0, len(todo), width):
-            chunk = todo[c0:c0 + width]
+        # Random anchors (catch/probe.py:391-401) consume np.random once per
+        # probe, group after group in INPUT order, while the groups below run
+        # largest first (and, over several ranks, only some of them here): the
+        # tables of all groups are then drawn up front, in input order, so that
+        # every schedule selects what the reference selects.
+        # (With --identify / --avoid-genomes the rank tables draw too, interleaved
+        # with the set tables group by group: then the groups simply keep their
+        # input order.)
+        need_ranks = self.identify or len(self.avoided_genomes) > 0
+        in_input_order = random_anchors and need_ranks and tables is None
+        if todo and random_anchors and tables is None and not need_ranks:
+            tables = self._anchor_tables_in_input_order(input_strs, nonempty,
+                                                        assume_unique)
+        if in_input_order:
+            chunks = [todo[i:i + width] for i in range(0, len(todo), width)]
+        else:
+            # largest first, as the reference hands its instances to the pool
+            # (catch/filter/set_cover_filter.py:880-887)
+            todo.sort(key=lambda i: (-len(input_strs[i]), i))
+            chunks = _chunks_by_size(
+                todo, lambda gi: sum(g.size() for g in target_genomes_grouped[gi]), width)
+        for chunk in chunks:
             ctxs = _contexts(len(chunk))
             specs, held, all_ranks = [], [], []
             try:
@@ -350,6 +358,13 @@ class SetCoverFilter(BaseFilter):
         import os
         from catch_amd import parallel
         n = len(input_strs)
+        if ((self.identify or self.avoided_genomes) and any(
+                probe.anchors_use_random(input_strs[i], self.mismatches, self.lcf_thres,
+                                         self.kmer_probe_map_k) for i in range(n))):
+            # random anchors for the set AND the rank tables, interleaved group by
+            # group: every rank does every group, in input order
+            return self._filter_strs(input_strs, target_genomes_grouped, assume_unique,
+                                     only=set(range(n)))
         costs = [sum(g.size() for g in target_genomes_grouped[i]) if len(input_strs[i]) else 0
                  for i in range(n)]
         eligible = (not self.identify and not self.avoided_genomes
@@ -437,8 +452,14 @@ class SetCoverFilter(BaseFilter):
                        candidates=0, unique_candidates=0)
         todo = [i for i, g in enumerate(target_genomes_grouped) if len(g) > 0]
         width = max(1, int(os.environ.get("CATCHHIP_GROUPS_IN_FLIGHT", "4")))
-        for c0 in range(0, len(todo), width):
-            chunk = todo[c0:c0 + width]
+        sizes = {i: sum(g.size() for g in target_genomes_grouped[i]) for i in todo}
+        # largest first (catch/filter/set_cover_filter.py:880-887); the random
+        # anchors of a group are drawn when its turn comes, so that order is kept
+        # only when no random numbers are involved
+        if not probe.anchors_use_random(["A" * probe_length], self.mismatches,
+                                        self.lcf_thres, self.kmer_probe_map_k):
+            todo.sort(key=lambda i: (-sizes[i], i))
+        for chunk in _chunks_by_size(todo, lambda gi: sizes[gi], width):
             ctxs = _contexts(len(chunk))
             specs, held, cands_of = [], [], []
             try:
@@ -636,6 +657,19 @@ class SetCoverFilter(BaseFilter):
             timings["greedy_ms"] += ms
             timings["greedy_launches"] += nl
             timings["picks"] += len(ids)
+
+
+def _chunks_by_size(todo, size_of, width):
+    """Groups in flight together.  Large groups (>= CATCHHIP_BIG_GROUP_BASES,
+    default 8 Mbases) fill the GPU on their own and run one at a time, largest
+    first (their kernels only get in each other's way: four S4 groups in flight
+    took 498 ms per pass against 333 ms one after the other); the small ones
+    run `width` at a time on their own streams."""
+    import os
+    big_bases = int(os.environ.get("CATCHHIP_BIG_GROUP_BASES", str(8_000_000)))
+    big = [[gi] for gi in todo if size_of(gi) >= big_bases]
+    small = [gi for gi in todo if size_of(gi) < big_bases]
+    return big + [small[i:i + width] for i in range(0, len(small), width)]
 
 
 _extra_ctxs = {}

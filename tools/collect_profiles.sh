@@ -46,21 +46,30 @@ kern = {}
 for k in sorted(set(fe) | set(wr)):
     kern[k] = {"FETCH_SIZE_KB_per_launch": fe[k][0] / max(fe[k][1], 1), "launches": fe[k][1] or wr[k][1],
                "WRITE_SIZE_KB_per_launch": wr[k][0] / max(wr[k][1], 1)}
-def unit(names):
-    return {"kernels": names,
-            "FETCH_SIZE_KB_per_launch": sum(kern[n]["FETCH_SIZE_KB_per_launch"] for n in names if n in kern),
-            "WRITE_SIZE_KB_per_launch": sum(kern[n]["WRITE_SIZE_KB_per_launch"] for n in names if n in kern)}
+def unit(names, per):
+    """total bytes of the unit's kernels over the run / launches of the kernels in `per`
+    (a solver round = one launch of each of its kernels: per = the count kernels)"""
+    names = [n for n in names if n in kern]
+    per = [n for n in per if n in kern]
+    launches = sum(kern[n]["launches"] for n in per) or 1
+    return {"kernels": names, "per_launch_of": per, "launches": launches,
+            "FETCH_SIZE_KB_per_launch": sum(kern[n]["FETCH_SIZE_KB_per_launch"] * kern[n]["launches"] for n in names) / launches,
+            "WRITE_SIZE_KB_per_launch": sum(kern[n]["WRITE_SIZE_KB_per_launch"] * kern[n]["launches"] for n in names) / launches}
 seed = [k for k in kern if k.startswith("seed_") and not k.startswith("seed_verify")]
 rows = [k for k in kern if k.startswith(("scan1_", "bucket_", "rows_emit", "scan_tiles"))]
+solver = [k for k in kern if k.startswith(("gf_count_claim", "gf_check_apply", "gr_count", "gr_claim", "gr_check", "gr_apply"))]
+verify = [k for k in kern if k.startswith("seed_verify")]
 rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
                "'python bench.py --workload %s --steps 2 --warmup 1 --no-cpu-baseline'; KB per launch averaged over "
-               "the launches of the run (all groups, all rounds); a unit sums the per-launch averages of its kernels "
-               "(one launch of each); on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x "
-               "(MI355X_MICROARCH.md), bench.py doubles it; other widths and WRITE_SIZE are uncalibrated" % wl,
+               "the launches of the run (all groups, all rounds); a unit = total KB of its kernels / launches of its "
+               "leading kernel(s) (a solver round = one count launch with its claim / check / apply launches); on "
+               "gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md), bench.py doubles it; "
+               "other widths and WRITE_SIZE are uncalibrated" % wl,
        "workload": wl,
-       "units": {"solver_round": unit([k for k in kern if k.startswith(("gf_count_claim", "gf_check_apply", "gfx_"))]),
-                 "seed_verify": unit([k for k in kern if k.startswith("seed_verify")]),
-                 "seed_table_lookup": unit(seed), "rows_build": unit(rows)},
+       "units": {"solver_round": unit(solver, [k for k in solver if k.startswith(("gf_count_claim", "gr_count"))]),
+                 "seed_verify": unit(verify, verify),
+                 "seed_table_lookup": unit(seed, [k for k in seed if k.startswith("seed_lookup")]),
+                 "rows_build": unit(rows, [k for k in rows if k.startswith("bucket_scatter")])},
        "kernels": kern}
 json.dump(rec, open(out + "/pmc_traffic.json", "w"), indent=1)
 for i, r in enumerate(csv.DictReader(open(ks))):
