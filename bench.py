@@ -431,7 +431,12 @@ def main():
                                ms=ms["rows_ms"], bytes=rows_bytes,
                                launches=float(len(stepper.resident)), pmc="rows_build"),
         }
-        dom = max(units_roof, key=lambda k: units_roof[k]["ms"])
+        # The dominant KERNEL: seed_verify4 is one kernel and has its own HIP-event
+        # timer; a solver round is 4 (flat) or 2 (fused) kernels, of which the
+        # largest takes ~0.3 of the round (rocprofv3: gr_claim 23.5 of 82.5 ms), and
+        # the row build is 6 -- so those units compete with that share of their time.
+        share = {"seed_verify": 1.0, "solver_rounds": 0.3, "rows_build": 0.45}
+        dom = max(units_roof, key=lambda k: units_roof[k]["ms"] * share[k])
         d = units_roof[dom]
         avg_ms = d["ms"] / max(d["launches"], 1)
         roof = dict(bound="hbm", kernel=d["kernel"], achieved=gbs(d["bytes"], d["ms"]),
