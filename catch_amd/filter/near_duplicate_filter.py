@@ -147,6 +147,9 @@ class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
         THIS process -- say so instead of silently computing the 3.10 answer."""
         import os
         import sys
+        if getattr(NearDuplicateFilterWithMinHash, "_warned", False):
+            return
+        NearDuplicateFilterWithMinHash._warned = True
         algo = getattr(sys.hash_info, "algorithm", "")
         seed = os.environ.get("PYTHONHASHSEED", "random")
         if algo != "siphash24" or seed != "0":

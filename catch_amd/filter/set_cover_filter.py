@@ -456,10 +456,15 @@ class SetCoverFilter(BaseFilter):
         # largest first (catch/filter/set_cover_filter.py:880-887); the random
         # anchors of a group are drawn when its turn comes, so that order is kept
         # only when no random numbers are involved
-        if not probe.anchors_use_random(["A" * probe_length], self.mismatches,
-                                        self.lcf_thres, self.kmer_probe_map_k):
+        # (nor while an LSH near-duplicate filter draws its positions / hash
+        # functions from `random` group after group)
+        if near_duplicate_filter is None and not probe.anchors_use_random(
+                ["A" * probe_length], self.mismatches, self.lcf_thres, self.kmer_probe_map_k):
             todo.sort(key=lambda i: (-sizes[i], i))
-        for chunk in _chunks_by_size(todo, lambda gi: sizes[gi], width):
+            chunks = _chunks_by_size(todo, lambda gi: sizes[gi], width)
+        else:
+            chunks = [todo[i:i + width] for i in range(0, len(todo), width)]
+        for chunk in chunks:
             ctxs = _contexts(len(chunk))
             specs, held, cands_of = [], [], []
             try:

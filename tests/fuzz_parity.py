@@ -44,14 +44,29 @@ def rand_group(rnd):
     return genomes
 
 
+SOLVER_ENV = ("CATCHHIP_FLAT_MIN_ROWS", "CATCHHIP_FLAT_STRIPED", "CATCHHIP_GF_LONG", "CATCHHIP_VERIFY_V1")
+
+
 def one_case(seed, ctx):
     rnd = random.Random(seed)
+    # which of the equivalent kernel families run (all must give the oracle's result)
+    for name in SOLVER_ENV:
+        os.environ.pop(name, None)
+    variant = random.Random(seed * 7919 + 13).choice(["default", "flat", "flat_striped", "long", "verify_v1"])
+    if variant.startswith("flat"):
+        os.environ["CATCHHIP_FLAT_MIN_ROWS"] = "0"
+        if variant == "flat_striped":
+            os.environ["CATCHHIP_FLAT_STRIPED"] = "1"
+    elif variant == "long":
+        os.environ["CATCHHIP_GF_LONG"] = "1"
+    elif variant == "verify_v1":
+        os.environ["CATCHHIP_VERIFY_V1"] = "1"
     L = rnd.choice([40, 60, 75, 100, 120])
     stride = rnd.choice([L // 4, L // 2, L])
     m = rnd.choice([0, 1, 2, 3, 5])
     thres = L if rnd.random() < 0.7 else rnd.randrange(L // 2, L)
     island = 0 if rnd.random() < 0.8 else rnd.randrange(5, 30)
-    ext = rnd.choice([0, 0, 10, 50])
+    ext = rnd.choice([0, 0, 10, 50, 50, 120])
     coverage = rnd.choice([1.0, 1.0, 1.0, 0.9, 0.5])
     groups = [rand_group(rnd) for _ in range(rnd.randrange(1, 4))]
     cands = []
@@ -65,7 +80,7 @@ def one_case(seed, ctx):
             c = list(dict.fromkeys(c))
         cands.append(c)
     np_seed = rnd.randrange(1 << 30)
-    desc = dict(seed=seed, L=L, stride=stride, m=m, thres=thres, island=island, ext=ext,
+    desc = dict(seed=seed, variant=variant, L=L, stride=stride, m=m, thres=thres, island=island, ext=ext,
                 coverage=coverage, groups=[(len(g), sum(len(s) for gen in g for s in gen)) for g in groups])
     np.random.seed(np_seed)
     want = oracle.set_cover_filter(cands, groups, m, thres, island=island, coverage=coverage,
@@ -96,6 +111,33 @@ def one_case(seed, ctx):
         got_rows = sorted(zip(a[0].tolist(), a[1].tolist(), a[2].tolist(), a[3].tolist()))
         rows.close(); p.close(); t.close()
         assert got_rows == exp, (desc, mode)
+    # the first group with its universes sharded 2 and 3 ways (full coverage, short rows)
+    from catch_amd import parallel
+    np.random.seed(np_seed)
+    kk, uq, ow, ep, eo = probe.anchor_table(cands[0], m, thres)
+    if thres == L and island == 0 and L + 2 * ext <= 250 and len(groups[0]) >= 2:
+        p = engine.Probes(ctx, uq, ow, ep, eo, kk)
+        t = engine.Targets(ctx, groups[0])
+        rows = engine.Rows.scan(ctx, p, t, m, thres, island, ext)
+        a = rows.fetch()
+        ok_len = a[0].size == 0 or int((a[3] - a[2]).max()) <= 257
+        whole = rows.greedy(len(cands[0]))
+        rows.close(); t.close()
+        if ok_len:
+            lens = [sum(len(x) for x in gen) for gen in groups[0]]
+            for world in (2, 3):
+                b = parallel.split_universes(lens, world)
+                held, shards = [], []
+                for v in range(world):
+                    tv = engine.Targets(ctx, groups[0][b[v]:b[v + 1]])
+                    rv = engine.Rows.scan(ctx, p, tv, m, thres, island, ext)
+                    held += [tv, rv]
+                    shards.append(engine.Shard(rv, len(cands[0])))
+                got_s = parallel.sharded_solve(shards, lambda w: engine.shards_allreduce_local(shards, w))
+                for h in shards + held[::-1]:
+                    h.close()
+                assert got_s == whole, (desc, "sharded", world)
+        p.close()
     # near-duplicate filters on the first group's candidates (equal lengths)
     strs = [s for s in cands[0] if len(s) == L][:1500]
     if len(strs) > 3:
