@@ -35,6 +35,9 @@ PROTOTYPES = {
     "catchhip_ctx_last_counters": (ctypes.c_int, [c_vp, c_i64p]),
     "catchhip_targets_create": (ctypes.c_int, [
         c_vp, c_u8p, c_i64p, c_i32p, ctypes.c_int64, ctypes.c_int32, c_vpp]),
+    "catchhip_targets_create_ptrs": (ctypes.c_int, [
+        c_vp, ctypes.POINTER(ctypes.c_void_p), c_i64p, c_i32p, ctypes.c_int64,
+        ctypes.c_int32, c_vpp]),
     "catchhip_targets_destroy": (ctypes.c_int, [c_vp]),
     "catchhip_probes_create": (ctypes.c_int, [
         c_vp, c_u8p, c_i64p, ctypes.c_int64, c_i32p, c_i32p, c_i32p,

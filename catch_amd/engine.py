@@ -30,6 +30,33 @@ def _concat(strs):
     return np.ascontiguousarray(buf), off
 
 
+_as_utf8 = None
+
+
+def _str_pointers(strs):
+    """(void*[n], int64 lengths) of the strings' own byte storage, or None when
+    some string is not plain ASCII (then the caller concatenates instead).
+    CPython keeps an ASCII str as one byte per character and
+    PyUnicode_AsUTF8AndSize hands out that buffer without a copy; it stays valid
+    while the str is alive, i.e. for the duration of the call it is passed to."""
+    global _as_utf8
+    if _as_utf8 is None:
+        _as_utf8 = ctypes.pythonapi.PyUnicode_AsUTF8AndSize
+        _as_utf8.restype = ctypes.c_void_p
+        _as_utf8.argtypes = [ctypes.py_object, ctypes.POINTER(ctypes.c_ssize_t)]
+    n = len(strs)
+    arr = (ctypes.c_void_p * n)()
+    lens = np.zeros(n, dtype=np.int64)
+    size = ctypes.c_ssize_t(0)
+    ref = ctypes.byref(size)
+    for i, s in enumerate(strs):
+        if not isinstance(s, str) or not s.isascii():
+            return None
+        arr[i] = _as_utf8(s, ref)
+        lens[i] = size.value
+    return arr, lens
+
+
 def device_count():
     n = ctypes.c_int(0)
     rc = _lib.lib().catchhip_device_count(ctypes.byref(n))
@@ -167,18 +194,29 @@ class Targets:
             for s in g:
                 seqs.append(s)
                 sg.append(j)
-        buf, off = _concat(seqs)
         sgn = np.asarray(sg, dtype=np.int32)
         if sgn.size == 0:
             sgn = np.zeros(1, dtype=np.int32)
         self.nseq = len(seqs)
         self.ngenomes = len(genomes)
+        self._h = ctypes.c_void_p()
+        ptrs = _str_pointers(seqs) if len(seqs) else None
+        if ptrs is not None:
+            # one pointer per sequence: the library gathers them into pinned
+            # memory itself (no 600 MB join + encode on the Python side)
+            parr, lens = ptrs
+            off = np.zeros(len(seqs) + 1, dtype=np.int64)
+            np.cumsum(lens, out=off[1:])
+            check(ctx._L.catchhip_targets_create_ptrs(
+                ctx._h, parr, _ptr(lens, c_i64p), _ptr(sgn, c_i32p), self.nseq,
+                self.ngenomes, ctypes.byref(self._h)))
+        else:
+            buf, off = _concat(seqs)
+            check(ctx._L.catchhip_targets_create(
+                ctx._h, _ptr(buf, c_u8p), _ptr(off, c_i64p), _ptr(sgn, c_i32p),
+                self.nseq, self.ngenomes, ctypes.byref(self._h)))
         self.total = int(off[-1])
         self.seq_off = off      # global start of every sequence (+ total)
-        self._h = ctypes.c_void_p()
-        check(ctx._L.catchhip_targets_create(
-            ctx._h, _ptr(buf, c_u8p), _ptr(off, c_i64p), _ptr(sgn, c_i32p),
-            self.nseq, self.ngenomes, ctypes.byref(self._h)))
 
     def set_groups(self, group_of_genome):
         """catchhip_targets_set_groups (one entry per genome)."""

@@ -83,6 +83,14 @@ int catchhip_targets_create(catchhip_ctx *ctx, const uint8_t *bytes,
                             const int64_t *seq_off, const int32_t *seq_genome,
                             int64_t nseq, int32_t ngenomes,
                             catchhip_targets **out);
+/* The same targets from one pointer per sequence (seq_ptr[i], seq_len[i] bytes
+ * each; what a host that keeps its sequences as separate strings has): the
+ * library gathers them into pinned memory with a few threads and uploads from
+ * there, instead of the caller concatenating them first. */
+int catchhip_targets_create_ptrs(catchhip_ctx *ctx, const uint8_t *const *seq_ptr,
+                                 const int64_t *seq_len, const int32_t *seq_genome,
+                                 int64_t nseq, int32_t ngenomes,
+                                 catchhip_targets **out);
 int catchhip_targets_destroy(catchhip_targets *t);
 
 /* Candidate probes + their seed ("anchor") table, i.e. the content of the
