@@ -87,6 +87,7 @@ PROTOTYPES = {
     "catchhip_shard_apply": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int32)]),
     "catchhip_shard_buffers": (ctypes.c_int, [c_vp, c_vpp, c_i64p, c_vpp, c_i64p]),
     "catchhip_shard_picks": (ctypes.c_int, [c_vp, c_i64p, c_i64p]),
+    "catchhip_shard_info": (ctypes.c_int, [c_vp, c_i64p]),
     "catchhip_shard_allreduce": (ctypes.c_int, [c_vp, ctypes.c_int32]),
     "catchhip_shard_buffer_copy": (ctypes.c_int, [c_vp, ctypes.c_int32, c_vp, ctypes.c_int32]),
     "catchhip_shard_allreduce_local": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(c_vp), ctypes.c_int32]),

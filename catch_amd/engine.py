@@ -548,16 +548,21 @@ class Shard:
         """RCCL exchange on the context's communicator (0 gain, 1 lost)."""
         check(self.ctx._L.catchhip_shard_allreduce(self._h, int(which)))
 
+    def _lost_dtype(self):
+        info = np.zeros(4, dtype=np.int64)
+        check(self.ctx._L.catchhip_shard_info(self._h, _ptr(info, c_i64p)))
+        return np.uint32 if info[2] == 4 else np.uint8
+
     def buffer_to_host(self, which):
-        """The gain (uint32[num_sets + 2]) or lost (uint8[num_sets]) buffer."""
+        """The gain (uint32[num_sets + 2]) or lost (uint8 or uint32 [num_sets]) buffer."""
         out = (np.zeros(self.num_sets + 2, dtype=np.uint32) if which == 0
-               else np.zeros(self.num_sets, dtype=np.uint8))
+               else np.zeros(self.num_sets, dtype=self._lost_dtype()))
         check(self.ctx._L.catchhip_shard_buffer_copy(
             self._h, int(which), out.ctypes.data_as(ctypes.c_void_p), 1))
         return out
 
     def buffer_from_host(self, which, arr):
-        a = np.ascontiguousarray(arr, dtype=np.uint32 if which == 0 else np.uint8)
+        a = np.ascontiguousarray(arr, dtype=np.uint32 if which == 0 else self._lost_dtype())
         assert a.size == (self.num_sets + 2 if which == 0 else self.num_sets)
         check(self.ctx._L.catchhip_shard_buffer_copy(
             self._h, int(which), a.ctypes.data_as(ctypes.c_void_p), 0))

@@ -247,7 +247,9 @@ int catchhip_comm_destroy(catchhip_ctx *ctx);
  * universe must be fully covered (p == 1) and rows at most 257 bases; other
  * instances are solved whole on one rank (catch_amd/parallel.py).
  * catchhip_shard_buffers exposes the two exchange buffers (device pointers:
- * uint32[gain_count], uint8[lost_count]) for callers with their own transport. */
+ * uint32[gain_count], lost_count elements of catchhip_shard_info's width; the
+ * gain buffer alternates between rounds: ask again every round) for callers
+ * with their own transport. */
 typedef struct catchhip_shard catchhip_shard;
 int catchhip_shard_create(catchhip_ctx *ctx, const catchhip_rows *rows,
                           int64_t num_sets, const int64_t *ranks,
@@ -261,6 +263,10 @@ int catchhip_shard_buffers(catchhip_shard *shard, void **gain,
                            int64_t *lost_count);
 int catchhip_shard_picks(catchhip_shard *shard, int64_t *out_ids,
                          int64_t *n_out);
+/* out4 = {elements of the gain buffer (uint32), elements of the lost buffer,
+ * bytes per lost element (1: flags; 4: round marks of the row-parallel
+ * kernels large shards use), 1 if those kernels run}. */
+int catchhip_shard_info(catchhip_shard *shard, int64_t *out4);
 /* which: 0 = gain buffer (SUM), 1 = lost buffer (MAX).  _allreduce uses the
  * context's RCCL communicator (stream-ordered); _allreduce_local reduces the
  * buffers of n shards that live in this process on one device. */

@@ -44,7 +44,8 @@ def rand_group(rnd):
     return genomes
 
 
-SOLVER_ENV = ("CATCHHIP_FLAT_MIN_ROWS", "CATCHHIP_FLAT_STRIPED", "CATCHHIP_GF_LONG", "CATCHHIP_VERIFY_V1")
+SOLVER_ENV = ("CATCHHIP_FLAT_MIN_ROWS", "CATCHHIP_FLAT_STRIPED", "CATCHHIP_GF_LONG", "CATCHHIP_VERIFY_V1",
+              "CATCHHIP_SHARD_FLAT")
 
 
 def one_case(seed, ctx):
@@ -53,6 +54,7 @@ def one_case(seed, ctx):
     for name in SOLVER_ENV:
         os.environ.pop(name, None)
     variant = random.Random(seed * 7919 + 13).choice(["default", "flat", "flat_striped", "long", "verify_v1"])
+    os.environ["CATCHHIP_SHARD_FLAT"] = "1" if seed % 2 else "0"
     if variant.startswith("flat"):
         os.environ["CATCHHIP_FLAT_MIN_ROWS"] = "0"
         if variant == "flat_striped":

@@ -570,14 +570,18 @@ def _sharded_picks(engine, ctx, probes, genomes, bounds, n_sets, ranks, exchange
             h.close()
 
 
+@pytest.mark.parametrize("flat", ["0", "1"])
 @pytest.mark.parametrize("with_ranks", [False, True])
-def test_universe_sharded_solver_equals_unsharded(ctx, oracle, with_ranks):
+def test_universe_sharded_solver_equals_unsharded(ctx, oracle, monkeypatch, with_ranks, flat):
     """One group cut into 1, 2, 3 and 5 universe ranges (split_universes), each
     scanned and held by its own shard, solved in rounds with the two
     all-reduces per round (here: between shards of this process): the picks
     and their order equal the unsharded solver's and the oracle's."""
     from catch_amd import parallel
     engine, probe = _engine(), _probe_mod()
+    # both kernel families behind the shard API: set-parallel (small instances)
+    # and row-parallel tile-ordered (what an instance worth sharding takes)
+    monkeypatch.setenv("CATCHHIP_SHARD_FLAT", flat)
     rng = np.random.Generator(np.random.PCG64(99))
     from catch_amd.utils import synthetic
     genomes = synthetic.make_species(rng, [6000], 23, 3, 0.06, 0.012)
