@@ -63,13 +63,14 @@ def _short_sequence(seq, L, min_n, allow_small_seqs):
 
 
 def _check_list(seqs):
-    if not isinstance(seqs, list):
-        raise TypeError("seqs must be a list of sequences")
-    if not seqs:
-        raise ValueError("seqs must have at least one sequence")
-    for seq in seqs:
-        if not isinstance(seq, str):
-            raise TypeError("seqs must be a list of Python strings")
+    """Same exception types as the reference for the same mistakes (:150-160)."""
+    if type(seqs) is not list and not isinstance(seqs, list):
+        raise TypeError("expected a list of sequence strings, got %s" % type(seqs).__name__)
+    if len(seqs) == 0:
+        raise ValueError("no sequences to make candidate probes from")
+    bad = next((x for x in seqs if not isinstance(x, str)), None)
+    if bad is not None:
+        raise TypeError("every sequence must be a str, found %s" % type(bad).__name__)
 
 
 def candidate_strings_from_sequences(seqs, probe_length, probe_stride,
