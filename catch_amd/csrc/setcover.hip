@@ -115,9 +115,16 @@ __device__ __forceinline__ u32 range_popcount_l2(const unsigned long long *bm, u
 // look-up per lane whatever its width (the round kernels are bound by that
 // rate).  p is 8-byte aligned; the arrays have >= 8 words of slack at the end.
 struct __attribute__((aligned(8))) u64x2 { unsigned long long a, b; };
-__device__ __forceinline__ void load_words5(const unsigned long long *p, unsigned long long (&v)[RP_MAXW]) {
-    const u64x2 q0 = *(const u64x2 *)p, q1 = *(const u64x2 *)(p + 2);
-    v[0] = q0.a; v[1] = q0.b; v[2] = q1.a; v[3] = q1.b; v[4] = p[4];
+// Only the loads that hold a word flagged in fl are issued (the others read as
+// 0): a lane that sits out a load costs no look-up, and a 200-base row spans
+// four words nine times out of ten, so the third load is rarely needed.
+__device__ __forceinline__ void load_words5(const unsigned long long *p, unsigned long long (&v)[RP_MAXW], u32 fl) {
+    u64x2 q0 = {0ull, 0ull}, q1 = {0ull, 0ull};
+    unsigned long long q2 = 0ull;
+    if (fl & 0x03u) q0 = *(const u64x2 *)p;
+    if (fl & 0x0cu) q1 = *(const u64x2 *)(p + 2);
+    if (fl & 0x10u) q2 = p[4];
+    v[0] = q0.a; v[1] = q0.b; v[2] = q1.a; v[3] = q1.b; v[4] = q2;
 }
 
 // ------------------------------------------------------------------------
