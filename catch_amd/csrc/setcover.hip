@@ -810,7 +810,7 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     const size_t o_bm = take(8 * (nwords + 8)), o_ow0 = take(8 * (nwords + 8)), o_ow1 = take(8 * (nwords + 8)),
                  o_blk = take(16 * (size_t)gblocks), o_st = take(sizeof(GreedyState)),
                  o_picked = take(4 * (size_t)nsets), o_claimed = take(4 * (size_t)nsets),
-                 o_rank = take(4 * (size_t)nsets);
+                 o_lost = take(4 * (size_t)nsets), o_rank = take(4 * (size_t)nsets);
     const size_t zero_bytes = off;
     const size_t o_usize = take(4 * (size_t)nuniv), o_gain = take(4 * (size_t)nsets),
                  o_setptr = take(4 * ((size_t)nsets + 1)), o_frow = take(8 * (size_t)nrows),
@@ -834,6 +834,7 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     fa.owner[0] = (unsigned long long *)(A + o_ow0); fa.owner[1] = (unsigned long long *)(A + o_ow1);
     fa.frow = (const uint2 *)(A + o_frow); fa.row_univ = (const i32 *)R->univ.p; fa.set_ptr = (const u32 *)(A + o_setptr); fa.rank = (const u32 *)(A + o_rank);
     fa.usize = (u32 *)(A + o_usize); fa.gain = (u32 *)(A + o_gain); fa.claimed = (u32 *)(A + o_claimed);
+    fa.lost = (u32 *)(A + o_lost);
     fa.picked = (u32 *)(A + o_picked); fa.picks = (u32 *)(A + o_picks);
     fa.pick_key = (unsigned long long *)(A + o_keys); fa.rowflag = A + o_flag;
     fa.blkcnt = (unsigned long long *)(A + o_blk); fa.st = (GreedyState *)(A + o_st);
