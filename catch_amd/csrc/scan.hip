@@ -353,8 +353,7 @@ seed_verify_kernel(const u32 *__restrict__ tplanes, i64 nwords, const u32 *__res
                 if (mask_range_zero<NW>(mw, (int)ent_pos[j], k)) ok = false;
         }
     }
-    if (ok) hit_record(sink, d, p, o, o + (u32)L, sq, lo, hi);
-    else sink.rank[d] = BK_NONE;
+    hit_file(sink, d, ok, p, o, o + (u32)L, sq, lo, hi);
 }
 
 // ---- cooperative verify: 4 lanes per seed ---------------------------------
@@ -502,8 +501,7 @@ seed_verify4_kernel(const uint4 *__restrict__ tq, const u32 *__restrict__ seq_of
     if (d < nseeds) {
         const u32 q = lane >> 4;
         const unsigned long long v = q == 0 ? verdict[0] : q == 1 ? verdict[1] : q == 2 ? verdict[2] : verdict[3];
-        if ((v >> ((lane & 15) * 4)) & 1ull) hit_record(sink, d, p, o, o + (u32)L, sq, lo, hi);
-        else sink.rank[d] = BK_NONE;
+        hit_file(sink, d, (v >> ((lane & 15) * 4)) & 1ull, p, o, o + (u32)L, sq, lo, hi);
     }
 }
 
@@ -1258,7 +1256,8 @@ static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchh
 struct BucketBuild {
     DevBuf<uint4> rec;
     DevBuf<uint4> S;   // hits grouped by bucket, then the merged rows, {start, end, segment, bucket}
-    DevBuf<u32> rank, bcnt, bstart, mcnt, blmax, rstart, res, tsum, tamax;
+    DevBuf<u32> rank, bcnt, bstart, mcnt, blmax, rstart, res, tsum, tamax, wcnt;
+    bool compact = false;   // the producer files its hits compactly (HitSink::wcnt)
     DevBuf<unsigned long long> bsum;
     u32 nb = 0, cap = 0;
 };
@@ -1269,6 +1268,8 @@ static int bucket_prepare(BucketBuild &B, u32 nb, u32 cap, bool want_sum) {
     B.nb = nb; B.cap = cap;
     TRY(B.rec.reserve(cap));
     TRY(B.rank.reserve(cap));
+    TRY(B.wcnt.reserve((size_t)cap / 64 + 2));
+    B.compact = false;
     TRY(B.S.reserve(cap));
     TRY(B.bcnt.reserve((size_t)nb + 1));
     TRY(B.bstart.reserve((size_t)nb + 2));
@@ -1314,7 +1315,7 @@ static int bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, cons
     if (nrec)
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)div_up((i64)nrec, 256)), dim3(256), 0, s,
                            (const uint4 *)B.rec.p, (const u32 *)B.rank.p, nrec, nrec_dev, (const u32 *)B.bstart.p,
-                           B.S.p);
+                           B.S.p, B.compact ? (const u32 *)B.wcnt.p : (const u32 *)nullptr);
     unsigned long long *bsum = want_sum ? B.bsum.p : nullptr;
     hipLaunchKernelGGL((bucket_merge_kernel<64, BK_SMALL>), dim3((unsigned)std::min<i64>(B.nb, (i64)1 << 20)), dim3(64),
                        0, s, (const u32 *)B.bstart.p, B.nb, B.S.p, B.mcnt.p, B.blmax.p, bsum,
@@ -1338,10 +1339,12 @@ static int bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, cons
 __global__ void __launch_bounds__(256)
 rec_keys_kernel(const uint4 *__restrict__ rec, const u32 *__restrict__ rank, u32 nrec_cap,
                 const u32 *__restrict__ nrec_dev, const u32 *__restrict__ bstart,
-                const i32 *__restrict__ bucket_set, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+                const i32 *__restrict__ bucket_set, u64 *__restrict__ keys, u32 *__restrict__ vals,
+                const u32 *__restrict__ wcnt) {
     const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 n = nrec_dev ? min(*nrec_dev, nrec_cap) : nrec_cap;
     if (d >= n) return;
+    if (wcnt && (d & 63u) >= wcnt[d >> 6]) return;
     const u32 rk = rank[d];
     if (rk == BK_NONE) return;
     const uint4 r = rec[d];
@@ -1368,7 +1371,7 @@ static int build_rows_radix(catchhip_ctx *ctx, const BucketBuild &B, u32 nrec, c
     TRY(M.vals.alloc(n));
     hipLaunchKernelGGL(rec_keys_kernel, dim3((unsigned)div_up((i64)nrec, 256)), dim3(256), 0, ctx->stream,
                        (const uint4 *)B.rec.p, (const u32 *)B.rank.p, nrec, nrec_dev, (const u32 *)B.bstart.p,
-                       bucket_set, M.keys.p, M.vals.p);
+                       bucket_set, M.keys.p, M.vals.p, B.compact ? (const u32 *)B.wcnt.p : (const u32 *)nullptr);
     tm.launch();
     int bits = 32 + ceil_log2_u64((u64)max_set_id + 1);
     if (bits > 64) bits = 64;
@@ -1440,6 +1443,9 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
             const auto dbg0 = std::chrono::steady_clock::now();
             TRY(bucket_prepare(O.B, nb, O.S.scap, by_sequence));
             sink.rec = O.B.rec.p; sink.rank = O.B.rank.p; sink.bcnt = O.B.bcnt.p;
+            // (the first-discovery keys pair record d with seed d: not compact then)
+            O.B.compact = !want_first && !getenv("CATCHHIP_HITS_SPARSE");
+            sink.wcnt = O.B.compact ? O.B.wcnt.p : nullptr;
             ts.restart();
             TRY(run_seed_async(ctx, P, T, mismatches, O.S, sink, nb, O.B.res.p, ts));
             if (getenv("CATCHHIP_TIMING"))
@@ -1532,6 +1538,8 @@ int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const ca
     if (P->has_groups) { sink.probe_group = P->group.p; sink.seq_group = T->seq_group.p; }
     TRY(bucket_prepare(O.B, nb, O.S.scap, false));
     sink.rec = O.B.rec.p; sink.rank = O.B.rank.p; sink.bcnt = O.B.bcnt.p;
+    O.B.compact = true;
+    sink.wcnt = O.B.wcnt.p;
     catchhip_rows *R = new catchhip_rows();
     R->ctx = ctx;
     R->total = T->total;
