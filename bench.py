@@ -422,7 +422,7 @@ def main():
             "seed_verify": dict(kernel="seed_verify4_kernel<%d>" % -(-PROBE_LEN // 32),
                                 ms=ms["verify_ms"], bytes=verify_bytes,
                                 launches=nlaunch["verify_launches"] / K, pmc="seed_verify"),
-            "solver_rounds": dict(kernel="frontier solver round: gr_count+gr_claim+gr_check+gr_apply (flat, >= 4 M "
+            "solver_rounds": dict(kernel="frontier solver round: gr_count+gr_claim+gr_apply (flat, >= 4 M "
                                          "rows) / gf_count_claim+gf_check_apply (fused)",
                                   ms=ms["rounds_ms"], bytes=k2_bytes,
                                   launches=max(nlaunch["rounds_launches"] // 2, 1) / K,
@@ -432,10 +432,11 @@ def main():
                                launches=float(len(stepper.resident)), pmc="rows_build"),
         }
         # The dominant KERNEL: seed_verify4 is one kernel and has its own HIP-event
-        # timer; a solver round is 4 (flat) or 2 (fused) kernels, of which the
-        # largest takes ~0.3 of the round (rocprofv3: gr_claim 23.5 of 82.5 ms), and
-        # the row build is 6 -- so those units compete with that share of their time.
-        share = {"seed_verify": 1.0, "solver_rounds": 0.3, "rows_build": 0.45}
+        # timer; a solver round is 3 (flat) or 2 (fused) kernels, of which the
+        # largest takes ~0.4 of the rounds (rocprofv3: gr_claim 29 of 73 ms), and
+        # the row build is 6 (the scatter ~0.55 of it) -- so those units compete
+        # with that share of their time.
+        share = {"seed_verify": 1.0, "solver_rounds": 0.4, "rows_build": 0.55}
         dom = max(units_roof, key=lambda k: units_roof[k]["ms"] * share[k])
         d = units_roof[dom]
         avg_ms = d["ms"] / max(d["launches"], 1)
@@ -446,7 +447,7 @@ def main():
                     avg_launch_ms=avg_ms, launches_per_step=d["launches"],
                     device_ms_per_step=d["ms"])
         if dom == "solver_rounds":
-            roof["launches_are"] = ("rounds (one count launch with its claim / check / apply "
+            roof["launches_are"] = ("rounds (one count launch with its claim / apply "
                                     "launches), including the no-op rounds queued after the last one")
         out = {
             "metric": "candidate-probe x target-bp / s through SetCoverFilter "

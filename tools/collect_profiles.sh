@@ -62,7 +62,7 @@ verify = [k for k in kern if k.startswith("seed_verify")]
 rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
                "'python bench.py --workload %s --steps 2 --warmup 1 --no-cpu-baseline'; KB per launch averaged over "
                "the launches of the run (all groups, all rounds); a unit = total KB of its kernels / launches of its "
-               "leading kernel(s) (a solver round = one count launch with its claim / check / apply launches); on "
+               "leading kernel(s) (a solver round = one count launch with its claim / apply launches); on "
                "gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md), bench.py doubles it; "
                "other widths and WRITE_SIZE are uncalibrated" % wl,
        "workload": wl,
