@@ -135,6 +135,9 @@ class Context:
             os.close(saved)
         check(rc)
 
+    def comm_destroy(self):
+        check(self._L.catchhip_comm_destroy(self._h))
+
     # -- near-duplicate filter --------------------------------------------
     def ndf_hamming(self, probe_strs, L, positions, dist_thres):
         n = len(probe_strs)

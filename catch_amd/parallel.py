@@ -197,7 +197,23 @@ def init_from_env():
     comm_ctx = engine.Context(device)
     rccl = os.environ.get("CATCHHIP_EXCHANGE", "rccl") != "gloo"
     if rccl:
-        comm_ctx.comm_init(ids[0], size, rank)
+        # RCCL refuses e.g. two ranks on one device; the ranks then agree (over gloo)
+        # to exchange through the host instead of dying one by one
+        err = None
+        try:
+            comm_ctx.comm_init(ids[0], size, rank)
+        except Exception as exc:   # noqa: BLE001 -- whatever the C ABI maps the RCCL error to
+            err = "%s: %s" % (type(exc).__name__, exc)
+        errs = [None] * size
+        dist.all_gather_object(errs, err)
+        if any(e is not None for e in errs):
+            if err is None:
+                comm_ctx.comm_destroy()
+            if rank == 0:
+                print("catch_amd.parallel: RCCL communicator not available (%s); the solver rounds "
+                      "exchange through host memory over gloo" % next(e for e in errs if e is not None),
+                      file=sys.stderr)
+            rccl = False
     _world = World(rank, size, dist, comm_ctx, rccl)
     return _world
 
