@@ -93,27 +93,35 @@ def sharded_solve(shards, exchange):
     return out[0]
 
 
-def plan_with_sharding(group_costs, world, min_cost=0):
-    """Two-level plan.  A group whose cost exceeds an even share of the total
-    (and min_cost) is SHARDED over all ranks (every rank takes 1/world of it);
-    the others go whole to ranks, longest first, onto the least loaded rank.
+def plan_with_sharding(group_costs, world, min_cost=0, slack=1.08):
+    """Two-level plan.  Groups are SHARDED over all ranks (every rank takes
+    1/world of each) until the others -- whole groups, longest first onto the
+    least loaded rank -- leave the busiest rank within `slack` of an even share:
+    the largest whole group of at least min_cost is sharded next as long as
+    they do not.  (A group above an even share always ends up sharded; so does
+    e.g. S4's 265-Mbase group on 2 ranks, 45 % of the work, which whole would
+    leave the ranks at 265 : 327.)
     Returns (sharded: list of group indices, whole: world lists of indices)."""
     costs = list(group_costs)
     if world <= 1:
         return [], [sorted(range(len(costs)), key=lambda i: (-costs[i], i))]
-    share = sum(costs) / float(world)
-    sharded = [i for i in range(len(costs))
-               if costs[i] > share and costs[i] >= min_cost and costs[i] > 0]
-    rest = [i for i in range(len(costs)) if i not in set(sharded)]
-    order = sorted(rest, key=lambda i: (-costs[i], i))
-    base = sum(costs[i] for i in sharded) / float(world)
-    heap = [(base, b) for b in range(world)]
-    bins = [[] for _ in range(world)]
-    for i in order:
-        load, b = heapq.heappop(heap)
-        bins[b].append(i)
-        heapq.heappush(heap, (load + costs[i], b))
-    return sharded, bins
+    even = sum(costs) / float(world)
+    sharded = set()
+    while True:
+        rest = [i for i in range(len(costs)) if i not in sharded]
+        order = sorted(rest, key=lambda i: (-costs[i], i))
+        base = sum(costs[i] for i in sharded) / float(world)
+        heap = [(base, b) for b in range(world)]
+        bins = [[] for _ in range(world)]
+        for i in order:
+            load, b = heapq.heappop(heap)
+            bins[b].append(i)
+            heapq.heappush(heap, (load + costs[i], b))
+        busiest = max(load for load, _ in heap)
+        cand = [i for i in order if costs[i] >= min_cost and costs[i] > 0]
+        if not cand or busiest <= slack * even:
+            return sorted(sharded), bins
+        sharded.add(cand[0])
 
 
 # ---------------------------------------------------------------------------
