@@ -551,24 +551,30 @@ class Shard:
         """RCCL exchange on the context's communicator (0 gain, 1 lost)."""
         check(self.ctx._L.catchhip_shard_allreduce(self._h, int(which)))
 
-    def _lost_dtype(self):
+    def _exchange_shape(self):
+        """(gain elements, lost elements, lost dtype) of the NEXT exchange: shards
+        that run the flat kernels pack their buffers (only the sets still alive
+        travel), so the sizes change from round to round."""
         info = np.zeros(4, dtype=np.int64)
         check(self.ctx._L.catchhip_shard_info(self._h, _ptr(info, c_i64p)))
-        return np.uint32 if info[2] == 4 else np.uint8
+        return int(info[0]), int(info[1]), (np.uint32 if info[2] == 4 else np.uint8)
 
     def buffer_to_host(self, which):
-        """The gain (uint32[num_sets + 2]) or lost (uint8 or uint32 [num_sets]) buffer."""
-        out = (np.zeros(self.num_sets + 2, dtype=np.uint32) if which == 0
-               else np.zeros(self.num_sets, dtype=self._lost_dtype()))
-        check(self.ctx._L.catchhip_shard_buffer_copy(
-            self._h, int(which), out.ctypes.data_as(ctypes.c_void_p), 1))
+        """The gain (uint32) or lost (uint8) exchange buffer."""
+        ng, nl, ldt = self._exchange_shape()
+        out = np.zeros(ng, dtype=np.uint32) if which == 0 else np.zeros(nl, dtype=ldt)
+        if out.size:
+            check(self.ctx._L.catchhip_shard_buffer_copy(
+                self._h, int(which), out.ctypes.data_as(ctypes.c_void_p), 1))
         return out
 
     def buffer_from_host(self, which, arr):
-        a = np.ascontiguousarray(arr, dtype=np.uint32 if which == 0 else self._lost_dtype())
-        assert a.size == (self.num_sets + 2 if which == 0 else self.num_sets)
-        check(self.ctx._L.catchhip_shard_buffer_copy(
-            self._h, int(which), a.ctypes.data_as(ctypes.c_void_p), 0))
+        ng, nl, ldt = self._exchange_shape()
+        a = np.ascontiguousarray(arr, dtype=np.uint32 if which == 0 else ldt)
+        assert a.size == (ng if which == 0 else nl)
+        if a.size:
+            check(self.ctx._L.catchhip_shard_buffer_copy(
+                self._h, int(which), a.ctypes.data_as(ctypes.c_void_p), 0))
 
     def picks(self):
         out = np.zeros(max(self.num_sets, 1), dtype=np.int64)

@@ -235,7 +235,7 @@ def host_exchange(dist, shards, which):
     acc = bufs[0].astype(np.int64)
     for b in bufs[1:]:
         acc = acc + b if which == 0 else np.maximum(acc, b)
-    if dist is not None:
+    if dist is not None and acc.size:      # (the size is the same on every rank)
         import torch
         t = torch.from_numpy(acc)
         dist.all_reduce(t, op=dist.ReduceOp.SUM if which == 0 else dist.ReduceOp.MAX)

@@ -247,9 +247,13 @@ int catchhip_comm_destroy(catchhip_ctx *ctx);
  * universe must be fully covered (p == 1) and rows at most 257 bases; other
  * instances are solved whole on one rank (catch_amd/parallel.py).
  * catchhip_shard_buffers exposes the two exchange buffers (device pointers:
- * uint32[gain_count], lost_count elements of catchhip_shard_info's width; the
- * gain buffer alternates between rounds: ask again every round) for callers
- * with their own transport. */
+ * uint32[gain_count], uint8[lost_count]) for callers with their own
+ * transport.  Ask again before EVERY exchange: large shards pack their
+ * buffers -- only the sets whose global gain was still positive after the
+ * previous round (gains) / is positive in this one (marks) travel, in set
+ * order, a list every rank derives from the same all-reduced gains -- so the
+ * counts shrink from round to round (they are the same on every rank) and may
+ * reach 0, in which case there is nothing to exchange. */
 typedef struct catchhip_shard catchhip_shard;
 int catchhip_shard_create(catchhip_ctx *ctx, const catchhip_rows *rows,
                           int64_t num_sets, const int64_t *ranks,
@@ -263,9 +267,9 @@ int catchhip_shard_buffers(catchhip_shard *shard, void **gain,
                            int64_t *lost_count);
 int catchhip_shard_picks(catchhip_shard *shard, int64_t *out_ids,
                          int64_t *n_out);
-/* out4 = {elements of the gain buffer (uint32), elements of the lost buffer,
- * bytes per lost element (1: flags; 4: round marks of the row-parallel
- * kernels large shards use), 1 if those kernels run}. */
+/* out4 = {elements of the gain buffer (uint32) and of the lost buffer (uint8)
+ * in the NEXT exchange, bytes per lost element (1), 1 if the row-parallel
+ * kernels of large shards run}. */
 int catchhip_shard_info(catchhip_shard *shard, int64_t *out4);
 /* which: 0 = gain buffer (SUM), 1 = lost buffer (MAX).  _allreduce uses the
  * context's RCCL communicator (stream-ordered); _allreduce_local reduces the
