@@ -611,10 +611,14 @@ def test_universe_sharded_solver_equals_unsharded(ctx, oracle, monkeypatch, with
     p.close()
 
 
-def test_universe_sharded_solver_over_rccl_single_rank(oracle):
+@pytest.mark.parametrize("flat", ["0", "1"])
+def test_universe_sharded_solver_over_rccl_single_rank(oracle, monkeypatch, flat):
     """The same round loop with the exchanges going through RCCL
-    (catchhip_shard_allreduce) on a one-rank communicator."""
+    (catchhip_shard_allreduce) on a one-rank communicator; with the row-parallel
+    kernels the exchange is packed (only the sets still alive travel): its sizes
+    never grow, and what travels last is next to nothing."""
     engine, probe = _engine(), _probe_mod()
+    monkeypatch.setenv("CATCHHIP_SHARD_FLAT", flat)
     c2 = engine.Context(0)
     c2.comm_init(engine.Context.comm_unique_id(), 1, 0)
     genomes = small_species(seed=17, n=9, length=4000)
@@ -623,9 +627,24 @@ def test_universe_sharded_solver_over_rccl_single_rank(oracle):
     p = engine.Probes(c2, uniq, owner, ep, eo, k)
     sel = oracle.set_cover_filter([cand], [genomes], 2, 100, coverage=1.0,
                                   cover_extension=50, return_intermediate=True)[1][0]["picks"]
-    got = _sharded_picks(engine, c2, p, genomes, [0, len(genomes)], len(cand), None,
-                         lambda sh: (lambda w: [s.allreduce(w) for s in sh]))
+    shapes = []
+
+    def exchange_over_rccl(sh):
+        def ex(w):
+            shapes.append((w, sh[0]._exchange_shape()[w]))
+            for x in sh:
+                x.allreduce(w)
+        return ex
+    got = _sharded_picks(engine, c2, p, genomes, [0, len(genomes)], len(cand), None, exchange_over_rccl)
     assert got == sel
+    gains = [n for w, n in shapes if w == 0]
+    marks = [n for w, n in shapes if w == 1]
+    assert gains[0] == len(cand) + 2 and marks[0] <= len(cand)
+    if flat == "1":
+        assert all(a >= b for a, b in zip(gains, gains[1:])) and all(a >= b for a, b in zip(marks, marks[1:]))
+        assert gains[-1] < gains[0] // 4 and all(g == m + 2 for g, m in zip(gains[1:], marks))
+    else:
+        assert all(n == len(cand) + 2 for n in gains)
     p.close()
     c2.close()
 
