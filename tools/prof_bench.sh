@@ -2,7 +2,7 @@
 # usage (on the GPU box): tools/prof_bench.sh <tag>  -> gpurun_out/prof_<tag>/ + compact kernel table
 tag=${1:-x}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_$tag -- python /root/repo/bench.py --steps 10 --warmup 2 > /root/repo/gpurun_out/prof_$tag.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_$tag -- python /root/repo/bench.py --steps 10 --warmup 2 --no-overlap-figure > /root/repo/gpurun_out/prof_$tag.json 2>/dev/null
 cd /root/repo
 python - <<PY
 import csv,glob,json

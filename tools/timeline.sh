@@ -2,7 +2,7 @@
 # usage (GPU box): tools/timeline.sh <tag>  -> kernel timeline of the last solve of the bench
 tag=${1:-tl}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /root/repo/gpurun_out/tl_$tag -- python /root/repo/bench.py --steps 3 --warmup 1 $BENCH_ARGS > /root/repo/gpurun_out/tl_$tag.json 2>/dev/null
+rocprofv3 --kernel-trace --output-format csv -d /root/repo/gpurun_out/tl_$tag -- python /root/repo/bench.py --steps 3 --warmup 1 --no-overlap-figure $BENCH_ARGS > /root/repo/gpurun_out/tl_$tag.json 2>/dev/null
 cd /root/repo
 python - <<PY
 import csv,glob,json
