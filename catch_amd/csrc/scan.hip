@@ -99,12 +99,15 @@ __device__ __forceinline__ u32 full_mismatches(const u32 *__restrict__ tplanes, 
 // ------------------------------------------------------------------------
 #include "rows_bucket.inc"
 
+// A slot is 16 bytes: {key (8 B; open addressing, EMPTY = ~0), first index into
+// ents, count} -- the look-up's probe per target position is ONE 16-byte gather
+// (key and range used to be two arrays: two dependent gathers per position).
 struct SeedTable {
-    unsigned long long *keys;   // open addressing, EMPTY = ~0
+    uint4 *slot;                // {key lo, key hi, first, count}
     u32 *cnt;                   // per slot: entries with this key (build time)
-    uint2 *range;               // per slot: (first index into ents, count)
     u32 *ents;                  // entry ids (probe * nanchor + anchor) grouped by key
     u32 mask;                   // capacity - 1
+    __device__ __forceinline__ unsigned long long *key_at(u32 s) const { return (unsigned long long *)(slot + s); }
 };
 #define SEED_EMPTY 0xffffffffffffffffull
 
@@ -158,7 +161,7 @@ seed_count_kernel(const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent
                                    (__builtin_amdgcn_alignbit(w1.x, w0.x, sh) & m);
     u32 s = seed_hash(key) & t.mask;
     for (;;) {
-        const unsigned long long prev = atomicCAS(&t.keys[s], SEED_EMPTY, key);
+        const unsigned long long prev = atomicCAS(t.key_at(s), SEED_EMPTY, key);
         if (prev == SEED_EMPTY || prev == key) break;
         s = (s + 1) & t.mask;
     }
@@ -168,10 +171,10 @@ seed_count_kernel(const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent
 
 // one launch instead of five memsets
 __global__ void __launch_bounds__(256)
-seed_init_kernel(unsigned long long *__restrict__ keys, u32 *__restrict__ cnt, u32 capacity, u32 *__restrict__ ctr,
+seed_init_kernel(uint4 *__restrict__ slot, u32 *__restrict__ cnt, u32 capacity, u32 *__restrict__ ctr,
                  u32 *__restrict__ bcnt, u32 nb, u32 *__restrict__ res) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    for (u32 i = t; i < capacity; i += stride) { keys[i] = SEED_EMPTY; cnt[i] = 0; }
+    for (u32 i = t; i < capacity; i += stride) { slot[i] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u); cnt[i] = 0; }
     for (u32 i = t; i < nb; i += stride) bcnt[i] = 0;
     if (t < 8) { ctr[t & 3] = 0; res[t] = 0; }
 }
@@ -201,9 +204,11 @@ seed_alloc_kernel(SeedTable t, u32 *__restrict__ cursor) {
     __syncthreads();
     if (s0 + 3 <= t.mask) {
         const u32 b = s_base + woff + ex;
-        uint4 *r = (uint4 *)(t.range + s0);
-        r[0] = make_uint4(b, n.x, b + n.x, n.y);
-        r[1] = make_uint4(b + n.x + n.y, n.z, b + n.x + n.y + n.z, n.w);
+        uint2 *r = (uint2 *)(t.slot + s0);       // the (first, count) half of slots s0 .. s0 + 3
+        r[1] = make_uint2(b, n.x);
+        r[3] = make_uint2(b + n.x, n.y);
+        r[5] = make_uint2(b + n.x + n.y, n.z);
+        r[7] = make_uint2(b + n.x + n.y + n.z, n.w);
     }
 }
 
@@ -215,7 +220,7 @@ seed_fill_kernel(u32 nent, SeedTable t, const u32 *__restrict__ slot_of) {
     const u32 s = slot_of[e];
     if (s == SEED_SKIP) return;
     const u32 j = atomicSub(&t.cnt[s], 1u) - 1u;
-    t.ents[t.range[s].x + j] = e;
+    t.ents[t.slot[s].z + j] = e;
 }
 
 // scan 1/2: every target position looks its k-mer up; the matching anchors
@@ -246,8 +251,9 @@ seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const
             const unsigned long long key = plane_key(tplanes, tplanes + nwords, i, kb);
             u32 s = seed_hash(key) & t.mask;
             for (;;) {
-                const unsigned long long ks = t.keys[s];   // written by the table-build launches
-                if (ks == key) { r = t.range[s]; break; }
+                const uint4 sl = t.slot[s];   // written by the table-build launches
+                const unsigned long long ks = ((unsigned long long)sl.y << 32) | sl.x;
+                if (ks == key) { r = make_uint2(sl.z, sl.w); break; }
                 if (ks == SEED_EMPTY) break;
                 s = (s + 1) & t.mask;
             }
@@ -1052,9 +1058,8 @@ static u32 seed_capacity(const catchhip_probes *P, const catchhip_targets *T) {
 // the number of seeds stays on the device (S.ctr[1]) and the hits go straight
 // into the bucketed row build as records indexed like the seeds.
 struct SeedRun {
-    DevBuf<unsigned long long> keys;
+    DevBuf<uint4> slot;
     DevBuf<u32> cnt, ents, slot_of, ctr, spos, sent, sseq, dummy;
-    DevBuf<uint2> range;
     u32 scap = 0;
 };
 
@@ -1070,9 +1075,8 @@ static int seed_table_lookup_async(catchhip_ctx *ctx, const catchhip_probes *P, 
     const u32 nent = (u32)nent64;
     u32 capacity = 1024;
     while ((u64)capacity < 2 * nent64) capacity <<= 1;
-    TRY(S.keys.reserve(capacity));
+    TRY(S.slot.reserve(capacity));
     TRY(S.cnt.reserve(capacity));
-    TRY(S.range.reserve(capacity));
     TRY(S.ents.reserve(nent));
     TRY(S.slot_of.reserve(nent));
     TRY(S.ctr.reserve(4));   // [0] ents cursor, [1] seeds
@@ -1080,10 +1084,10 @@ static int seed_table_lookup_async(catchhip_ctx *ctx, const catchhip_probes *P, 
     TRY(S.sent.reserve(S.scap));
     TRY(S.sseq.reserve(S.scap));
     if (!res) { TRY(S.dummy.reserve(8)); res = S.dummy.p; }
-    SeedTable t = {S.keys.p, S.cnt.p, S.range.p, S.ents.p, capacity - 1};
+    SeedTable t = {S.slot.p, S.cnt.p, S.ents.p, capacity - 1};
     const dim3 eb((unsigned)div_up((i64)nent, 256)), tb(256);
     hipLaunchKernelGGL(seed_init_kernel, dim3((unsigned)std::min<i64>(div_up((i64)capacity, 256), 2048)), tb, 0,
-                       ctx->stream, S.keys.p, S.cnt.p, capacity, S.ctr.p, bcnt, nb, res);
+                       ctx->stream, S.slot.p, S.cnt.p, capacity, S.ctr.p, bcnt, nb, res);
     hipLaunchKernelGGL(seed_count_kernel, eb, tb, 0, ctx->stream, (const uint4 *)P->planes.p,
                        (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p, nent, pos_limit,
                        P->pigeonhole ? (int)(P->L / k) : 0, k, (int)P->pwords, kb, t, S.slot_of.p);
