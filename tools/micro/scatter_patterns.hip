@@ -18,7 +18,7 @@ __global__ void fill_bstart(u32 *bstart, u32 nb, u32 per) {
     if (i <= nb) bstart[i] = i * per;
 }
 // mode 0: as in the product; 1: no bstart gather; 2: XCD-contiguous blocks; 3: 8-bucket transposed lines;
-// 4: read only (no write); 5: 4-byte write; 6: sequential write (copy)
+// 4: read only (no write); 5: 4-byte write; 6: sequential write (copy); 7: as 0 with non-temporal stores
 __global__ void __launch_bounds__(256) scatter(const uint4 *__restrict__ rec, const u32 *__restrict__ rank,
                                                const u32 *__restrict__ bstart, uint4 *__restrict__ S, u32 n, u32 per, int mode) {
     u32 blk = blockIdx.x;
@@ -34,6 +34,12 @@ __global__ void __launch_bounds__(256) scatter(const uint4 *__restrict__ rec, co
     else slot = bstart[r.w] + rk;
     if (mode == 4) { if (slot == 0xffffffffu) S[0] = r; return; }
     if (mode == 5) { ((u32 *)S)[slot] = r.x; return; }
+    if (mode == 7) {
+        u32 *q = (u32 *)(S + slot);
+        __builtin_nontemporal_store(r.x, q); __builtin_nontemporal_store(r.y, q + 1);
+        __builtin_nontemporal_store(r.z, q + 2); __builtin_nontemporal_store(r.w, q + 3);
+        return;
+    }
     S[slot] = r;
 }
 int main() {
@@ -44,8 +50,8 @@ int main() {
     fill_bstart<<<nb / 256 + 1, 256>>>(bstart, nb, per);
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const char *names[] = {"product", "no bstart gather", "XCD-contiguous", "8-bucket transposed lines", "read only", "4-byte write", "sequential copy"};
-    for (int mode = 0; mode < 7; ++mode) {
+    const char *names[] = {"product", "no bstart gather", "XCD-contiguous", "8-bucket transposed lines", "read only", "4-byte write", "sequential copy", "non-temporal stores"};
+    for (int mode = 0; mode < 8; ++mode) {
         float best = 1e9;
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0));
