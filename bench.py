@@ -404,13 +404,17 @@ def main():
         # ---- bytes per step ("Roofline accounting") ----
         # seed_verify, per seed: 12 B work item + 0.375 B/base of a (L+32)-base
         #   target window and of the L-base probe + 4 B rank; per hit a 16 B record
-        verify_bytes = seeds * (12 + 0.375 * (PROBE_LEN + 32) + 0.375 * PROBE_LEN + 4) + 16.0 * hits
+        #   (a list entry the look-up's anchor-pair filter left empty is a 4-B read and nothing else)
+        dropped = per.get("seeds_dropped", 0)
+        live = seeds - dropped
+        verify_bytes = live * (12 + 0.375 * (PROBE_LEN + 32) + 0.375 * PROBE_LEN + 4) + 4.0 * dropped + 16.0 * hits
         # SURVEY 8(d) K1 (brute-force tiles, T_p = 1024) for the same groups
         survey_k1 = sum(0.375 * g.G * -(-g.n_sets // 1024) + 0.375 * PROBE_LEN * g.n_sets
                         for g in stepper.resident) + 16.0 * rows
         # whole seed scan as implemented: planes 0/1 + a 16 B table probe per
         # position, per seed 24 B list + 60 B window + 64 B probe image + 20 B record
-        k1_impl = 16.25 * G + 168.0 * seeds
+        # (+ the 24 B of sibling-anchor keys the look-up reads per table match)
+        k1_impl = 16.25 * G + 28.0 * seeds + 4.0 * dropped + 168.0 * live
         rows_bytes = 44.0 * hits + 40.0 * rows
         # 12 B per (set, universe, interval) row re-counted + 8 B
         #   per bitmap word read for the popcounts
@@ -507,7 +511,7 @@ def main():
                                 traffic=pmc_traffic("solver_round", args.workload, args.scale),
                                 us_per_pick=ms["rounds_ms"] * 1e3 / max(per.get("picks", 0), 1),
                                 rounds_per_step=per.get("greedy_iters", 0)),
-            "work_per_step": {"seeds": seeds, "hits": hits, "rows": rows,
+            "work_per_step": {"table_matches": seeds, "seeds_verified": live, "hits": hits, "rows": rows,
                               "rows_recounted": per.get("rows_recounted", 0),
                               "bitmap_words_read": per.get("bitmap_words_read", 0)},
             "dataset_generation_s": gen_s,

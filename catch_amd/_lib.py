@@ -33,6 +33,7 @@ PROTOTYPES = {
     "catchhip_ctx_last_kernel_ms": (ctypes.c_int, [
         c_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), c_i64p]),
     "catchhip_ctx_last_counters": (ctypes.c_int, [c_vp, c_i64p]),
+    "catchhip_ctx_last_seeds_dropped": (ctypes.c_int, [c_vp, c_i64p]),
     "catchhip_targets_create": (ctypes.c_int, [
         c_vp, c_u8p, c_i64p, c_i32p, ctypes.c_int64, ctypes.c_int32, c_vpp]),
     "catchhip_targets_create_ptrs": (ctypes.c_int, [

@@ -233,6 +233,12 @@ extern "C" int catchhip_ctx_last_counters(catchhip_ctx *c, i64 *out8) {
     return 0;
 }
 
+extern "C" int catchhip_ctx_last_seeds_dropped(catchhip_ctx *c, i64 *out) {
+    ARG_CHECK(c != nullptr && out != nullptr);
+    *out = c->seeds_dropped;
+    return 0;
+}
+
 // ------------------------------------------------------------------------
 // bit-plane packing: 32 bases per u32 word, 3 planes (code bit 0, 1, 2) with
 // A=0 C=1 G=2 T=3 other(N)=4.  Base i of a stream lives in bit (i & 31) of

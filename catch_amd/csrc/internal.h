@@ -106,6 +106,7 @@ struct catchhip_ctx {
     double phase_ms[NPHASE] = {};
     i64 phase_launches[NPHASE] = {};
     i64 counters[8] = {};
+    i64 seeds_dropped = 0;   // of counters[1]: work-list entries the seed look-up's anchor-pair filter left empty
     // pinned staging word(s) for small device->host reads
     u64 *h_pin = nullptr;
     // larger pinned staging area (grown on demand) so that result read-backs are

@@ -107,9 +107,16 @@ struct SeedTable {
     u32 *cnt;                   // per slot: entries with this key (build time)
     u32 *ents;                  // entry ids (probe * nanchor + anchor) grouped by key
     u32 mask;                   // capacity - 1
+    // anchor-pair filter (seed_lookup_kernel; null when it does not apply): per entry (p, a) ONE 32-byte record
+    // {entry id, 0, key of the probe's other anchors in anchor order (SEED_SIB of them; bit 62 = the anchor
+    // holds an N)} -- a position's entries are then one or two lines, not a line of ents plus two of keys
+    const uint4 *sib;
     __device__ __forceinline__ unsigned long long *key_at(u32 s) const { return (unsigned long long *)(slot + s); }
 };
 #define SEED_EMPTY 0xffffffffffffffffull
+#define SEED_DEAD 0xffffffffu   // work-list entry without a seed (the tail of a look-up workgroup's range)
+#define SEED_SIB 3              // other anchors per entry: the filter takes tables of <= 4 anchors per probe
+#define SEED_KEYBITS 0x3fffffffffffffffull
 
 __device__ __forceinline__ u32 seed_hash(unsigned long long k) {
     k ^= k >> 29; k *= 0xbf58476d1ce4e5b9ull; k ^= k >> 32;
@@ -139,6 +146,19 @@ __device__ __forceinline__ unsigned long long plane_key(const u32 *__restrict__ 
     return ((unsigned long long)b << 32) | a;
 }
 
+// the same with bit 63 set when plane 2 (N) is set anywhere in the k-mer
+__device__ __forceinline__ unsigned long long plane_key_n(const u32 *__restrict__ tplanes, i64 nwords, u32 o, int kb,
+                                                          int has_n) {
+    unsigned long long key = plane_key(tplanes, tplanes + nwords, o, kb);
+    if (has_n) {
+        const u32 wi = o >> 5, sh = o & 31;
+        const u32 m = kb >= 32 ? 0xffffffffu : ((1u << kb) - 1u);
+        const u32 *p2 = tplanes + 2 * nwords;
+        if (__builtin_amdgcn_alignbit(p2[wi + 1], p2[wi], sh) & m) key |= 1ull << 63;
+    }
+    return key;
+}
+
 // table build 1/3: claim the key's slot, count the entries per slot.  Entries
 // are the probes' anchors sorted by (probe, position); with pigeonhole anchors
 // only positions below pos_limit enter the table (see run_seed_async).
@@ -146,12 +166,12 @@ __device__ __forceinline__ unsigned long long plane_key(const u32 *__restrict__ 
 __global__ void __launch_bounds__(256)
 seed_count_kernel(const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent_probe,
                   const u32 *__restrict__ ent_pos, u32 nent, u32 pos_limit, int nanch, int k, int NW, int kb,
-                  SeedTable t, u32 *__restrict__ slot_of) {
+                  SeedTable t, u32 *__restrict__ slot_of, unsigned long long *__restrict__ ekey) {
     const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nent) return;
     const u32 p = nanch ? e / (u32)nanch : ent_probe[e];
     const u32 o = nanch ? (e % (u32)nanch) * (u32)k : ent_pos[e];
-    if (o >= pos_limit) { slot_of[e] = SEED_SKIP; return; }
+    if (o >= pos_limit && !ekey) { slot_of[e] = SEED_SKIP; return; }
     // the probe image is [word][4]: planes 0/1 of the two words the k-mer starts in
     const u32 wi = o >> 5, sh = o & 31;
     const uint4 w0 = pplanes[(size_t)p * NW + wi];
@@ -159,6 +179,10 @@ seed_count_kernel(const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent
     const u32 m = kb >= 32 ? 0xffffffffu : ((1u << kb) - 1u);
     const unsigned long long key = ((unsigned long long)(__builtin_amdgcn_alignbit(w1.y, w0.y, sh) & m) << 32) |
                                    (__builtin_amdgcn_alignbit(w1.x, w0.x, sh) & m);
+    // (the anchor-pair filter wants the key of EVERY anchor, also of those that stay out of the table;
+    // bit 62: the anchor holds an N -- such a key equals no target key, whose N flag is bit 63)
+    if (ekey) ekey[e] = key | ((__builtin_amdgcn_alignbit(w1.z, w0.z, sh) & m) ? (1ull << 62) : 0ull);
+    if (o >= pos_limit) { slot_of[e] = SEED_SKIP; return; }
     u32 s = seed_hash(key) & t.mask;
     for (;;) {
         const unsigned long long prev = atomicCAS(t.key_at(s), SEED_EMPTY, key);
@@ -214,13 +238,25 @@ seed_alloc_kernel(SeedTable t, u32 *__restrict__ cursor) {
 
 // table build 3/3: drop the entries into their slot's range
 __global__ void __launch_bounds__(256)
-seed_fill_kernel(u32 nent, SeedTable t, const u32 *__restrict__ slot_of) {
+seed_fill_kernel(u32 nent, SeedTable t, const u32 *__restrict__ slot_of, int nanch,
+                 const unsigned long long *__restrict__ ekey, uint4 *__restrict__ sib) {
     const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nent) return;
     const u32 s = slot_of[e];
     if (s == SEED_SKIP) return;
     const u32 j = atomicSub(&t.cnt[s], 1u) - 1u;
-    t.ents[t.slot[s].z + j] = e;
+    const u32 idx = t.slot[s].z + j;
+    t.ents[idx] = e;
+    if (sib) {
+        const u32 a = e % (u32)nanch, e0 = e - a;
+        unsigned long long kk[SEED_SIB];
+        u32 q = 0;
+        for (u32 b = 0; b < (u32)nanch; ++b)
+            if (b != a && q < SEED_SIB) kk[q++] = ekey[e0 + b];
+        for (; q < SEED_SIB; ++q) kk[q] = SEED_EMPTY;
+        sib[2 * (size_t)idx] = make_uint4(e, 0u, (u32)kk[0], (u32)(kk[0] >> 32));
+        sib[2 * (size_t)idx + 1] = make_uint4((u32)kk[1], (u32)(kk[1] >> 32), (u32)kk[2], (u32)(kk[2] >> 32));
+    }
 }
 
 // scan 1/2: every target position looks its k-mer up; the matching anchors
@@ -231,24 +267,46 @@ seed_fill_kernel(u32 nent, SeedTable t, const u32 *__restrict__ slot_of) {
 #define SL_THREADS 512
 #define SL_PPT 4
 #define SL_TILE (SL_THREADS * SL_PPT)
+#define SL_HALO 96   // target keys kept on either side of the tile: (anchors per probe - 1) * k <= 90
+// The anchor-pair filter (t.sib; pigeonhole tables with A = L / k <= 4 anchors per probe, k <= 30, A - m >= 2).
+// A window with <= m mismatches leaves at least A - m of the A disjoint anchors exact, and it is reported
+// from its LOWEST exact anchor only.  So the seed of anchor a at position i (window start i - a k) is needed
+// only if (1) no lower anchor b < a of the probe is exact -- the target's k-mer at i - (a - b) k differs from
+// that anchor's key or one of them holds an N (key flags, bits 62 / 63): otherwise the pair is reported from
+// b, whose own seed passes this test by induction down to the lowest exact anchor -- and (2) with A - m >= 2,
+// some HIGHER anchor matches on planes 0/1 as well (a superset of "is exact"): a window whose only matching
+// anchor is a has more than m mismatches.  The keys of a probe's other anchors sit beside the table entry,
+// the target's keys of the tile (+ SL_HALO positions either side) in LDS.  On S4 (-m 2, A = 4) this keeps
+// 41 % of the seeds; every true pair keeps exactly one.  The survivors are written densely at the front of
+// the workgroup's reservation in the list (sizes are fixed before the entries are read) and ranges[] tells
+// the verify kernel where they are: a workgroup of it walks one range, so nothing is launched for the rest.
 __global__ void __launch_bounds__(SL_THREADS)
 seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const u32 *__restrict__ seq_off, u32 nseq,
-                   int k, int kb, SeedTable t, u32 *__restrict__ seed_pos, u32 *__restrict__ seed_ent,
-                   u32 *__restrict__ seed_seq, u32 *__restrict__ seed_count, u32 seed_cap) {
+                   int k, int kb, int nanch, int need2, int t_has_n, SeedTable t, u32 *__restrict__ seed_pos,
+                   u32 *__restrict__ seed_ent, u32 *__restrict__ seed_seq, u32 *__restrict__ seed_count, u32 seed_cap,
+                   uint2 *__restrict__ ranges) {
     __shared__ u32 s_off[SL_TILE + 1], s_rx[SL_TILE], s_sq[SL_TILE], s_part[SL_THREADS / 64], s_base;
+    __shared__ unsigned long long s_key[SL_TILE + 2 * SL_HALO];
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 tile0 = blockIdx.x * SL_TILE;
     // the tile's first sequence, found once (the same addresses for every lane); a
     // seeded position then walks on from there -- a tile rarely spans more than one
     // or two sequence ends -- instead of a binary search of its own
     const u32 sq0 = find_segment(seq_off, nseq, min(tile0, total - 1));
+    if (t.sib && tid < 2 * SL_HALO) {
+        const long long pos = tid < SL_HALO ? (long long)tile0 - SL_HALO + tid : (long long)tile0 + SL_TILE + (tid - SL_HALO);
+        const bool ok = pos >= 0 && pos + k <= (long long)total;
+        s_key[tid < SL_HALO ? tid : SL_TILE + tid] = ok ? plane_key_n(tplanes, nwords, (u32)pos, kb, t_has_n) : SEED_EMPTY;
+    }
     u32 cnt[SL_PPT], mine = 0;
 #pragma unroll
     for (int j = 0; j < SL_PPT; ++j) {
         const u32 q = tid * SL_PPT + j, i = tile0 + q;
         uint2 r = make_uint2(0, 0);
+        if (t.sib) s_key[SL_HALO + q] = SEED_EMPTY;
         if (i < total && i + (u32)k <= total) {
             const unsigned long long key = plane_key(tplanes, tplanes + nwords, i, kb);
+            if (t.sib) s_key[SL_HALO + q] = plane_key_n(tplanes, nwords, i, kb, t_has_n);
             u32 s = seed_hash(key) & t.mask;
             for (;;) {
                 const uint4 sl = t.slot[s];   // written by the table-build launches
@@ -274,23 +332,75 @@ seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const
     __syncthreads();
     u32 woff = 0, tot = 0;
     for (int w = 0; w < SL_THREADS / 64; ++w) { if (w < (int)wave) woff += s_part[w]; tot += s_part[w]; }
-    if (tot == 0) return;
+    if (tot == 0) { if (t.sib && tid == 0) ranges[blockIdx.x] = make_uint2(0u, 0u); return; }
     u32 run = woff + ex;
 #pragma unroll
     for (int j = 0; j < SL_PPT; ++j) { s_off[tid * SL_PPT + j] = run; run += cnt[j]; }
-    if (tid == 0) { s_off[SL_TILE] = tot; s_base = atomicAdd(seed_count, tot); }
+    // (filtered: ranges of whole 64-entry groups, as the verify kernel files its hits per group of 64)
+    if (tid == 0) { s_off[SL_TILE] = tot; s_base = atomicAdd(seed_count, t.sib ? (tot + 63u) & ~63u : tot); }
     __syncthreads();
     const u32 base = s_base;
-    for (u32 d = tid; d < tot; d += SL_THREADS) {
-        // last position q with s_off[q] <= d (positions without seeds share the next one's offset)
-        u32 lo = 0, hi = SL_TILE;
-        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_off[mid] <= d) lo = mid; else hi = mid; }
-        const u32 o = base + d;
-        if (o < seed_cap) {
-            seed_pos[o] = tile0 + lo;
-            seed_ent[o] = t.ents[s_rx[lo] + (d - s_off[lo])];
-            seed_seq[o] = s_sq[lo];
+    if (!t.sib) {
+        if (tid == 0) atomicAdd(seed_count + 1, tot);   // ctr[2]: seeds to verify
+        for (u32 d = tid; d < tot; d += SL_THREADS) {
+            // last position q with s_off[q] <= d (positions without seeds share the next one's offset)
+            u32 lo = 0, hi = SL_TILE;
+            while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_off[mid] <= d) lo = mid; else hi = mid; }
+            const u32 o = base + d;
+            if (o < seed_cap) {
+                seed_pos[o] = tile0 + lo;
+                seed_ent[o] = t.ents[s_rx[lo] + (d - s_off[lo])];
+                seed_seq[o] = s_sq[lo];
+            }
         }
+        return;
+    }
+    // filtered: 512 candidates at a time, the kept ones appended in order
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    u32 out_run = 0;
+    for (u32 c0 = 0; c0 < tot; c0 += SL_THREADS) {
+        const u32 d = c0 + tid;
+        bool keep = false;
+        u32 lo = 0, ent = 0;
+        if (d < tot) {
+            u32 hi = SL_TILE;
+            while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_off[mid] <= d) lo = mid; else hi = mid; }
+            const u32 idx = s_rx[lo] + (d - s_off[lo]);
+            const uint4 r0 = t.sib[2 * (size_t)idx], r1 = t.sib[2 * (size_t)idx + 1];
+            ent = r0.x;
+            const u32 a = ent % (u32)nanch;
+            const unsigned long long sk[SEED_SIB] = {((unsigned long long)r0.w << 32) | r0.z, ((unsigned long long)r1.y << 32) | r1.x,
+                                                     ((unsigned long long)r1.w << 32) | r1.z};
+            bool lower_exact = false, higher = need2 == 0;
+#pragma unroll
+            for (u32 j = 0; j < SEED_SIB; ++j) {
+                const u32 b = j < a ? j : j + 1;
+                if (b >= (u32)nanch) continue;
+                const int off = (int)lo + ((int)b - (int)a) * k + SL_HALO;
+                const unsigned long long tk = (off >= 0 && off < SL_TILE + 2 * SL_HALO) ? s_key[off] : SEED_EMPTY;
+                const unsigned long long pk = sk[j];
+                if (b < a) lower_exact = lower_exact || tk == pk;
+                else higher = higher || (tk != SEED_EMPTY && ((tk ^ pk) & SEED_KEYBITS) == 0ull);
+            }
+            keep = !lower_exact && higher;
+        }
+        const unsigned long long bal = __ballot(keep);
+        __syncthreads();                 // (the previous chunk is done with s_part)
+        if (lane == 0) s_part[wave] = (u32)__popcll(bal);
+        __syncthreads();
+        u32 wo = 0, ctot = 0;
+        for (int w = 0; w < SL_THREADS / 64; ++w) { if (w < (int)wave) wo += s_part[w]; ctot += s_part[w]; }
+        if (keep) {
+            const u32 o = base + out_run + wo + (u32)__popcll(bal & lt);
+            if (o < seed_cap) { seed_pos[o] = tile0 + lo; seed_ent[o] = ent; seed_seq[o] = s_sq[lo]; }
+        }
+        out_run += ctot;
+    }
+    // the verify kernel walks ranges[]: [base, base + kept) of every look-up workgroup; the rest of the
+    // reservation is never touched
+    if (tid == 0) {
+        ranges[blockIdx.x] = make_uint2(base, out_run);
+        if (out_run) atomicAdd(seed_count + 1, out_run);   // ctr[2]: seeds to verify
     }
 }
 
@@ -321,12 +431,14 @@ seed_verify_kernel(const u32 *__restrict__ tplanes, i64 nwords, const u32 *__res
                    HitSink sink) {
     const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= min(*seed_count, seed_cap)) return;
-    const u32 i = seed_pos[d], e = seed_ent[d], sq = seed_seq[d];
+    const u32 e0 = seed_ent[d];
+    const bool alive = e0 != SEED_DEAD;   // (dead: the unused tail of a look-up workgroup's range)
+    const u32 i = alive ? seed_pos[d] : 0u, e = alive ? e0 : 0u, sq = alive ? seed_seq[d] : 0u;
     // pigeonhole tables (nanch = L/k anchors per probe, sorted) need no look-ups
     const u32 p = nanch ? e / (u32)nanch : ent_probe[e];
     const u32 apos = nanch ? (e % (u32)nanch) * (u32)k : ent_pos[e];
     const u32 lo = seq_off[sq], hi = seq_off[sq + 1];
-    bool ok = i >= lo + apos;
+    bool ok = alive && i >= lo + apos;
     if (sink.probe_group) ok = ok && sink.probe_group[p] == sink.seq_group[sq];   // another instance's sequence
     const u32 o = i - apos;                     // where the probe would start
     ok = ok && o + (u32)L <= hi;                // window inside this sequence
@@ -402,17 +514,35 @@ seed_verify4_kernel(const uint4 *__restrict__ tq, const u32 *__restrict__ seq_of
                     const u32 *__restrict__ ent_pos, const u32 *__restrict__ ent_ptr, int nanch, int ntab, int L, int k,
                     int mm, u32 tailmask, int use_n, const u32 *__restrict__ seed_pos,
                     const u32 *__restrict__ seed_ent, const u32 *__restrict__ seed_seq,
-                    const u32 *__restrict__ seed_count, u32 seed_cap, HitSink sink) {
+                    const u32 *__restrict__ seed_count, u32 seed_cap, HitSink sink, const uint2 *__restrict__ ranges) {
     static_assert(NW >= 1 && NW <= 7, "the window needs NW + 1 <= 8 words");
-    const u32 nseeds = min(*seed_count, seed_cap);
     const u32 lane = threadIdx.x & 63, sub = lane & 3, grp = lane >> 2;
-    const u32 d0 = (u32)((((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 6);
-    if (d0 >= nseeds) return;
+    // ranges (filtered look-up): this workgroup walks the seeds [base, base + kept) of look-up workgroup
+    // blockIdx.x, 256 at a time; otherwise every wavefront takes the 64 list entries of its global index
+    u32 d0, nseeds = min(*seed_count, seed_cap);
+    if (ranges) {
+        const uint2 r = ranges[blockIdx.x];
+        d0 = r.x + (threadIdx.x >> 6) * 64u;
+        nseeds = min(nseeds, r.x + r.y);
+    } else {
+        d0 = (u32)((((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 6);
+    }
+    // per-lane constants: which of the window's words this lane owns, and the
+    // pigeonhole anchors' bit ranges inside them
+    const u32 wa = 2 * sub, wb = 2 * sub + 1;
+    const bool va = wa < (u32)NW, vb = wb < (u32)NW;
+    u32 ma[SV_AMAX], mb[SV_AMAX];
+#pragma unroll
+    for (int a = 0; a < SV_AMAX; ++a) {
+        ma[a] = (nanch && a < ntab) ? word_range_mask((int)wa, a * k, k) : 0u;
+        mb[a] = (nanch && a < ntab) ? word_range_mask((int)wb, a * k, k) : 0u;
+    }
+  for (; d0 < nseeds; d0 += 256u) {
     // ---- A: this lane's own work item (coalesced) -------------------------
     const u32 d = d0 + lane;
     u32 i = 0, e = 0, sq = 0, p = 0, aidx = 0, apos = 0, lo = 0, hi = 0, o = 0, first_ent = 0;
     bool pre = false;
-    if (d < nseeds) {
+    if (d < nseeds && seed_ent[d] != SEED_DEAD) {   // (dead: the unused tail of a look-up workgroup's range)
         i = seed_pos[d]; e = seed_ent[d]; sq = seed_seq[d];
         p = nanch ? e / (u32)nanch : ent_probe[e];
         aidx = nanch ? e - p * (u32)nanch : 0u;          // index of the seeding anchor (pigeonhole)
@@ -425,16 +555,6 @@ seed_verify4_kernel(const uint4 *__restrict__ tq, const u32 *__restrict__ seq_of
         if (!nanch && pre) first_ent = ent_ptr[p];
     }
     const unsigned long long premask = __ballot(pre);
-    // per-lane constants: which of the window's words this lane owns, and the
-    // pigeonhole anchors' bit ranges inside them
-    const u32 wa = 2 * sub, wb = 2 * sub + 1;
-    const bool va = wa < (u32)NW, vb = wb < (u32)NW;
-    u32 ma[SV_AMAX], mb[SV_AMAX];
-#pragma unroll
-    for (int a = 0; a < SV_AMAX; ++a) {
-        ma[a] = (nanch && a < ntab) ? word_range_mask((int)wa, a * k, k) : 0u;
-        mb[a] = (nanch && a < ntab) ? word_range_mask((int)wb, a * k, k) : 0u;
-    }
     unsigned long long verdict[4] = {0, 0, 0, 0};
     // ---- B: 16 seeds at a time, 4 lanes each -----------------------------
 #pragma unroll
@@ -509,6 +629,8 @@ seed_verify4_kernel(const uint4 *__restrict__ tq, const u32 *__restrict__ seq_of
         const unsigned long long v = q == 0 ? verdict[0] : q == 1 ? verdict[1] : q == 2 ? verdict[2] : verdict[3];
         hit_file(sink, d, (v >> ((lane & 15) * 4)) & 1ull, p, o, o + (u32)L, sq, lo, hi);
     }
+    if (!ranges) break;
+  }
 }
 
 typedef void (*seed_verify_fn)(const u32 *, i64, const u32 *, const uint4 *, const u32 *, const u32 *, const u32 *,
@@ -530,7 +652,7 @@ static seed_verify_fn pick_seed_verify(int nw) {
 
 typedef void (*seed_verify4_fn)(const uint4 *, const u32 *, const uint4 *, const u32 *, const u32 *, const u32 *, int, int,
                                 int, int, int, u32, int, const u32 *, const u32 *, const u32 *, const u32 *, u32,
-                                HitSink);
+                                HitSink, const uint2 *);
 static seed_verify4_fn pick_seed_verify4(int nw) {
     switch (nw) {
     case 1: return seed_verify4_kernel<1>;
@@ -1034,7 +1156,7 @@ static int run_fast(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
         HIP_TRY(hipGetLastError());
         u32 n;
         TRY(read_count(ctx, H.count.p, &n));
-        if (n <= cap) { H.n = n; H.has_end = false; ctx->counters[0] = n; ctx->counters[1] = 0; return 0; }
+        if (n <= cap) { H.n = n; H.has_end = false; ctx->counters[0] = n; ctx->counters[1] = 0; ctx->seeds_dropped = 0; return 0; }
         cap = n;  // overflow: rerun with the exact size
     }
     chip_set_error("fast scan: hit buffer overflow");
@@ -1059,6 +1181,10 @@ static u32 seed_capacity(const catchhip_probes *P, const catchhip_targets *T) {
 // into the bucketed row build as records indexed like the seeds.
 struct SeedRun {
     DevBuf<uint4> slot;
+    DevBuf<unsigned long long> ekey;
+    DevBuf<uint4> sib;
+    DevBuf<uint2> ranges;    // filtered look-up: per look-up workgroup (first list entry, seeds kept)
+    u32 nranges = 0;         // 0: unfiltered
     DevBuf<u32> cnt, ents, slot_of, ctr, spos, sent, sseq, dummy;
     u32 scap = 0;
 };
@@ -1068,7 +1194,7 @@ struct SeedRun {
 // beyond this probe offset stay out of the table.  bcnt/nb/res: arrays of the
 // bucketed row build zeroed by the same init launch (may be null / 0).
 static int seed_table_lookup_async(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, u32 pos_limit,
-                                   SeedRun &S, u32 *bcnt, u32 nb, u32 *res, PhaseTimer &tm) {
+                                   int mm, bool allow_filter, SeedRun &S, u32 *bcnt, u32 nb, u32 *res, PhaseTimer &tm) {
     const int k = P->k, kb = std::min(k, 32);
     const u64 nent64 = (u64)P->nent;
     if (nent64 >= ((u64)1 << 31)) { chip_set_error("seed scan: too many anchors"); return CATCHHIP_EINVAL; }
@@ -1079,23 +1205,34 @@ static int seed_table_lookup_async(catchhip_ctx *ctx, const catchhip_probes *P, 
     TRY(S.cnt.reserve(capacity));
     TRY(S.ents.reserve(nent));
     TRY(S.slot_of.reserve(nent));
-    TRY(S.ctr.reserve(4));   // [0] ents cursor, [1] seeds
+    TRY(S.ctr.reserve(4));   // [0] ents cursor, [1] entries of the work list, [2] of them SEED_DEAD
+    // the anchor-pair filter of the look-up (seed_lookup_kernel): pigeonhole tables of <= 4 anchors per probe
+    // whose keys are whole k-mers with room for the N flags
+    const int nanch_tab = P->pigeonhole ? (int)(P->L / k) : 0;
+    const bool filt = allow_filter && nanch_tab >= 2 && nanch_tab <= SEED_SIB + 1 && pos_limit != 0xffffffffu && k <= 30 &&
+                      (nanch_tab - 1) * k <= SL_HALO && !getenv("CATCHHIP_SEED_KEEP_ALL");
+    const int need2 = filt && nanch_tab - mm >= 2 ? 1 : 0;
+    const u32 nblk = (u32)div_up(T->total, SL_TILE);
+    S.nranges = filt ? nblk : 0;
+    if (filt) { TRY(S.ekey.reserve(nent)); TRY(S.sib.reserve((size_t)nent * 2)); TRY(S.ranges.reserve(nblk)); }
     TRY(S.spos.reserve(S.scap));
     TRY(S.sent.reserve(S.scap));
     TRY(S.sseq.reserve(S.scap));
     if (!res) { TRY(S.dummy.reserve(8)); res = S.dummy.p; }
-    SeedTable t = {S.slot.p, S.cnt.p, S.ents.p, capacity - 1};
+    SeedTable t = {S.slot.p, S.cnt.p, S.ents.p, capacity - 1, filt ? (const uint4 *)S.sib.p : nullptr};
     const dim3 eb((unsigned)div_up((i64)nent, 256)), tb(256);
     hipLaunchKernelGGL(seed_init_kernel, dim3((unsigned)std::min<i64>(div_up((i64)capacity, 256), 2048)), tb, 0,
                        ctx->stream, S.slot.p, S.cnt.p, capacity, S.ctr.p, bcnt, nb, res);
     hipLaunchKernelGGL(seed_count_kernel, eb, tb, 0, ctx->stream, (const uint4 *)P->planes.p,
                        (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p, nent, pos_limit,
-                       P->pigeonhole ? (int)(P->L / k) : 0, k, (int)P->pwords, kb, t, S.slot_of.p);
+                       nanch_tab, k, (int)P->pwords, kb, t, S.slot_of.p, filt ? S.ekey.p : nullptr);
     hipLaunchKernelGGL(seed_alloc_kernel, dim3(capacity / SA_SLOTS), dim3(256), 0, ctx->stream, t, S.ctr.p);
-    hipLaunchKernelGGL(seed_fill_kernel, eb, tb, 0, ctx->stream, nent, t, (const u32 *)S.slot_of.p);
+    hipLaunchKernelGGL(seed_fill_kernel, eb, tb, 0, ctx->stream, nent, t, (const u32 *)S.slot_of.p, nanch_tab,
+                       (const unsigned long long *)S.ekey.p, filt ? S.sib.p : nullptr);
     hipLaunchKernelGGL(seed_lookup_kernel, dim3((unsigned)div_up(T->total, SL_TILE)), dim3(SL_THREADS), 0, ctx->stream,
                        (const u32 *)T->planes.p, T->nwords, (u32)T->total, (const u32 *)T->seq_off.p,
-                       (u32)T->nseq, k, kb, t, S.spos.p, S.sent.p, S.sseq.p, S.ctr.p + 1, S.scap);
+                       (u32)T->nseq, k, kb, nanch_tab, need2, T->has_n ? 1 : 0, t, S.spos.p, S.sent.p, S.sseq.p,
+                       S.ctr.p + 1, S.scap, filt ? S.ranges.p : (uint2 *)nullptr);
     tm.launch(5);
     return 0;
 }
@@ -1112,22 +1249,26 @@ static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     const u32 pos_limit = P->pigeonhole ? (u32)std::min<i64>((i64)(mm + 1) * k, P->L) : 0xffffffffu;
     seed_verify_fn verify = pick_seed_verify((int)P->pwords);
     if (!verify) { chip_set_error("seed scan: unsupported probe length"); return CATCHHIP_EINVAL; }
-    TRY(seed_table_lookup_async(ctx, P, T, pos_limit, S, sink.bcnt, nb, res, tm));
-    const u32 tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
-    // the verify launch alone is phase 5 (read lazily by catchhip_ctx_last_kernel_ms)
-    (void)hipEventRecord(ctx->ev[2 * PHASE_VERIFY], ctx->stream);
     seed_verify4_fn verify4 = getenv("CATCHHIP_VERIFY_V1") ? nullptr : pick_seed_verify4((int)P->pwords);
     // anchors per probe in the table (pigeonhole: those below pos_limit), <= 31 for the bit set
     const int nanch = P->pigeonhole ? (int)(P->L / k) : 0;
     const int ntab = nanch ? (int)std::min<i64>(nanch, div_up((i64)pos_limit, k)) : 0;
     if (ntab > 31) verify4 = nullptr;
+    // (the filtered look-up hands its seeds over as ranges, which only the cooperative verify kernel walks,
+    // and it needs the hits filed compactly: a group of 64 list entries outside the ranges is never visited)
+    TRY(seed_table_lookup_async(ctx, P, T, pos_limit, mm, verify4 != nullptr && sink.wcnt != nullptr, S, sink.bcnt, nb, res,
+                                tm));
+    if (S.nranges) HIP_TRY(hipMemsetAsync(sink.wcnt, 0, sizeof(u32) * ((size_t)S.scap / 64 + 1), ctx->stream));
+    const u32 tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
+    // the verify launch alone is phase 5 (read lazily by catchhip_ctx_last_kernel_ms)
+    (void)hipEventRecord(ctx->ev[2 * PHASE_VERIFY], ctx->stream);
     if (verify4)
-        hipLaunchKernelGGL(verify4, dim3((unsigned)div_up((i64)S.scap, 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(verify4, dim3(S.nranges ? S.nranges : (unsigned)div_up((i64)S.scap, 256)), dim3(256), 0, ctx->stream,
                            (const uint4 *)T->tq.p, (const u32 *)T->seq_off.p, (const uint4 *)P->planes.p,
                            (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p, (const u32 *)P->ent_ptr.p,
                            nanch, ntab, (int)P->L, k, mm, tailmask, use_n ? 1 : 0,
                            (const u32 *)S.spos.p, (const u32 *)S.sent.p, (const u32 *)S.sseq.p,
-                           (const u32 *)(S.ctr.p + 1), S.scap, sink);
+                           (const u32 *)(S.ctr.p + 1), S.scap, sink, S.nranges ? (const uint2 *)S.ranges.p : (const uint2 *)nullptr);
     else
     hipLaunchKernelGGL(verify, dim3((unsigned)div_up((i64)S.scap, 256)), dim3(256), 0, ctx->stream,
                        (const u32 *)T->planes.p, T->nwords, (const u32 *)T->seq_off.p,
@@ -1165,7 +1306,7 @@ static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchh
     if (table) {
         S.scap = seed_capacity(P, T);
         for (int attempt = 0;; ++attempt) {
-            TRY(seed_table_lookup_async(ctx, P, T, 0xffffffffu, S, nullptr, 0, nullptr, tm));
+            TRY(seed_table_lookup_async(ctx, P, T, 0xffffffffu, 0, false, S, nullptr, 0, nullptr, tm));
             HIP_TRY(hipGetLastError());
             TRY(read_count(ctx, S.ctr.p + 1, &nseeds));
             if (nseeds <= S.scap) break;
@@ -1251,6 +1392,7 @@ static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchh
     TRY(read_count(ctx, H.count.p, &H.n));
     ctx->counters[0] = H.n;
     ctx->counters[1] = nseeds;
+    ctx->seeds_dropped = 0;
     return 0;
 }
 
@@ -1472,6 +1614,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
                 continue;
             }
             ctx->counters[1] = nseeds;
+            ctx->seeds_dropped = (i64)nseeds - (i64)((volatile u32 *)h)[10];   // list entries without a seed
             P->seed_ratio_hint = std::max(P->seed_ratio_hint, (double)nseeds / (double)std::max<i64>(T->total, 1));   // see seed_capacity
             break;
         }

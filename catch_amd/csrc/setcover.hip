@@ -923,6 +923,7 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
         chip_phase_collect(ctx, PHASE_ROWS);
         ctx->counters[0] = h_info[2];
         ctx->counters[1] = h_info[9];
+        ctx->seeds_dropped = (i64)h_info[9] - (i64)h_info[10];
         R->seed_ratio_seen = (double)h_info[9] / (double)std::max<i64>(R->total, 1);
         ctx->counters[7] = h_info[4];   // rows of the deferred table
         if (h_st->done == 3) { *retry = 1; return 0; }

@@ -108,7 +108,11 @@ class Context:
         check(self._L.catchhip_ctx_last_counters(self._h, _ptr(out, c_i64p)))
         names = ["raw_hits", "seed_hits", "greedy_iters", "picks",
                  "winner_rows", "rows_recounted", "bitmap_words_read", "_"]
-        return dict(zip(names, (int(x) for x in out)))
+        d = dict(zip(names, (int(x) for x in out)))
+        dropped = np.zeros(1, dtype=np.int64)
+        check(self._L.catchhip_ctx_last_seeds_dropped(self._h, _ptr(dropped, c_i64p)))
+        d["seeds_dropped"] = int(dropped[0])   # of seed_hits: left without a seed by the look-up's filter
+        return d
 
     # -- RCCL -----------------------------------------------------------
     @staticmethod

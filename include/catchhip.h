@@ -72,6 +72,12 @@ int catchhip_ctx_last_kernel_ms(catchhip_ctx *ctx, int phase, double *ms,
  * words read while re-counting, [7] cover rows of the last fused
  * catchhip_setcover_filter call. */
 int catchhip_ctx_last_counters(catchhip_ctx *ctx, int64_t *out8);
+/* Of counter [1] (entries of the last seed scan's work list): those the
+ * look-up's anchor-pair filter left without a seed -- a lower anchor of the same
+ * probe is exact at the same window (the pair is reported from that anchor's
+ * seed), or no second anchor of the probe matches (more than m mismatches).
+ * They cost the verification 4 bytes each and none of its gathers. */
+int catchhip_ctx_last_seeds_dropped(catchhip_ctx *ctx, int64_t *out);
 
 /* ---- inputs ------------------------------------------------------------ */
 /* Target sequences (catch/genome.py Genome.seqs of every genome of a group).
