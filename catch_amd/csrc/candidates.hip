@@ -657,6 +657,7 @@ extern "C" int catchhip_probes_from_candidates(catchhip_ctx *ctx, const catchhip
         hipLaunchKernelGGL(cand_gather_kernel, dim3((unsigned)div_up(std::max<i64>(p->total, n + 1), 256)), dim3(256), 0,
                            s, (const u8 *)C->T->bytes.p, (const u32 *)C->upos.p, (u32)n, (u32)L, p->bytes.p,
                            p->probe_off.p, p->set_id.p, p->bucket_of.p, p->bucket_set.p);
+        p->bucket_identity = true;
         if (pigeon) {
             const u32 nanch = (u32)(L / k);
             p->pigeonhole = n > 0;

@@ -168,6 +168,7 @@ struct catchhip_probes {
     bool dna5 = false;
     bool has_n = false;
     bool pigeonhole = false;  // anchors are exactly {0,k,2k,..,L-k} for every probe
+    bool bucket_identity = false;   // bucket_of[p] == p and bucket_set[b] == b (probes from the device front end): no look-ups
     bool sorted_unique = false;   // the caller's anchor entries were sorted by (probe, position), no duplicates
     bool has_groups = false;
     DevBuf<i32> group;       // nprobes: instance of each probe (catchhip_probes_set_groups)

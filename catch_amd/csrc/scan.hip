@@ -1570,7 +1570,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     const u32 nb = by_sequence ? (u32)P->nprobes : (u32)P->nbuckets;
     const bool force_radix = getenv("CATCHHIP_ROWS_RADIX") != nullptr && !dedupe;
     HitSink sink;
-    sink.bucket_of = by_sequence ? nullptr : P->bucket_of.p;
+    sink.bucket_of = by_sequence || P->bucket_identity ? nullptr : P->bucket_of.p;   // (null: the probe index itself)
     sink.seq_genome = by_sequence ? nullptr : T->seq_genome.p;
     sink.ext = ext;
     if (!by_sequence) {
@@ -1678,7 +1678,7 @@ int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const ca
     O.S.scap = (u32)scap64;
     const u32 nb = (u32)P->nbuckets;
     HitSink sink;
-    sink.bucket_of = P->bucket_of.p;
+    sink.bucket_of = P->bucket_identity ? nullptr : P->bucket_of.p;
     sink.seq_genome = T->seq_genome.p;
     sink.ext = (u32)cover_extension;
     if (P->has_groups != T->has_groups) return 1;   // the synchronous path reports the error
@@ -1710,7 +1710,8 @@ int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const ca
         PhaseTimer tr(ctx, PHASE_ROWS);
         if ((rc = bucket_finish_async(ctx, O.B, O.S.scap, O.S.ctr.p + 1, false, true, tr))) break;
         hipLaunchKernelGGL(rows_emit_kernel, dim3((unsigned)div_up(R->n, 256)), dim3(256), 0, ctx->stream,
-                           (const u32 *)O.B.rstart.p, O.B.nb, (const u32 *)O.B.bstart.p, (const i32 *)P->bucket_set.p,
+                           (const u32 *)O.B.rstart.p, O.B.nb, (const u32 *)O.B.bstart.p,
+                           P->bucket_identity ? (const i32 *)nullptr : (const i32 *)P->bucket_set.p,
                            (const uint4 *)O.B.S.p, (u32)R->n,
                            (const u32 *)(O.B.res.p + 4), R->set_id.p, R->univ.p, R->gs.p, R->ge.p);
         hipLaunchKernelGGL(rows_info_kernel, dim3(1), dim3(64), 0, ctx->stream, (const u32 *)O.B.res.p,
@@ -1839,7 +1840,7 @@ static int cover_scan_impl(catchhip_ctx *ctx, const catchhip_probes *P, const ca
             if (R->n) {
                 hipLaunchKernelGGL(rows_emit_kernel, dim3((unsigned)div_up(R->n, 256)), dim3(256), 0, ctx->stream,
                                    (const u32 *)O.B.rstart.p, O.B.nb, (const u32 *)O.B.bstart.p,
-                                   (const i32 *)P->bucket_set.p, (const uint4 *)O.B.S.p, (u32)R->n, (const u32 *)nullptr, R->set_id.p, R->univ.p,
+                                   P->bucket_identity ? (const i32 *)nullptr : (const i32 *)P->bucket_set.p, (const uint4 *)O.B.S.p, (u32)R->n, (const u32 *)nullptr, R->set_id.p, R->univ.p,
                                    R->gs.p, R->ge.p);
                 tm.launch();
             }
