@@ -201,11 +201,15 @@ class Stepper:
                          ("verify_ms", engine.PHASE_VERIFY),
                          ("rows_ms", engine.PHASE_ROWS),
                          ("greedy_ms", engine.PHASE_GREEDY),
-                         ("rounds_ms", engine.PHASE_GREEDY_ROUNDS)):
+                         ("rounds_ms", engine.PHASE_GREEDY_ROUNDS),
+                         ("claim_ms", engine.PHASE_CLAIM)):
             ms, nl = c.kernel_ms(ph)
             st[name] = ms
             st[name.replace("_ms", "_launches")] = nl
         st.update(c.counters())
+        # the claim kernel of the row-parallel solver streams the same records and as many (owner) words as
+        # the count kernel whose work the counters give
+        st["claim_bytes"] = (12.0 * st["rows_recounted"] + 8.0 * st["bitmap_words_read"]) if st["claim_launches"] else 0.0
         stats.append(st)
 
     def sync(self):
@@ -232,7 +236,7 @@ def pmc_traffic(unit, workload, scale):
             rec = json.load(f)
         if rec.get("workload") != workload or scale != 1.0:
             return None
-        k = rec["units"][unit]
+        k = rec["units"].get(unit) or rec["kernels"][unit + "_kernel"]   # a unit, or one kernel by name
         return (2.0 * k["FETCH_SIZE_KB_per_launch"]
                 + k["WRITE_SIZE_KB_per_launch"]) * 1024.0
     except (OSError, KeyError, ValueError):
@@ -419,8 +423,8 @@ def main():
         # 12 B per (set, universe, interval) row re-counted + 8 B
         #   per bitmap word read for the popcounts
         k2_bytes = 12.0 * per.get("rows_recounted", 0) + 8.0 * per.get("bitmap_words_read", 0)
-        ms = {k: per.get(k, 0.0) for k in ("scan_ms", "verify_ms", "rows_ms", "greedy_ms", "rounds_ms")}
-        nlaunch = {k: tot.get(k, 0) for k in ("verify_launches", "rounds_launches", "scan_launches")}
+        ms = {k: per.get(k, 0.0) for k in ("scan_ms", "verify_ms", "rows_ms", "greedy_ms", "rounds_ms", "claim_ms")}
+        nlaunch = {k: tot.get(k, 0) for k in ("verify_launches", "rounds_launches", "scan_launches", "claim_launches")}
 
         def gbs(b, t_ms):
             return b / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
@@ -428,21 +432,17 @@ def main():
             "seed_verify": dict(kernel="seed_verify4_kernel<%d>" % -(-PROBE_LEN // 32),
                                 ms=ms["verify_ms"], bytes=verify_bytes,
                                 launches=nlaunch["verify_launches"] / K, pmc="seed_verify"),
-            "solver_rounds": dict(kernel="frontier solver round: gr_count+gr_claim+gr_apply (flat, >= 4 M "
-                                         "rows) / gf_count_claim+gf_check_apply (fused)",
-                                  ms=ms["rounds_ms"], bytes=k2_bytes,
-                                  launches=max(nlaunch["rounds_launches"] // 2, 1) / K,
-                                  pmc="solver_round"),
+            "solver_claim": dict(kernel="gr_claim_kernel (row-parallel solver, groups of >= 4 M rows)",
+                                 ms=ms["claim_ms"], bytes=per.get("claim_bytes", 0.0),
+                                 launches=max(nlaunch["claim_launches"], 1) / K, pmc="gr_claim"),
             "rows_build": dict(kernel="bucketed row build (per group: scatter, merge, scans, emit)",
                                ms=ms["rows_ms"], bytes=rows_bytes,
                                launches=float(len(stepper.resident)), pmc="rows_build"),
         }
-        # The dominant KERNEL: seed_verify4 is one kernel and has its own HIP-event
-        # timer; a solver round is 3 (flat) or 2 (fused) kernels, of which the
-        # largest takes ~0.4 of the rounds (rocprofv3: gr_claim 29 of 73 ms), and
-        # the row build is 6 (the scatter ~0.55 of it) -- so those units compete
-        # with that share of their time.
-        share = {"seed_verify": 1.0, "solver_rounds": 0.4, "rows_build": 0.55}
+        # The dominant KERNEL by its own HIP-event timer: the seed-verify launch (phase 5), the claim launches of
+        # the row-parallel solver (phase 6: an event pair per launch), or -- several kernels, priced by the
+        # scatter's share of them in rocprofv3's summary -- the row build.
+        share = {"seed_verify": 1.0, "solver_claim": 1.0, "rows_build": 0.55}
         dom = max(units_roof, key=lambda k: units_roof[k]["ms"] * share[k])
         d = units_roof[dom]
         avg_ms = d["ms"] / max(d["launches"], 1)
@@ -452,9 +452,6 @@ def main():
                     algorithmic_bytes_per_launch=d["bytes"] / max(d["launches"], 1),
                     avg_launch_ms=avg_ms, launches_per_step=d["launches"],
                     device_ms_per_step=d["ms"])
-        if dom == "solver_rounds":
-            roof["launches_are"] = ("rounds (one count launch with its claim / apply "
-                                    "launches), including the no-op rounds queued after the last one")
         out = {
             "metric": "candidate-probe x target-bp / s through SetCoverFilter "
                       "(K1 scan + K2 greedy)",

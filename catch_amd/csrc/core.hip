@@ -170,6 +170,7 @@ extern "C" int catchhip_ctx_create(int device, catchhip_ctx **out) {
         return CATCHHIP_EHIP;
     }
     for (int i = 0; i < 2 * NPHASE; ++i) (void)hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < 2 * CHIP_EVX; ++i) (void)hipEventCreate(&c->evx[i]);
     if (hipHostMalloc((void **)&c->h_pin, 64 * sizeof(u64), hipHostMallocDefault) != hipSuccess) {
         chip_set_error("hipHostMalloc failed");
         delete c;
@@ -206,6 +207,8 @@ extern "C" int catchhip_ctx_destroy(catchhip_ctx *c) {
     chip_pool_release_owner(c);
     for (int i = 0; i < 2 * NPHASE; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 2 * CHIP_EVX; ++i)
+        if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_big) (void)hipHostFree(c->h_big);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -97,12 +97,15 @@ template <typename T> struct DevBuf {
     }
 };
 
-enum { PHASE_SCAN = 0, PHASE_ROWS = 1, PHASE_GREEDY = 2, PHASE_NDF = 3, PHASE_GREEDY_ROUNDS = 4, PHASE_VERIFY = 5, NPHASE = 6 };
+enum { PHASE_SCAN = 0, PHASE_ROWS = 1, PHASE_GREEDY = 2, PHASE_NDF = 3, PHASE_GREEDY_ROUNDS = 4, PHASE_VERIFY = 5,
+       PHASE_CLAIM = 6, NPHASE = 7 };
+#define CHIP_EVX 16   // event pairs for per-launch timing inside a batch of solver rounds (PHASE_CLAIM)
 
 struct catchhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[2 * NPHASE] = {};
+    hipEvent_t evx[2 * CHIP_EVX] = {};
     double phase_ms[NPHASE] = {};
     i64 phase_launches[NPHASE] = {};
     i64 counters[8] = {};

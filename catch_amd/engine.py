@@ -14,6 +14,7 @@ from catch_amd._lib import (c_f32p, c_f64p, c_i32p, c_i64p, c_u16p, c_u32p,
 SCAN_AUTO, SCAN_GENERAL, SCAN_FAST, SCAN_SEED = 0, 1, 2, 3
 PHASE_SCAN, PHASE_ROWS, PHASE_GREEDY, PHASE_NDF, PHASE_GREEDY_ROUNDS = 0, 1, 2, 3, 4
 PHASE_VERIFY = 5
+PHASE_CLAIM = 6
 
 
 def _ptr(a, t):

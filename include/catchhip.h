@@ -61,7 +61,9 @@ int catchhip_pool_stats(int64_t *out4);
  * scan kernels (K1 hit search), 1 = row build (sort/merge), 2 = greedy
  * set-cover kernels (set-up + solver), 3 = near-duplicate kernels, 4 = only the
  * (count+claim, check+apply) launch pairs of the frontier solver's rounds,
- * 5 = only the seed-verify launch of the seed scan (part of phase 0).
+ * 5 = only the seed-verify launch of the seed scan (part of phase 0),
+ * 6 = only the claim launches of the row-parallel solver (part of phase 4;
+ * 0 launches when the last solve used the other kernels).
  * *launches = kernel launches timed. */
 int catchhip_ctx_last_kernel_ms(catchhip_ctx *ctx, int phase, double *ms,
                                 int64_t *launches);

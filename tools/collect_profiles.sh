@@ -67,6 +67,7 @@ rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                "other widths and WRITE_SIZE are uncalibrated" % wl,
        "workload": wl,
        "units": {"solver_round": unit(solver, [k for k in solver if k.startswith(("gf_count_claim", "gr_count"))]),
+                 "gr_claim": unit([k for k in solver if k.startswith("gr_claim")], [k for k in solver if k.startswith("gr_claim")]),
                  "seed_verify": unit(verify, verify),
                  "seed_table_lookup": unit(seed, [k for k in seed if k.startswith("seed_lookup")]),
                  "rows_build": unit(rows, [k for k in rows if k.startswith("bucket_scatter")])},
