@@ -75,6 +75,57 @@ def test_scan_fast_matches_oracle(ctx, oracle, L, stride, m, ext):
     assert got_s == exp
 
 
+def test_seed_lookup_anchor_pair_filter_edge_cases(ctx, oracle):
+    """The look-up's anchor-pair filter (-m 2, L = 100: four anchors of 25, at
+    least two exact in a covered window, reported from the lowest exact one):
+    copies of a window whose mismatches sit in chosen anchors -- every pattern
+    of 0..3 mismatches over the four anchors --, N's on either side inside and
+    outside anchors, windows at the very start / end of short sequences, and
+    copies straddling the look-up's 2048-position tiles."""
+    engine = _engine()
+    rng = np.random.Generator(np.random.PCG64(4711))
+    alpha = np.array(list("ACGT"))
+
+    def rnd(n):
+        return "".join(alpha[rng.integers(0, 4, size=n)])
+
+    def mutate(w, positions, to_n=False):
+        w = list(w)
+        for q in positions:
+            w[q] = "N" if to_n else alpha[(list("ACGT").index(w[q]) + 1 + rng.integers(0, 3)) % 4] if w[q] in "ACGT" else "A"
+        return "".join(w)
+
+    base = rnd(100)
+    probes = [base, mutate(base, [10], to_n=True), rnd(100)]
+    copies = []
+    for mask in range(16):                       # which anchors get a mismatch
+        hit = [a for a in range(4) if mask >> a & 1]
+        for extra in (0, 1):                     # one or two mismatches in the first chosen anchor
+            pos = [a * 25 + int(rng.integers(0, 25)) for a in hit]
+            if extra and hit:
+                pos.append(hit[0] * 25 + (pos[0] % 25 + 7) % 25)
+            copies.append(mutate(base, pos))
+    copies.append(mutate(base, [30], to_n=True))            # N in the target inside anchor 1
+    copies.append(mutate(base, [10], to_n=True))            # the same N as probe 1 has
+    copies.append(mutate(base, [3, 60], to_n=True))
+    filler = lambda: rnd(int(rng.integers(3, 60)))
+    seq = filler().join(copies)
+    pad = rnd(2048 * 2 - len(seq) % 2048 - 40)              # the next copies straddle a tile boundary
+    long_seq = seq + pad + base + rnd(13) + mutate(base, [5, 80]) + rnd(30)
+    genomes = [[long_seq], [base], [base[:60] + rnd(40) + base], [rnd(20) + base], [mutate(base, [99]) + rnd(9)]]
+    exp = _oracle_rows(oracle, probes, genomes, 2, 100, 0, 10)
+    assert len(exp) > 30
+    for mode in (engine.SCAN_SEED, engine.SCAN_GENERAL):
+        assert _scan_rows(ctx, probes, genomes, 2, 100, 0, 10, mode) == exp, mode
+    # the same through the unfiltered look-up (CATCHHIP_SEED_KEEP_ALL) -- the filter must not change a row
+    import os
+    os.environ["CATCHHIP_SEED_KEEP_ALL"] = "1"
+    try:
+        assert _scan_rows(ctx, probes, genomes, 2, 100, 0, 10, engine.SCAN_SEED) == exp
+    finally:
+        del os.environ["CATCHHIP_SEED_KEEP_ALL"]
+
+
 def test_scan_fast_no_n_two_planes(ctx, oracle):
     engine = _engine()
     genomes = small_species(seed=5, with_n=False)
