@@ -1713,7 +1713,8 @@ int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const ca
                            (const u32 *)O.B.rstart.p, O.B.nb, (const u32 *)O.B.bstart.p,
                            P->bucket_identity ? (const i32 *)nullptr : (const i32 *)P->bucket_set.p,
                            (const uint4 *)O.B.S.p, (u32)R->n,
-                           (const u32 *)(O.B.res.p + 4), R->set_id.p, R->univ.p, R->gs.p, R->ge.p);
+                           (const u32 *)(O.B.res.p + 4), R->set_id.p, R->univ.p, R->gs.p, R->ge.p,
+                           (const u32 *)(O.B.res.p + 2), -1);
         hipLaunchKernelGGL(rows_info_kernel, dim3(1), dim3(64), 0, ctx->stream, (const u32 *)O.B.res.p,
                            (const u32 *)O.S.ctr.p, O.S.scap, R->info.p);
         tr.launch(2);
@@ -1841,7 +1842,7 @@ static int cover_scan_impl(catchhip_ctx *ctx, const catchhip_probes *P, const ca
                 hipLaunchKernelGGL(rows_emit_kernel, dim3((unsigned)div_up(R->n, 256)), dim3(256), 0, ctx->stream,
                                    (const u32 *)O.B.rstart.p, O.B.nb, (const u32 *)O.B.bstart.p,
                                    P->bucket_identity ? (const i32 *)nullptr : (const i32 *)P->bucket_set.p, (const uint4 *)O.B.S.p, (u32)R->n, (const u32 *)nullptr, R->set_id.p, R->univ.p,
-                                   R->gs.p, R->ge.p);
+                                   R->gs.p, R->ge.p, (const u32 *)nullptr, O.nhits == O.nrows ? 1 : 0);
                 tm.launch();
             }
         } else {
