@@ -108,7 +108,7 @@ struct SeedTable {
     u32 *ents;                  // entry ids (probe * nanchor + anchor) grouped by key
     u32 mask;                   // capacity - 1
     // anchor-pair filter (seed_lookup_kernel; null when it does not apply): per entry (p, a) ONE 32-byte record
-    // {entry id, 0, key of the probe's other anchors in anchor order (SEED_SIB of them; bit 62 = the anchor
+    // {entry id, its anchor index, key of the probe's other anchors in anchor order (SEED_SIB of them; bit 62 = the anchor
     // holds an N)} -- a position's entries are then one or two lines, not a line of ents plus two of keys
     const uint4 *sib;
     __device__ __forceinline__ unsigned long long *key_at(u32 s) const { return (unsigned long long *)(slot + s); }
@@ -254,7 +254,7 @@ seed_fill_kernel(u32 nent, SeedTable t, const u32 *__restrict__ slot_of, int nan
         for (u32 b = 0; b < (u32)nanch; ++b)
             if (b != a && q < SEED_SIB) kk[q++] = ekey[e0 + b];
         for (; q < SEED_SIB; ++q) kk[q] = SEED_EMPTY;
-        sib[2 * (size_t)idx] = make_uint4(e, 0u, (u32)kk[0], (u32)(kk[0] >> 32));
+        sib[2 * (size_t)idx] = make_uint4(e, a, (u32)kk[0], (u32)(kk[0] >> 32));
         sib[2 * (size_t)idx + 1] = make_uint4((u32)kk[1], (u32)(kk[1] >> 32), (u32)kk[2], (u32)(kk[2] >> 32));
     }
 }
@@ -368,7 +368,7 @@ seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const
             const u32 idx = s_rx[lo] + (d - s_off[lo]);
             const uint4 r0 = t.sib[2 * (size_t)idx], r1 = t.sib[2 * (size_t)idx + 1];
             ent = r0.x;
-            const u32 a = ent % (u32)nanch;
+            const u32 a = r0.y;              // the entry's anchor index (= ent % nanch)
             const unsigned long long sk[SEED_SIB] = {((unsigned long long)r0.w << 32) | r0.z, ((unsigned long long)r1.y << 32) | r1.x,
                                                      ((unsigned long long)r1.w << 32) | r1.z};
             bool lower_exact = false, higher = need2 == 0;
