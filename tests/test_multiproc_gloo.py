@@ -222,5 +222,17 @@ def test_plan_helpers_single_process():
     assert sharded == [0, 1, 2] and all(w == [] for w in whole)
     sharded, whole = parallel.plan_with_sharding([10, 10, 10], 1)
     assert sharded == [] and whole == [[0, 1, 2]]
+    # the S4 shape (Mbases per group): two ranks balance without sharding, from three on the 265-Mbase group
+    # is sharded and the busiest rank stays within 8 % of an even share
+    s4 = [265.4, 37.1, 25.8, 13.4, 27.7, 2.0, 3.2, 43.0, 23.1, 27.4, 8.8, 10.7, 8.8, 10.4, 5.3, 26.5, 18.3, 14.1, 2.3, 18.9]
+    for world in (2, 3, 4, 8):
+        sharded, whole = parallel.plan_with_sharding(s4, world, min_cost=30)
+        assert sharded == ([] if world == 2 else [0])
+        assert sorted(i for w in whole for i in w) == [i for i in range(len(s4)) if i not in sharded]
+        loads = [sum(s4[i] for i in w) + sum(s4[i] for i in sharded) / world for w in whole]
+        assert max(loads) <= 1.08 * sum(s4) / world
+    # nothing large enough to shard: plain longest-first
+    sharded, whole = parallel.plan_with_sharding([50, 40, 5], 2, min_cost=100)
+    assert sharded == [] and whole == [[0], [1, 2]]
     assert parallel.merge_picks([7, 3, 9], [50, 90, 70]) == [3, 9, 7]
     assert parallel.merge_picks([7, 3, 9], [50, 90, 70], {7: 0, 3: 1, 9: 0}) == [9, 7, 3]
