@@ -53,7 +53,7 @@ def _short_sequence(seq, L, min_n, allow_small_seqs):
         raise ValueError("sequence of %d bases is shorter than the probe length "
                          "%d (--small-seq-skip leaves such sequences out)"
                          % (len(seq), L))
-    if len(seq) < allow_small_seqs:
+    if allow_small_seqs > len(seq):
         raise ValueError("sequence of %d bases is below the --small-seq-min "
                          "of %d" % (len(seq), allow_small_seqs))
     if _n_runs(seq, min_n):
@@ -66,17 +66,15 @@ def _check_list(seqs):
     """Same exception types as the reference for the same mistakes (:150-160)."""
     if type(seqs) is not list and not isinstance(seqs, list):
         raise TypeError("expected a list of sequence strings, got %s" % type(seqs).__name__)
-    if len(seqs) == 0:
+    if not seqs:
         raise ValueError("no sequences to make candidate probes from")
     bad = next((x for x in seqs if not isinstance(x, str)), None)
     if bad is not None:
         raise TypeError("every sequence must be a str, found %s" % type(bad).__name__)
 
 
-def candidate_strings_from_sequences(seqs, probe_length, probe_stride,
-                                     min_n_string_length=2,
-                                     allow_small_seqs=None,
-                                     seq_length_to_skip=None):
+def candidate_strings_from_sequences(seqs, probe_length, probe_stride, min_n_string_length=2,
+                                     allow_small_seqs=None, seq_length_to_skip=None):
     """Candidate windows of all sequences as plain strings, in the order the
     reference generates its Probe objects."""
     _check_list(seqs)
@@ -98,8 +96,7 @@ def candidate_strings_from_sequences(seqs, probe_length, probe_stride,
     return out
 
 
-def make_candidate_probes_from_sequence(seq, probe_length, probe_stride,
-                                        min_n_string_length=2,
+def make_candidate_probes_from_sequence(seq, probe_length, probe_stride, min_n_string_length=2,
                                         allow_small_seqs=None):
     """Probe objects of one sequence (is_flanking_n_string set on the windows
     next to an N run)."""
@@ -117,15 +114,14 @@ def make_candidate_probes_from_sequence(seq, probe_length, probe_stride,
     return out
 
 
-def make_candidate_probes_from_sequences(seqs, probe_length, probe_stride,
-                                         min_n_string_length=2,
-                                         allow_small_seqs=None,
-                                         seq_length_to_skip=None):
+def make_candidate_probes_from_sequences(seqs, probe_length, probe_stride, min_n_string_length=2,
+                                         allow_small_seqs=None, seq_length_to_skip=None):
     _check_list(seqs)
     out = []
-    for seq in seqs:
-        if seq_length_to_skip is not None and len(seq) <= seq_length_to_skip:
+    for one in seqs:
+        if seq_length_to_skip is not None and len(one) <= seq_length_to_skip:
             continue
+        seq = one
         out += make_candidate_probes_from_sequence(
             seq, probe_length, probe_stride, min_n_string_length,
             allow_small_seqs)

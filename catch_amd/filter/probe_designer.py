@@ -18,20 +18,16 @@ logger = logging.getLogger(__name__)
 
 
 class ProbeDesigner:
-    def __init__(self, genomes, filters, probe_length, probe_stride,
-                 allow_small_seqs=None, seq_length_to_skip=None,
-                 cluster_threshold=None, cluster_merge_after=None,
+    def __init__(self, genomes, filters, probe_length, probe_stride, allow_small_seqs=None,
+                 seq_length_to_skip=None, cluster_threshold=None, cluster_merge_after=None,
                  cluster_method=None, cluster_fragment_length=None):
-        self.genomes = genomes
-        self.filters = filters
-        self.probe_length = probe_length
-        self.probe_stride = probe_stride
-        self.allow_small_seqs = allow_small_seqs
-        self.seq_length_to_skip = seq_length_to_skip
-        self.cluster_threshold = cluster_threshold
-        self.cluster_merge_after = cluster_merge_after
-        self.cluster_method = cluster_method
-        self.cluster_fragment_length = cluster_fragment_length
+        # the reference's constructor arguments, kept under the reference's attribute names
+        # (catch/filter/probe_designer.py:34-76)
+        given = dict(locals())
+        for name in ("genomes", "filters", "probe_length", "probe_stride", "allow_small_seqs",
+                     "seq_length_to_skip", "cluster_threshold", "cluster_merge_after", "cluster_method",
+                     "cluster_fragment_length"):
+            setattr(self, name, given[name])
         self._candidates = None
         self._candidate_strs = None
         self.final_probes = None
@@ -104,9 +100,14 @@ class ProbeDesigner:
         if not seqs:
             return []
         return candidate_probes.make_candidate_probes_from_sequences(
-            seqs, self.probe_length, self.probe_stride,
-            allow_small_seqs=self.allow_small_seqs,
-            seq_length_to_skip=self.seq_length_to_skip)
+            seqs, self.probe_length, self.probe_stride, **self._window_options())
+
+    def _window_options(self, small=True):
+        """The keyword arguments of the candidate generators."""
+        opts = {"seq_length_to_skip": self.seq_length_to_skip}
+        if small:
+            opts["allow_small_seqs"] = self.allow_small_seqs
+        return opts
 
     def _design_for_genomes(self, genomes, filters):
         """(candidates per group, what the filters leave of them)."""
@@ -135,14 +136,11 @@ class ProbeDesigner:
                          None if type(first) is DuplicateFilter else first)
             return [[probe.Probe.from_str(s) for s in grp] for grp in chosen]
         cand = []
-        for genomes_from_group in genomes:
+        for grp in genomes:
             c = []
-            for g in genomes_from_group:
+            for g in grp:
                 c += candidate_probes.candidate_strings_from_sequences(
-                    list(g.seqs), probe_length=self.probe_length,
-                    probe_stride=self.probe_stride,
-                    allow_small_seqs=self.allow_small_seqs,
-                    seq_length_to_skip=self.seq_length_to_skip)
+                    list(g.seqs), self.probe_length, self.probe_stride, **self._window_options())
             if len(c) == 0:
                 logger.warning("There are no candidate probes for a grouping "
                                "of genomes")
@@ -215,9 +213,7 @@ class ProbeDesigner:
             # the device front end never built them: do it now, on request
             self._candidate_strs = [
                 [s for g in grp for s in candidate_probes.candidate_strings_from_sequences(
-                    list(g.seqs), probe_length=self.probe_length,
-                    probe_stride=self.probe_stride,
-                    seq_length_to_skip=self.seq_length_to_skip)]
+                    list(g.seqs), self.probe_length, self.probe_stride, **self._window_options(small=False))]
                 for grp in self._candidate_genomes]
         if self._candidates is None and self._candidate_strs is not None:
             self._candidates = [probe.Probe.from_str(s) for s in
@@ -229,13 +225,13 @@ class ProbeDesigner:
         self._candidates = value
 
     def design(self):
-        if self.cluster_threshold is None:
+        clustered = self.cluster_threshold is not None
+        if not clustered:
             genomes, before, after = self.genomes, self.filters, []
-        else:
+        if clustered:
             # design per cluster up to cluster_merge_after, then run the
             # remaining filters on the merged probes (:291-315)
-            assert self.cluster_merge_after is not None
-            assert self.cluster_merge_after in self.filters
+            assert self.cluster_merge_after is not None and self.cluster_merge_after in self.filters
             merge_idx = self.filters.index(self.cluster_merge_after) + 1
             before, after = self.filters[:merge_idx], self.filters[merge_idx:]
             genomes = self._cluster_genomes()
