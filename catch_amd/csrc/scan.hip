@@ -537,13 +537,20 @@ seed_verify4_kernel(const uint4 *__restrict__ tq, const u32 *__restrict__ seq_of
         ma[a] = (nanch && a < ntab) ? word_range_mask((int)wa, a * k, k) : 0u;
         mb[a] = (nanch && a < ntab) ? word_range_mask((int)wb, a * k, k) : 0u;
     }
+    // (ranges: the next 64 work items of this wavefront are requested while the current ones are verified --
+    // a pass of the loop is a chain of dependent round trips, and this takes one off it)
+    u32 n_i = 0, n_e = SEED_DEAD, n_sq = 0;
+    if (d0 + lane < nseeds) { n_i = seed_pos[d0 + lane]; n_e = seed_ent[d0 + lane]; n_sq = seed_seq[d0 + lane]; }
   for (; d0 < nseeds; d0 += 256u) {
     // ---- A: this lane's own work item (coalesced) -------------------------
     const u32 d = d0 + lane;
     u32 i = 0, e = 0, sq = 0, p = 0, aidx = 0, apos = 0, lo = 0, hi = 0, o = 0, first_ent = 0;
     bool pre = false;
-    if (d < nseeds && seed_ent[d] != SEED_DEAD) {   // (dead: the unused tail of a look-up workgroup's range)
-        i = seed_pos[d]; e = seed_ent[d]; sq = seed_seq[d];
+    const u32 c_i = n_i, c_e = n_e, c_sq = n_sq;
+    n_e = SEED_DEAD;
+    if (ranges && d + 256u < nseeds) { n_i = seed_pos[d + 256u]; n_e = seed_ent[d + 256u]; n_sq = seed_seq[d + 256u]; }
+    if (d < nseeds && c_e != SEED_DEAD) {   // (dead: the unused tail of a look-up workgroup's range)
+        i = c_i; e = c_e; sq = c_sq;
         p = nanch ? e / (u32)nanch : ent_probe[e];
         aidx = nanch ? e - p * (u32)nanch : 0u;          // index of the seeding anchor (pigeonhole)
         apos = nanch ? aidx * (u32)k : ent_pos[e];
