@@ -5,7 +5,7 @@ K2 greedy set cover) on MI355X.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S4|S2|S3]
 
 Workload (default S4 = BASELINE.json configs[3], the largest configuration
-that fits one GPU and the "V-All-scale" input the metric is quoted on): the
+that fits one GPU; configs[4], the V-All-scale input, is `--workload S5`): the
 seeded synthetic pool of 20 species / 20 groups (catch_amd/utils/synthetic.py,
 SURVEY.md 8(d); the reference ships no input at this scale), `design.py
 -pl 100 -ps 50 -m 2 -e 50 -c 1.0`.  `--workload S2` is configs[1] (the round-1
@@ -28,6 +28,15 @@ all-reduce of the per-candidate gains and one MAX all-reduce of the lost flags
 per round over RCCL; the other groups go whole to ranks, longest first, with
 no data-path collective.  The picks must equal the committed digests whatever N.
 
+`value` is the resident-input rate the measurement contract prescribes (inputs
+already in HBM when the timed region starts).  The wall-clock the metric also
+names -- SURVEY 8(d) M2: pack + H2D + front end + scan + solve + ids out, from
+host strings, nothing resident -- is measured in the same run through the
+plugin's own path (SetCoverFilter._filter_genomes_device, which packs and
+uploads group i + 1 on an upload context while group i is scanned and solved):
+`m2_setcoverfilter_wall_s`, `value_incl_h2d`, and the same without the overlap
+(`m2_serial_wall_s`).
+
 Prints one JSON line on rank 0 (fields: README / DESIGN.md section 6).
 """
 import argparse
@@ -49,7 +58,7 @@ from catch_amd.utils import synthetic  # noqa: E402
 PROBE_LEN, STRIDE, MISMATCHES, EXT = 100, 50, 2, 50
 SCAN_MODE = int(os.environ.get("CATCHHIP_SCAN_MODE", "0"))   # 0 auto, 1 general, 2 fast
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
-CONFIG_OF = {"S1": 0, "S2": 1, "S3": 2, "S4": 3}
+CONFIG_OF = {"S1": 0, "S2": 1, "S3": 2, "S4": 3, "S5": 4}
 
 
 class ResidentGroup:
@@ -68,10 +77,58 @@ class ResidentGroup:
         self.G = self.targets.total
         self.n_genomes = len(genomes)
 
+    def run(self):
+        return engine.setcover_filter(self.ctx, self.probes, self.targets, MISMATCHES, PROBE_LEN, 0, EXT,
+                                      self.n_sets, mode=SCAN_MODE)
+
     def close(self):
         self.probes.close()
         self.cands.close()
         self.targets.close()
+
+
+class NdfGroup(ResidentGroup):
+    """configs[2] (`--filter-with-lsh-hamming 2`): the targets are resident; a
+    step = device front end (candidate windows + exact de-duplication) ->
+    Hamming near-duplicate filter (K3: hash of 20 sampled positions per table,
+    radix sort, pair verification, resolution rounds) -> scan + solve over the
+    candidates the filter keeps."""
+    HAMMING = 2
+
+    def __init__(self, ctx, index, genomes):
+        self.ctx, self.index = ctx, index
+        self.targets = engine.Targets(ctx, genomes)
+        self.G = self.targets.total
+        self.n_genomes = len(genomes)
+        self.cands = self.probes = None
+        self.ndf_stats = {}
+        self.run()                       # sizes (n_sets) for the unit count
+
+    def run(self):
+        import random
+        from catch_amd.filter.near_duplicate_filter import NearDuplicateFilterWithHammingDistance
+        if self.probes is not None:
+            self.probes.close()
+            self.cands.close()
+        t0 = time.perf_counter()
+        self.cands = engine.Candidates(self.ctx, self.targets, PROBE_LEN, STRIDE)
+        windows, unique = self.cands.ncandidates, self.cands.n
+        front_ms = self.ctx.kernel_ms(engine.PHASE_NDF)[0]
+        random.seed(7)                   # the seed the committed digests were made with
+        ndf = NearDuplicateFilterWithHammingDistance(self.HAMMING, PROBE_LEN)
+        t1 = time.perf_counter()
+        ndf._apply_to_candidates(self.cands)
+        t2 = time.perf_counter()
+        ms, nl = self.ctx.kernel_ms(engine.PHASE_NDF)
+        cn = self.ctx.ndf_counters()
+        self.ndf_stats = dict(ndf_ms=ms, ndf_launches=nl, ndf_wall_ms=(t2 - t1) * 1e3,
+                              front_end_ms=front_ms, front_end_wall_ms=(t1 - t0) * 1e3, windows=windows,
+                              unique_windows=unique, ndf_probes=cn["probes"], ndf_tables=cn["tables"],
+                              ndf_pairs=cn["pairs_compared"], ndf_edges=cn["edges"], ndf_kept=self.cands.n)
+        k, ep, eo = probe.anchor_entries_equal_length(self.cands.n, PROBE_LEN, MISMATCHES, PROBE_LEN)
+        self.probes = self.cands.probes(k, ep, eo)
+        self.n_sets = self.cands.n
+        return ResidentGroup.run(self)
 
 
 class ShardedGroup:
@@ -136,6 +193,7 @@ class Stepper:
     kernels of large groups only get in each other's way (seed_lookup went
     from 0.6-8 ms to 12 ms per launch with four S4 groups in flight)."""
     BIG_BASES = int(os.environ.get("CATCHHIP_BENCH_BIG_BASES", str(8_000_000)))
+    ndf = False        # configs[2]: the Hamming near-duplicate filter is part of the step
 
     def __init__(self, device, groups, indices, width):
         sizes = {i: sum(len(s) for g in groups[i] for s in g) for i in indices}
@@ -145,9 +203,10 @@ class Stepper:
         self.width = max(1, min(width, len(small))) if small else 1
         self.ctxs = [engine.default_context() if w == 0 else engine.Context(device)
                      for w in range(self.width)]
-        self.big = [ResidentGroup(self.ctxs[0], i, groups[i]) for i in big]
+        Group = NdfGroup if self.ndf else ResidentGroup
+        self.big = [Group(self.ctxs[0], i, groups[i]) for i in big]
         lanes = parallel.lpt_assign([sizes[i] for i in small], self.width)
-        self.lanes = [[ResidentGroup(self.ctxs[w], small[j], groups[small[j]])
+        self.lanes = [[Group(self.ctxs[w], small[j], groups[small[j]])
                        for j in lane] for w, lane in enumerate(lanes)]
         for c in self.ctxs:
             c.sync()
@@ -158,9 +217,7 @@ class Stepper:
     def _run_lane(self, lane, stats):
         out = []
         for g in lane:
-            ids, nrows = engine.setcover_filter(
-                g.ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN, 0, EXT,
-                g.n_sets, mode=SCAN_MODE)
+            ids, nrows = g.run()
             if stats is not None:
                 self._collect(g, ids, nrows, stats)
             out.append((g.index, ids))
@@ -170,7 +227,7 @@ class Stepper:
         """One pass over every group of this rank -> {group index: pick ids}."""
         out = dict(self._run_lane(self.big, stats))
         small = [g for lane in self.lanes for g in lane]
-        if len(small) > 1 and len(small) <= self.width:
+        if len(small) > 1 and len(small) <= self.width and not self.ndf:
             # one group per lane: the C side's persistent helper threads
             specs = [(g.ctx, g.probes, g.targets, g.n_sets, None, None)
                      for g in small]
@@ -207,9 +264,10 @@ class Stepper:
             st[name] = ms
             st[name.replace("_ms", "_launches")] = nl
         st.update(c.counters())
-        # the claim kernel of the row-parallel solver streams the same records and as many (owner) words as
-        # the count kernel whose work the counters give
-        st["claim_bytes"] = (12.0 * st["rows_recounted"] + 8.0 * st["bitmap_words_read"]) if st["claim_launches"] else 0.0
+        st.update(getattr(g, "ndf_stats", {}))
+        # the claim kernel of the row-parallel solver streams every alive record (12 B) and looks at the
+        # owner word (8 B) of every flagged word of it
+        st["claim_bytes"] = (12.0 * st["flat_rows_streamed"] + 8.0 * st["flat_owner_words"]) if st["claim_launches"] else 0.0
         stats.append(st)
 
     def sync(self):
@@ -246,6 +304,11 @@ def pmc_traffic(unit, workload, scale):
 def digest(ids):
     a = np.sort(np.asarray(ids, dtype=np.int64))
     return hashlib.sha256(a.astype("<i8").tobytes()).hexdigest()
+
+
+def digest_in_order(ids):
+    """Order-sensitive: the solvers return the picks in the sequential pick order."""
+    return hashlib.sha256(np.asarray(ids, dtype="<i8").tobytes()).hexdigest()
 
 
 def golden_digests(workload, scale):
@@ -302,6 +365,226 @@ def cpu_baseline(groups, sample, budget_s=20.0):
                           "" if reps == 1 else "es", cores)), sel
 
 
+def cpu_baseline_s3(ctx, scale=0.03):
+    """configs[2] on the CPU: candidate windows -> Hamming near-duplicate
+    filter (oracle's C port, one core: the reference's filter is sequential) ->
+    set cover (threaded scans + greedy), on S3 x `scale`; the GPU runs the same
+    chain on the same input and must select the same ids."""
+    import random
+    from catch_amd.filter import candidate_probes
+    from catch_amd.filter.near_duplicate_filter import NearDuplicateFilterWithHammingDistance
+    from oracle import oracle as orc
+    orc.build()
+    genomes = synthetic.dataset("S3", scale=scale)[0]
+    seqs = [s for g in genomes for s in g]
+    cores = orc.set_threads(orc.hw_threads())
+    strs = candidate_probes.candidate_strings_from_sequences(seqs, PROBE_LEN, STRIDE)
+    t0 = time.perf_counter()
+    random.seed(7)
+    pos = orc.lsh_draw_positions(orc.lsh_num_tables(NdfGroup.HAMMING, PROBE_LEN, 20), 20, PROBE_LEN)
+    kept = orc.ndf_hamming_c(strs, NdfGroup.HAMMING, pos)
+    exp = orc.set_cover_filter([kept], [genomes], MISMATCHES, PROBE_LEN, coverage=1.0,
+                               cover_extension=EXT)[0]
+    el = time.perf_counter() - t0
+    orc.set_threads(1)
+    g = NdfGroup(ctx, 0, genomes)
+    ctx.sync()
+    t1 = time.perf_counter()
+    ids, _ = g.run()
+    ctx.sync()
+    gpu_s = time.perf_counter() - t1
+    same = g.n_sets == len(kept) and sorted(ids) == sorted(exp)
+    units = float(len(kept)) * sum(len(s) for s in seqs)
+    g.close()
+    return dict(value=units / el, unit="probe*bp/s", cores=cores, kind="port", seconds=el, passes=1,
+                sample="S3 x %g (%d records, %d bp, %d windows -> %d after the Hamming filter): plain-C oracle, "
+                       "near-duplicate filter on 1 core (sequential in the reference), scans on %d OpenMP "
+                       "threads, greedy on 1" % (scale, len(genomes), sum(len(s) for s in seqs), len(strs),
+                                                 len(kept), cores)), gpu_s, same
+
+
+def m2_passes(groups, steps, warm, depth):
+    """SURVEY 8(d) M2 through the plugin: every pass starts from the host's
+    sequence strings (nothing resident) and ends with the selected ids on the
+    host.  depth = groups the upload context may run ahead (0: no overlap)."""
+    from catch_amd import genome
+    from catch_amd.filter.set_cover_filter import SetCoverFilter
+    from collections import OrderedDict
+    gobjs = [[genome.Genome(list(g)) if len(g) == 1 else
+              genome.Genome.from_chrs(OrderedDict((str(i), s) for i, s in enumerate(g)))
+              for g in grp] for grp in groups]
+    f = SetCoverFilter(mismatches=MISMATCHES, lcf_thres=PROBE_LEN, coverage=1.0,
+                       cover_extension=EXT)
+    f.scan_mode = SCAN_MODE
+    old = os.environ.get("CATCHHIP_PREFETCH_DEPTH")
+    os.environ["CATCHHIP_PREFETCH_DEPTH"] = str(depth)
+    times, ids = [], None
+    try:
+        for i in range(warm + steps):
+            t = time.perf_counter()
+            ids = f._filter_genomes_device(gobjs, PROBE_LEN, STRIDE, return_ids=True)
+            dt = time.perf_counter() - t
+            if i >= warm:
+                times.append(dt)
+    finally:
+        if old is None:
+            os.environ.pop("CATCHHIP_PREFETCH_DEPTH", None)
+        else:
+            os.environ["CATCHHIP_PREFETCH_DEPTH"] = old
+    return times, dict(enumerate(ids))
+
+
+def digests_ok(gold, picks):
+    if gold is None:
+        return None
+    return all(len(ids) == gold[gi]["n_picks"] and digest(ids) == gold[gi]["picks_sha256"]
+               and ("picks_in_order_sha256" not in gold[gi]
+                    or digest_in_order(ids) == gold[gi]["picks_in_order_sha256"])
+               for gi, ids in picks.items() if gi in gold)
+
+
+def seed_verify_bytes(seeds, dropped, hits, L=PROBE_LEN):
+    """Algorithmic bytes of the seed-verify launches: per live seed a 12-B work item +
+    0.375 B/base of the (L+32)-base target window and of the L-base probe + a 4-B rank, per dropped list
+    entry 4 B, per hit a 16-B record."""
+    live = seeds - dropped
+    return live * (12 + 0.375 * (L + 32) + 0.375 * L + 4) + 4.0 * dropped + 16.0 * hits
+
+
+def bench_design_large(args):
+    """--workload S5 = BASELINE configs[4]: the design_large chain on the
+    synthetic V-All-shaped pool (one FASTA's worth of genomes, ONE group):
+    50-kb fragments -> MinHash-signature clustering at 0.15 -> per cluster
+    candidate windows, MinHash near-duplicate filter 0.6, set cover with
+    -m 5 -e 50 (20 random anchors per probe) -- bin/design.py:502,583,753,794,846,
+    catch/filter/probe_designer.py:78-184.  A step starts from the host's
+    sequence strings (nothing resident: this IS the M2 figure) and ends with the
+    selected probe strings on the host; Probe objects / FASTA output are not
+    part of it.  One GPU."""
+    import itertools
+    import random
+    from catch_amd import genome
+    from catch_amd.filter import near_duplicate_filter, probe_designer, set_cover_filter
+    t_gen = time.perf_counter()
+    genomes = synthetic.dataset("S5", scale=args.scale)[0]
+    gen_s = time.perf_counter() - t_gen
+    gobjs = [[genome.Genome.from_one_seq(g[0]) for g in genomes]]
+    bases = sum(len(s) for g in genomes for s in g)
+    pool0 = engine.pool_stats()
+
+    def one_step(env=None):
+        old = {}
+        for k, v in (env or {}).items():
+            old[k] = os.environ.get(k)
+            os.environ[k] = v
+        try:
+            random.seed(21)
+            np.random.seed(22)
+            ndf = near_duplicate_filter.NearDuplicateFilterWithMinHash(0.6)
+            scf = set_cover_filter.SetCoverFilter(mismatches=5, lcf_thres=PROBE_LEN, coverage=1.0,
+                                                  cover_extension=EXT, kmer_probe_map_k=20)
+            pd = probe_designer.ProbeDesigner(gobjs, [ndf, scf], probe_length=PROBE_LEN, probe_stride=STRIDE,
+                                              cluster_threshold=0.15, cluster_merge_after=scf,
+                                              cluster_method="choose", cluster_fragment_length=50000)
+            t0 = time.perf_counter()
+            clusters = pd._cluster_genomes()
+            t1 = time.perf_counter()
+            mode = pd._device_front_end_mode(clusters, ndf, scf)
+            run = scf._filter_genomes_device if mode == "per group" else scf._filter_genomes_device_union
+            chosen = run(clusters, PROBE_LEN, STRIDE, None, ndf)
+            t2 = time.perf_counter()
+            probes = list(dict.fromkeys(itertools.chain(*chosen)))
+            t3 = time.perf_counter()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        tm = dict(scf.last_timings)
+        tm.update(cluster_s=t1 - t0, filter_s=t2 - t1, merge_s=t3 - t2, wall_s=t3 - t0,
+                  clusters=len(clusters), fragments=sum(len(c) for c in clusters), mode=mode)
+        return probes, tm
+
+    def probes_digest(probes):
+        return hashlib.sha256("\n".join(sorted(set(probes))).encode()).hexdigest()
+
+    for _ in range(args.warmup):
+        one_step()
+    engine.default_context().sync()
+    t0 = time.perf_counter()
+    steps = []
+    probes = None
+    for _ in range(args.steps):
+        probes, tm = one_step()
+        steps.append(tm)
+    engine.default_context().sync()
+    elapsed = time.perf_counter() - t0
+    K = args.steps
+    per = {k: sum(st[k] for st in steps) / K for k in steps[0] if isinstance(steps[0][k], (int, float))}
+    units = per.get("probe_bp_units", 0.0)
+    dg = probes_digest(probes)
+    gold = None
+    try:
+        with open(os.path.join(REPO, "tests", "golden", "full_size_picks.json")) as f:
+            gold = json.load(f).get("S5:%g" % args.scale, {}).get("design")
+    except (OSError, ValueError):
+        pass
+    seeds, dropped, hits = per.get("seed_hits", 0), per.get("seeds_dropped", 0), per.get("raw_hits", 0)
+    vb = seed_verify_bytes(seeds, dropped, hits)
+    rows = per.get("rows", 0)
+
+    def gbs(b, t_ms):
+        return b / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+    lookup_ms = per.get("scan_ms", 0.0) - per.get("verify_ms", 0.0)
+    cands_ms = {"seed_verify4_kernel (K1 verify)": (per.get("verify_ms", 0.0), vb, per.get("verify_launches", 0)),
+                "bucketed row build": (per.get("rows_ms", 0.0), 44.0 * hits + 40.0 * rows, per.get("rows_launches", 0)),
+                "frontier solver rounds (K2)": (per.get("rounds_ms", 0.0),
+                                                12.0 * per.get("rows_recounted", 0) + 8.0 * per.get("bitmap_words_read", 0),
+                                                per.get("rounds_launches", 0))}
+    dom = max(cands_ms, key=lambda k: cands_ms[k][0])
+    dms, dbytes, dl = cands_ms[dom]
+    out = {
+        "metric": "candidate-probe x target-bp / s through the design_large chain "
+                  "(clustering + MinHash near-duplicate filter + SetCoverFilter), from host strings",
+        "value": units * K / elapsed, "unit": "probe*bp/s", "n_gpus": 1, "steps": K, "warmup": args.warmup,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 bit-planes / u64 bitmap (integer)", "data": "synthetic",
+        "config": {"workload": "S5 (BASELINE configs[4]%s): design_large defaults on %d genomes, %d bp in one group: "
+                               "-m 5 -e 50 -pl 100 -ps 50, cluster 0.15 from 50-kb fragments, MinHash NDF 0.6"
+                               % ("" if args.scale == 1.0 else " scaled x%g" % args.scale, len(genomes), bases),
+                   "scale": args.scale, "clusters": per.get("clusters"), "fragments": per.get("fragments"),
+                   "front_end": steps[-1]["mode"]},
+        "m2_setcoverfilter_wall_s": elapsed / K,
+        "wall_s_per_step": {"clustering": per["cluster_s"], "filters (front end + MinHash NDF + scan + solve + strings out)": per["filter_s"],
+                            "merge": per["merge_s"]},
+        "kernel_ms_per_step": {"k1_scan": per.get("scan_ms", 0.0), "k1_seed_verify": per.get("verify_ms", 0.0),
+                               "k1_table_lookup": lookup_ms, "rows_build": per.get("rows_ms", 0.0),
+                               "k2_greedy": per.get("greedy_ms", 0.0), "k2_greedy_rounds_only": per.get("rounds_ms", 0.0)},
+        "roofline": dict(bound="hbm", kernel=dom, achieved=gbs(dbytes, dms), peak=HBM_PEAK_GBS, unit="GB/s",
+                         frac=gbs(dbytes, dms) / HBM_PEAK_GBS, traffic=None,
+                         algorithmic_bytes_per_launch=dbytes / max(dl, 1), avg_launch_ms=dms / max(dl, 1),
+                         launches_per_step=dl, device_ms_per_step=dms),
+        "work_per_step": {"candidates": per.get("candidates"), "unique_candidates": per.get("unique_candidates"),
+                          "table_matches": seeds, "hits": hits, "rows": rows, "picks": per.get("picks"),
+                          "rounds": per.get("greedy_iters"), "probes": len(set(probes))},
+        "probes_sha256": dg,
+        "parity_vs_golden_digests": (None if gold is None else dg == gold["probes_sha256"]),
+        "dataset_generation_s": gen_s,
+        "step_seconds": [st["wall_s"] for st in steps],
+        "device_memory": engine.pool_stats(),
+    }
+    if not args.no_solver_check:
+        # property check where no oracle digest exists: the two kernel families of the frontier solver
+        # (set-parallel fused / row-parallel flat) must select the same probes
+        cur_flat = per.get("flat_rows_streamed", 0) > 0
+        p2, tm2 = one_step({"CATCHHIP_FLAT_MIN_ROWS": str(1 << 40) if cur_flat else "0"})
+        out["solver_families_agree"] = probes_digest(p2) == dg
+        out["solver_family_timed"] = "flat (row-parallel)" if cur_flat else "fused (set-parallel)"
+        out["other_family_wall_s"] = tm2["wall_s"]
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,11 +593,19 @@ def main():
     ap.add_argument("--workload", default="S4")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-m2", action="store_true", help="skip the M2 (cold, PCIe-inclusive) passes")
+    ap.add_argument("--m2-steps", type=int, default=3)
     ap.add_argument("--no-overlap-figure", action="store_true",
                     help="skip the extra passes with all groups on three streams (N = 1 only)")
     ap.add_argument("--groups-in-flight", type=int, default=4,
                     help="groups running at once per GPU, each on its own stream")
+    ap.add_argument("--no-solver-check", action="store_true",
+                    help="S5: skip the extra pass through the other solver family")
     args = ap.parse_args()
+    if args.workload == "S5":
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise SystemExit("--workload S5 runs on one GPU (the clustered design is one process)")
+        return bench_design_large(args)
 
     W = parallel.init_from_env()          # gloo plumbing + RCCL communicator when WORLD_SIZE > 1
     rank, world, dist = W.rank, W.size, W.dist
@@ -330,6 +621,7 @@ def main():
         bases, world, min_cost=int(os.environ.get("CATCHHIP_SHARD_MIN_BASES", "30000000")))
     mine = plan[rank]
 
+    Stepper.ndf = args.workload == "S3"
     t_up0 = time.perf_counter()
     stepper = Stepper(device, groups, mine, args.groups_in_flight)
     sharded = [ShardedGroup(W, i, groups[i]) for i in sharded_idx]
@@ -377,7 +669,9 @@ def main():
             if gi in gold:
                 gold_n += 1
                 gold_ok = gold_ok and (len(ids) == gold[gi]["n_picks"] and
-                                       digest(ids) == gold[gi]["picks_sha256"])
+                                       digest(ids) == gold[gi]["picks_sha256"] and
+                                       ("picks_in_order_sha256" not in gold[gi] or
+                                        digest_in_order(ids) == gold[gi]["picks_in_order_sha256"]))
     total_units, all_elapsed = float(units), [elapsed]
     if dist is not None:
         import torch
@@ -422,7 +716,14 @@ def main():
         rows_bytes = 44.0 * hits + 40.0 * rows
         # 12 B per (set, universe, interval) row re-counted + 8 B
         #   per bitmap word read for the popcounts
+        #   per bitmap word read for the popcounts -- E_dirty pricing: only rows whose words changed
         k2_bytes = 12.0 * per.get("rows_recounted", 0) + 8.0 * per.get("bitmap_words_read", 0)
+        # what the rounds move as implemented: the row-parallel solver also streams the rows that are NOT
+        # counted again (12 B read by the count launch, 12 B written for every survivor, 12 B read by the
+        # claim launch) and looks at one owner word per flagged word
+        streamed = per.get("flat_rows_streamed", 0)
+        k2_impl = (k2_bytes + 12.0 * (streamed - per.get("flat_rows_recounted", 0)) + 24.0 * streamed
+                   + 8.0 * per.get("flat_owner_words", 0))
         ms = {k: per.get(k, 0.0) for k in ("scan_ms", "verify_ms", "rows_ms", "greedy_ms", "rounds_ms", "claim_ms")}
         nlaunch = {k: tot.get(k, 0) for k in ("verify_launches", "rounds_launches", "scan_launches", "claim_launches")}
 
@@ -506,15 +807,22 @@ def main():
                                 peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=gbs(k2_bytes, ms["rounds_ms"]) / HBM_PEAK_GBS,
                                 traffic=pmc_traffic("solver_round", args.workload, args.scale),
+                                implementation_bytes=k2_impl,
+                                achieved_implementation=gbs(k2_impl, ms["rounds_ms"]),
+                                note="bytes = SURVEY 8(d) K2: 12 B per row counted again (a word of it changed) + "
+                                     "8 B per bitmap word read; implementation_bytes adds the record streams of "
+                                     "the row-parallel solver (count, compaction, claim) and the owner words",
                                 us_per_pick=ms["rounds_ms"] * 1e3 / max(per.get("picks", 0), 1),
                                 rounds_per_step=per.get("greedy_iters", 0)),
+            "roofline_k3": None,
             "work_per_step": {"table_matches": seeds, "seeds_verified": live, "hits": hits, "rows": rows,
                               "rows_recounted": per.get("rows_recounted", 0),
-                              "bitmap_words_read": per.get("bitmap_words_read", 0)},
+                              "bitmap_words_read": per.get("bitmap_words_read", 0),
+                              "flat_rows_streamed": streamed,
+                              "flat_rows_recounted": per.get("flat_rows_recounted", 0),
+                              "flat_owner_words": per.get("flat_owner_words", 0)},
             "dataset_generation_s": gen_s,
-            "pack_h2d_s": upload_s,
-            "m2_setcoverfilter_wall_s": upload_s + elapsed / K,
-            "value_incl_h2d": total_units / (elapsed / K + upload_s),
+            "first_upload_s": upload_s,
             "rank_seconds": all_elapsed,
             "step_seconds_rank0": step_s,
             "device_memory": dict(pool1, hipmalloc_calls_in_timed_region=(
@@ -522,7 +830,30 @@ def main():
             "parity_vs_golden_digests": (gold_ok if gold_n else None),
             "groups_checked_against_digests": gold_n,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if Stepper.ndf:
+            # N (ceil(0.375 L) + T (8 + 4) passes) + 2 ceil(0.375 L) C -- N probes, T tables,
+            # 8 radix passes over 64-bit keys + 32-bit indices, C pairs sharing a bucket that were compared
+            N, T, C = per.get("ndf_probes", 0), per.get("ndf_tables", 0) / max(len(stepper.resident), 1), per.get("ndf_pairs", 0)
+            lb = -(-3 * PROBE_LEN // 8)
+            k3_bytes = N * (lb + T * 12 * 8) + 2.0 * lb * C
+            out["roofline_k3"] = dict(bound="hbm", kernel="ndf_key + radix sort + ndf_edge + resolution rounds (Hamming LSH filter)",
+                                      achieved=gbs(k3_bytes, per.get("ndf_ms", 0.0)), peak=HBM_PEAK_GBS, unit="GB/s",
+                                      frac=gbs(k3_bytes, per.get("ndf_ms", 0.0)) / HBM_PEAK_GBS,
+                                      traffic=pmc_traffic("ndf", args.workload, args.scale),
+                                      algorithmic_bytes=k3_bytes, device_ms_per_step=per.get("ndf_ms", 0.0),
+                                      probes=N, tables=T, pairs_compared=C, edges=per.get("ndf_edges", 0),
+                                      kept=per.get("ndf_kept", 0), windows=per.get("windows", 0),
+                                      front_end_ms=per.get("front_end_ms", 0.0))
+            out["config"]["workload"] += "; step = device front end + --filter-with-lsh-hamming 2 (K3) + scan + solve, targets resident"
+        if world == 1 and not args.no_cpu_baseline and Stepper.ndf:
+            # configs[2]: the oracle's chain (Hamming filter, then the set cover) on a down-scaled S3 of the
+            # same generator, and the GPU on that same input
+            base, gpu_s, same = cpu_baseline_s3(stepper.ctxs[0])
+            out["cpu_baseline"] = base
+            out["parity_vs_oracle"] = same
+            out["gpu_ms_on_cpu_sample"] = gpu_s * 1e3
+            out["speedup_vs_cpu_oracle"] = base["seconds"] / gpu_s
+        elif world == 1 and not args.no_cpu_baseline:
             order = sorted(range(len(groups)), key=lambda i: bases[i])
             sample, acc = [], 0
             for i in order:
@@ -535,8 +866,44 @@ def main():
             # the timed GPU result must equal the oracle's (parity guard)
             out["parity_vs_oracle"] = all(sorted(picks[gi]) == sorted(sel[gi])
                                           for gi in sample)
-            out["speedup_vs_cpu_oracle"] = out["value"] / base["value"]
-            out["speedup_vs_cpu_oracle_incl_h2d"] = out["value_incl_h2d"] / base["value"]
+            # like for like: the GPU on exactly the CPU sample's groups (resident inputs, one
+            # after the other), against the CPU's time per pass over the same groups
+            by_index = {g.index: g for g in stepper.resident}
+            reps = 5
+            for _ in range(2):
+                for gi in sample:
+                    g = by_index[gi]
+                    engine.setcover_filter(g.ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN, 0, EXT,
+                                           g.n_sets, mode=SCAN_MODE)
+            stepper.sync()
+            tg = time.perf_counter()
+            for _ in range(reps):
+                for gi in sample:
+                    g = by_index[gi]
+                    engine.setcover_filter(g.ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN, 0, EXT,
+                                           g.n_sets, mode=SCAN_MODE)
+            stepper.sync()
+            gpu_sample_s = (time.perf_counter() - tg) / reps
+            out["gpu_ms_on_cpu_sample"] = gpu_sample_s * 1e3
+            out["speedup_vs_cpu_oracle"] = (base["seconds"] / base["passes"]) / gpu_sample_s
+            out["speedup_note"] = ("CPU seconds per pass over the sample's groups / GPU seconds for the same "
+                                   "groups (resident inputs); `value` / cpu_baseline.value is NOT comparable: "
+                                   "probe*bp grows quadratically with the group size")
+        if world == 1 and not args.no_m2 and not Stepper.ndf:
+            # M2: from host strings to ids on the host, nothing resident, through the
+            # plugin's pipelined path; then one pass without the overlap for comparison
+            tm2, picks_m2 = m2_passes(groups, args.m2_steps, 1, int(os.environ.get("CATCHHIP_PREFETCH_DEPTH", "2")))
+            m2 = sum(tm2) / len(tm2)
+            ts2, picks_s2 = m2_passes(groups, 1, 0, 0)
+            out["m2_setcoverfilter_wall_s"] = m2
+            out["m2_steps_s"] = tm2
+            out["m2_serial_wall_s"] = ts2[0]
+            out["value_incl_h2d"] = total_units / m2
+            out["m2_parity_vs_golden_digests"] = (None if gold is None else
+                                                  bool(digests_ok(gold, picks_m2) and digests_ok(gold, picks_s2)))
+            out["m2_note"] = ("pack + H2D + device front end + scan + solve + ids out per pass, host strings in, "
+                              "via SetCoverFilter._filter_genomes_device; the upload context packs group i+1 "
+                              "while group i is scanned and solved (m2_serial_wall_s: the same without overlap)")
         if world == 1 and not args.no_overlap_figure and not args.no_cpu_baseline:   # (both extras off under the profiler)
             # The same work with every group on one of three streams (what the plugin's
             # CATCHHIP_GROUPS_IN_FLIGHT does): faster, but kernels of different groups then
@@ -558,8 +925,7 @@ def main():
             el2 = (time.perf_counter() - t2) / 3
             ok2 = None
             if gold is not None:
-                ok2 = all(len(ids) == gold[gi]["n_picks"] and digest(ids) == gold[gi]["picks_sha256"]
-                          for gi, ids in picks2.items() if gi in gold)
+                ok2 = bool(digests_ok(gold, picks2))
             out["groups_overlapped"] = {"groups_in_flight": st2.width, "steps": 3, "ms_per_step": el2 * 1e3,
                                         "value": total_units / el2, "parity_vs_golden_digests": ok2,
                                         "note": "not the headline: per-kernel times (roofline) are only "

@@ -34,12 +34,17 @@ PROTOTYPES = {
         c_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), c_i64p]),
     "catchhip_ctx_last_counters": (ctypes.c_int, [c_vp, c_i64p]),
     "catchhip_ctx_last_seeds_dropped": (ctypes.c_int, [c_vp, c_i64p]),
+    "catchhip_ctx_last_solver_counters": (ctypes.c_int, [c_vp, c_i64p]),
+    "catchhip_ctx_last_ndf_counters": (ctypes.c_int, [c_vp, c_i64p]),
     "catchhip_targets_create": (ctypes.c_int, [
         c_vp, c_u8p, c_i64p, c_i32p, ctypes.c_int64, ctypes.c_int32, c_vpp]),
     "catchhip_targets_create_ptrs": (ctypes.c_int, [
         c_vp, ctypes.POINTER(ctypes.c_void_p), c_i64p, c_i32p, ctypes.c_int64,
         ctypes.c_int32, c_vpp]),
     "catchhip_targets_destroy": (ctypes.c_int, [c_vp]),
+    "catchhip_targets_rebind": (ctypes.c_int, [c_vp, c_vp]),
+    "catchhip_probes_rebind": (ctypes.c_int, [c_vp, c_vp]),
+    "catchhip_candidates_rebind": (ctypes.c_int, [c_vp, c_vp]),
     "catchhip_probes_create": (ctypes.c_int, [
         c_vp, c_u8p, c_i64p, ctypes.c_int64, c_i32p, c_i32p, c_i32p,
         ctypes.c_int64, ctypes.c_int32, c_vpp]),

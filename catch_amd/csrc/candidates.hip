@@ -396,6 +396,15 @@ extern "C" int catchhip_candidates_create(catchhip_ctx *ctx, const catchhip_targ
     return 0;
 }
 
+// see catchhip_targets_rebind (core.hip)
+extern "C" int catchhip_candidates_rebind(catchhip_candidates *C, catchhip_ctx *to) {
+    ARG_CHECK(C && C->ctx && to && C->ctx->device == to->device);
+    HIP_TRY(hipSetDevice(to->device));
+    if (C->ctx != to) HIP_TRY(hipStreamSynchronize(C->ctx->stream));
+    C->ctx = to;
+    return 0;
+}
+
 extern "C" void catchhip_candidates_destroy(catchhip_candidates *C) {
     if (!C) return;
     PoolScope pool_scope(C->ctx);

@@ -236,6 +236,18 @@ extern "C" int catchhip_ctx_last_counters(catchhip_ctx *c, i64 *out8) {
     return 0;
 }
 
+extern "C" int catchhip_ctx_last_solver_counters(catchhip_ctx *c, i64 *out4) {
+    ARG_CHECK(c != nullptr && out4 != nullptr);
+    for (int i = 0; i < 4; ++i) out4[i] = c->solver_counters[i];
+    return 0;
+}
+
+extern "C" int catchhip_ctx_last_ndf_counters(catchhip_ctx *c, i64 *out4) {
+    ARG_CHECK(c != nullptr && out4 != nullptr);
+    for (int i = 0; i < 4; ++i) out4[i] = c->ndf_counters[i];
+    return 0;
+}
+
 extern "C" int catchhip_ctx_last_seeds_dropped(catchhip_ctx *c, i64 *out) {
     ARG_CHECK(c != nullptr && out != nullptr);
     *out = c->seeds_dropped;
@@ -424,6 +436,7 @@ extern "C" int catchhip_targets_create(catchhip_ctx *ctx, const u8 *bytes, const
 // of the 0.31 s a bench upload took).  The sequences are gathered into pinned
 // memory by a few host threads, which also look at the alphabet, and uploaded
 // from there.
+#include <chrono>
 #include <thread>
 extern "C" int catchhip_targets_create_ptrs(catchhip_ctx *ctx, const u8 *const *seq_ptr, const i64 *seq_len,
                                             const i32 *seq_genome, i64 nseq, i32 ngenomes,
@@ -443,21 +456,35 @@ extern "C" int catchhip_targets_create_ptrs(catchhip_ctx *ctx, const u8 *const *
     }
     TRY(chip_pinned_reserve(ctx, (size_t)total + 64));
     u8 *stage = (u8 *)ctx->h_big;
-    const int nthreads = (int)std::max<i64>(1, std::min<i64>(8, total >> 22));   // one per 4 MB, at most 8
-    std::vector<unsigned char> seen((size_t)nthreads * 256, 0);
+    // one thread per 2 MB, at most 16 (the copy runs at memory speed from a handful of cores; the
+    // alphabet test is three compares per byte that the compiler vectorises)
+    static const int max_threads = getenv("CATCHHIP_GATHER_THREADS") ? std::max(1, atoi(getenv("CATCHHIP_GATHER_THREADS"))) : 16;
+    const int nthreads = (int)std::max<i64>(1, std::min<i64>(max_threads, total >> 21));
+    std::vector<unsigned char> seen((size_t)nthreads * 2, 0);   // per thread: {an N, some other symbol}
+    const auto t_g0 = std::chrono::steady_clock::now();
     auto work = [&](int tix) {
-        unsigned char *present = seen.data() + (size_t)tix * 256;
-        // thread tix takes the sequences whose bytes fall into its slice of the total
+        // thread tix takes the sequences whose bytes start in its slice of the total
         const i64 lo = total * tix / nthreads, hi = total * (tix + 1) / nthreads;
         i64 i = std::upper_bound(off.begin(), off.end(), lo) - off.begin() - 1;
         if (i < 0) i = 0;
+        unsigned char any_n = 0, any_other = 0;
         for (; i < nseq && off[i] < hi; ++i) {
             if (off[i] < lo) continue;          // belongs to the previous slice
             const u8 *src = seq_ptr[i];
             const i64 n = seq_len[i];
             u8 *dst = stage + off[i];
-            for (i64 j = 0; j < n; ++j) { const u8 c = src[j]; dst[j] = c; present[c] = 1; }
+            memcpy(dst, src, (size_t)n);
+            unsigned char nn = 0, oo = 0;
+            for (i64 j = 0; j < n; ++j) {
+                const u8 c = dst[j];
+                const unsigned char acgt = (unsigned char)((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T'));
+                const unsigned char isn = (unsigned char)(c == 'N');
+                nn |= isn;
+                oo |= (unsigned char)!(acgt | isn);
+            }
+            any_n |= nn; any_other |= oo;
         }
+        seen[(size_t)tix * 2] = any_n; seen[(size_t)tix * 2 + 1] = any_other;
     };
     if (nthreads == 1) work(0);
     else {
@@ -465,16 +492,40 @@ extern "C" int catchhip_targets_create_ptrs(catchhip_ctx *ctx, const u8 *const *
         for (int tix = 0; tix < nthreads; ++tix) th.emplace_back(work, tix);
         for (auto &x : th) x.join();
     }
-    bool alpha[2] = {true, false};
-    for (int c = 0; c < 256; ++c) {
-        bool any = false;
-        for (int tix = 0; tix < nthreads; ++tix) any = any || seen[(size_t)tix * 256 + c];
-        if (!any || c == 'A' || c == 'C' || c == 'G' || c == 'T') continue;
-        alpha[1] = true;
-        if (c != 'N') alpha[0] = false;
+    bool alpha[2] = {true, false};   // {subset of ACGTN, something other than ACGT}
+    for (int tix = 0; tix < nthreads; ++tix) {
+        if (seen[(size_t)tix * 2] || seen[(size_t)tix * 2 + 1]) alpha[1] = true;
+        if (seen[(size_t)tix * 2 + 1]) alpha[0] = false;
     }
+    if (getenv("CATCHHIP_TIMING"))
+        fprintf(stderr, "[catchhip] targets: gathered %lld bytes on %d threads in %.3f ms\n", (long long)total, nthreads,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_g0).count());
     const int rc = targets_create_impl(ctx, stage, off.data(), seq_genome, nseq, ngenomes, alpha, out);
     return rc;
+}
+
+// Hand-over between contexts of one device (an upload context packs the next
+// group while the compute context's stream works on the current one): waits
+// for the stream the object was built on, after which it belongs to `to`.  Its
+// device blocks keep their pool owner and return to the builder's cache when
+// the object is destroyed -- by then every user of them has finished.
+static int rebind_check(catchhip_ctx *from, catchhip_ctx *to) {
+    ARG_CHECK(from && to && from->device == to->device);
+    HIP_TRY(hipSetDevice(from->device));
+    if (from != to) HIP_TRY(hipStreamSynchronize(from->stream));
+    return 0;
+}
+extern "C" int catchhip_targets_rebind(catchhip_targets *t, catchhip_ctx *to) {
+    ARG_CHECK(t != nullptr);
+    TRY(rebind_check(t->ctx, to));
+    t->ctx = to;
+    return 0;
+}
+extern "C" int catchhip_probes_rebind(catchhip_probes *p, catchhip_ctx *to) {
+    ARG_CHECK(p != nullptr);
+    TRY(rebind_check(p->ctx, to));
+    p->ctx = to;
+    return 0;
 }
 
 extern "C" int catchhip_targets_destroy(catchhip_targets *t) {

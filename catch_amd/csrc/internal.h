@@ -109,6 +109,8 @@ struct catchhip_ctx {
     double phase_ms[NPHASE] = {};
     i64 phase_launches[NPHASE] = {};
     i64 counters[8] = {};
+    i64 ndf_counters[4] = {};      // last Hamming near-duplicate filter: probes, tables, pairs compared, edges
+    i64 solver_counters[4] = {};   // row-parallel solver: records streamed, rows counted again, bitmap words read, owner words looked at
     i64 seeds_dropped = 0;   // of counters[1]: work-list entries the seed look-up's anchor-pair filter left empty
     // pinned staging word(s) for small device->host reads
     u64 *h_pin = nullptr;

@@ -85,21 +85,28 @@ ndf_edge_kernel(const u64 *__restrict__ padded, u32 n, int W, int d, const i32 *
                 u32 *__restrict__ e_j, u32 *__restrict__ count, u32 cap, const u32 *__restrict__ grp,
                 size_t pos_group_stride) {
     u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= n) return;
-    const u64 key = keys[x];
-    const u32 i = vals[x];
-    const u64 *a = padded + (size_t)i * W;
-    if (grp) pos += (size_t)grp[i] * pos_group_stride;
-    for (u32 y = x; y-- > 0;) {
-        if (keys[y] != key) break;
-        const u32 j = vals[y];  // j < i: stable sort keeps indices ascending in a run
-        if (grp && grp[j] != grp[i]) continue;   // another group under the same key
-        if (ndf_near(a, padded + (size_t)j * W, W, d, pos, k)) {
-            const u32 shard = (x >> 6) & (ES_SHARDS - 1);
-            const u32 slot = atomicAdd(&count[shard * ES_STRIDE], 1u);
-            if (slot < cap) { e_i[(size_t)shard * cap + slot] = i; e_j[(size_t)shard * cap + slot] = j; }
+    u32 npairs = 0;
+    if (x < n) {
+        const u64 key = keys[x];
+        const u32 i = vals[x];
+        const u64 *a = padded + (size_t)i * W;
+        if (grp) pos += (size_t)grp[i] * pos_group_stride;
+        for (u32 y = x; y-- > 0;) {
+            if (keys[y] != key) break;
+            const u32 j = vals[y];  // j < i: stable sort keeps indices ascending in a run
+            if (grp && grp[j] != grp[i]) continue;   // another group under the same key
+            ++npairs;
+            if (ndf_near(a, padded + (size_t)j * W, W, d, pos, k)) {
+                const u32 shard = (x >> 6) & (ES_SHARDS - 1);
+                const u32 slot = atomicAdd(&count[shard * ES_STRIDE], 1u);
+                if (slot < cap) { e_i[(size_t)shard * cap + slot] = i; e_j[(size_t)shard * cap + slot] = j; }
+            }
         }
     }
+    // pairs compared (SURVEY 8(d) K3's C): one 64-bit add per wavefront, beside its shard's edge counter
+    for (int o = 32; o > 0; o >>= 1) npairs += __shfl_down(npairs, o, WAVE);
+    if ((threadIdx.x & 63) == 0 && npairs)
+        atomicAdd((unsigned long long *)(count + ((x >> 6) & (ES_SHARDS - 1)) * ES_STRIDE + 2), (unsigned long long)npairs);
 }
 
 // status: 0 undecided, 1 kept, 2 dropped.  flags: bit0 = has kept higher
@@ -139,7 +146,15 @@ static int ndf_fullest_shard(catchhip_ctx *ctx, const u32 *count, u32 *out) {
     HIP_TRY(hipMemcpyAsync(ctx->h_big, count, sizeof(u32) * ES_WORDS, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     u32 m = 0;
-    for (int sh = 0; sh < ES_SHARDS; ++sh) { const u32 v = ((const volatile u32 *)ctx->h_big)[sh * ES_STRIDE]; if (v > m) m = v; }
+    i64 edges = 0, pairs = 0;
+    for (int sh = 0; sh < ES_SHARDS; ++sh) {
+        const u32 v = ((const volatile u32 *)ctx->h_big)[sh * ES_STRIDE];
+        if (v > m) m = v;
+        edges += v;
+        pairs += (i64)((const volatile unsigned long long *)((const u32 *)ctx->h_big + sh * ES_STRIDE + 2))[0];
+    }
+    ctx->ndf_counters[2] = pairs;   // pairs sharing a bucket that were compared (all tables)
+    ctx->ndf_counters[3] = edges;   // of them within the distance
     *out = m;
     return 0;
 }
@@ -211,6 +226,7 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
                        (const u8 *)d_bytes.p, (u32)n, (int)L, W * 8, (u8 *)padded.p);
 
     PhaseTimer tm(ctx, PHASE_NDF);
+    ctx->ndf_counters[0] = n; ctx->ndf_counters[1] = ntables; ctx->ndf_counters[2] = ctx->ndf_counters[3] = 0;
     const unsigned nb = (unsigned)div_up(nn, 256);
     u32 cap = (u32)std::max<i64>((i64)1 << 14, std::min<i64>(n * 16, (i64)1 << 28) / ES_SHARDS);   // per shard
     u32 ne = 0;

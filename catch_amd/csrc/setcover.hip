@@ -969,6 +969,7 @@ int chip_greedy_deferred(catchhip_ctx *ctx, catchhip_rows *R, i64 num_sets, cons
     *retry = 0;
     *n_out = 0;
     ctx->phase_ms[PHASE_CLAIM] = 0.0; ctx->phase_launches[PHASE_CLAIM] = 0;   // (only the row-parallel solver fills it)
+    memset(ctx->solver_counters, 0, sizeof(ctx->solver_counters));
     if (num_sets <= 0 || num_sets >= (i64)ID_MASK || !R->deferred) { *retry = 1; return 0; }
     HIP_TRY(hipSetDevice(ctx->device));
     PoolScope pool_scope(ctx);
@@ -984,6 +985,7 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     PoolScope pool_scope(ctx);
     *n_out = 0;
     ctx->phase_ms[PHASE_CLAIM] = 0.0; ctx->phase_launches[PHASE_CLAIM] = 0;   // (only the row-parallel solver fills it)
+    memset(ctx->solver_counters, 0, sizeof(ctx->solver_counters));
     if (num_sets == 0 || R->n == 0) return 0;  // no universe has anything to cover
     ARG_CHECK(out_ids != nullptr);
     if (num_sets >= (i64)ID_MASK) { chip_set_error("setcover: more than 2^32-2 sets not supported"); return CATCHHIP_EINVAL; }

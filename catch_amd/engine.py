@@ -113,7 +113,18 @@ class Context:
         dropped = np.zeros(1, dtype=np.int64)
         check(self._L.catchhip_ctx_last_seeds_dropped(self._h, _ptr(dropped, c_i64p)))
         d["seeds_dropped"] = int(dropped[0])   # of seed_hits: left without a seed by the look-up's filter
+        sc = np.zeros(4, dtype=np.int64)
+        check(self._L.catchhip_ctx_last_solver_counters(self._h, _ptr(sc, c_i64p)))
+        d.update(zip(("flat_rows_streamed", "flat_rows_recounted", "flat_bitmap_words",
+                      "flat_owner_words"), (int(x) for x in sc)))
         return d
+
+    def ndf_counters(self):
+        """catchhip_ctx_last_ndf_counters -> dict (last Hamming filter)."""
+        out = np.zeros(4, dtype=np.int64)
+        check(self._L.catchhip_ctx_last_ndf_counters(self._h, _ptr(out, c_i64p)))
+        return dict(zip(("probes", "tables", "pairs_compared", "edges"),
+                        (int(x) for x in out)))
 
     # -- RCCL -----------------------------------------------------------
     @staticmethod
@@ -226,6 +237,13 @@ class Targets:
         self.total = int(off[-1])
         self.seq_off = off      # global start of every sequence (+ total)
 
+    def rebind(self, ctx):
+        """catchhip_targets_rebind: hand the object to another context of the
+        same device (waits for the stream it was built on)."""
+        check(ctx._L.catchhip_targets_rebind(self._h, ctx._h))
+        self.ctx = ctx
+        return self
+
     def set_groups(self, group_of_genome):
         """catchhip_targets_set_groups (one entry per genome)."""
         g = np.ascontiguousarray(group_of_genome, dtype=np.int32)
@@ -269,6 +287,12 @@ class Probes:
             _ptr(owner, c_i32p), _ptr(ep, c_i32p), _ptr(eo, c_i32p), nent,
             int(k or 0), ctypes.byref(self._h)))
 
+    def rebind(self, ctx):
+        """catchhip_probes_rebind (see Targets.rebind)."""
+        check(ctx._L.catchhip_probes_rebind(self._h, ctx._h))
+        self.ctx = ctx
+        return self
+
     def set_groups(self, group_of_probe):
         """catchhip_probes_set_groups (one entry per unique probe)."""
         g = np.ascontiguousarray(group_of_probe, dtype=np.int32)
@@ -306,6 +330,12 @@ class Candidates:
             -1 if seq_length_to_skip is None else int(seq_length_to_skip),
             ctypes.byref(self._h), ctypes.byref(nc), ctypes.byref(nu)))
         self.ncandidates, self.n = nc.value, nu.value
+
+    def rebind(self, ctx):
+        """catchhip_candidates_rebind (see Targets.rebind)."""
+        check(ctx._L.catchhip_candidates_rebind(self._h, ctx._h))
+        self.ctx = ctx
+        return self
 
     def positions(self, ids=None):
         """Global start (concatenated target coordinate) of unique candidates
@@ -722,6 +752,81 @@ def setcover_filter_many(groups, mismatches, lcf_thres, island,
             int(cover_extension), int(mode), _ptr(nsets, c_i64p), rk_p, up_p,
             out_p, _ptr(n_out, c_i64p), _ptr(nrows, c_i64p)))
     return [(outs[g][:n_out[g]].tolist(), int(nrows[g])) for g in range(n)]
+
+
+class Prefetch:
+    """Runs build(item) for the items in order on a helper thread, at most
+    `depth` finished results ahead of the consumer: the packing and upload of
+    group i + 1 (host gather into pinned memory, H2D, the front-end kernels on
+    the upload context's stream) overlap the scan and solve of group i on the
+    compute context.  Iterating yields (item, result) in order; an exception in
+    build() is re-raised at the consumer.  close() stops the helper and hands
+    every result that was built but not consumed to `discard`."""
+
+    def __init__(self, items, build, depth=2, discard=None):
+        import queue
+        import threading
+        self._q = queue.Queue(maxsize=max(1, int(depth)))
+        self._stop = threading.Event()
+        self._discard = discard
+        self._items = list(items)
+
+        def run():
+            for it in self._items:
+                if self._stop.is_set():
+                    break
+                try:
+                    res, err = build(it), None
+                except BaseException as e:      # handed to the consumer
+                    res, err = None, e
+                taken = False
+                while not self._stop.is_set():
+                    try:
+                        self._q.put((it, res, err), timeout=0.05)
+                        taken = True
+                        break
+                    except queue.Full:
+                        continue
+                if not taken and res is not None and self._discard:
+                    self._discard(res)          # stopped before it was handed over
+                if err is not None:
+                    break
+
+        self._thread = threading.Thread(target=run, name="catchhip-prefetch",
+                                        daemon=True)
+        self._thread.start()
+
+    def __iter__(self):
+        for _ in range(len(self._items)):
+            it, res, err = self._q.get()
+            if err is not None:
+                raise err
+            yield it, res
+
+    def close(self):
+        import queue
+        self._stop.set()
+        self._thread.join()
+        while True:
+            try:
+                _it, res, _err = self._q.get_nowait()
+            except queue.Empty:
+                break
+            if res is not None and self._discard:
+                self._discard(res)
+
+
+_upload_ctxs = {}
+
+
+def upload_context(device=None):
+    """The context whose stream packs and uploads the NEXT group's inputs while
+    the compute context works (one per device, made on first use)."""
+    if device is None:
+        device = default_context().device
+    if device not in _upload_ctxs:
+        _upload_ctxs[device] = Context(device)
+    return _upload_ctxs[device]
 
 
 _default_ctx = None

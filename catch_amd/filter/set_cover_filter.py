@@ -309,15 +309,7 @@ class SetCoverFilter(BaseFilter):
                     h.close()
             for ctx, gi, ranks, (ids, nrows) in zip(ctxs, chunk, all_ranks,
                                                     results):
-                ms, nl = ctx.kernel_ms(engine.PHASE_SCAN)
-                timings["scan_ms"] += ms
-                timings["scan_launches"] += nl
-                timings["rows_ms"] += ctx.kernel_ms(engine.PHASE_ROWS)[0]
-                timings["rows"] += nrows
-                ms, nl = ctx.kernel_ms(engine.PHASE_GREEDY)
-                timings["greedy_ms"] += ms
-                timings["greedy_launches"] += nl
-                timings["picks"] += len(ids)
+                _accumulate(timings, ctx, nrows, len(ids))
                 num_bad = int(np.count_nonzero(ranks[ids] > 0)) if len(ids) else 0
                 if num_bad > 0:
                     logger.warning(("Group %d: forced to choose %d less-than-ideal "
@@ -433,7 +425,7 @@ class SetCoverFilter(BaseFilter):
 
     def _filter_genomes_device(self, target_genomes_grouped, probe_length,
                                probe_stride, seq_length_to_skip=None,
-                               near_duplicate_filter=None):
+                               near_duplicate_filter=None, return_ids=False):
         """[DuplicateFilter | near-duplicate filter, SetCoverFilter] with the
         front end on the device (near_duplicate_filter: an LSH filter object to
         apply to the unique candidates, in their multiplicity order, before the
@@ -442,8 +434,10 @@ class SetCoverFilter(BaseFilter):
         de-duplicated on the GPU (catchhip_candidates_create), gathered into a
         probes object and solved; only the selected candidates are looked up
         again, as slices of the host's sequence strings.  Returns the selected
-        probe strings per group, in pick order.  No ranks (identify / avoided
-        genomes need every candidate's string)."""
+        probe strings per group, in pick order (return_ids: the ids of the
+        selected unique candidates instead -- what bench.py's M2 figure times:
+        pack + H2D + front end + scan + solve + ids out).  No ranks (identify /
+        avoided genomes need every candidate's string)."""
         import os
         assert not self.identify and not self.avoided_genomes
         out = [[] for _ in target_genomes_grouped]
@@ -464,56 +458,95 @@ class SetCoverFilter(BaseFilter):
             chunks = _chunks_by_size(todo, lambda gi: sizes[gi], width)
         else:
             chunks = [todo[i:i + width] for i in range(0, len(todo), width)]
-        for chunk in chunks:
-            ctxs = _contexts(len(chunk))
-            specs, held, cands_of = [], [], []
+        # The inputs of the NEXT groups are packed and uploaded while the current
+        # chunk is scanned and solved: a helper thread builds (targets, candidates,
+        # probes) on the upload context -- host gather into pinned memory, H2D,
+        # the front-end kernels on that context's stream -- in the order the
+        # chunks consume them (so `random` / np.random are drawn from in the same
+        # order as without the overlap), at most CATCHHIP_PREFETCH_DEPTH groups
+        # ahead; the finished objects change hands (engine.*.rebind).
+        depth = int(os.environ.get("CATCHHIP_PREFETCH_DEPTH", "2"))
+        order = [gi for chunk in chunks for gi in chunk]
+
+        def build(gi, ctx=None):
+            uctx = ctx or engine.upload_context()
+            target_genomes = target_genomes_grouped[gi]
+            made = []
             try:
-                for ctx, gi in zip(ctxs, chunk):
-                    target_genomes = target_genomes_grouped[gi]
-                    targets = engine.Targets(ctx, [g.seqs for g in target_genomes])
-                    held.append(targets)
-                    cands = engine.Candidates(ctx, targets, probe_length,
-                                              probe_stride, seq_length_to_skip)
-                    held.append(cands)
-                    timings["candidates"] += cands.ncandidates
-                    timings["unique_candidates"] += cands.n
-                    if near_duplicate_filter is not None:
-                        near_duplicate_filter._apply_to_candidates(cands)
-                    cands_of.append((cands, targets, target_genomes))
-                    if cands.n == 0:
-                        logger.warning("There are no candidate probes for a "
-                                       "grouping of genomes")
-                    k, ep, eo = probe.anchor_entries_equal_length(
-                        cands.n, probe_length, self.mismatches, self.lcf_thres,
-                        min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
-                    probes = cands.probes(k, ep, eo)
-                    held.append(probes)
-                    specs.append((ctx, probes, targets, cands.n, None,
-                                  self._make_universe_p(target_genomes)))
-                results = engine.setcover_filter_many(
-                    specs, self.mismatches, self.lcf_thres,
-                    self.island_of_exact_match, self.cover_extension,
-                    self.scan_mode)
-                for ctx, gi, (cands, targets, target_genomes), (ids, nrows) in zip(
-                        ctxs, chunk, cands_of, results):
-                    seqs = [s for g in target_genomes for s in g.seqs]
-                    pos = cands.positions(np.asarray(ids, dtype=np.int64))
-                    which = np.searchsorted(targets.seq_off, pos, side="right") - 1
-                    local = pos - targets.seq_off[which]
-                    out[gi] = [seqs[q][o:o + probe_length]
-                               for q, o in zip(which.tolist(), local.tolist())]
-                    ms, nl = ctx.kernel_ms(engine.PHASE_SCAN)
-                    timings["scan_ms"] += ms
-                    timings["scan_launches"] += nl
-                    timings["rows_ms"] += ctx.kernel_ms(engine.PHASE_ROWS)[0]
-                    timings["rows"] += nrows
-                    ms, nl = ctx.kernel_ms(engine.PHASE_GREEDY)
-                    timings["greedy_ms"] += ms
-                    timings["greedy_launches"] += nl
-                    timings["picks"] += len(ids)
-            finally:
-                for h in reversed(held):
+                targets = engine.Targets(uctx, [g.seqs for g in target_genomes])
+                made.append(targets)
+                cands = engine.Candidates(uctx, targets, probe_length,
+                                          probe_stride, seq_length_to_skip)
+                made.append(cands)
+                ncand, nuniq = cands.ncandidates, cands.n
+                if near_duplicate_filter is not None:
+                    near_duplicate_filter._apply_to_candidates(cands)
+                k, ep, eo = probe.anchor_entries_equal_length(
+                    cands.n, probe_length, self.mismatches, self.lcf_thres,
+                    min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
+                probes = cands.probes(k, ep, eo)
+                made.append(probes)
+            except BaseException:
+                for h in reversed(made):
                     h.close()
+                raise
+            return targets, cands, probes, ncand, nuniq
+
+        def discard(res):
+            for h in (res[2], res[1], res[0]):
+                h.close()
+
+        pre = engine.Prefetch(order, build, depth, discard) if depth > 0 else None
+        feed = iter(pre) if pre is not None else None
+        try:
+            for chunk in chunks:
+                ctxs = _contexts(len(chunk))
+                specs, held, cands_of = [], [], []
+                try:
+                    for ctx, gi in zip(ctxs, chunk):
+                        target_genomes = target_genomes_grouped[gi]
+                        if feed is not None:
+                            got, res = next(feed)
+                            assert got == gi
+                            held.extend(res[:3])
+                            targets, cands, probes, ncand, nuniq = res
+                            for h in (targets, cands, probes):
+                                h.rebind(ctx)
+                        else:
+                            targets, cands, probes, ncand, nuniq = build(gi, ctx)
+                            held.extend((targets, cands, probes))
+                        timings["candidates"] += ncand
+                        timings["unique_candidates"] += nuniq
+                        timings["probe_bp_units"] = timings.get("probe_bp_units", 0.0) + float(cands.n) * float(
+                            sum(g.size() for g in target_genomes))
+                        cands_of.append((cands, targets, target_genomes))
+                        if cands.n == 0:
+                            logger.warning("There are no candidate probes for a "
+                                           "grouping of genomes")
+                        specs.append((ctx, probes, targets, cands.n, None,
+                                      self._make_universe_p(target_genomes)))
+                    results = engine.setcover_filter_many(
+                        specs, self.mismatches, self.lcf_thres,
+                        self.island_of_exact_match, self.cover_extension,
+                        self.scan_mode)
+                    for ctx, gi, (cands, targets, target_genomes), (ids, nrows) in zip(
+                            ctxs, chunk, cands_of, results):
+                        if return_ids:
+                            out[gi] = ids
+                        else:
+                            seqs = [s for g in target_genomes for s in g.seqs]
+                            pos = cands.positions(np.asarray(ids, dtype=np.int64))
+                            which = np.searchsorted(targets.seq_off, pos, side="right") - 1
+                            local = pos - targets.seq_off[which]
+                            out[gi] = [seqs[q][o:o + probe_length]
+                                       for q, o in zip(which.tolist(), local.tolist())]
+                        _accumulate(timings, ctx, nrows, len(ids))
+                finally:
+                    for h in reversed(held):
+                        h.close()
+        finally:
+            if pre is not None:
+                pre.close()
         self.last_timings = timings
         return out
 
@@ -572,6 +605,10 @@ class SetCoverFilter(BaseFilter):
                     self.island_of_exact_match, self.cover_extension, cands.n,
                     None, universe_p, self.scan_mode)
                 ids = np.asarray(ids, dtype=np.int64)
+                # candidate-probe x target-bp of the chunk: every cluster's own candidates x its bases
+                per_group = np.bincount(cands.groups(), minlength=len(chunk)) if cands.n else np.zeros(len(chunk), np.int64)
+                gbases = np.array([sum(g.size() for g in target_genomes_grouped[gi]) for gi in chunk], dtype=np.float64)
+                timings["probe_bp_units"] = timings.get("probe_bp_units", 0.0) + float(np.dot(per_group[:len(chunk)], gbases))
                 if ids.size:
                     grp = cands.groups()[ids]
                     pos = cands.positions(ids)
@@ -583,15 +620,7 @@ class SetCoverFilter(BaseFilter):
                 for h in (probes, cands, targets):
                     if h is not None:
                         h.close()
-            ms, nl = ctx.kernel_ms(engine.PHASE_SCAN)
-            timings["scan_ms"] += ms
-            timings["scan_launches"] += nl
-            timings["rows_ms"] += ctx.kernel_ms(engine.PHASE_ROWS)[0]
-            timings["rows"] += nrows
-            ms, nl = ctx.kernel_ms(engine.PHASE_GREEDY)
-            timings["greedy_ms"] += ms
-            timings["greedy_launches"] += nl
-            timings["picks"] += int(ids.size)
+            _accumulate(timings, ctx, nrows, int(ids.size))
         self.last_timings = timings
         return out
 
@@ -653,15 +682,24 @@ class SetCoverFilter(BaseFilter):
             grp = np.searchsorted(offsets, ids, side="right") - 1
             for j, gi in enumerate(chunk):
                 selected[gi] = (ids[grp == j] - offsets[j]).tolist()
-            ms, nl = ctx.kernel_ms(engine.PHASE_SCAN)
-            timings["scan_ms"] += ms
-            timings["scan_launches"] += nl
-            timings["rows_ms"] += ctx.kernel_ms(engine.PHASE_ROWS)[0]
-            timings["rows"] += nrows
-            ms, nl = ctx.kernel_ms(engine.PHASE_GREEDY)
-            timings["greedy_ms"] += ms
-            timings["greedy_launches"] += nl
-            timings["picks"] += len(ids)
+            _accumulate(timings, ctx, nrows, len(ids))
+
+
+def _accumulate(timings, ctx, nrows, npicks):
+    """Adds the device times (HIP events per phase) and work counters of the
+    context's last fused filter call to `timings`."""
+    for name, ph in (("scan_ms", engine.PHASE_SCAN), ("verify_ms", engine.PHASE_VERIFY),
+                     ("rows_ms", engine.PHASE_ROWS), ("greedy_ms", engine.PHASE_GREEDY),
+                     ("rounds_ms", engine.PHASE_GREEDY_ROUNDS), ("claim_ms", engine.PHASE_CLAIM)):
+        ms, nl = ctx.kernel_ms(ph)
+        timings[name] = timings.get(name, 0.0) + ms
+        ln = name.replace("_ms", "_launches")
+        timings[ln] = timings.get(ln, 0) + nl
+    timings["rows"] = timings.get("rows", 0) + nrows
+    timings["picks"] = timings.get("picks", 0) + npicks
+    for k, v in ctx.counters().items():
+        if k not in ("picks", "_"):
+            timings[k] = timings.get(k, 0) + v
 
 
 def _chunks_by_size(todo, size_of, width):

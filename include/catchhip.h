@@ -70,7 +70,8 @@ int catchhip_ctx_last_kernel_ms(catchhip_ctx *ctx, int phase, double *ms,
 /* Work counters of the most recent calls (for roofline accounting), 8 values:
  * [0] raw hits found by the last cover scan, [1] seeds verified (seed scan /
  * seed join), [2] greedy iterations (rounds), [3] picks, [4] winner rows applied
- * (sequential solver), [5] rows re-counted by the greedy solver, [6] bitmap
+ * (sequential solver; row-parallel solver: row records streamed), [5] rows
+ * re-counted by the greedy solver, [6] bitmap
  * words read while re-counting, [7] cover rows of the last fused
  * catchhip_setcover_filter call. */
 int catchhip_ctx_last_counters(catchhip_ctx *ctx, int64_t *out8);
@@ -80,6 +81,18 @@ int catchhip_ctx_last_counters(catchhip_ctx *ctx, int64_t *out8);
  * seed), or no second anchor of the probe matches (more than m mismatches).
  * They cost the verification 4 bytes each and none of its gathers. */
 int catchhip_ctx_last_seeds_dropped(catchhip_ctx *ctx, int64_t *out);
+/* Work of the row-parallel frontier solver in the last solve that used it (zeros
+ * otherwise), 4 values: row records streamed by the count launches (alive rows,
+ * summed over the rounds); of those, rows whose bitmap words were read again
+ * because one of them had changed (SURVEY 8(d) K2's E_dirty -- the reference's
+ * memo invalidation by overlap, catch/utils/set_cover.py:552-613, is the same
+ * idea); bitmap words read for them; owner words the claim launches looked at. */
+int catchhip_ctx_last_solver_counters(catchhip_ctx *ctx, int64_t *out4);
+/* Work of the last Hamming near-duplicate filter on this context (SURVEY 8(d)
+ * K3's quantities; catch/filter/near_duplicate_filter.py:47-142 does the same
+ * look-ups probe by probe): probes N, tables T, pairs sharing a bucket that were
+ * compared (C, all tables), pairs within the distance (edges). */
+int catchhip_ctx_last_ndf_counters(catchhip_ctx *ctx, int64_t *out4);
 
 /* ---- inputs ------------------------------------------------------------ */
 /* Target sequences (catch/genome.py Genome.seqs of every genome of a group).
@@ -100,6 +113,13 @@ int catchhip_targets_create_ptrs(catchhip_ctx *ctx, const uint8_t *const *seq_pt
                                  int64_t nseq, int32_t ngenomes,
                                  catchhip_targets **out);
 int catchhip_targets_destroy(catchhip_targets *t);
+/* Hand-over of an input object to another context of the same device.  The
+ * reference overlaps nothing here (catch/filter/set_cover_filter.py:816-846
+ * builds a group's sets, then solves it); this path packs and uploads group
+ * i + 1 on an upload context while the compute context scans and solves group
+ * i, and the finished object changes hands: the call waits for the stream the
+ * object was built on, after which only calls on `to` may use it. */
+int catchhip_targets_rebind(catchhip_targets *t, catchhip_ctx *to);
 
 /* Candidate probes + their seed ("anchor") table, i.e. the content of the
  * reference's kmer_probe_map (catch/probe.py:507-577 builds it,
@@ -113,6 +133,7 @@ int catchhip_probes_create(catchhip_ctx *ctx, const uint8_t *bytes,
                            const int32_t *ent_pos, int64_t nent, int32_t k,
                            catchhip_probes **out);
 int catchhip_probes_destroy(catchhip_probes *p);
+int catchhip_probes_rebind(catchhip_probes *p, catchhip_ctx *to);   /* see catchhip_targets_rebind */
 
 /* ---- K1: coverage scan -------------------------------------------------- */
 #define CATCHHIP_SCAN_AUTO 0     /* seed scan when its preconditions hold, else general */
@@ -428,6 +449,7 @@ int catchhip_candidates_create(catchhip_ctx *ctx, const catchhip_targets *target
                                catchhip_candidates **out, int64_t *ncandidates,
                                int64_t *nunique);
 void catchhip_candidates_destroy(catchhip_candidates *cands);
+int catchhip_candidates_rebind(catchhip_candidates *cands, catchhip_ctx *to);   /* see catchhip_targets_rebind */
 /* global_start[i] = position (in the targets' concatenated coordinate) of the
  * first occurrence of unique candidate ids[i] (ids == NULL: candidates 0..n-1) */
 int catchhip_candidates_fetch(catchhip_ctx *ctx, const catchhip_candidates *cands,

@@ -6,7 +6,8 @@ the CPU oracle at these sizes inside a test, so the expected answers are
 computed here -- with the oracle that tests/test_oracle_golden.py pins to the
 reference (threaded per-sequence scans + the lazy evaluation of the greedy,
 which that file proves equal to the line-by-line restatement) -- and committed
-as data: per group (n_candidates, n_picks, sha256 of the sorted pick ids).
+as data: per group (n_candidates, n_picks, sha256 of the sorted pick ids and of
+the ids in pick order; the same for -c 0.9 on the same rows).
 tests/test_gpu_parity.py::test_full_size_* assert them on the MI355X.
 
     python tests/golden/make_full_size.py S4 [S3] [S5:0.05]  -> tests/golden/full_size_picks.json
@@ -36,6 +37,11 @@ def digest(ids):
     return hashlib.sha256(a.astype("<i8").tobytes()).hexdigest()
 
 
+def digest_in_order(ids):
+    """Order-sensitive: the ids in the sequential pick order."""
+    return hashlib.sha256(np.asarray(ids, dtype="<i8").tobytes()).hexdigest()
+
+
 def set_cover_groups(name, scale):
     groups = synthetic.dataset(name, scale=scale)
     recs = []
@@ -46,12 +52,18 @@ def set_cover_groups(name, scale):
             candidate_probes.candidate_strings_from_sequences(seqs, L, STRIDE)))
         k, entries = orc.anchor_table(cands, MISMATCHES, L)
         rows = orc.make_sets(cands, entries, k, genomes, MISMATCHES, L, 0, EXT)
-        picks = orc.lazy_greedy(rows[0], rows[1], rows[2], rows[3], len(cands),
-                                [sum(len(s) for s in g) for g in genomes])
+        glen = [sum(len(s) for s in g) for g in genomes]
+        picks = orc.lazy_greedy(rows[0], rows[1], rows[2], rows[3], len(cands), glen)
+        # the same rows under partial coverage (-c 0.9: 90 % of every genome)
+        picks09 = orc.lazy_greedy(rows[0], rows[1], rows[2], rows[3], len(cands), glen,
+                                  universe_p=[0.9] * len(genomes))
         recs.append(dict(group=gi, genomes=len(genomes),
                          bases=sum(len(s) for s in seqs),
                          n_candidates=len(cands), n_rows=int(rows[0].size),
-                         n_picks=len(picks), picks_sha256=digest(picks)))
+                         n_picks=len(picks), picks_sha256=digest(picks),
+                         picks_in_order_sha256=digest_in_order(picks),
+                         n_picks_c09=len(picks09), picks_c09_sha256=digest(picks09),
+                         picks_c09_in_order_sha256=digest_in_order(picks09)))
         sys.stderr.write("%s x%g group %d: %s (%.0f s)\n"
                          % (name, scale, gi, recs[-1], time.perf_counter() - t0))
         sys.stderr.flush()
@@ -82,7 +94,7 @@ def config3(scale):
                n_windows=len(strs), n_candidates=len(kept),
                kept_sha256=hashlib.sha256("\n".join(kept).encode()).hexdigest(),
                n_rows=int(rows[0].size), n_picks=len(picks),
-               picks_sha256=digest(picks))
+               picks_sha256=digest(picks), picks_in_order_sha256=digest_in_order(picks))
     sys.stderr.write("S3 x%g: %s (ndf %.0f s, total %.0f s)\n"
                      % (scale, rec, t1 - t0, time.perf_counter() - t0))
     return dict(flags="-pl 100 -ps 50 -m 2 -e 50 -c 1.0 --filter-with-lsh-hamming 2 "

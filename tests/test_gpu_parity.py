@@ -349,15 +349,22 @@ def test_greedy_random_instances_match_oracle(ctx, oracle):
         assert got == exp, trial
 
 
-@pytest.mark.parametrize("flat", [False, True])
+@pytest.mark.parametrize("flat", [False, True, "lds", "contiguous", "contiguous-lds"])
 def test_greedy_batched_rounds_restore_sequential_order(ctx, oracle, monkeypatch, flat):
     """Larger full-coverage instances (many locally maximal sets per round,
     with and without ranks): the frontier solver -- set-parallel fused kernels
     and, forced here on these small instances, the row-parallel kernels large
     instances take -- must return the oracle's sequential pick order, and so
-    must the one-pick-per-iteration solver."""
+    must the one-pick-per-iteration solver.  The row-parallel kernels count a
+    row again only when one of its bitmap words changed (cached counts): run
+    with the changed bits read from global memory and staged in LDS, with
+    striped and with contiguous tiles."""
     engine = _engine()
     monkeypatch.setenv("CATCHHIP_FLAT_MIN_ROWS", "0" if flat else str(1 << 40))
+    if flat in ("lds", "contiguous-lds"):
+        monkeypatch.setenv("CATCHHIP_FLAT_CHG_FORCE_LDS", "1")
+    if flat in ("contiguous", "contiguous-lds"):
+        monkeypatch.setenv("CATCHHIP_FLAT_TILE_SHIFT", "16")
     rng = np.random.Generator(np.random.PCG64(321))
     for trial in range(6):
         P = int(rng.integers(300, 2500))
@@ -380,7 +387,12 @@ def test_greedy_batched_rounds_restore_sequential_order(ctx, oracle, monkeypatch
                                           U, None, None, ranks)
         dev = engine.Rows.from_host(ctx, r[:, 0], r[:, 1], r[:, 2], r[:, 3], glen)
         got = dev.greedy(P, ranks, None)
-        rounds = ctx.counters()["greedy_iters"]
+        cn = ctx.counters()
+        rounds = cn["greedy_iters"]
+        if flat:
+            assert 0 < cn["flat_rows_recounted"] < cn["flat_rows_streamed"]
+        else:
+            assert cn["flat_rows_streamed"] == 0
         os.environ["CATCHHIP_GREEDY_SEQUENTIAL"] = "1"
         try:
             got_seq = dev.greedy(P, ranks, None)
@@ -1118,6 +1130,71 @@ def test_string_pipeline_equals_object_pipeline(ctx, first):
     want = list(dict.fromkeys(p for g in probes for p in g))
     assert sorted(p.seq_str for p in a.final_probes) == sorted(p.seq_str for p in want)
     assert [p.seq_str for p in a.candidate_probes] == [p.seq_str for g in cands for p in g]
+
+
+@pytest.mark.parametrize("first", ["dup", "hamming", "minhash"])
+@pytest.mark.parametrize("m", [2, 5])
+def test_prefetched_groups_select_what_inline_groups_select(ctx, monkeypatch, first, m):
+    """The device front end with the NEXT groups packed and uploaded on the
+    upload context while the current chunk computes (objects change hands via
+    catchhip_*_rebind) == the same groups built one after the other on the
+    compute context: same probes in the same order, with pigeonhole (-m 2) and
+    random (-m 5: np.random) anchors, and with LSH filters that draw from
+    `random` group after group.  Seven groups, so that chunks of one (large
+    groups alone) and of several (small ones in flight together) both occur."""
+    from catch_amd import genome
+    from catch_amd.filter import near_duplicate_filter, set_cover_filter
+    from catch_amd.utils import synthetic
+    monkeypatch.setenv("CATCHHIP_BIG_GROUP_BASES", "20000")
+    rng = np.random.Generator(np.random.PCG64(1234 + m))
+    groups = [[genome.Genome.from_one_seq(g[0]) for g in
+               synthetic.make_species(rng, [int(ln)], n, 2, 0.04, 0.01)]
+              for ln, n in ((9000, 6), (2500, 3), (2600, 4), (15000, 3), (2400, 2), (3000, 3), (2800, 5))]
+
+    def run(depth):
+        monkeypatch.setenv("CATCHHIP_PREFETCH_DEPTH", str(depth))
+        random.seed(5)
+        np.random.seed(6)
+        ndf = {"dup": lambda: None,
+               "hamming": lambda: near_duplicate_filter.NearDuplicateFilterWithHammingDistance(2, 100),
+               "minhash": lambda: near_duplicate_filter.NearDuplicateFilterWithMinHash(0.5)}[first]()
+        scf = set_cover_filter.SetCoverFilter(mismatches=m, lcf_thres=100, cover_extension=25)
+        out = scf._filter_genomes_device(groups, 100, 50, None, ndf)
+        ids = scf._filter_genomes_device(groups, 100, 50, None, ndf, return_ids=True) if first == "dup" else None
+        return out, ids, scf.last_timings
+
+    inline, ids0, t0 = run(0)
+    ahead, ids2, t2 = run(2)
+    deep, ids5, t5 = run(5)
+    assert inline == ahead == deep
+    assert ids0 == ids2 == ids5
+    assert all(len(g) > 0 for g in inline)
+    if ids0 is not None:
+        assert [len(g) for g in ids0] == [len(g) for g in inline]
+    assert t0["picks"] == t2["picks"] == t5["picks"] and t0["probe_bp_units"] == t2["probe_bp_units"] > 0
+
+
+def test_ndf_hamming_counts_its_pairs(ctx):
+    """catchhip_ctx_last_ndf_counters: probes, tables, pairs compared (SURVEY
+    8(d) K3's C) and edges of the last Hamming filter."""
+    engine = _engine()
+    from catch_amd.utils import lsh
+    rng = np.random.Generator(np.random.PCG64(99))
+    base = rng.integers(0, 4, size=100)
+    strs = []
+    for i in range(400):
+        v = base.copy()
+        for j in rng.integers(0, 100, size=int(rng.integers(0, 4))):
+            v[j] = (v[j] + 1) & 3
+        strs.append("".join("ACGT"[c] for c in v))
+    strs = list(dict.fromkeys(strs))
+    random.seed(3)
+    pos = np.array([sorted(random.sample(range(100), 20)) for _ in range(5)], dtype=np.int32)
+    keep = ctx.ndf_hamming(strs, 100, pos, 2)
+    cn = ctx.ndf_counters()
+    assert cn["probes"] == len(strs) and cn["tables"] == 5
+    assert cn["pairs_compared"] >= cn["edges"] > 0
+    assert 0 < int(keep.sum()) < len(strs)
 
 
 # ---------------------------------------------------------------- clustering pre-step

@@ -336,3 +336,51 @@ def test_probe_designer_object_pipeline_without_gpu():
     with pytest.raises(ValueError):
         probe_designer.ProbeDesigner(small, [duplicate_filter.DuplicateFilter()], probe_length=6,
                                      probe_stride=3).design()
+
+
+def test_prefetch_order_errors_and_discard():
+    """engine.Prefetch (the helper thread that packs group i + 1 while group i
+    computes): results arrive in order, at most `depth` ahead; an exception in
+    build() surfaces at the consumer; results built but never consumed are
+    handed to `discard`."""
+    import threading
+    import time
+    from catch_amd import engine
+    built, dropped = [], []
+    lock = threading.Lock()
+
+    def build(i):
+        with lock:
+            built.append(i)
+        if i == 7:
+            raise ValueError("boom")
+        return i * i
+
+    pre = engine.Prefetch(range(5), build, depth=2, discard=dropped.append)
+    got = list(pre)
+    pre.close()
+    assert got == [(i, i * i) for i in range(5)] and dropped == []
+
+    # bounded run-ahead: after the consumer took item 0, the helper may have
+    # built at most items 1..3 (two queued + one waiting to be queued)
+    del built[:]
+    pre = engine.Prefetch(range(10), build, depth=2, discard=dropped.append)
+    it = iter(pre)
+    assert next(it) == (0, 0)
+    time.sleep(0.3)
+    with lock:
+        assert max(built) <= 3
+    with pytest.raises(ValueError):
+        for _ in it:
+            pass
+    pre.close()
+    assert 7 in built and 8 not in built
+
+    # stopped early: what was built and not consumed is discarded exactly once
+    del built[:], dropped[:]
+    pre = engine.Prefetch(range(6), lambda i: i + 100, depth=2, discard=dropped.append)
+    it = iter(pre)
+    assert next(it) == (0, 100)
+    time.sleep(0.2)
+    pre.close()
+    assert sorted(dropped) == sorted(set(dropped)) and all(100 < d < 106 for d in dropped) and len(dropped) >= 2
