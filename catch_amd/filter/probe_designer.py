@@ -195,7 +195,12 @@ class ProbeDesigner:
                     total += n
         if ngroups == 0:
             return None
-        if ngroups < 8 or total >= 200000 * ngroups:
+        # per group: few groups, or groups large enough to fill the GPU on their own (S4: 30 Mbases
+        # each).  Many clusters of a clustered design go through union instances whatever their size:
+        # a set cover over one long genome is a chain of ties (its picks come one per round), and in a
+        # union the chains of all clusters advance in the same rounds (S5 x 0.25, 2,293 clusters of
+        # 0.4 Mbases: 164,418 rounds one cluster at a time)
+        if ngroups < 8 or total >= int(os.environ.get("CATCHHIP_UNION_MAX_MEAN_BASES", "4000000")) * ngroups:
             return "per group"
         return "union"
 

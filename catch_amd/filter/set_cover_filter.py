@@ -553,14 +553,16 @@ class SetCoverFilter(BaseFilter):
     def _filter_genomes_device_union(self, target_genomes_grouped, probe_length,
                                      probe_stride, seq_length_to_skip=None,
                                      near_duplicate_filter=None,
-                                     max_bases=1 << 30):
+                                     max_bases=600_000_000):
         """_filter_genomes_device for many small groups (the clusters of a
         clustered design): the groups of a chunk share one targets / candidates
         / probes triple that carries group numbers -- duplicates are removed
         inside a group only, the MinHash filter (if any) runs over all groups in
         one pass with each group's own hash functions, the scan pairs a probe
         with its own group's genomes only, and one greedy solve over the
-        disjoint union makes every group's own picks in its own order."""
+        disjoint union makes every group's own picks in its own order.
+        max_bases: bases per instance (a probes object holds < 2^31 bytes of
+        probe text: ~21 M candidates of 100 bases, one per 50 target bases)."""
         assert not self.identify and not self.avoided_genomes
         ngroups = len(target_genomes_grouped)
         out = [[] for _ in range(ngroups)]
