@@ -53,6 +53,7 @@ struct GreedyState {
     u32 fr_live[2];    // frontier solver: sizes of the live-set lists (large instances), by round parity
     unsigned long long prof[8];  // shader-clock ticks per phase (thread 0)
     unsigned long long n_wrows, n_recount, n_words;  // work counters
+    u32 need_live, ticket;   // row-parallel solver, partial coverage: universes still in need (being counted) / workgroups done
 };
 
 // packed key = (gain << 32) | (0xFFFFFFFF - set id): gains are < 2^32 (a group's
@@ -656,6 +657,7 @@ greedy_wg_kernel(GreedyArgs a) {
 
 #include "setcover_batched.inc"
 #include "setcover_flat.inc"
+#include "setcover_lazy.inc"
 
 // ------------------------------------------------------------------------
 // multi-launch solver (one gain launch + one apply launch per pick); used when
@@ -1019,6 +1021,13 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     if (batched && R->lmax <= 257 && (i64)nrows >= flat_min_rows)
         return greedy_flat(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out);
     if (batched) return greedy_frontier(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out, &no_retry);
+    // Partial coverage (some universe_p < 1) with rows of at most 257 bases: frontier rounds of the
+    // row-parallel kernels with the universe test (setcover_flat.inc, "PARTIAL") whatever the size --
+    // the one-workgroup solvers below take 3.9 ms per pick on S4's largest group (54.6 s for S4 under
+    // -c 0.9 against 0.17 s under -c 1.0)
+    if (universe_p && !distributed && R->lmax <= 257 && !getenv("CATCHHIP_GREEDY_SEQUENTIAL") &&
+        !getenv("CATCHHIP_PARTIAL_SEQUENTIAL") && (i64)nrows >= (getenv("CATCHHIP_PARTIAL_MIN_ROWS") ? atoll(getenv("CATCHHIP_PARTIAL_MIN_ROWS")) : 0))
+        return greedy_flat(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out, universe_p);
 
     DevBuf<u32> set_ptr, flag, idx, tmp, seg_row, seg_univ, seg_set, row_seg, set_seg_ptr, usize, can, left, rank,
         picked, picks;
@@ -1083,7 +1092,53 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         tm.launch(6);
     }
     int rc = 0;
-    if (!distributed) {
+    // Lazy evaluation in one persistent workgroup (setcover_lazy.inc) from a few hundred thousand rows:
+    // the eager workgroup below re-counts everything a pick touches and is only cheaper on small instances
+    const u32 lz_n1 = (u32)div_up((i64)nsets, 64), lz_n2 = (u32)div_up((i64)lz_n1, 64);
+    const bool use_lazy = !distributed && lz_n2 <= LZ_MAXT2 &&
+                          (getenv("CATCHHIP_GREEDY_LAZY") ? atoi(getenv("CATCHHIP_GREEDY_LAZY")) != 0 : nrows >= (1u << 18));
+    if (use_lazy) {
+        DevBuf<u32> segcnt, ub;
+        DevBuf<uint4> lrow;
+        DevBuf<unsigned long long> t1, t2;
+        TRY(segcnt.alloc(nseg));
+        TRY(ub.alloc(nsets));
+        TRY(lrow.alloc(nrows));
+        TRY(t1.alloc(lz_n1));
+        TRY(t2.alloc(lz_n2));
+        HIP_TRY(hipMemsetAsync(segcnt.p, 0, sizeof(u32) * nseg, s));
+        hipLaunchKernelGGL(rowcnt_init_kernel, dim3(rb), dim3(256), 0, s, R->gs.p, R->ge.p, row_seg.p, nrows, segcnt.p);
+        hipLaunchKernelGGL(lazy_gain_init_kernel, dim3(sb), dim3(256), 0, s, (const u32 *)segcnt.p, (const u32 *)seg_univ.p,
+                           (const u32 *)left.p, (const u32 *)set_seg_ptr.p, nsets, ub.p);
+        hipLaunchKernelGGL(lrow_fill_kernel, dim3(rb), dim3(256), 0, s, R->gs.p, R->ge.p, R->univ.p, (const u32 *)row_seg.p,
+                           nrows, lrow.p);
+        hipLaunchKernelGGL(lazy_t1_kernel, dim3((unsigned)div_up((i64)lz_n1, 4)), dim3(256), 0, s, (const u32 *)ub.p,
+                           (const u32 *)rank.p, 0u, nsets, lz_n1, t1.p);
+        hipLaunchKernelGGL(lazy_t2_kernel, dim3((unsigned)div_up((i64)lz_n2, 4)), dim3(256), 0, s,
+                           (const unsigned long long *)t1.p, lz_n1, lz_n2, t2.p);
+        static bool lz_attr_set = false;
+        if (!lz_attr_set) {
+            (void)hipFuncSetAttribute((const void *)lazy_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      LZ_MAXT2 * (int)sizeof(unsigned long long));
+            lz_attr_set = true;
+        }
+        LazyArgs a;
+        a.bm = bm.p; a.lrow = lrow.p; a.set_ptr = set_ptr.p; a.set_seg_ptr = set_seg_ptr.p; a.seg_row = seg_row.p;
+        a.can = can.p; a.rank = rank.p; a.usize = usize.p; a.left = left.p; a.ub = ub.p; a.t1 = t1.p; a.t2g = t2.p;
+        a.picks = picks.p; a.st = st.p;
+        a.nsets = nsets; a.n1 = lz_n1; a.n2 = lz_n2; a.nuniv = nuniv;
+        hipLaunchKernelGGL(lazy_wg_kernel, dim3(1), dim3(LZ_THREADS), (size_t)lz_n2 * sizeof(unsigned long long), s, a);
+        tm.launch(6);
+        tm.stop();
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&h_st, st.p, sizeof(h_st), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        tm.finish();
+        ctx->phase_launches[PHASE_GREEDY] = h_st.iters;
+        // [2] iterations (evaluations + rank changes), [4] rows walked, [5] sets evaluated
+        ctx->counters[2] = h_st.iters; ctx->counters[3] = h_st.npicks; ctx->counters[4] = (i64)h_st.n_wrows;
+        ctx->counters[5] = (i64)h_st.n_recount; ctx->counters[6] = 0;
+    } else if (!distributed) {
         // ---- persistent single-workgroup solver ---------------------------
         DevBuf<u32> prowcnt, segcnt, segcontrib, gain, dirty, pos_row, pos_row_alt, useg, useg_alt, useg_ptr,
             bucket;

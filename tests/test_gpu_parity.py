@@ -292,10 +292,22 @@ def test_scan_empty_inputs(ctx):
 
 
 # ---------------------------------------------------------------- K2
-def test_greedy_reference_test_vectors(ctx):
+def _partial_solver(monkeypatch, solver):
+    """Which solver takes instances with universe_p < 1: the frontier rounds of
+    the row-parallel kernels with the universe test (default), or one of the
+    two persistent-workgroup solvers (eager re-count / lazy evaluation)."""
+    if solver != "frontier":
+        monkeypatch.setenv("CATCHHIP_PARTIAL_SEQUENTIAL", "1")
+        monkeypatch.setenv("CATCHHIP_GREEDY_LAZY", "1" if solver == "lazy" else "0")
+
+
+@pytest.mark.parametrize("solver", ["frontier", "eager", "lazy"])
+def test_greedy_reference_test_vectors(ctx, monkeypatch, solver):
     """set_cover.approx_multiuniverse known answers
-    (catch/utils/tests/test_set_cover.py), unit-cost instances."""
+    (catch/utils/tests/test_set_cover.py), unit-cost instances; partial
+    coverage through each of the three solvers that take it."""
     engine = _engine()
+    _partial_solver(monkeypatch, solver)
     recs = load_golden("setcover")
     n = 0
     for c in recs:
@@ -315,8 +327,10 @@ def test_greedy_reference_test_vectors(ctx):
     assert n >= 20
 
 
-def test_greedy_random_instances_match_oracle(ctx, oracle):
+@pytest.mark.parametrize("solver", ["frontier", "eager", "lazy"])
+def test_greedy_random_instances_match_oracle(ctx, oracle, monkeypatch, solver):
     engine = _engine()
+    _partial_solver(monkeypatch, solver)
     rng = np.random.Generator(np.random.PCG64(123))
     for trial in range(30):
         P = int(rng.integers(1, 60))
@@ -395,13 +409,94 @@ def test_greedy_batched_rounds_restore_sequential_order(ctx, oracle, monkeypatch
             assert cn["flat_rows_streamed"] == 0
         os.environ["CATCHHIP_GREEDY_SEQUENTIAL"] = "1"
         try:
+            os.environ["CATCHHIP_GREEDY_LAZY"] = "0"
             got_seq = dev.greedy(P, ranks, None)
+            os.environ["CATCHHIP_GREEDY_LAZY"] = "1"      # lazy evaluation in the persistent workgroup
+            got_lazy = dev.greedy(P, ranks, None)
+            evals = ctx.counters()["rows_recounted"]
         finally:
             del os.environ["CATCHHIP_GREEDY_SEQUENTIAL"]
+            del os.environ["CATCHHIP_GREEDY_LAZY"]
         dev.close()
         assert got == exp, trial
         assert got_seq == exp, trial
+        assert got_lazy == exp, trial
+        assert evals >= len(exp)           # every pick is evaluated at least once
         assert rounds < len(exp)      # really batched
+
+
+def test_lazy_solver_partial_cover_many_universes(ctx, oracle, monkeypatch):
+    """The lazy persistent workgroup on sets that touch more universes than
+    its LDS accumulators hold at once (> 4,096 segments per set), with partial
+    coverage (min(left, count) binds at the end of every universe), ranks, and
+    rows longer than five bitmap words: the oracle's picks in its order."""
+    engine = _engine()
+    _partial_solver(monkeypatch, "lazy")
+    rng = np.random.Generator(np.random.PCG64(2024))
+    for trial in range(3):
+        P, U = 40, 4500 + 700 * trial
+        glen = rng.integers(300, 700, size=U)
+        rows = []
+        for s in range(P):
+            dens = 1.0 if s < 3 else rng.uniform(0.05, 0.6)
+            for u in np.nonzero(rng.random(U) < dens)[0]:
+                pos = int(rng.integers(0, glen[u] - 60))
+                ln = int(rng.integers(20, 400 if s % 5 == 0 else 60))
+                rows.append((s, int(u), pos, min(pos + ln, int(glen[u]))))
+        r = np.array(sorted(rows), dtype=np.int64)
+        ranks = rng.integers(0, 2, size=P) if trial == 1 else None
+        up = [float(x) for x in rng.choice([1.0, 0.9, 0.5], size=U)]
+        exp = oracle.lazy_greedy(r[:, 0], r[:, 1], r[:, 2], r[:, 3], P, glen, up, ranks)
+        dev = engine.Rows.from_host(ctx, r[:, 0], r[:, 1], r[:, 2], r[:, 3], glen)
+        got = dev.greedy(P, ranks, up)
+        cn = ctx.counters()
+        dev.close()
+        assert got == exp, trial
+        assert cn["rows_recounted"] >= len(exp)
+
+
+@pytest.mark.parametrize("tiles", ["striped", "contiguous"])
+def test_partial_cover_frontier_rounds_match_oracle(ctx, oracle, monkeypatch, tiles):
+    """universe_p < 1 through the frontier rounds of the row-parallel kernels
+    (per-row min(need, count), complex sets through gr_fixup, the universe test
+    of gr_apply with the thresholds of gr_usel, finished universes dropping
+    out): instances shaped like a design -- many universes of similar genomes,
+    sets with one row in most universes and now and then two in one -- with
+    p in {0.9, 0.5, mixed incl. 1.0 and 0}, with and without ranks.  The picks
+    and their ORDER are the oracle's."""
+    engine = _engine()
+    if tiles == "contiguous":
+        monkeypatch.setenv("CATCHHIP_FLAT_TILE_SHIFT", "16")
+        monkeypatch.setenv("CATCHHIP_FLAT_CHG_FORCE_LDS", "1")
+    rng = np.random.Generator(np.random.PCG64(4242))
+    for trial in range(6):
+        U = int(rng.integers(20, 90))
+        base_len = int(rng.integers(1500, 5000))
+        glen = base_len + rng.integers(-40, 40, size=U)
+        P = int(base_len // 25)
+        rows = []
+        for s in range(P):
+            centre = int(rng.integers(0, base_len - 260))
+            hit = rng.random(U) < rng.uniform(0.2, 0.9)
+            for u in np.nonzero(hit)[0]:
+                pos = min(max(0, centre + int(rng.integers(-15, 15))), int(glen[u]) - 257)
+                ln = int(rng.integers(100, 257))
+                rows.append((s, int(u), pos, pos + ln))
+                if rng.random() < 0.04 and pos + ln + 40 + 120 < glen[u]:      # a second row in the same universe
+                    rows.append((s, int(u), pos + ln + 40, pos + ln + 40 + int(rng.integers(30, 120))))
+        r = np.array(sorted(set(rows)), dtype=np.int64)
+        ranks = rng.integers(0, 3, size=P) if trial % 3 == 2 else None
+        up = ([0.9] * U if trial % 3 == 0 else [0.5] * U if trial % 3 == 1 else
+              [float(x) for x in rng.choice([1.0, 0.9, 0.7, 0.0], size=U)])
+        exp = oracle.lazy_greedy(r[:, 0], r[:, 1], r[:, 2], r[:, 3], P, glen, up, ranks)
+        dev = engine.Rows.from_host(ctx, r[:, 0], r[:, 1], r[:, 2], r[:, 3], glen)
+        got = dev.greedy(P, ranks, up)
+        cn = ctx.counters()
+        dev.close()
+        assert got == exp, (trial, len(got), len(exp))
+        assert cn["flat_rows_streamed"] > 0                    # the row-parallel kernels ran
+        # every round makes at least one pick (the set with the largest key passes the universe test)
+        assert cn["greedy_iters"] <= len(exp) + 2, (trial, cn["greedy_iters"], len(exp))
 
 
 @pytest.mark.parametrize("force_long", [False, True])
