@@ -594,14 +594,22 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-m2", action="store_true", help="skip the M2 (cold, PCIe-inclusive) passes")
+    ap.add_argument("--no-partial", action="store_true", help="skip the extra pass under -c 0.9")
     ap.add_argument("--m2-steps", type=int, default=3)
     ap.add_argument("--no-overlap-figure", action="store_true",
                     help="skip the extra passes with all groups on three streams (N = 1 only)")
     ap.add_argument("--groups-in-flight", type=int, default=4,
                     help="groups running at once per GPU, each on its own stream")
+    ap.add_argument("--preflight", action="store_true",
+                    help="one untimed-quality step on every rank: asserts the digests and prints per-rank "
+                         "pack / scan / rows / solve / exchange times and the RCCL copy in use -- what to look "
+                         "at first when a multi-GPU run misbehaves")
     ap.add_argument("--no-solver-check", action="store_true",
                     help="S5: skip the extra pass through the other solver family")
     args = ap.parse_args()
+    if args.preflight:
+        args.steps, args.warmup = 1, 0
+        args.no_cpu_baseline = args.no_m2 = args.no_partial = args.no_overlap_figure = True
     if args.workload == "S5":
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:
             raise SystemExit("--workload S5 runs on one GPU (the clustered design is one process)")
@@ -673,6 +681,22 @@ def main():
                                        ("picks_in_order_sha256" not in gold[gi] or
                                         digest_in_order(ids) == gold[gi]["picks_in_order_sha256"]))
     total_units, all_elapsed = float(units), [elapsed]
+    preflight = None
+    if args.preflight:
+        mine_tot = {}
+        for st in stats:
+            for k, v in st.items():
+                if isinstance(v, (int, float)):
+                    mine_tot[k] = mine_tot.get(k, 0) + v
+        me = dict(rank=rank, device=device, groups=[g.index for g in stepper.resident],
+                  sharded_groups=list(sharded_idx), pack_h2d_s=upload_s, step_s=elapsed,
+                  scan_ms=mine_tot.get("scan_ms", 0.0), rows_ms=mine_tot.get("rows_ms", 0.0),
+                  greedy_ms=mine_tot.get("greedy_ms", 0.0),
+                  sharded_scan_wall_ms=mine_tot.get("sharded_scan_wall_ms", 0.0),
+                  sharded_solve_wall_ms=mine_tot.get("sharded_solve_wall_ms", 0.0),
+                  exchange="rccl" if W.rccl else ("gloo through host memory" if world > 1 else "none"),
+                  rccl=engine.Context.comm_info(), digests_ok=bool(gold_ok), groups_checked=gold_n)
+        preflight = W.allgather(me)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -829,7 +853,10 @@ def main():
                 pool1["hipmalloc_calls"] - pool0["hipmalloc_calls"])),
             "parity_vs_golden_digests": (gold_ok if gold_n else None),
             "groups_checked_against_digests": gold_n,
+            "rccl": engine.Context.comm_info() if world > 1 else None,
         }
+        if preflight is not None:
+            out["preflight"] = preflight
         if Stepper.ndf:
             # N (ceil(0.375 L) + T (8 + 4) passes) + 2 ceil(0.375 L) C -- N probes, T tables,
             # 8 radix passes over 64-bit keys + 32-bit indices, C pairs sharing a bucket that were compared
@@ -889,6 +916,36 @@ def main():
             out["speedup_note"] = ("CPU seconds per pass over the sample's groups / GPU seconds for the same "
                                    "groups (resident inputs); `value` / cpu_baseline.value is NOT comparable: "
                                    "probe*bp grows quadratically with the group size")
+        if world == 1 and not args.no_partial and not Stepper.ndf and args.workload == "S4":
+            # the same resident groups under -c 0.9 (partial coverage): frontier rounds with the universe
+            # test; digests of the picks in order against the committed ones
+            def c09_pass(collect):
+                out09, st09 = {}, dict(greedy_ms=0.0, rounds=0, picks=0)
+                for g in stepper.resident:
+                    ids, _ = engine.setcover_filter(g.ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN, 0, EXT, g.n_sets,
+                                                    universe_p=[0.9] * g.n_genomes, mode=SCAN_MODE)
+                    out09[g.index] = ids
+                    if collect:
+                        st09["greedy_ms"] += g.ctx.kernel_ms(engine.PHASE_GREEDY)[0]
+                        st09["rounds"] += g.ctx.counters()["greedy_iters"]
+                        st09["picks"] += len(ids)
+                return out09, st09
+            c09_pass(False)
+            stepper.sync()
+            t9 = time.perf_counter()
+            p09, st09 = c09_pass(True)
+            stepper.sync()
+            el9 = time.perf_counter() - t9
+            ok9 = None
+            if gold is not None and all("picks_c09_sha256" in gold[gi] for gi in p09 if gi in gold):
+                ok9 = all(len(ids) == gold[gi]["n_picks_c09"] and digest(ids) == gold[gi]["picks_c09_sha256"]
+                          and digest_in_order(ids) == gold[gi]["picks_c09_in_order_sha256"]
+                          for gi, ids in p09.items() if gi in gold)
+            out["partial_coverage"] = {"coverage": 0.9, "ms_per_step": el9 * 1e3, "k2_greedy_ms": st09["greedy_ms"],
+                                       "k2_greedy_ms_full_coverage": ms["greedy_ms"], "rounds": st09["rounds"],
+                                       "picks": st09["picks"], "parity_vs_golden_digests": ok9,
+                                       "note": "one pass over the resident groups, groups one after the other; digests "
+                                               "are of the picks in pick order"}
         if world == 1 and not args.no_m2 and not Stepper.ndf:
             # M2: from host strings to ids on the host, nothing resident, through the
             # plugin's pipelined path; then one pass without the overlap for comparison

@@ -86,6 +86,7 @@ PROTOTYPES = {
     "catchhip_comm_init": (ctypes.c_int, [
         c_vp, c_u8p, ctypes.c_int32, ctypes.c_int32]),
     "catchhip_comm_destroy": (ctypes.c_int, [c_vp]),
+    "catchhip_comm_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64]),
     "catchhip_shard_create": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_i64p, c_vpp]),
     "catchhip_shard_destroy": (ctypes.c_int, [c_vp]),
     "catchhip_shard_count": (ctypes.c_int, [c_vp]),
@@ -108,6 +109,8 @@ PROTOTYPES = {
     "catchhip_sigs_common_row": (ctypes.c_int, [
         c_vp, c_vp, ctypes.c_uint32, c_u16p]),
     "catchhip_sigs_condensed": (ctypes.c_int, [c_vp, c_vp, c_f32p, c_f32p]),
+    "catchhip_sigs_neighbors": (ctypes.c_int, [
+        c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_u64p, ctypes.c_int64, c_i64p]),
     "catchhip_cover_scan_first_seen": (ctypes.c_int, [
         c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_int32, c_u32p, c_vpp, c_i64p]),

@@ -264,6 +264,35 @@ __global__ __launch_bounds__(64) void sig_row_lds_kernel(const u32 *__restrict__
         N, [&](u32 i) { return s_a[i]; }, [&](u32 i) { return s_b[i * 64 + threadIdx.x]; });
 }
 
+// The same row, reduced on the device to what the connected-components search looks at: the
+// sequences whose walk against j finds at least min_common values (distance within the threshold), as
+// (index << 16 | common) in arrival order (the host sorts the few of them)
+__global__ __launch_bounds__(64) void sig_neigh_lds_kernel(const u32 *__restrict__ sig, const u32 *__restrict__ sigT,
+                                                           u32 nseq, u32 N, u32 j, u32 min_common,
+                                                           unsigned long long *__restrict__ out, u32 cap,
+                                                           u32 *__restrict__ count) {
+    extern __shared__ u32 s_mem[];
+    u32 *s_a = s_mem, *s_b = s_mem + N;   // s_b[i * 64 + lane]
+    for (u32 t = threadIdx.x; t < N; t += 64) s_a[t] = sig[(size_t)j * N + t];
+    const u32 kq = blockIdx.x * 64 + threadIdx.x;
+    const u32 kc = kq < nseq ? kq : nseq - 1;
+    for (u32 i = 0; i < N; ++i) s_b[i * 64 + threadIdx.x] = sigT[(size_t)i * nseq + kc];
+    __syncthreads();
+    u32 c = 0;
+    if (kq < nseq)
+        c = walk_common(N, [&](u32 i) { return s_a[i]; }, [&](u32 i) { return s_b[i * 64 + threadIdx.x]; });
+    const bool hit = kq < nseq && c >= min_common;
+    const unsigned long long b = __ballot(hit);
+    if (!b) return;
+    u32 base = 0;
+    if (threadIdx.x == 0) base = atomicAdd(count, (u32)__popcll(b));
+    base = __shfl(base, 0, WAVE);
+    if (hit) {
+        const u32 pos = base + (u32)__popcll(b & ((1ull << threadIdx.x) - 1ull));
+        if (pos < cap) out[pos] = ((unsigned long long)kq << 16) | (unsigned long long)c;
+    }
+}
+
 __global__ __launch_bounds__(256) void sig_pairs_kernel(const u32 *__restrict__ sig, u32 nseq, u32 N, u32 T,
                                                         const float *__restrict__ lut, float *__restrict__ out) {
     extern __shared__ u32 s_ab[];
@@ -408,6 +437,44 @@ extern "C" int catchhip_sigs_common_row(catchhip_ctx *ctx, const catchhip_sigs *
     HIP_TRY(hipStreamSynchronize(st));
     tm.finish();
     memcpy(common, ctx->h_big, sizeof(uint16_t) * (size_t)S->nseq);
+    return 0;
+}
+
+extern "C" int catchhip_sigs_neighbors(catchhip_ctx *ctx, const catchhip_sigs *S, u32 j, u32 min_common,
+                                       unsigned long long *out, i64 cap, i64 *count) {
+    ARG_CHECK(ctx && S && S->ctx == ctx && out && count && cap >= 0 && j < S->nseq);
+    ARG_CHECK(S->N <= 176);   // (the caller uses catchhip_sigs_common_row for longer signatures)
+    PoolScope pool_scope(ctx);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const u32 dcap = S->nseq;
+    DevBuf<unsigned long long> d;
+    DevBuf<u32> d_n;
+    TRY(d.alloc((size_t)dcap + 1));
+    TRY(d_n.alloc(1));
+    // the count and the first entries come back together; a longer list takes a second copy
+    const size_t first = 4096;
+    TRY(chip_pinned_reserve(ctx, sizeof(unsigned long long) * ((size_t)dcap + 2)));
+    HIP_TRY(hipMemsetAsync(d_n.p, 0, sizeof(u32), st));
+    PhaseTimer tm(ctx, PHASE_NDF);
+    hipLaunchKernelGGL(sig_neigh_lds_kernel, dim3((S->nseq + 63) / 64), dim3(64), sizeof(u32) * 65 * (size_t)S->N, st,
+                       (const u32 *)S->sig.p, (const u32 *)S->sigT.p, S->nseq, S->N, j, min_common, d.p, dcap, d_n.p);
+    tm.launch(1);
+    HIP_TRY(hipGetLastError());
+    unsigned long long *h = (unsigned long long *)ctx->h_big;
+    const size_t n0 = std::min<size_t>(first, dcap);
+    HIP_TRY(hipMemcpyAsync(h, d_n.p, sizeof(u32), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h + 1, d.p, sizeof(unsigned long long) * n0, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const u32 n = *(volatile u32 *)h;
+    if (n > n0) {
+        HIP_TRY(hipMemcpyAsync(h + 1 + n0, d.p + n0, sizeof(unsigned long long) * (n - n0), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    tm.finish();
+    *count = n;
+    if ((i64)n > cap) { chip_set_error("sigs_neighbors: %u neighbours, room for %lld", n, (long long)cap); return CATCHHIP_EINVAL; }
+    memcpy(out, h + 1, sizeof(unsigned long long) * (size_t)n);
     return 0;
 }
 

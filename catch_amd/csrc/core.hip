@@ -80,6 +80,30 @@ void *chip_pool_alloc(size_t bytes) {
             return p;
         }
     }
+    // The cache keeps what it was given; a request it cannot serve while the library already holds most
+    // of the device (a union instance of a clustered design: work lists of 100+ GB whose sizes differ from
+    // chunk to chunk) first returns this owner's idle blocks to the driver, so that the runtime's own
+    // allocations (kernel arguments, scratch) do not fail with the memory sitting unused in here.
+    // (hipFree waits for the device, so blocks that queued work still reads are safe to return.)
+    {
+        static size_t soft_limit = 0;
+        if (!soft_limit) {
+            size_t fr = 0, tot = 0;
+            soft_limit = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) ? (size_t)((double)tot * 0.72) : ~(size_t)0 >> 1;
+            if (const char *e = getenv("CATCHHIP_POOL_SOFT_LIMIT_GB")) soft_limit = (size_t)atof(e) << 30;
+        }
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if ((size_t)g_pool_stats[1] + cls > soft_limit && g_pool_stats[2] > 0) {
+            for (auto it = g_pool_free.begin(); it != g_pool_free.end();) {
+                if (it->first.first == owner) {
+                    (void)hipFree(it->second);
+                    g_pool_stats[1] -= (long long)it->first.second;
+                    g_pool_stats[2] -= (long long)it->first.second;
+                    it = g_pool_free.erase(it);
+                } else ++it;
+            }
+        }
+    }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, cls);
     g_pool_stats[0]++;

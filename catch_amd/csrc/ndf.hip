@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256)
 ndf_edge_kernel(const u64 *__restrict__ padded, u32 n, int W, int d, const i32 *__restrict__ pos, int k,
                 const u64 *__restrict__ keys, const u32 *__restrict__ vals, u32 *__restrict__ e_i,
                 u32 *__restrict__ e_j, u32 *__restrict__ count, u32 cap, const u32 *__restrict__ grp,
-                size_t pos_group_stride) {
+                size_t pos_group_stride, int n_earlier) {
     u32 x = blockIdx.x * blockDim.x + threadIdx.x;
     u32 npairs = 0;
     if (x < n) {
@@ -95,6 +95,16 @@ ndf_edge_kernel(const u64 *__restrict__ padded, u32 n, int W, int d, const i32 *
             if (keys[y] != key) break;
             const u32 j = vals[y];  // j < i: stable sort keeps indices ascending in a run
             if (grp && grp[j] != grp[i]) continue;   // another group under the same key
+            // (pos points at THIS table's positions; the earlier tables' lie k entries apart before it)
+            const u8 *ab = (const u8 *)a, *bb = (const u8 *)(padded + (size_t)j * W);
+            bool seen = false;
+            for (int tp = 1; tp <= n_earlier && !seen; ++tp) {
+                const i32 *pe = pos - (size_t)tp * k;
+                bool eq = true;
+                for (int q = 0; q < k && eq; ++q) eq = ab[pe[q]] == bb[pe[q]];
+                seen = eq;      // the pair met in that table's bucket: compared there
+            }
+            if (seen) continue;
             ++npairs;
             if (ndf_near(a, padded + (size_t)j * W, W, d, pos, k)) {
                 const u32 shard = (x >> 6) & (ES_SHARDS - 1);
@@ -240,7 +250,10 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
             TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nn, 64));
             hipLaunchKernelGGL(ndf_edge_kernel, dim3(nb), dim3(256), 0, s, (const u64 *)padded.p, nn, W,
                                (int)dist_thres, d_pos.p + (size_t)t * k, (int)k, keys.p, vals.p, e_i.p,
-                               e_j.p, count.p, cap, d_grp, pstride);
+                               e_j.p, count.p, cap, d_grp, pstride,
+                               // (with two or three tables the look at the earlier tables' positions costs more than
+                               // the comparisons it saves: S3, 2 tables, 15.1 -> 18.0 ms)
+                               (ntables < 4 || getenv("CATCHHIP_MH_NO_DEDUPE")) ? 0 : t);
             tm.launch(2 + 24);
         }
         HIP_TRY(hipGetLastError());
@@ -471,7 +484,8 @@ __global__ void __launch_bounds__(256)
 mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, const u64 *__restrict__ id_hi,
                const u64 *__restrict__ id_lo, const u32 *__restrict__ sig, int k, double thres, u32 n,
                const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ grp,
-               u32 *__restrict__ e_i, u32 *__restrict__ e_j, u32 *__restrict__ count, u32 cap) {
+               u32 *__restrict__ e_i, u32 *__restrict__ e_j, u32 *__restrict__ count, u32 cap,
+               const u32 *__restrict__ sig_earlier, int n_earlier) {
     const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n) return;
     const u64 key = keys[x];
@@ -481,7 +495,19 @@ mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
         const u32 j = vals[y];  // j < i: stable sort keeps indices ascending in a run
         bool same = !grp || grp[i] == grp[j];   // same bucket = same group and signature (the key only groups)
         for (int f = 0; f < k; ++f) same = same && sig[(size_t)i * k + f] == sig[(size_t)j * k + f];
-        if (same && mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j],
+        if (!same) continue;
+        // The pair shared a bucket in an earlier table already: it was compared there and its edge
+        // (if any) is in the list -- near-identical probes meet in almost every table, and their
+        // distance is the same each time (S5 x 0.25: 13.2 s of the filter's 14 s were these repeats).
+        bool seen = false;
+        for (int tp = 0; tp < n_earlier && !seen; ++tp) {
+            const u32 *si = sig_earlier + ((size_t)tp * n + i) * k, *sj = sig_earlier + ((size_t)tp * n + j) * k;
+            bool eq = true;
+            for (int f = 0; f < k; ++f) eq = eq && si[f] == sj[f];
+            seen = eq;
+        }
+        if (seen) continue;
+        if (mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j],
                             thres)) {
             const u32 shard = (x >> 6) & (ES_SHARDS - 1);
             const u32 slot = atomicAdd(&count[shard * ES_STRIDE], 1u);
@@ -539,8 +565,9 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
     TRY(id_hi.alloc(nkm));
     TRY(id_lo.alloc(nkm));
     TRY(nuniq.alloc(nn));
-    // signatures / keys of a chunk of tables at a time (<= 2 GB of signatures)
-    const int tchunk = (int)std::max<i64>(1, std::min<i64>(ntables, ((i64)1 << 29) / std::max<i64>(1, n * k)));
+    // signatures / keys of a chunk of tables at a time (<= 16 GB of signatures: all tables of any input
+    // that fits a probes object, so that a pair is compared in the first table it meets in only)
+    const int tchunk = (int)std::max<i64>(1, std::min<i64>(ntables, ((i64)1 << 32) / std::max<i64>(1, n * k)));
     DevBuf<u64> keys_all;
     TRY(sig.alloc((size_t)tchunk * nn * k));
     TRY(keys_all.alloc((size_t)tchunk * nn));
@@ -585,7 +612,8 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
             hipLaunchKernelGGL(mh_edge_kernel, dim3(nb), dim3(256), 0, s, (const u32 *)d_koff.p, (const u32 *)nuniq.p,
                                (const u64 *)id_hi.p, (const u64 *)id_lo.p,
                                (const u32 *)(sig.p + (size_t)tc * nn * k), (int)k, dist_thres, nn,
-                               (const u64 *)keys.p, (const u32 *)vals.p, grp, e_i.p, e_j.p, count.p, cap);
+                               (const u64 *)keys.p, (const u32 *)vals.p, grp, e_i.p, e_j.p, count.p, cap,
+                               (const u32 *)sig.p, getenv("CATCHHIP_MH_NO_DEDUPE") ? 0 : tc);
             tm.launch(2 + 24);
         }
         HIP_TRY(hipGetLastError());

@@ -1179,7 +1179,10 @@ static u32 seed_capacity(const catchhip_probes *P, const catchhip_targets *T) {
     const double want = per_base * (double)T->total;
     // u32 indices; 32 B of work list + record per seed (a 288 GB part holds the
     // 1.2e9 seeds of S4's largest group, 38 GB, without a second pass)
-    return (u32)std::max<double>((double)((i64)1 << 20), std::min<double>(want, 4.0e9));
+    // (a first scan without a hint is held to 2.5e9 seeds -- list, records and ranks of a seed take 68 B
+    // until the rows are built, 170 GB at that size; a group that needs more pays the second scan once)
+    const double cap = P->seed_ratio_hint > 0.0 ? 4.0e9 : 2.5e9;
+    return (u32)std::max<double>((double)((i64)1 << 20), std::min<double>(want, cap));
 }
 
 // K1c host side: hash table of the anchor k-mers, one lookup per target

@@ -36,6 +36,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
+#include <string>
 
 #include "internal.h"
 
@@ -753,12 +755,74 @@ apply_kernel(unsigned long long *__restrict__ bm, const u32 *__restrict__ gs, co
 }
 
 // ------------------------------------------------------------------------
+// Which RCCL.  A process that imported torch first has torch's own librccl mapped
+// under the same soname this library was linked against, and the loader would
+// bind these calls to whichever copy came first.  The communicator therefore goes
+// through ONE copy chosen here: the file named by CATCHHIP_RCCL_PATH, else
+// /opt/rocm/lib/librccl.so, opened by path (a second, private copy if another
+// file of that soname is already mapped -- a communicator never crosses copies);
+// only if neither can be opened, whatever the loader bound.  catchhip_comm_info
+// reports the version and the file actually in use.
+#include <dlfcn.h>
+namespace {
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    std::string path, how;
+    bool ready = false;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+
+const RcclApi &rccl() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.ready) return g_rccl;
+    void *h = nullptr;
+    const char *want = getenv("CATCHHIP_RCCL_PATH");
+    const char *tries[2] = {want && *want ? want : "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so"};
+    for (int i = 0; i < 2 && !h; ++i) {
+        h = dlopen(tries[i], RTLD_NOW | RTLD_LOCAL);
+        if (h) g_rccl.how = std::string("dlopen ") + tries[i];
+    }
+    auto sym = [&](const char *name) -> void * { return h ? dlsym(h, name) : nullptr; };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    g_rccl.GetVersion = (decltype(g_rccl.GetVersion))sym("ncclGetVersion");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.GetErrorString) {
+        // the copy the loader bound this library's own references to
+        g_rccl.GetUniqueId = &ncclGetUniqueId; g_rccl.CommInitRank = &ncclCommInitRank; g_rccl.CommDestroy = &ncclCommDestroy;
+        g_rccl.AllReduce = &ncclAllReduce; g_rccl.GetErrorString = &ncclGetErrorString; g_rccl.GetVersion = &ncclGetVersion;
+        g_rccl.how = "as linked (no RCCL file could be opened by path)";
+    }
+    Dl_info info;
+    if (dladdr((void *)g_rccl.CommInitRank, &info) && info.dli_fname) g_rccl.path = info.dli_fname;
+    g_rccl.ready = true;
+    return g_rccl;
+}
+}  // namespace
+
+extern "C" int catchhip_comm_info(char *buf, i64 len) {
+    ARG_CHECK(buf && len > 0);
+    const RcclApi &R = rccl();
+    int v = 0;
+    if (R.GetVersion) (void)R.GetVersion(&v);
+    snprintf(buf, (size_t)len, "RCCL version code %d from %s (%s)", v, R.path.c_str(), R.how.c_str());
+    return 0;
+}
+
 extern "C" int catchhip_comm_unique_id(u8 *id128) {
     ARG_CHECK(id128 != nullptr);
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
     ncclUniqueId id;
-    ncclResult_t r = ncclGetUniqueId(&id);
-    if (r != ncclSuccess) { chip_set_error("ncclGetUniqueId: %s", ncclGetErrorString(r)); return CATCHHIP_ECOMM; }
+    ncclResult_t r = rccl().GetUniqueId(&id);
+    if (r != ncclSuccess) { chip_set_error("ncclGetUniqueId: %s", rccl().GetErrorString(r)); return CATCHHIP_ECOMM; }
     memcpy(id128, &id, 128);
     return 0;
 }
@@ -770,8 +834,8 @@ extern "C" int catchhip_comm_init(catchhip_ctx *ctx, const u8 *id128, i32 nranks
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     ncclComm_t comm;
-    ncclResult_t r = ncclCommInitRank(&comm, nranks, id, rank);
-    if (r != ncclSuccess) { chip_set_error("ncclCommInitRank: %s", ncclGetErrorString(r)); return CATCHHIP_ECOMM; }
+    ncclResult_t r = rccl().CommInitRank(&comm, nranks, id, rank);
+    if (r != ncclSuccess) { chip_set_error("ncclCommInitRank: %s", rccl().GetErrorString(r)); return CATCHHIP_ECOMM; }
     ctx->comm = (void *)comm;
     ctx->nranks = nranks;
     ctx->rank = rank;
@@ -780,7 +844,7 @@ extern "C" int catchhip_comm_init(catchhip_ctx *ctx, const u8 *id128, i32 nranks
 
 extern "C" int catchhip_comm_destroy(catchhip_ctx *ctx) {
     if (ctx && ctx->comm) {
-        (void)ncclCommDestroy((ncclComm_t)ctx->comm);
+        (void)rccl().CommDestroy((ncclComm_t)ctx->comm);
         ctx->comm = nullptr;
         ctx->nranks = 1;
         ctx->rank = 0;
@@ -1213,9 +1277,9 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
                 hipLaunchKernelGGL(gain_kernel, dim3(gb), dim3(256), 0, s, (const u64 *)bm.p, R->gs.p, R->ge.p,
                                    seg_row.p, seg_univ.p, set_seg_ptr.p, left.p, rank.p, picked.p, nsets, nranks,
                                    myrank, st.p);
-                ncclResult_t r = ncclAllReduce(&st.p->best_key, &st.p->best_key, 1, ncclUint64, ncclMax,
-                                               (ncclComm_t)ctx->comm, s);
-                if (r != ncclSuccess) { chip_set_error("ncclAllReduce: %s", ncclGetErrorString(r)); return CATCHHIP_ECOMM; }
+                ncclResult_t r = rccl().AllReduce(&st.p->best_key, &st.p->best_key, 1, ncclUint64, ncclMax,
+                                                  (ncclComm_t)ctx->comm, s);
+                if (r != ncclSuccess) { chip_set_error("ncclAllReduce: %s", rccl().GetErrorString(r)); return CATCHHIP_ECOMM; }
                 hipLaunchKernelGGL(apply_kernel, dim3(1), dim3(256), 0, s, bm.p, R->gs.p, R->ge.p, R->univ.p,
                                    set_ptr.p, seg_univ.p, set_seg_ptr.p, usize.p, can.p, left.p, picked.p, picks.p,
                                    st.p);

@@ -133,6 +133,13 @@ class Context:
         check(_lib.lib().catchhip_comm_unique_id(_ptr(buf, c_u8p)))
         return buf.tobytes()
 
+    @staticmethod
+    def comm_info():
+        """catchhip_comm_info: the RCCL copy (version, file) communicators use."""
+        buf = ctypes.create_string_buffer(1024)
+        check(_lib.lib().catchhip_comm_info(buf, 1024))
+        return buf.value.decode("utf-8", "replace")
+
     def comm_init(self, unique_id, nranks, rank):
         import os
         import sys
@@ -687,6 +694,19 @@ class Signatures:
         check(self.ctx._L.catchhip_sigs_common_row(self.ctx._h, self._h,
                                                    int(j), _ptr(out, c_u16p)))
         return out[:self.n]
+
+    def neighbors(self, j, min_common):
+        """catchhip_sigs_neighbors -> (indices ascending, their common counts):
+        the sequences whose merge walk against signature j finds at least
+        min_common shared values."""
+        if not hasattr(self, "_nb_buf"):
+            self._nb_buf = np.zeros(max(self.n, 1), dtype=np.uint64)
+        cnt = ctypes.c_int64(0)
+        check(self.ctx._L.catchhip_sigs_neighbors(
+            self.ctx._h, self._h, int(j), int(min_common), _ptr(self._nb_buf, c_u64p),
+            int(self._nb_buf.size), ctypes.byref(cnt)))
+        got = np.sort(self._nb_buf[:cnt.value])
+        return (got >> np.uint64(16)).astype(np.int64), (got & np.uint64(0xffff)).astype(np.int64)
 
     def condensed(self, lut):
         """float32[n(n-1)/2] in SciPy's condensed order; entry = lut[common]."""

@@ -361,41 +361,63 @@ class SetCoverFilter(BaseFilter):
                  for i in range(n)]
         eligible = (not self.identify and not self.avoided_genomes
                     and self.coverage == 1.0)
+        # (a group with fewer genomes than ranks is not sharded: some rank would hold an empty shard)
         sharded, whole = parallel.plan_with_sharding(
             costs, W.size,
             min_cost=int(os.environ.get("CATCHHIP_SHARD_MIN_BASES", "30000000"))
-            if eligible else float("inf"))
+            if eligible else float("inf"),
+            eligible=[len(target_genomes_grouped[i]) >= W.size for i in range(n)])
         selected = [[] for _ in range(n)]
         timings = dict(scan_ms=0.0, rows_ms=0.0, greedy_ms=0.0, picks=0, rows=0,
                        scan_launches=0, greedy_launches=0, sharded_groups=list(sharded))
         ctx = W.comm_ctx
         fallback = []
         nonempty = [i for i in range(n) if len(input_strs[i]) > 0]
+        # Random anchors: every rank must scan a sharded group with the SAME tables, and the
+        # selection must be the single-rank one: rank 0's np.random state goes to every rank before
+        # the tables of all groups are drawn (in input order, as one rank draws them)
+        if any(probe.anchors_use_random(input_strs[i], self.mismatches, self.lcf_thres,
+                                        self.kmer_probe_map_k) for i in nonempty):
+            np.random.set_state(W.broadcast(np.random.get_state()))
         tables = self._anchor_tables_in_input_order(input_strs, nonempty, assume_unique)
         for gi in sharded:                       # all ranks together, same order
             strs, genomes = input_strs[gi], target_genomes_grouped[gi]
             logger.info("Set cover of group %d of %d sharded over %d ranks",
                         gi + 1, n, W.size)
-            k, uniq, owner, ep, eo = (
-                tables[gi] if tables is not None else
-                probe.anchor_table(
-                    strs, self.mismatches, self.lcf_thres,
-                    min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k,
-                    assume_unique=assume_unique))
-            b = parallel.split_universes([g.size() for g in genomes], W.size)
-            targets = engine.Targets(ctx, [g.seqs for g in genomes[b[W.rank]:b[W.rank + 1]]])
-            probes = engine.Probes(ctx, uniq, owner, ep, eo, k)
-            rows = shard = None
+            rows = shard = probes = targets = None
+            err, qualifies = None, False
             try:
-                rows = engine.Rows.scan(ctx, probes, targets, self.mismatches,
-                                        self.lcf_thres, self.island_of_exact_match,
-                                        self.cover_extension, self.scan_mode)
+                # a failure on one rank (out of memory, a library error) is reported to ALL ranks below:
+                # nobody may walk into the solver's all-reduces alone
                 try:
-                    shard = engine.Shard(rows, len(strs))
-                except Exception:                 # rows too long for the sharded kernels
-                    shard = None
+                    k, uniq, owner, ep, eo = (
+                        tables[gi] if tables is not None else
+                        probe.anchor_table(
+                            strs, self.mismatches, self.lcf_thres,
+                            min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k,
+                            assume_unique=assume_unique))
+                    b = parallel.split_universes([g.size() for g in genomes], W.size)
+                    targets = engine.Targets(ctx, [g.seqs for g in genomes[b[W.rank]:b[W.rank + 1]]])
+                    probes = engine.Probes(ctx, uniq, owner, ep, eo, k)
+                    rows = engine.Rows.scan(ctx, probes, targets, self.mismatches,
+                                            self.lcf_thres, self.island_of_exact_match,
+                                            self.cover_extension, self.scan_mode)
+                    try:
+                        shard = engine.Shard(rows, len(strs))
+                        qualifies = True
+                    except ValueError as exc:
+                        # the one expected refusal: rows too long for the sharded kernels -> whole group
+                        if "longer than 257" not in str(exc):
+                            raise
+                except Exception as exc:          # noqa: BLE001 -- reported collectively
+                    err = "%s: %s" % (type(exc).__name__, exc)
+                status = W.allgather((err, qualifies))
+                W_errs = [(r, e) for r, (e, _q) in enumerate(status) if e]
+                if W_errs:
+                    raise RuntimeError("sharded set cover of group %d failed: %s" % (
+                        gi + 1, "; ".join("rank %d: %s" % re for re in W_errs)))
                 # every rank must take the same path
-                if all(W.allgather(shard is not None)):
+                if all(q for _e, q in status):
                     selected[gi] = parallel.sharded_solve([shard], W.exchange_for([shard]))
                     timings["rows"] += rows.n
                     timings["picks"] += len(selected[gi])
@@ -411,8 +433,13 @@ class SetCoverFilter(BaseFilter):
             r = min(range(W.size), key=lambda q: (loads[q], q))
             whole[r].append(gi)
             loads[r] += costs[gi]
-        mine = self._filter_strs(input_strs, target_genomes_grouped, assume_unique,
-                                 only=set(whole[W.rank]), tables=tables)
+        err, mine = None, None
+        try:
+            mine = self._filter_strs(input_strs, target_genomes_grouped, assume_unique,
+                                     only=set(whole[W.rank]), tables=tables)
+        except Exception as exc:                  # noqa: BLE001 -- reported collectively
+            err = "%s: %s" % (type(exc).__name__, exc)
+        W.agree(err)                              # a rank that failed must not leave the others in the gather
         for k_, v in self.last_timings.items():
             if isinstance(v, (int, float)):
                 timings[k_] = timings.get(k_, 0) + v
@@ -553,7 +580,7 @@ class SetCoverFilter(BaseFilter):
     def _filter_genomes_device_union(self, target_genomes_grouped, probe_length,
                                      probe_stride, seq_length_to_skip=None,
                                      near_duplicate_filter=None,
-                                     max_bases=600_000_000):
+                                     max_bases=300_000_000):
         """_filter_genomes_device for many small groups (the clusters of a
         clustered design): the groups of a chunk share one targets / candidates
         / probes triple that carries group numbers -- duplicates are removed
@@ -562,7 +589,9 @@ class SetCoverFilter(BaseFilter):
         with its own group's genomes only, and one greedy solve over the
         disjoint union makes every group's own picks in its own order.
         max_bases: bases per instance (a probes object holds < 2^31 bytes of
-        probe text: ~21 M candidates of 100 bases, one per 50 target bases)."""
+        probe text: ~21 M candidates of 100 bases, one per 50 target bases; and
+        the seed work list of a first scan is sized for 6 seeds per base, 68 B
+        each until the rows are built: 300 Mbases -> ~120 GB at most)."""
         assert not self.identify and not self.avoided_genomes
         ngroups = len(target_genomes_grouped)
         out = [[] for _ in range(ngroups)]

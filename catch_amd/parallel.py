@@ -93,7 +93,7 @@ def sharded_solve(shards, exchange):
     return out[0]
 
 
-def plan_with_sharding(group_costs, world, min_cost=0, slack=1.08):
+def plan_with_sharding(group_costs, world, min_cost=0, slack=1.08, eligible=None):
     """Two-level plan.  Groups are SHARDED over all ranks (every rank takes
     1/world of each) until the others -- whole groups, longest first onto the
     least loaded rank -- leave the busiest rank within `slack` of an even share:
@@ -101,6 +101,9 @@ def plan_with_sharding(group_costs, world, min_cost=0, slack=1.08):
     they do not.  (A group above an even share always ends up sharded; so does
     e.g. S4's 265-Mbase group on 2 ranks, 45 % of the work, which whole would
     leave the ranks at 265 : 327.)
+    eligible: per group, whether it may be sharded at all (e.g. it has at least
+    as many genomes as there are ranks: a rank without a genome would hold an
+    empty shard); None = every group.
     Returns (sharded: list of group indices, whole: world lists of indices)."""
     costs = list(group_costs)
     if world <= 1:
@@ -118,7 +121,8 @@ def plan_with_sharding(group_costs, world, min_cost=0, slack=1.08):
             bins[b].append(i)
             heapq.heappush(heap, (load + costs[i], b))
         busiest = max(load for load, _ in heap)
-        cand = [i for i in order if costs[i] >= min_cost and costs[i] > 0]
+        cand = [i for i in order if costs[i] >= min_cost and costs[i] > 0
+                and (eligible is None or eligible[i])]
         if not cand or busiest <= slack * even:
             return sorted(sharded), bins
         sharded.add(cand[0])
@@ -148,6 +152,24 @@ class World:
         out = [None] * self.size
         self.dist.all_gather_object(out, obj)
         return out
+
+    def broadcast(self, obj, src=0):
+        """Rank src's host object on every rank (gloo)."""
+        if self.dist is None:
+            return obj
+        box = [obj if self.rank == src else None]
+        self.dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def agree(self, error):
+        """Collective error check: every rank passes its own failure (a string)
+        or None; if any rank failed, EVERY rank raises -- a rank that left a
+        collective section alone would leave the others waiting in the next
+        all-reduce for ever."""
+        errs = self.allgather(error)
+        bad = [(r, e) for r, e in enumerate(errs) if e]
+        if bad:
+            raise RuntimeError("multi-rank filter: " + "; ".join("rank %d: %s" % be for be in bad))
 
     def exchange_for(self, shards):
         """The exchange callable sharded_solve wants: RCCL on the device buffers,

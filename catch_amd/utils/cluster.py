@@ -12,6 +12,7 @@ reference calls.
 """
 from collections import defaultdict
 import logging
+import os
 
 import numpy as np
 
@@ -70,44 +71,142 @@ def cluster_hierarchically_from_dist_matrix(dist_matrix, threshold):
     return [members[c] for c in numbers]
 
 
-def _components(n, row_fn, threshold, early_stop_threshold):
+def _table_size_after_inserts(m):
+    """Slots of a CPython set's hash table after m insertions into an empty
+    set (setobject.c, 3.7 and later: a table starts with 8 slots and is rebuilt
+    when fill * 5 >= mask * 3, to the smallest power of two above used * 4, or
+    above used * 2 beyond 50,000 entries)."""
+    size, used = 8, 0
+    while True:
+        mask = size - 1
+        first = -(-3 * mask // 5)             # the insertion that triggers the rebuild
+        if m < first:
+            return size
+        used = first
+        want = used * (2 if used > 50000 else 4)
+        size = 8
+        while size <= want:
+            size <<= 1
+        if m == used:
+            return size
+
+
+def _diff_iterates_ascending(n, m, q):
+    """True when `remaining - queued` (|remaining| = m, queued a subset of it
+    with q elements, all elements in range(n)) is certain to iterate in
+    ascending order: its hash table then has more than n - 1 slots, every int
+    sits in the slot of its own value (hash(i) == i) and iteration is by slot.
+    CPython builds the difference in one of two ways (setobject.c
+    set_difference): when len(remaining) // 4 > len(queued) it copies
+    `remaining` into a table of the smallest power of two above 2 m slots and
+    discards the members of `queued` (never enough of them to trigger a
+    rebuild); otherwise it inserts the m - q survivors one by one into a fresh
+    set.  Any other table may hold displaced entries, and its order is left to
+    the interpreter (the caller then builds the real set)."""
+    if (m >> 2) > q:
+        size = 8
+        if m * 5 >= 21:
+            while size <= 2 * m:
+                size <<= 1
+    else:
+        size = _table_size_after_inserts(m - q)
+    return size > n - 1
+
+
+_fast_order_ok = None
+
+
+def _fast_order_available():
+    """Whether this interpreter's sets behave as _diff_iterates_ascending
+    assumes (checked once on a few hundred differences; any surprise disables
+    the shortcut and every difference is built for real)."""
+    global _fast_order_ok
+    if _fast_order_ok is None:
+        import random as _random
+        rnd = _random.Random(12345)      # (a private generator: the callers' `random` stream is untouched)
+        ok = True
+        for n in (9, 40, 300, 2500, 70000):
+            remaining = set(range(n))
+            for _ in range(40):
+                m = len(remaining)
+                if m == 0:
+                    break
+                pool = rnd.sample(sorted(remaining), min(m, rnd.choice((1, 3, m // 5 + 1, m // 3 + 1))))
+                queued = set()
+                for k in pool:
+                    queued.add(k)
+                if _diff_iterates_ascending(n, m, len(queued)):
+                    d = list(remaining - queued)
+                    ok = ok and d == sorted(d)
+                remaining -= set(pool[:len(pool) // 2 + 1])
+        _fast_order_ok = ok
+    return _fast_order_ok
+
+
+def _components(n, row_fn, threshold, early_stop_threshold, neighbors_fn=None):
     """Connected components by depth-first search with the reference's
     early-stop heuristic (:235-355): a neighbour within early_stop_threshold is
     absorbed into the component without being explored itself, so the result
     can depend on the order neighbours are examined in.  That order is the
     iteration order of `remaining - queued`; the same set operations are
     applied to the same sets in the same sequence here, so CPython produces
-    the same order.  row_fn(j, candidates as an int64 array) -> float64 distances."""
+    the same order.  row_fn(j, candidates as an int64 array) -> float64 distances.
+    neighbors_fn(j) -> (indices ascending, distances) of ALL vertices within
+    `threshold` of j, or None: used while the difference is known to iterate in
+    ascending order (_diff_iterates_ascending -- the first two thirds of the
+    search or so), when the neighbours that count are simply those of them
+    still in `remaining` and not yet queued, in that order; the O(n) set
+    difference and distance row per explored vertex are then not needed."""
     remaining = set(range(n))
     done = set()
     components = []
+    fast = neighbors_fn is not None and _fast_order_available()
+    if fast:
+        in_remaining = np.ones(n, dtype=bool)
+        queued_in = np.zeros(n, dtype=np.int64)      # the component (1-based) that queued the vertex
+    comp_no = 0
     for start in range(n):
         if start in done:
             continue
+        comp_no += 1
         seen = set()
         stack = [start]
         queued = {start}
+        if fast:
+            queued_in[start] = comp_no
         while len(stack) > 0:
             j = stack.pop()
             if j in seen:
                 continue
             seen.add(j)
-            diff = remaining - queued
-            if not diff:
+            # (queued is a subset of remaining: its members come out of differences with it)
+            if len(remaining) == len(queued):
                 continue
-            # the set's own iteration order, as an index array in one pass
-            cand = np.fromiter(diff, dtype=np.int64, count=len(diff))
-            d = row_fn(j, cand)
-            adjacent = np.nonzero(d <= threshold)[0]
-            near = d[adjacent] <= early_stop_threshold
-            for k, is_near in zip(cand[adjacent].tolist(), near.tolist()):
+            if fast and _diff_iterates_ascending(n, len(remaining), len(queued)):
+                idx, dist = neighbors_fn(j)
+                keep = in_remaining[idx] & (queued_in[idx] != comp_no)
+                ks, near = idx[keep], dist[keep] <= early_stop_threshold
+            else:
+                diff = remaining - queued
+                if not diff:
+                    continue
+                # the set's own iteration order, as an index array in one pass
+                cand = np.fromiter(diff, dtype=np.int64, count=len(diff))
+                d = row_fn(j, cand)
+                adjacent = np.nonzero(d <= threshold)[0]
+                ks, near = cand[adjacent], d[adjacent] <= early_stop_threshold
+            for k, is_near in zip(ks.tolist(), near.tolist()):
                 if is_near:
                     seen.add(k)
                 else:
                     stack.append(k)
                 queued.add(k)
+            if fast and len(ks):
+                queued_in[ks] = comp_no
         done.update(seen)
         remaining -= seen
+        if fast:
+            in_remaining[np.fromiter(seen, dtype=np.int64, count=len(seen))] = False
         components.append(sorted(seen))
     components.sort(key=len, reverse=True)
     return components
@@ -129,7 +228,18 @@ def _components_of_signatures(sigs, threshold,
         common = sigs.common_row(j)
         # float(intersect_count) / union_count, 1.0 - similarity (lsh.py:212-215)
         return 1.0 - common[cand].astype(np.float64) / N
-    return _components(sigs.n, row, threshold, early_stop_threshold)
+
+    # the smallest number of shared values whose distance is within the threshold (the distance falls
+    # as the number grows; evaluated with the expression above, so the comparison is the same)
+    within = np.nonzero(1.0 - np.arange(sigs.N + 1, dtype=np.float64) / N <= threshold)[0]
+    neighbors = None
+    if sigs.N <= 176 and len(within) and not os.environ.get("CATCHHIP_CLUSTER_ROWS_ONLY"):
+        min_common = int(within[0])
+
+        def neighbors(j):
+            idx, common = sigs.neighbors(j, min_common)
+            return idx, 1.0 - common.astype(np.float64) / N
+    return _components(sigs.n, row, threshold, early_stop_threshold, neighbors)
 
 
 def cluster_with_minhash_signatures(seqs, k=12, N=100, threshold=0.1,

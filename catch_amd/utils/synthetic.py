@@ -23,6 +23,26 @@ def _mutate(codes, d, rng):
     return out
 
 
+def _indels(codes, rate, rng):
+    """Insertions and deletions: Poisson(rate * length) events, each at a
+    uniform position, deletion or insertion with equal probability, length
+    geometric (mean ~3, at most 30); applied from the end so that positions
+    stay valid.  Sibling strains then no longer sit at identical offsets."""
+    n = int(rng.poisson(rate * codes.size))
+    if n == 0:
+        return codes
+    pos = np.sort(rng.integers(0, codes.size, size=n))[::-1]
+    kinds = rng.random(n) < 0.5
+    lens = np.minimum(rng.geometric(0.35, size=n), 30)
+    out = codes
+    for p, is_del, ln in zip(pos.tolist(), kinds.tolist(), lens.tolist()):
+        if is_del:
+            out = np.concatenate((out[:p], out[p + ln:]))
+        else:
+            out = np.concatenate((out[:p], rng.integers(0, 4, size=ln, dtype=np.uint8), out[p:]))
+    return out
+
+
 def _to_str(codes, rng, with_n=True):
     b = _ACGT[codes].copy()
     if with_n:
@@ -36,16 +56,25 @@ def _to_str(codes, rng, with_n=True):
 
 
 def make_species(rng, segment_lengths, n_strains, n_clades, d1, d2,
-                 with_n=True):
-    """Returns a list of genomes; each genome is a list of segment strings."""
+                 with_n=True, indel=0.0):
+    """Returns a list of genomes; each genome is a list of segment strings.
+    indel > 0: insertions / deletions per base at the clade and at the strain
+    level (the S*i datasets; 0 leaves the random stream of S1-S5 untouched)."""
     roots = [rng.integers(0, 4, size=ln, dtype=np.uint8)
              for ln in segment_lengths]
-    clades = [[_mutate(r, d1, rng) for r in roots] for _ in range(n_clades)]
+    if indel <= 0:
+        clades = [[_mutate(r, d1, rng) for r in roots] for _ in range(n_clades)]
+    else:
+        clades = [[_indels(_mutate(r, d1, rng), indel, rng) for r in roots] for _ in range(n_clades)]
     genomes = []
     for i in range(n_strains):
         c = clades[i % n_clades]
-        genomes.append([_to_str(_mutate(seg, d2, rng), rng, with_n)
-                        for seg in c])
+        if indel <= 0:
+            genomes.append([_to_str(_mutate(seg, d2, rng), rng, with_n)
+                            for seg in c])
+        else:
+            genomes.append([_to_str(_indels(_mutate(seg, d2, rng), indel, rng), rng, with_n)
+                            for seg in c])
     return genomes
 
 
@@ -61,6 +90,8 @@ def dataset(name, seed=None, scale=1.0):
       S3: 8 segments x (5,000*scale) strains in 40 clades, every segment its
           own genome record, d1 = 12 %, d2 = 2 % (config 3 shape)
       S4: 20 species = 20 groups (config 4 shape), sizes scaled by `scale`
+      S2i, S4i: the shapes of S2 / S4 with per-clade and per-strain insertions
+          and deletions (Poisson, 1 per kb; lengths geometric)
       S5: 588 species in ONE group (config 5 shape: `design_large` clusters
           all sequences itself), strain counts Zipf(1.3) capped at 20,000,
           scaled by `scale`; genome lengths log-uniform 3-200 kb; at scale 1
@@ -75,6 +106,25 @@ def dataset(name, seed=None, scale=1.0):
         n2 = max(1, int(round(40 * scale)))
         return [make_species(rng, [18950], n1, 4, 0.05, 0.01),
                 make_species(rng, [7270, 3400], n2, 4, 0.05, 0.01)]
+    if name == "S2i":
+        # S2's shape with insertions / deletions (1 per kb at both levels): hits of a probe in sibling
+        # strains are no longer at identical offsets
+        rng = np.random.Generator(np.random.PCG64(12 if seed is None else seed))
+        n1 = max(1, int(round(60 * scale)))
+        n2 = max(1, int(round(40 * scale)))
+        return [make_species(rng, [18950], n1, 4, 0.05, 0.01, indel=1e-3),
+                make_species(rng, [7270, 3400], n2, 4, 0.05, 0.01, indel=1e-3)]
+    if name == "S4i":
+        # S4's shape (20 species = 20 groups) with insertions / deletions
+        rng = np.random.Generator(np.random.PCG64(14 if seed is None else seed))
+        groups = []
+        for i in range(20):
+            ln = int(np.exp(rng.uniform(np.log(7000), np.log(30000))))
+            if i == 0:
+                ln = 150000
+            n = max(1, int(round(int(rng.integers(50, 2001)) * scale)))
+            groups.append(make_species(rng, [ln], n, min(8, n), 0.08, 0.015, indel=1e-3))
+        return groups
     if name == "S3":
         rng = np.random.Generator(np.random.PCG64(3 if seed is None else seed))
         n = max(1, int(round(5000 * scale)))

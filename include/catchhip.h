@@ -256,6 +256,12 @@ int catchhip_comm_unique_id(uint8_t *id128);
 int catchhip_comm_init(catchhip_ctx *ctx, const uint8_t *id128, int32_t nranks,
                        int32_t rank);
 int catchhip_comm_destroy(catchhip_ctx *ctx);
+/* Which RCCL the communicators of this library go through: "RCCL version code V
+ * from <file> (<how it was chosen>)".  The library opens ONE copy by path
+ * (CATCHHIP_RCCL_PATH, else /opt/rocm/lib/librccl.so) instead of whatever file of
+ * that soname the process mapped first (torch ships its own).  No reference
+ * counterpart (the reference is single-process Python). */
+int catchhip_comm_info(char *buf, int64_t len);
 
 /* ONE set cover instance with its UNIVERSES (target genomes) sharded over
  * ranks -- set_cover.approx_multiuniverse (catch/utils/set_cover.py:147-615)
@@ -378,6 +384,14 @@ int catchhip_sigs_fetch(catchhip_ctx *ctx, const catchhip_sigs *sigs,
  * 1.0 - common[k] / N in float64, which the caller forms). */
 int catchhip_sigs_common_row(catchhip_ctx *ctx, const catchhip_sigs *sigs,
                              uint32_t j, uint16_t *common);
+/* The same row reduced to the neighbours the connected-components search
+ * (catch/utils/cluster.py:235-355) looks at: out[i] = (k << 16 | common[k]) for
+ * every sequence k with common[k] >= min_common (its distance to j is within the
+ * threshold), in no particular order; *count = how many (an error when it
+ * exceeds cap).  Signatures of at most 176 values. */
+int catchhip_sigs_neighbors(catchhip_ctx *ctx, const catchhip_sigs *sigs,
+                            uint32_t j, uint32_t min_common,
+                            unsigned long long *out, int64_t cap, int64_t *count);
 /* cluster.create_condensed_dist_matrix (catch/utils/cluster.py:102-194) for the
  * signature distance: out[n(n-1)/2] float32 in SciPy's condensed order, entry
  * (i, j) = lut[common(i, j)] with lut[N+1] supplied by the caller (the float32

@@ -829,6 +829,37 @@ def test_plugin_over_several_ranks_selects_what_one_rank_selects(nranks):
     assert "MULTIRANK_PLUGIN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def test_bench_preflight_over_two_ranks():
+    """`bench.py --gpus 2 --preflight` (both ranks on this box's one GPU, so RCCL
+    refuses and the ranks agree on the gloo exchange): one step of the S2
+    workload per rank, every rank's line of diagnostics present -- its groups,
+    pack / scan / solve times, the exchange in use and which RCCL copy the
+    library is pinned to (the file opened by path, whatever torch mapped)."""
+    import json
+    import subprocess
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CATCHHIP_SHARD_MIN_BASES="1")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(repo, "bench.py"), "--gpus", "2", "--workload", "S2", "--preflight"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and "cpu_baseline" not in d
+    pf = d["preflight"]
+    assert [p["rank"] for p in pf] == [0, 1]
+    assert all("librccl" in p["rccl"] and "/opt/rocm" in p["rccl"] for p in pf)
+    assert all(p["step_s"] > 0 and p["pack_h2d_s"] > 0 for p in pf)
+    assert sorted(g for p in pf for g in p["groups"]) + sorted(pf[0]["sharded_groups"]) != []
+    assert d["rccl"] and "version" in d["rccl"]
+
+
 # ---------------------------------------------------------------- other configs
 @pytest.mark.parametrize("name,scale", [("S3", 0.02), ("S4", 0.01)])
 def test_scaled_baseline_configs_match_oracle(ctx, oracle, name, scale):
@@ -886,12 +917,19 @@ def _digest(ids):
     return hashlib.sha256(a.astype("<i8").tobytes()).hexdigest()
 
 
+def _digest_in_order(ids):
+    import hashlib
+    return hashlib.sha256(np.asarray(ids, dtype="<i8").tobytes()).hexdigest()
+
+
 def test_full_size_config4_matches_oracle_digests(ctx):
     """BASELINE configs[3] at FULL size (S4: 20,755 genomes in 20 groups, 592
     Mbp, 8.9 M candidates, 519 M cover rows): per group the number of
     candidates, the number of picks and the sha256 of the sorted pick ids equal
     what the pinned CPU oracle computed in the authoring container
-    (tests/golden/make_full_size.py; the oracle needs ~20 minutes there)."""
+    (tests/golden/make_full_size.py; the oracle needs ~20 minutes there) -- and
+    so does the sha256 of the ids in PICK ORDER; the same for `-c 0.9` (partial
+    coverage) on the same rows, in fewer than an eighth as many rounds as picks."""
     from catch_amd import probe
     from catch_amd.utils import synthetic
     engine = _engine()
@@ -904,10 +942,19 @@ def test_full_size_config4_matches_oracle_digests(ctx):
         k, ep, eo = probe.anchor_entries_equal_length(c.n, 100, 2, 100)
         p = c.probes(k, ep, eo)
         ids, nrows = engine.setcover_filter(ctx, p, t, 2, 100, 0, 50, c.n)
+        # the same group under -c 0.9 (partial coverage: frontier rounds with the universe test)
+        ids09, nrows09 = engine.setcover_filter(ctx, p, t, 2, 100, 0, 50, c.n,
+                                                universe_p=[0.9] * len(genomes))
+        rounds09 = ctx.counters()["greedy_iters"]
         p.close(); c.close(); t.close()
         g = gold[gi]
         assert (c.n, nrows, len(ids)) == (g["n_candidates"], g["n_rows"], g["n_picks"]), gi
         assert _digest(ids) == g["picks_sha256"], gi
+        assert _digest_in_order(ids) == g["picks_in_order_sha256"], gi      # the sequential pick ORDER
+        assert (nrows09, len(ids09)) == (g["n_rows"], g["n_picks_c09"]), gi
+        assert _digest(ids09) == g["picks_c09_sha256"], gi
+        assert _digest_in_order(ids09) == g["picks_c09_in_order_sha256"], gi
+        assert rounds09 < len(ids09) // 8, (gi, rounds09, len(ids09))
 
 
 def test_full_size_config3_matches_oracle_digests(ctx):
@@ -942,6 +989,7 @@ def test_full_size_config3_matches_oracle_digests(ctx):
     p.close(); c.close(); t.close()
     assert (nrows, len(ids)) == (g["n_rows"], g["n_picks"])
     assert _digest(ids) == g["picks_sha256"]
+    assert _digest_in_order(ids) == g["picks_in_order_sha256"]
 
 
 def test_full_size_config5_design_large_matches_oracle_digest(ctx, tmp_path, capsys):
@@ -1371,6 +1419,24 @@ def test_signatures_of_long_sequences(ctx, oracle):
     sigs.close()
     for i in (0, 1, 30, 60, 61):
         assert got[i].tolist() == list(oracle.minhash_signature(seqs[i], 12, 100, a, b))
+
+
+def test_cluster_neighbor_lists_equal_full_rows(ctx, monkeypatch):
+    """The connected-components search fed by device-made neighbour lists
+    (catchhip_sigs_neighbors, used while the set difference is known to iterate
+    in ascending order) == the search on full distance rows, on S5-shaped
+    fragments (many singletons, a few clusters of hundreds)."""
+    from catch_amd.utils import cluster, synthetic
+    genomes = synthetic.dataset("S5", scale=0.004)[0]
+    seqs = dict(enumerate(s for g in genomes for s in g))
+    assert len(seqs) > 300
+    random.seed(5)
+    fast = cluster.cluster_with_minhash_signatures(seqs, threshold=0.15, cluster_method="simple")
+    monkeypatch.setenv("CATCHHIP_CLUSTER_ROWS_ONLY", "1")
+    random.seed(5)
+    rows = cluster.cluster_with_minhash_signatures(seqs, threshold=0.15, cluster_method="simple")
+    assert fast == rows
+    assert 1 < len(fast) < len(seqs)
 
 
 def test_cluster_with_minhash_signatures_golden(ctx):

@@ -384,3 +384,63 @@ def test_prefetch_order_errors_and_discard():
     time.sleep(0.2)
     pre.close()
     assert sorted(dropped) == sorted(set(dropped)) and all(100 < d < 106 for d in dropped) and len(dropped) >= 2
+
+
+def test_components_search_shortcut_equals_the_set_order():
+    """The connected-components search with device-made neighbour lists
+    (catch_amd/utils/cluster.py: while `remaining - queued` is known to iterate
+    in ascending order the difference is never built) == the search that builds
+    every difference and follows the interpreter's iteration order, on graphs
+    where the early-stop heuristic makes the visiting order matter; and the
+    table-size model behind it, against this interpreter's sets."""
+    import sys
+    from catch_amd.utils import cluster
+    assert cluster._fast_order_available()
+    # the model of CPython's table growth: sys.getsizeof gives the real slot count (16 bytes each
+    # beyond the 8 slots inside the object)
+    base = sys.getsizeof(set())
+    for m in (0, 3, 4, 5, 18, 19, 20, 75, 76, 77, 307, 1228, 1229, 4915, 19660, 19661, 50000, 78643, 78644, 200000):
+        s = set()
+        for i in range(m):
+            s.add(3 * i + 1)
+        slots = 8 if sys.getsizeof(s) == base else (sys.getsizeof(s) - base) // 16
+        assert cluster._table_size_after_inserts(m) == slots, m
+    rng = np.random.Generator(np.random.PCG64(77))
+    # whenever the predicate says so, the difference really iterates in ascending order
+    for n in (12, 100, 1000, 20000):
+        remaining = set(range(n))
+        for _ in range(60):
+            m = len(remaining)
+            if m < 2:
+                break
+            q = int(rng.integers(1, max(2, m // int(rng.choice([2, 3, 5, 9, 40])))))
+            members = rng.choice(np.fromiter(remaining, dtype=np.int64), size=q, replace=False).tolist()
+            queued = set()
+            for k in members:
+                queued.add(k)
+            if cluster._diff_iterates_ascending(n, m, len(queued)):
+                d = list(remaining - queued)
+                assert d == sorted(d), (n, m, q)
+            remaining -= set(members[:max(1, q // 2)])
+    # whole searches: random geometric-ish graphs with near (absorbing) and far (explored) edges
+    used_fast = 0
+    for trial in range(25):
+        n = int(rng.integers(30, 400))
+        x = rng.random(n) * rng.choice([3.0, 10.0, 40.0])
+        dist = np.abs(x[:, None] - x[None, :]) * rng.uniform(0.5, 1.5, size=(n, n))
+        dist = np.minimum(dist, dist.T)
+        thr, early = 0.3, 0.08
+
+        def row(j, cand):
+            return dist[j, cand]
+        calls = []
+
+        def neighbors(j):
+            calls.append(j)
+            idx = np.nonzero(dist[j] <= thr)[0]
+            return idx.astype(np.int64), dist[j, idx]
+        slow = cluster._components(n, row, thr, early)
+        fast = cluster._components(n, row, thr, early, neighbors)
+        assert fast == slow, trial
+        used_fast += len(calls)
+    assert used_fast > 1000

@@ -195,8 +195,10 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_solve_and_plan_over_gloo():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_solve_and_plan_over_gloo(world):
+    """world 2, and world 3 -- where the two-universe instance leaves one rank
+    with an EMPTY shard that still has to take part in every exchange."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -206,7 +208,7 @@ def test_two_rank_sharded_solve_and_plan_over_gloo():
     res = sorted(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
 
 
 def test_plan_helpers_single_process():
@@ -231,6 +233,9 @@ def test_plan_helpers_single_process():
         assert sorted(i for w in whole for i in w) == [i for i in range(len(s4)) if i not in sharded]
         loads = [sum(s4[i] for i in w) + sum(s4[i] for i in sharded) / world for w in whole]
         assert max(loads) <= 1.08 * sum(s4) / world
+    # groups that may not be sharded (fewer genomes than ranks) stay whole however large they are
+    sharded, whole = parallel.plan_with_sharding([900, 40, 35], 4, eligible=[False, True, True])
+    assert 0 not in sharded and any(0 in w for w in whole)
     # nothing large enough to shard: plain longest-first
     sharded, whole = parallel.plan_with_sharding([50, 40, 5], 2, min_cost=100)
     assert sharded == [] and whole == [[0], [1, 2]]

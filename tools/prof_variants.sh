@@ -2,7 +2,7 @@
 # usage (GPU box): tools/prof_variants.sh <tag> "<ENV=1 ...>" [bench args]  -> top kernels of an S4 bench run under rocprofv3
 tag=$1; envs=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
-env $envs rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/pv_$tag -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-m2 --no-overlap-figure "$@" > /root/repo/gpurun_out/pv_$tag.json 2>/root/repo/gpurun_out/pv_$tag.err
+env $envs rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/pv_$tag -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure "$@" > /root/repo/gpurun_out/pv_$tag.json 2>/root/repo/gpurun_out/pv_$tag.err
 cd /root/repo
 TAG=$tag python - <<'PY'
 import csv,glob,json,os
