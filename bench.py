@@ -466,7 +466,7 @@ def bench_design_large(args):
     from catch_amd import genome
     from catch_amd.filter import near_duplicate_filter, probe_designer, set_cover_filter
     t_gen = time.perf_counter()
-    genomes = synthetic.dataset("S5", scale=args.scale)[0]
+    genomes = synthetic.dataset(args.workload, scale=args.scale)[0]     # S5, or S5m: its first 40 species
     gen_s = time.perf_counter() - t_gen
     gobjs = [[genome.Genome.from_one_seq(g[0]) for g in genomes]]
     bases = sum(len(s) for g in genomes for s in g)
@@ -527,7 +527,7 @@ def bench_design_large(args):
     gold = None
     try:
         with open(os.path.join(REPO, "tests", "golden", "full_size_picks.json")) as f:
-            gold = json.load(f).get("S5:%g" % args.scale, {}).get("design")
+            gold = json.load(f).get("%s:%g" % (args.workload, args.scale), {}).get("design")
     except (OSError, ValueError):
         pass
     seeds, dropped, hits = per.get("seed_hits", 0), per.get("seeds_dropped", 0), per.get("raw_hits", 0)
@@ -550,7 +550,7 @@ def bench_design_large(args):
         "value": units * K / elapsed, "unit": "probe*bp/s", "n_gpus": 1, "steps": K, "warmup": args.warmup,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32 bit-planes / u64 bitmap (integer)", "data": "synthetic",
-        "config": {"workload": "S5 (BASELINE configs[4]%s): design_large defaults on %d genomes, %d bp in one group: "
+        "config": {"workload": args.workload + " (BASELINE configs[4]%s): design_large defaults on %d genomes, %d bp in one group: "
                                "-m 5 -e 50 -pl 100 -ps 50, cluster 0.15 from 50-kb fragments, MinHash NDF 0.6"
                                % ("" if args.scale == 1.0 else " scaled x%g" % args.scale, len(genomes), bases),
                    "scale": args.scale, "clusters": per.get("clusters"), "fragments": per.get("fragments"),
@@ -610,7 +610,7 @@ def main():
     if args.preflight:
         args.steps, args.warmup = 1, 0
         args.no_cpu_baseline = args.no_m2 = args.no_partial = args.no_overlap_figure = True
-    if args.workload == "S5":
+    if args.workload in ("S5", "S5m"):
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:
             raise SystemExit("--workload S5 runs on one GPU (the clustered design is one process)")
         return bench_design_large(args)

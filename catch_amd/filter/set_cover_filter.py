@@ -479,8 +479,9 @@ class SetCoverFilter(BaseFilter):
         # only when no random numbers are involved
         # (nor while an LSH near-duplicate filter draws its positions / hash
         # functions from `random` group after group)
-        if near_duplicate_filter is None and not probe.anchors_use_random(
-                ["A" * probe_length], self.mismatches, self.lcf_thres, self.kmer_probe_map_k):
+        keep_input_order = not (near_duplicate_filter is None and not probe.anchors_use_random(
+            ["A" * probe_length], self.mismatches, self.lcf_thres, self.kmer_probe_map_k))
+        if not keep_input_order:
             todo.sort(key=lambda i: (-sizes[i], i))
             chunks = _chunks_by_size(todo, lambda gi: sizes[gi], width)
         else:
@@ -523,54 +524,171 @@ class SetCoverFilter(BaseFilter):
             for h in (res[2], res[1], res[0]):
                 h.close()
 
-        pre = engine.Prefetch(order, build, depth, discard) if depth > 0 else None
-        feed = iter(pre) if pre is not None else None
+        # Lanes (CATCHHIP_GROUP_LANES=1, the default with the prefetch on): `width` worker threads, each with
+        # its own context / stream and a FIXED list of groups (longest-processing-time-first over the
+        # groups' sizes, so the same group meets the same context -- and its cached device blocks -- on
+        # every call); a lane starts its next group as soon as it is free: the largest group keeps one
+        # lane busy while the others work through the rest, instead of chunks that wait for their slowest
+        # member.  The groups are still BUILT one at a time by one thread, in an order that serves the
+        # lanes as they become free (and, when random numbers are drawn while building, simply in
+        # `order`: the draws must stay where they are).
+        # (CATCHHIP_GROUP_LANES: 0 = off, chunks instead; 1 = three lanes -- S4 from host strings: 0.187 s per
+        # pass with three, 0.192 with four, 0.205 with two, 0.215 in chunks --; n >= 2 = that many)
+        lane_env = int(os.environ.get("CATCHHIP_GROUP_LANES", "1"))
+        lanes = depth > 0 and lane_env != 0 and len(order) > 1
+        lane_count = 3 if lane_env == 1 else lane_env
+        pre = feed = None
+        if depth > 0 and not lanes:
+            pre = engine.Prefetch(order, build, depth, discard)
+            feed = iter(pre)
+
+        def finish(ctx, gi, targets, cands, probes, ncand, nuniq, ids, nrows, lock=None):
+            """A group's result into out / timings (lock: several lanes finish groups at once)."""
+            target_genomes = target_genomes_grouped[gi]
+            if return_ids:
+                res = ids
+            else:
+                seqs = [s for g in target_genomes for s in g.seqs]
+                pos = cands.positions(np.asarray(ids, dtype=np.int64))
+                which = np.searchsorted(targets.seq_off, pos, side="right") - 1
+                local = pos - targets.seq_off[which]
+                res = [seqs[q][o:o + probe_length]
+                       for q, o in zip(which.tolist(), local.tolist())]
+            if lock is not None:
+                lock.acquire()
+            try:
+                out[gi] = res
+                timings["candidates"] += ncand
+                timings["unique_candidates"] += nuniq
+                timings["probe_bp_units"] = timings.get("probe_bp_units", 0.0) + float(cands.n) * float(
+                    sum(g.size() for g in target_genomes))
+                _accumulate(timings, ctx, nrows, len(ids))
+            finally:
+                if lock is not None:
+                    lock.release()
+
         try:
-            for chunk in chunks:
-                ctxs = _contexts(len(chunk))
-                specs, held, cands_of = [], [], []
-                try:
-                    for ctx, gi in zip(ctxs, chunk):
-                        target_genomes = target_genomes_grouped[gi]
-                        if feed is not None:
-                            got, res = next(feed)
-                            assert got == gi
-                            held.extend(res[:3])
-                            targets, cands, probes, ncand, nuniq = res
+            if lanes:
+                import threading
+                nl = max(1, min(lane_count, len(order)))
+                ctxs = _contexts(nl)
+                lists = [[order[j] for j in lane] for lane in _lpt([sizes[gi] for gi in order], nl)]
+                lane_of = {gi: li for li, lst in enumerate(lists) for gi in lst}
+                if keep_input_order:
+                    production = list(order)
+                else:
+                    # the order in which the lanes will ask for their groups if time goes as size
+                    production, at, clock = [], [0] * nl, [0.0] * nl
+                    while len(production) < len(order):
+                        li = min((l for l in range(nl) if at[l] < len(lists[l])), key=lambda l: (clock[l], l))
+                        gi = lists[li][at[li]]
+                        production.append(gi)
+                        clock[li] += sizes[gi]
+                        at[li] += 1
+                if keep_input_order:
+                    # (the lanes then take their groups in production order too)
+                    lists = [[gi for gi in production if lane_of[gi] == li] for li in range(nl)]
+                cv = threading.Condition()
+                built, errors = {}, []
+                slots = threading.Semaphore(max(2, depth) * nl)
+                res_lock = threading.Lock()
+
+                def producer():
+                    for gi in production:
+                        slots.acquire()
+                        if errors:
+                            return
+                        try:
+                            res = build(gi)
+                        except BaseException as exc:
+                            with cv:
+                                errors.append(exc)
+                                cv.notify_all()
+                            return
+                        with cv:
+                            built[gi] = res
+                            cv.notify_all()
+
+                def lane(li):
+                    ctx = ctxs[li]
+                    for gi in lists[li]:
+                        with cv:
+                            while gi not in built and not errors:
+                                cv.wait()
+                            if errors:
+                                return
+                            targets, cands, probes, ncand, nuniq = built.pop(gi)
+                        slots.release()
+                        try:
                             for h in (targets, cands, probes):
                                 h.rebind(ctx)
-                        else:
-                            targets, cands, probes, ncand, nuniq = build(gi, ctx)
-                            held.extend((targets, cands, probes))
-                        timings["candidates"] += ncand
-                        timings["unique_candidates"] += nuniq
-                        timings["probe_bp_units"] = timings.get("probe_bp_units", 0.0) + float(cands.n) * float(
-                            sum(g.size() for g in target_genomes))
-                        cands_of.append((cands, targets, target_genomes))
-                        if cands.n == 0:
-                            logger.warning("There are no candidate probes for a "
-                                           "grouping of genomes")
-                        specs.append((ctx, probes, targets, cands.n, None,
-                                      self._make_universe_p(target_genomes)))
-                    results = engine.setcover_filter_many(
-                        specs, self.mismatches, self.lcf_thres,
-                        self.island_of_exact_match, self.cover_extension,
-                        self.scan_mode)
-                    for ctx, gi, (cands, targets, target_genomes), (ids, nrows) in zip(
-                            ctxs, chunk, cands_of, results):
-                        if return_ids:
-                            out[gi] = ids
-                        else:
-                            seqs = [s for g in target_genomes for s in g.seqs]
-                            pos = cands.positions(np.asarray(ids, dtype=np.int64))
-                            which = np.searchsorted(targets.seq_off, pos, side="right") - 1
-                            local = pos - targets.seq_off[which]
-                            out[gi] = [seqs[q][o:o + probe_length]
-                                       for q, o in zip(which.tolist(), local.tolist())]
-                        _accumulate(timings, ctx, nrows, len(ids))
-                finally:
-                    for h in reversed(held):
-                        h.close()
+                            if cands.n == 0:
+                                logger.warning("There are no candidate probes for a "
+                                               "grouping of genomes")
+                            ids, nrows = engine.setcover_filter(
+                                ctx, probes, targets, self.mismatches, self.lcf_thres,
+                                self.island_of_exact_match, self.cover_extension, cands.n, None,
+                                self._make_universe_p(target_genomes_grouped[gi]), self.scan_mode)
+                            finish(ctx, gi, targets, cands, probes, ncand, nuniq, ids, nrows, res_lock)
+                        except BaseException as exc:
+                            with cv:
+                                errors.append(exc)
+                                cv.notify_all()
+                            slots.release()          # (the producer may be waiting for a slot)
+                        finally:
+                            for h in (probes, cands, targets):
+                                h.close()
+                        if errors:
+                            return
+
+                prod = threading.Thread(target=producer, name="catchhip-prefetch")
+                threads = [threading.Thread(target=lane, args=(li,), name="catchhip-lane") for li in range(1, nl)]
+                prod.start()
+                for t in threads:
+                    t.start()
+                lane(0)
+                for t in threads:
+                    t.join()
+                if errors:
+                    for _ in range(len(production) + 1):
+                        slots.release()              # let the producer run into the error flag and stop
+                prod.join()
+                for res in built.values():           # built, never consumed (after an error)
+                    discard(res)
+                if errors:
+                    raise errors[0]
+            else:
+                for chunk in chunks:
+                    ctxs = _contexts(len(chunk))
+                    specs, held, built = [], [], []
+                    try:
+                        for ctx, gi in zip(ctxs, chunk):
+                            target_genomes = target_genomes_grouped[gi]
+                            if feed is not None:
+                                got, res = next(feed)
+                                assert got == gi
+                                held.extend(res[:3])
+                                targets, cands, probes, ncand, nuniq = res
+                                for h in (targets, cands, probes):
+                                    h.rebind(ctx)
+                            else:
+                                targets, cands, probes, ncand, nuniq = build(gi, ctx)
+                                held.extend((targets, cands, probes))
+                            built.append((targets, cands, probes, ncand, nuniq))
+                            if cands.n == 0:
+                                logger.warning("There are no candidate probes for a "
+                                               "grouping of genomes")
+                            specs.append((ctx, probes, targets, cands.n, None,
+                                          self._make_universe_p(target_genomes)))
+                        results = engine.setcover_filter_many(
+                            specs, self.mismatches, self.lcf_thres,
+                            self.island_of_exact_match, self.cover_extension,
+                            self.scan_mode)
+                        for ctx, gi, b, (ids, nrows) in zip(ctxs, chunk, built, results):
+                            finish(ctx, gi, b[0], b[1], b[2], b[3], b[4], ids, nrows)
+                    finally:
+                        for h in reversed(held):
+                            h.close()
         finally:
             if pre is not None:
                 pre.close()
@@ -714,6 +832,11 @@ class SetCoverFilter(BaseFilter):
             for j, gi in enumerate(chunk):
                 selected[gi] = (ids[grp == j] - offsets[j]).tolist()
             _accumulate(timings, ctx, nrows, len(ids))
+
+
+def _lpt(costs, nbins):
+    from catch_amd import parallel
+    return parallel.lpt_assign(costs, nbins)
 
 
 def _accumulate(timings, ctx, nrows, npicks):

@@ -96,6 +96,8 @@ def dataset(name, seed=None, scale=1.0):
           all sequences itself), strain counts Zipf(1.3) capped at 20,000,
           scaled by `scale`; genome lengths log-uniform 3-200 kb; at scale 1
           about 2 x 10^9 bases
+      S5m: the first 40 species of S5 (for timing the live reference's
+          design_large chain)
     """
     if name == "S1":
         rng = np.random.Generator(np.random.PCG64(1 if seed is None else seed))
@@ -142,10 +144,12 @@ def dataset(name, seed=None, scale=1.0):
             n = max(1, int(round(int(rng.integers(50, 2001)) * scale)))
             groups.append(make_species(rng, [ln], n, min(8, n), 0.08, 0.015))
         return groups
-    if name == "S5":
+    if name in ("S5", "S5m"):
+        # S5m: the first 40 species of the same stream (a few Mbases: what the Python reference's
+        # design_large chain finishes in minutes)
         rng = np.random.Generator(np.random.PCG64(5 if seed is None else seed))
         genomes = []
-        for _ in range(588):
+        for _ in range(588 if name == "S5" else 40):
             ln = int(np.exp(rng.uniform(np.log(3000), np.log(200000))))
             n = min(int(rng.zipf(1.3)), 20000)
             # keep the target of ~2e9 bases at scale 1: long genomes get fewer strains

@@ -1,5 +1,6 @@
 """Pins the CPU oracle (oracle/) to golden vectors recorded from the live
 reference (tests/golden/make_golden.py).  No GPU needed."""
+import os
 import numpy as np
 import pytest
 
@@ -347,3 +348,28 @@ def test_ndf_hamming_c_equals_python(oracle):
         assert a == b and len(a) < len(set(strs))
         n += 1
     assert n >= 8
+
+
+def test_oracle_selects_what_the_live_reference_selected_on_indel_input(oracle):
+    """S2i (S2's shape with insertions and deletions: a probe's hits in sibling
+    strains are no longer at identical offsets, ranges touch and merge
+    differently): the oracle's SetCoverFilter selection == the LIVE reference's
+    (tests/golden/reference_runs.json, recorded by tools/time_reference.py)."""
+    import hashlib
+    import json
+    from catch_amd.filter import candidate_probes
+    from catch_amd.utils import synthetic
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_runs.json")) as f:
+        run = [r for r in json.load(f)["runs"] if r["input"] == "S2i"][0]
+    groups = synthetic.dataset("S2i", scale=run["scale"])
+    cands = [list(dict.fromkeys(candidate_probes.candidate_strings_from_sequences(
+        [s for g in grp for s in g], 100, 50))) for grp in groups]
+    assert sum(map(len, cands)) == run["P"]
+    oracle.set_threads(oracle.hw_threads())
+    try:
+        ids = oracle.set_cover_filter(cands, groups, 2, 100, coverage=1.0, cover_extension=50, lazy=True)
+    finally:
+        oracle.set_threads(1)
+    sel = [sorted(c[i] for i in g) for c, g in zip(cands, ids)]
+    assert sum(map(len, sel)) == run["probes_out"]
+    assert hashlib.sha256("\n".join(",".join(g) for g in sel).encode()).hexdigest() == run["picks_sha256"]

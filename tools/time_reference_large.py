@@ -9,7 +9,7 @@ per cluster candidate probes, MinHash near-duplicate filter 0.6, SetCoverFilter
 (random.seed(21), np.random.seed(22)); must run under PYTHONHASHSEED=0 (the
 MinHash filter hashes k-mers with the interpreter's str hash).
 
-    PYTHONHASHSEED=0 python tools/time_reference_large.py 0.001 0.002 > profiles/r03_reference_timings_S5.json
+    PYTHONHASHSEED=0 python tools/time_reference_large.py S5m:0.01 S5m:0.05 > profiles/r03_reference_timings_S5.json
 """
 import hashlib
 import json
@@ -34,8 +34,10 @@ from catch.filter import set_cover_filter as scf  # noqa: E402
 from catch_amd.utils import synthetic  # noqa: E402
 
 
-def run(scale):
-    genomes = synthetic.dataset("S5", scale=scale)[0]
+def run(spec):
+    name, _, sc = spec.partition(":")
+    scale = float(sc) if sc else 1.0
+    genomes = synthetic.dataset(name, scale=scale)[0]
     grouped = [[genome.Genome.from_one_seq(g[0]) for g in genomes]]
     random.seed(21)
     np.random.seed(22)
@@ -49,7 +51,7 @@ def run(scale):
     pd.design()
     wall = time.perf_counter() - t0
     probes = sorted(set(p.seq_str for p in pd.final_probes))
-    return dict(input="S5", scale=scale, genomes=len(genomes), bases=sum(len(s) for g in genomes for s in g),
+    return dict(input=name, scale=scale, genomes=len(genomes), bases=sum(len(s) for g in genomes for s in g),
                 design_wall_s=round(wall, 2), probes_out=len(probes),
                 probes_sha256=hashlib.sha256("\n".join(probes).encode()).hexdigest(),
                 processes=min(multiprocessing.cpu_count(), 8))
@@ -58,8 +60,8 @@ def run(scale):
 def main():
     logging.basicConfig(level=logging.WARNING)
     res = []
-    for sc in sys.argv[1:]:
-        r = run(float(sc))
+    for spec in sys.argv[1:]:
+        r = run(spec)
         res.append(r)
         sys.stderr.write(json.dumps(r) + "\n")
         sys.stderr.flush()
