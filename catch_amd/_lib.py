@@ -41,6 +41,8 @@ PROTOTYPES = {
     "catchhip_targets_create_ptrs": (ctypes.c_int, [
         c_vp, ctypes.POINTER(ctypes.c_void_p), c_i64p, c_i32p, ctypes.c_int64,
         ctypes.c_int32, c_vpp]),
+    "catchhip_pyset_order": (ctypes.c_int, [c_i64p, ctypes.c_int64, c_i64p]),
+    "catchhip_pyset_order_strs": (ctypes.c_int, [c_u8p, c_i64p, ctypes.c_int64, c_i64p]),
     "catchhip_targets_destroy": (ctypes.c_int, [c_vp]),
     "catchhip_targets_rebind": (ctypes.c_int, [c_vp, c_vp]),
     "catchhip_probes_rebind": (ctypes.c_int, [c_vp, c_vp]),

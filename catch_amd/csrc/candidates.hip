@@ -486,7 +486,55 @@ static int cand_priority_rows(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<
     return 0;
 }
 
-// keep[] (host) -> the candidate list becomes the kept ones, in priority order
+// hash(seq_str) of every candidate (PYTHONHASHSEED=0 semantics, internal.h)
+__global__ void __launch_bounds__(256)
+cand_pyhash_kernel(const u8 *__restrict__ tbytes, const u32 *__restrict__ pos, u32 n, u32 L, long long *__restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = chip_pyhash_seed0(tbytes + pos[i], (int)L);
+}
+
+// The kept candidates as the reference hands them on: `list(to_include)`, a set of probes
+// (near_duplicate_filter.py:76-103) -- per group (one _filter call each) the iteration order of a set
+// the kept probes were added to in inclusion order (chip_pyset_order).  kept / kgrp: the kept candidates
+// in inclusion order (groups non-decreasing).
+static int cand_set_order(catchhip_ctx *ctx, const catchhip_candidates *C, DevBuf<u32> &kept, DevBuf<u32> &kgrp, u32 nk) {
+    if (nk < 2) return 0;
+    hipStream_t s = ctx->stream;
+    DevBuf<long long> d_hash;
+    TRY(d_hash.alloc(nk));
+    hipLaunchKernelGGL(cand_pyhash_kernel, dim3((unsigned)div_up((i64)nk, 256)), dim3(256), 0, s,
+                       (const u8 *)C->T->bytes.p, (const u32 *)kept.p, nk, (u32)C->L, d_hash.p);
+    std::vector<i64> h_hash(nk), order(nk);
+    std::vector<u32> h_grp;
+    HIP_TRY(hipMemcpyAsync(h_hash.data(), d_hash.p, sizeof(i64) * nk, hipMemcpyDeviceToHost, s));
+    if (C->grouped) {
+        h_grp.resize(nk);
+        HIP_TRY(hipMemcpyAsync(h_grp.data(), kgrp.p, sizeof(u32) * nk, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    for (u32 a = 0; a < nk;) {
+        u32 b = a + 1;
+        if (C->grouped) while (b < nk && h_grp[b] == h_grp[a]) ++b;
+        else b = nk;
+        chip_pyset_order(h_hash.data() + a, (i64)(b - a), order.data() + a);
+        for (u32 i = a; i < b; ++i) order[i] += a;
+        a = b;
+    }
+    std::vector<u32> o32(nk);
+    for (u32 i = 0; i < nk; ++i) o32[i] = (u32)order[i];
+    DevBuf<u32> d_order, out;
+    TRY(d_order.alloc(nk));
+    TRY(out.alloc((size_t)nk + 1));
+    HIP_TRY(hipMemcpyAsync(d_order.p, o32.data(), sizeof(u32) * nk, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(cand_permute_kernel, dim3((unsigned)div_up((i64)nk, 256)), dim3(256), 0, s,
+                       (const u32 *)kept.p, (const u32 *)d_order.p, nk, out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));     // (o32 is read by the copy until here)
+    kept.swap(out);                       // groups: a permutation inside every group leaves kgrp as it is
+    return 0;
+}
+
+// keep[] (host) -> the candidate list becomes the kept ones, in the reference's order (see cand_set_order)
 static int cand_apply_keep(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<u32> &opos, DevBuf<u32> &ogrp,
                            const std::vector<u8> &keep, i64 *nkept) {
     hipStream_t s = ctx->stream;
@@ -510,6 +558,7 @@ static int cand_apply_keep(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<u32
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
+    if (!getenv("CATCHHIP_NDF_INCLUSION_ORDER")) TRY(cand_set_order(ctx, C, out, gout, nk));
     C->upos.swap(out);
     if (C->grouped) C->ugrp.swap(gout);
     C->nuniq = nk;

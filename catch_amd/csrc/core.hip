@@ -712,6 +712,68 @@ extern "C" int catchhip_rows_destroy(catchhip_rows *r) {
     return 0;
 }
 
+// ---- iteration order of a CPython set ---------------------------------------
+// The reference's near-duplicate filters return `list(to_include)`, a SET of probes
+// (catch/filter/near_duplicate_filter.py:76-103), and the set cover filter numbers its
+// candidates in the order it is handed them: which of two equally good probes is picked
+// follows from the set's iteration order.  That order is a function of the keys' hashes
+// and of the order they were added in (Objects/setobject.c, CPython 3.7-3.12: open
+// addressing, home slot hash & mask, 9 linear probes, then i = i * 5 + 1 + (perturb >>= 5);
+// a table of 8 slots rebuilt -- entries re-inserted in slot order -- when fill * 5 >=
+// mask * 3, to the smallest power of two above 4 x used, 2 x used beyond 50,000), and
+// list(set) walks the table by slot.  Only insertions of distinct keys occur here.
+void chip_pyset_order(const i64 *hash, i64 n, i64 *order) {
+    size_t size = 8, fill = 0;
+    std::vector<i64> table(size, -1);
+    auto insert_clean = [&](std::vector<i64> &tab, size_t mask, i64 idx) {
+        const u64 h = (u64)hash[idx];
+        size_t perturb = (size_t)h, i = (size_t)h & mask;
+        for (;;) {
+            if (tab[i] < 0) { tab[i] = idx; return; }
+            if (i + 9 <= mask)
+                for (size_t j = 1; j <= 9; ++j)
+                    if (tab[i + j] < 0) { tab[i + j] = idx; return; }
+            perturb >>= 5;
+            i = (i * 5 + 1 + perturb) & mask;
+        }
+    };
+    for (i64 idx = 0; idx < n; ++idx) {
+        const size_t mask = size - 1;
+        insert_clean(table, mask, idx);
+        ++fill;
+        if (fill * 5 >= mask * 3) {
+            const size_t want = fill > 50000 ? fill * 2 : fill * 4;
+            size_t nsize = 8;
+            while (nsize <= want) nsize <<= 1;
+            std::vector<i64> nt(nsize, -1);
+            for (size_t sl = 0; sl < size; ++sl)
+                if (table[sl] >= 0) insert_clean(nt, nsize - 1, table[sl]);
+            table.swap(nt);
+            size = nsize;
+        }
+    }
+    i64 at = 0;
+    for (size_t sl = 0; sl < size; ++sl)
+        if (table[sl] >= 0) order[at++] = table[sl];
+}
+
+extern "C" int catchhip_pyset_order(const i64 *hashes, i64 n, i64 *order) {
+    ARG_CHECK(n >= 0 && (n == 0 || (hashes && order)));
+    chip_pyset_order(hashes, n, order);
+    return 0;
+}
+
+extern "C" int catchhip_pyset_order_strs(const u8 *bytes, const i64 *off, i64 n, i64 *order) {
+    ARG_CHECK(n >= 0 && (n == 0 || (bytes && off && order)));
+    std::vector<i64> h((size_t)n);
+    for (i64 i = 0; i < n; ++i) {
+        ARG_CHECK(off[i + 1] >= off[i] && off[i + 1] - off[i] < ((i64)1 << 31));
+        h[(size_t)i] = chip_pyhash_seed0(bytes + off[i], (int)(off[i + 1] - off[i]));
+    }
+    chip_pyset_order(h.data(), n, order);
+    return 0;
+}
+
 // ---- independent instances inside one probes / targets pair ----------------
 extern "C" int catchhip_probes_set_groups(catchhip_ctx *ctx, catchhip_probes *P, const i32 *group_of_probe) {
     ARG_CHECK(ctx && P && P->ctx == ctx);

@@ -287,6 +287,39 @@ __host__ __device__ static inline u32 mod_mersenne31(u64 v) {
     return (u32)(t >= P ? t - P : t);
 }
 
+// CPython <= 3.10 hash(str) of `len` ASCII characters under PYTHONHASHSEED=0: SipHash-2-4 with an all-zero
+// key (PEP 456, Python/pyhash.c).  The reference hashes Probe objects by hash(seq_str) (catch/probe.py:
+// 324-329): its sets of probes iterate in an order that follows from these values.
+__host__ __device__ static inline long long chip_pyhash_seed0(const u8 *src, int len) {
+    u64 v0 = 0x736f6d6570736575ull, v1 = 0x646f72616e646f6dull, v2 = 0x6c7967656e657261ull, v3 = 0x7465646279746573ull;
+#define CHIP_SIPROUND do { \
+    v0 += v1; v1 = (v1 << 13) | (v1 >> 51); v1 ^= v0; v0 = (v0 << 32) | (v0 >> 32); \
+    v2 += v3; v3 = (v3 << 16) | (v3 >> 48); v3 ^= v2; \
+    v0 += v3; v3 = (v3 << 21) | (v3 >> 43); v3 ^= v0; \
+    v2 += v1; v1 = (v1 << 17) | (v1 >> 47); v1 ^= v2; v2 = (v2 << 32) | (v2 >> 32); } while (0)
+    u64 b = (u64)len << 56;
+    int n = len;
+    const u8 *p = src;
+    while (n >= 8) {
+        u64 mi = 0;
+        for (int i = 0; i < 8; ++i) mi |= (u64)p[i] << (8 * i);
+        v3 ^= mi; CHIP_SIPROUND; CHIP_SIPROUND; v0 ^= mi;
+        p += 8; n -= 8;
+    }
+    u64 t = 0;
+    for (int i = 0; i < n; ++i) t |= (u64)p[i] << (8 * i);
+    b |= t;
+    v3 ^= b; CHIP_SIPROUND; CHIP_SIPROUND; v0 ^= b;
+    v2 ^= 0xff; CHIP_SIPROUND; CHIP_SIPROUND; CHIP_SIPROUND; CHIP_SIPROUND;
+#undef CHIP_SIPROUND
+    long long x = (long long)((v0 ^ v1) ^ (v2 ^ v3));
+    if (x == -1) x = -2;
+    return x;
+}
+// order[] = the indices 0..n-1 in the order a CPython set iterates n distinct keys with these hashes
+// after they were added in index order (core.hip)
+void chip_pyset_order(const i64 *hash, i64 n, i64 *order);
+
 static inline int ceil_log2_u64(u64 x) {
     int b = 0;
     while (b < 64 && ((u64)1 << b) < x) ++b;

@@ -306,36 +306,8 @@ extern "C" int catchhip_ndf_hamming(catchhip_ctx *ctx, const u8 *bytes, i64 n, i
 #define MH_P 2147483647ull
 #define MH_MAXK 256   // k-mers per probe one wavefront sorts
 
-__device__ __forceinline__ u64 mh_rotl(u64 x, int b) { return (x << b) | (x >> (64 - b)); }
-
-// CPython <= 3.10 str hash of `len` ASCII characters, zero key (see above)
-__device__ __forceinline__ long long mh_pyhash(const u8 *__restrict__ src, int len) {
-    u64 v0 = 0x736f6d6570736575ull, v1 = 0x646f72616e646f6dull, v2 = 0x6c7967656e657261ull,
-        v3 = 0x7465646279746573ull;
-#define MH_ROUND do { \
-    v0 += v1; v1 = mh_rotl(v1, 13); v1 ^= v0; v0 = mh_rotl(v0, 32); \
-    v2 += v3; v3 = mh_rotl(v3, 16); v3 ^= v2; \
-    v0 += v3; v3 = mh_rotl(v3, 21); v3 ^= v0; \
-    v2 += v1; v1 = mh_rotl(v1, 17); v1 ^= v2; v2 = mh_rotl(v2, 32); } while (0)
-    u64 b = (u64)len << 56;
-    int n = len;
-    const u8 *p = src;
-    while (n >= 8) {
-        u64 mi = 0;
-        for (int i = 0; i < 8; ++i) mi |= (u64)p[i] << (8 * i);
-        v3 ^= mi; MH_ROUND; MH_ROUND; v0 ^= mi;
-        p += 8; n -= 8;
-    }
-    u64 t = 0;
-    for (int i = 0; i < n; ++i) t |= (u64)p[i] << (8 * i);
-    b |= t;
-    v3 ^= b; MH_ROUND; MH_ROUND; v0 ^= b;
-    v2 ^= 0xff; MH_ROUND; MH_ROUND; MH_ROUND; MH_ROUND;
-#undef MH_ROUND
-    long long x = (long long)((v0 ^ v1) ^ (v2 ^ v3));
-    if (x == -1) x = -2;
-    return x;
-}
+// CPython <= 3.10 str hash of `len` ASCII characters, zero key (see above; internal.h)
+__device__ __forceinline__ long long mh_pyhash(const u8 *__restrict__ src, int len) { return chip_pyhash_seed0(src, len); }
 
 __global__ void __launch_bounds__(64)
 mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, const u32 *__restrict__ koff, u32 n,

@@ -58,6 +58,28 @@ def _str_pointers(strs):
     return arr, lens
 
 
+def pyset_order(hashes):
+    """catchhip_pyset_order: indices in the order a CPython set iterates keys
+    with these hashes after they were added in index order."""
+    h = np.ascontiguousarray(hashes, dtype=np.int64)
+    out = np.zeros(max(h.size, 1), dtype=np.int64)
+    check(_lib.lib().catchhip_pyset_order(_ptr(h, c_i64p), int(h.size), _ptr(out, c_i64p)))
+    return out[:h.size]
+
+
+def pyset_order_strs(strs):
+    """catchhip_pyset_order_strs: the order `list(set)` would give the distinct
+    ASCII strings after they were added one by one (hash(str) of CPython <=
+    3.10 under PYTHONHASHSEED=0)."""
+    n = len(strs)
+    if n == 0:
+        return np.zeros(0, dtype=np.int64)
+    buf, off = _concat(strs)
+    out = np.zeros(n, dtype=np.int64)
+    check(_lib.lib().catchhip_pyset_order_strs(_ptr(buf, c_u8p), _ptr(off, c_i64p), n, _ptr(out, c_i64p)))
+    return out
+
+
 def device_count():
     n = ctypes.c_int(0)
     rc = _lib.lib().catchhip_device_count(ctypes.byref(n))

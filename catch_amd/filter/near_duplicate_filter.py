@@ -16,6 +16,7 @@ do not survive the fork of the reference's BaseFilter)
 """
 import logging
 import math
+import os
 import operator
 import random
 from collections import defaultdict
@@ -40,6 +41,23 @@ class NearDuplicateFilter(BaseFilter):
         return [p for p, _ in sorted(occurrences.items(),
                                      key=operator.itemgetter(1),
                                      reverse=True)]
+
+
+def _as_the_reference_returns_them(kept, key=None):
+    """The kept probes (inclusion order in, any sequence type) in the order the
+    reference returns them: `list(to_include)`, the iteration order of a SET
+    of Probe objects hashed by hash(seq_str)
+    (catch/filter/near_duplicate_filter.py:76-103, catch/probe.py:324-329).
+    The set cover filter numbers its candidates in the order it gets them, so
+    this order decides which of two equally good probes is selected.  It is
+    reproducible in the reference only under a fixed PYTHONHASHSEED; the order
+    computed here is the one of PYTHONHASHSEED=0 on CPython <= 3.10
+    (engine.pyset_order_strs emulates the set), whatever this process' own hash
+    seed is -- the same stance as for the MinHash family's hash."""
+    if len(kept) < 2 or os.environ.get("CATCHHIP_NDF_INCLUSION_ORDER"):
+        return list(kept)
+    order = engine.pyset_order_strs([k if key is None else key(k) for k in kept])
+    return [kept[i] for i in order.tolist()]
 
 
 def _order_strs_by_multiplicity(strs):
@@ -81,7 +99,8 @@ class NearDuplicateFilterWithHammingDistance(NearDuplicateFilter):
         ctx = engine.default_context()
         keep = ctx.ndf_hamming([p.seq_str for p in order], self.dim,
                                positions, self.dist_thres)
-        return [p for p, kp in zip(order, keep) if kp]
+        return _as_the_reference_returns_them([p for p, kp in zip(order, keep) if kp],
+                                              key=lambda p: p.seq_str)
 
     def _filter_strs(self, strs):
         """_filter on plain probe strings (the front end's string pipeline)."""
@@ -93,7 +112,7 @@ class NearDuplicateFilterWithHammingDistance(NearDuplicateFilter):
             raise ValueError("Sequences must be of same length")
         keep = engine.default_context().ndf_hamming(order, self.dim, positions,
                                                     self.dist_thres)
-        return [s for s, kp in zip(order, keep) if kp]
+        return _as_the_reference_returns_them([s for s, kp in zip(order, keep) if kp])
 
     def _apply_to_grouped_candidates(self, cands, ngroups):
         """The same on candidates of grouped targets: sampled positions drawn
@@ -184,7 +203,8 @@ class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
         ctx = engine.default_context()
         keep = ctx.ndf_minhash([p.seq_str for p in order], self.kmer_size,
                                params, self.dist_thres)
-        return [p for p, kp in zip(order, keep) if kp]
+        return _as_the_reference_returns_them([p for p, kp in zip(order, keep) if kp],
+                                              key=lambda p: p.seq_str)
 
     def _filter_strs(self, strs):
         """_filter on plain probe strings (the front end's string pipeline)."""
@@ -196,7 +216,7 @@ class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
             raise AssertionError("k-mer size exceeds a sequence's length")
         keep = engine.default_context().ndf_minhash(order, self.kmer_size, params,
                                                     self.dist_thres)
-        return [s for s, kp in zip(order, keep) if kp]
+        return _as_the_reference_returns_them([s for s, kp in zip(order, keep) if kp])
 
     def _apply_to_grouped_candidates(self, cands, ngroups):
         """The same on candidates of grouped targets: hash functions drawn per
@@ -230,5 +250,5 @@ class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
                 raise AssertionError("k-mer size exceeds a sequence's length")
         keeps = engine.default_context().ndf_minhash_many(
             orders, self.kmer_size, params, self.dist_thres)
-        return [[s for s, kp in zip(order, keep) if kp]
+        return [_as_the_reference_returns_them([s for s, kp in zip(order, keep) if kp])
                 for order, keep in zip(orders, keeps)]

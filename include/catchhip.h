@@ -463,6 +463,20 @@ int catchhip_candidates_create(catchhip_ctx *ctx, const catchhip_targets *target
                                catchhip_candidates **out, int64_t *ncandidates,
                                int64_t *nunique);
 void catchhip_candidates_destroy(catchhip_candidates *cands);
+/* Iteration order of a CPython set.  The reference's near-duplicate filters
+ * return `list(to_include)` -- a set of Probe objects hashed by hash(seq_str)
+ * (catch/filter/near_duplicate_filter.py:76-103, catch/probe.py:324-329) -- and
+ * SetCoverFilter numbers its candidates in the order it receives them, so which of
+ * two equally good probes is picked follows from that order.  order[i] = index of
+ * the i-th key a set iterates after the n distinct keys with these hashes were added
+ * in index order (Objects/setobject.c of CPython 3.7-3.12).  ..._strs hashes the
+ * strings as CPython <= 3.10 does under PYTHONHASHSEED=0 (SipHash-2-4, zero key) --
+ * the one setting under which the reference's own order is reproducible; the
+ * catchhip_candidates_ndf_* calls leave their candidates in this order.
+ * Host-only integer work (no device involved). */
+int catchhip_pyset_order(const int64_t *hashes, int64_t n, int64_t *order);
+int catchhip_pyset_order_strs(const uint8_t *bytes, const int64_t *off, int64_t n,
+                              int64_t *order);
 int catchhip_candidates_rebind(catchhip_candidates *cands, catchhip_ctx *to);   /* see catchhip_targets_rebind */
 /* global_start[i] = position (in the targets' concatenated coordinate) of the
  * first occurrence of unique candidate ids[i] (ids == NULL: candidates 0..n-1) */

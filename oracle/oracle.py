@@ -512,10 +512,23 @@ def lsh_draw_positions(num_tables, k, dim):
             for _ in range(num_tables)]
 
 
-def ndf_hamming(probe_strs, dist_thres, positions):
+def as_list_of_set(kept):
+    """`list(to_include)` (near_duplicate_filter.py:103): the kept probes in the
+    iteration order of the Python SET they were added to in inclusion order.
+    Probe objects hash by hash(seq_str) (catch/probe.py:324-329); a real set of
+    stand-ins with the PYTHONHASHSEED=0 hashes (pyhash_seed0) gives the order
+    the reference produces under that setting, in any interpreter."""
+    include = set()
+    for p in kept:
+        include.add(_HashedProbe(p, pyhash_seed0(p)))
+    return [h.s for h in include]
+
+
+def ndf_hamming(probe_strs, dist_thres, positions, inclusion_order=False):
     """NearDuplicateFilter._filter with the Hamming family; `positions` is the
-    per-table list of sampled positions.  Returns the kept probe strings in
-    inclusion order (= multiplicity-sorted order)."""
+    per-table list of sampled positions.  Returns the kept probe strings as
+    the reference does, `list(to_include)` (as_list_of_set); inclusion_order:
+    in the order they were included instead (= multiplicity-sorted order)."""
     occ = {}
     for p in probe_strs:
         occ[p] = occ.get(p, 0) + 1
@@ -544,10 +557,10 @@ def ndf_hamming(probe_strs, dist_thres, positions):
                     raise ValueError("Sequences must be of same length")
                 if int(np.count_nonzero(arr[p] != arr[q])) <= dist_thres:
                     exclude.add(q)
-    return kept
+    return kept if inclusion_order else as_list_of_set(kept)
 
 
-def ndf_hamming_c(probe_strs, dist_thres, positions):
+def ndf_hamming_c(probe_strs, dist_thres, positions, inclusion_order=False):
     """ndf_hamming with the bucket search and the sequential pass in C
     (orc_ndf_hamming), for inputs of millions of probes.  Same result."""
     occ = {}
@@ -566,7 +579,8 @@ def ndf_hamming_c(probe_strs, dist_thres, positions):
     lib().orc_ndf_hamming(_p(buf, _u8p), len(order), L, _p(pos, _i32p),
                           pos.shape[0], pos.shape[1], int(dist_thres),
                           _p(keep, _u8p))
-    return [p for p, k in zip(order, keep) if k]
+    kept = [p for p, k in zip(order, keep) if k]
+    return kept if inclusion_order else as_list_of_set(kept)
 
 
 # --------------------------------------------------------------------------
@@ -607,10 +621,10 @@ def jaccard_dist(a, b, kmer_size):
     return 1.0 - float(len(ak & bk)) / len(ak | bk)
 
 
-def ndf_minhash(probe_strs, dist_thres, params, kmer_size=10):
+def ndf_minhash(probe_strs, dist_thres, params, kmer_size=10, inclusion_order=False):
     """NearDuplicateFilter._filter with the MinHash family (N = 1, hash(str)
     under PYTHONHASHSEED=0); `params` = minhash_draw_params(...).  Returns the
-    kept probe strings in inclusion order."""
+    kept probe strings as the reference does (as_list_of_set)."""
     occ = {}
     for p in probe_strs:
         occ[p] = occ.get(p, 0) + 1
@@ -641,7 +655,7 @@ def ndf_minhash(probe_strs, dist_thres, params, kmer_size=10):
                     continue
                 if jaccard_dist(p, q, kmer_size) <= dist_thres:
                     exclude.add(q)
-    return kept
+    return kept if inclusion_order else as_list_of_set(kept)
 
 
 # --------------------------------------------------------------------------

@@ -1025,6 +1025,53 @@ def test_full_size_config5_design_large_matches_oracle_digest(ctx, tmp_path, cap
     assert hashlib.sha256("\n".join(got).encode()).hexdigest() == g["probes_sha256"]
 
 
+def test_ndf_then_scf_chains_equal_the_live_reference(ctx):
+    """Near-duplicate filter -> set cover filter, recorded from the LIVE
+    reference under PYTHONHASHSEED=0 (tests/golden/ndf_scf_chains.json): the
+    reference's filter returns `list(to_include)`, a set of probes, and the set
+    cover numbers its candidates in that order.  Both front ends -- strings on
+    the host, candidates on the device -- must hand the set cover filter the
+    kept probes in exactly that order (emulated: catchhip_pyset_order) and
+    select the reference's probes."""
+    import hashlib
+    import json
+    from catch_amd import genome
+    from catch_amd.filter import candidate_probes
+    from catch_amd.filter.near_duplicate_filter import (NearDuplicateFilterWithHammingDistance,
+                                                        NearDuplicateFilterWithMinHash)
+    from catch_amd.filter.set_cover_filter import SetCoverFilter
+    from catch_amd.utils import synthetic
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ndf_scf_chains.json")) as f:
+        runs = json.load(f)["runs"]
+
+    def sha(strs):
+        return hashlib.sha256("\n".join(strs).encode()).hexdigest()
+    assert len(runs) >= 4
+    for r in runs:
+        genomes = synthetic.dataset(r["dataset"], scale=r["scale"])[r["group"]]
+        gobjs = [genome.Genome(list(g), chrs=dict(("c%d" % i, s) for i, s in enumerate(g))) if len(g) > 1
+                 else genome.Genome.from_one_seq(g[0]) for g in genomes]
+
+        def make():
+            random.seed(r["seed"])
+            np.random.seed(r["seed"] + 1)
+            ndf = (NearDuplicateFilterWithHammingDistance(r["threshold"], 100) if r["filter"] == "hamming"
+                   else NearDuplicateFilterWithMinHash(r["threshold"]))
+            return ndf, SetCoverFilter(mismatches=r["mismatches"], lcf_thres=100, coverage=1.0, cover_extension=50)
+        # strings on the host
+        ndf, scf = make()
+        cands = candidate_probes.candidate_strings_from_sequences([s for g in genomes for s in g], 100, 50)
+        kept = ndf._filter_strs(cands)
+        assert len(kept) == r["kept"] and sha(kept) == r["kept_in_order_sha256"], r
+        ids = scf._filter_strs([kept], [gobjs], assume_unique=True)[0]
+        picks = sorted(kept[i] for i in ids)
+        assert len(picks) == r["picks"] and sha(picks) == r["picks_sorted_sha256"], r
+        # candidates on the device
+        ndf, scf = make()
+        out = scf._filter_genomes_device([gobjs], 100, 50, None, ndf)[0]
+        assert sha(sorted(out)) == r["picks_sorted_sha256"], r
+
+
 def test_selection_equals_live_reference_runs(ctx):
     """The inputs the LIVE reference was run on in the authoring container
     (tools/time_reference.py: S1, S2 in full, S3 and S4 scaled down to what the
