@@ -283,12 +283,14 @@ class Stepper:
 
 def pmc_traffic(unit, workload, scale):
     """HBM bytes per launch of `unit` from the committed rocprofv3 PMC passes of
-    this same command (profiles/r02_pmc_traffic_<workload>.json: FETCH_SIZE and
+    this same command (profiles/r03_pmc_traffic_<workload>.json, else the round-2 file: FETCH_SIZE and
     WRITE_SIZE collected in separate runs, tools/collect_profiles.sh;
     FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes).  None
     when no matching record exists: counters cannot be collected from inside
     the timed run."""
-    path = os.path.join(REPO, "profiles", "r02_pmc_traffic_%s.json" % workload)
+    path = os.path.join(REPO, "profiles", "r03_pmc_traffic_%s.json" % workload)
+    if not os.path.exists(path):
+        path = os.path.join(REPO, "profiles", "r02_pmc_traffic_%s.json" % workload)
     try:
         with open(path) as f:
             rec = json.load(f)
@@ -872,6 +874,15 @@ def main():
                                       kept=per.get("ndf_kept", 0), windows=per.get("windows", 0),
                                       front_end_ms=per.get("front_end_ms", 0.0))
             out["config"]["workload"] += "; step = device front end + --filter-with-lsh-hamming 2 (K3) + scan + solve, targets resident"
+            if per.get("ndf_ms", 0.0) > d["ms"] * share[dom]:
+                # configs[2]: the filter is the dominant unit of the step (one filter call per group = one "launch")
+                nf = float(len(stepper.resident))
+                k3 = out["roofline_k3"]
+                out["roofline"] = dict(bound="hbm", kernel=k3["kernel"], achieved=k3["achieved"], peak=HBM_PEAK_GBS,
+                                       unit="GB/s", frac=k3["frac"], traffic=k3["traffic"],
+                                       algorithmic_bytes_per_launch=k3_bytes / nf,
+                                       avg_launch_ms=per.get("ndf_ms", 0.0) / nf, launches_per_step=nf,
+                                       device_ms_per_step=per.get("ndf_ms", 0.0))
         if world == 1 and not args.no_cpu_baseline and Stepper.ndf:
             # configs[2]: the oracle's chain (Hamming filter, then the set cover) on a down-scaled S3 of the
             # same generator, and the GPU on that same input

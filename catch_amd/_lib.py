@@ -43,6 +43,7 @@ PROTOTYPES = {
         ctypes.c_int32, c_vpp]),
     "catchhip_pyset_order": (ctypes.c_int, [c_i64p, ctypes.c_int64, c_i64p]),
     "catchhip_pyset_order_strs": (ctypes.c_int, [c_u8p, c_i64p, ctypes.c_int64, c_i64p]),
+    "catchhip_pyset_order_device": (ctypes.c_int, [c_vp, c_i64p, ctypes.c_int64, c_i64p]),
     "catchhip_targets_destroy": (ctypes.c_int, [c_vp]),
     "catchhip_targets_rebind": (ctypes.c_int, [c_vp, c_vp]),
     "catchhip_probes_rebind": (ctypes.c_int, [c_vp, c_vp]),

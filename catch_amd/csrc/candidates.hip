@@ -493,6 +493,127 @@ cand_pyhash_kernel(const u8 *__restrict__ tbytes, const u32 *__restrict__ pos, u
     if (i < n) out[i] = chip_pyhash_seed0(tbytes + pos[i], (int)L);
 }
 
+// ---- the iteration order of a CPython set, built on the device --------------------------
+// chip_pyset_order (core.hip) inserts one key after the other; here all insertions of one table
+// generation run at once.  What sequential insertion computes is the one assignment in which
+// every key sits in the first slot of its probe sequence that no EARLIER key holds, so the
+// slots hold (priority, index) words, a key claims a slot with atomicMin and whoever it
+// displaces walks on from that slot: the fixed point is the sequential table whatever the
+// interleaving (slot words only ever decrease, so a slot once lost to a key stays lost).
+// A rebuild re-inserts the entries in slot order -- priority = position in the previous
+// generation's iteration order -- and the keys added afterwards follow in input order.
+#define PYSET_EMPTY (~0ull)
+
+struct PysetProbe {       // setobject.c set_add_entry / set_insert_clean: slot, 9 linear probes, perturbed jump
+    u64 base, perturb, mask;
+    u32 j;
+    __device__ __forceinline__ void start(u64 h, u64 m) { mask = m; perturb = h; base = h & m; j = 0; }
+    __device__ __forceinline__ u64 slot() const { return base + j; }
+    __device__ __forceinline__ void next() {
+        if (j == 0 ? (base + 9 <= mask) : (j < 9)) { ++j; return; }
+        perturb >>= 5;
+        base = (base * 5 + 1 + perturb) & mask;
+        j = 0;
+    }
+};
+
+__global__ void __launch_bounds__(256)
+pyset_insert_kernel(const long long *__restrict__ hash, const u32 *__restrict__ ord, u32 n_re, u32 fresh_end, u64 mask,
+                    u64 *__restrict__ tab) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= fresh_end) return;
+    const u32 idx0 = t < n_re ? ord[t] : t;          // (the keys before n_re are exactly those already in the set)
+    u64 mine = ((u64)t << 32) | idx0;
+    PysetProbe pr;
+    pr.start((u64)hash[idx0], mask);
+    for (;;) {
+        const u64 sl = pr.slot();
+        const u64 old = atomicMin((unsigned long long *)&tab[sl], (unsigned long long)mine);
+        if (old == PYSET_EMPTY) return;
+        if (old > mine) {                            // displaced a later key: carry it on from this slot
+            mine = old;
+            pr.start((u64)hash[(u32)old], mask);
+            while (pr.slot() != sl) pr.next();
+        }
+        pr.next();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+pyset_flag_kernel(const u64 *__restrict__ tab, u64 size, u32 *__restrict__ flag) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= size) flag[i] = (i < size && tab[i] != PYSET_EMPTY) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256)
+pyset_list_kernel(const u64 *__restrict__ tab, u64 size, const u32 *__restrict__ at, u32 add, u32 *__restrict__ ord) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < size && tab[i] != PYSET_EMPTY) ord[at[i]] = (u32)tab[i] + add;
+}
+
+// d_hash[0 .. n): hashes in insertion order (distinct keys) -> d_order[0 .. n): `add` + the indices in the set's iteration order
+static int pyset_order_device(catchhip_ctx *ctx, const long long *d_hash, u32 n, u32 add, u32 *d_order) {
+    hipStream_t s = ctx->stream;
+    // the last table: the generation the n-th insertion leaves behind
+    std::vector<std::pair<u64, u32>> gens;           // (slots, keys in the set when this generation is complete)
+    {
+        u64 size = 8;
+        u32 done = 0;
+        for (;;) {
+            const u64 mask = size - 1, first_rebuild = (mask * 3 + 4) / 5;
+            done = (u32)std::min<u64>(n, first_rebuild);
+            gens.push_back({size, done});
+            if ((u64)done * 5 < mask * 3) break;
+            const u64 want = done > 50000 ? (u64)done * 2 : (u64)done * 4;
+            size = 8;
+            while (size <= want) size <<= 1;
+            if (done == n) { gens.push_back({size, done}); break; }
+        }
+    }
+    const u64 last = gens.back().first;
+    DevBuf<u64> tab;
+    DevBuf<u32> flag, at, tmp, ord;
+    TRY(tab.alloc((size_t)last));
+    TRY(flag.alloc((size_t)last + 1));
+    TRY(ord.alloc((size_t)n + 1));
+    u32 n_re = 0;
+    for (size_t g = 0; g < gens.size(); ++g) {
+        const u64 size = gens[g].first;
+        const u32 upto = gens[g].second;
+        const bool final_gen = g + 1 == gens.size();
+        HIP_TRY(hipMemsetAsync(tab.p, 0xff, sizeof(u64) * size, s));
+        hipLaunchKernelGGL(pyset_insert_kernel, dim3((unsigned)div_up((i64)upto, 256)), dim3(256), 0, s,
+                           d_hash, (const u32 *)ord.p, n_re, upto, size - 1, tab.p);
+        hipLaunchKernelGGL(pyset_flag_kernel, dim3((unsigned)div_up((i64)size + 1, 256)), dim3(256), 0, s,
+                           (const u64 *)tab.p, size, flag.p);
+        TRY(cand_scan(ctx, flag, at, (i64)size + 1, tmp));
+        hipLaunchKernelGGL(pyset_list_kernel, dim3((unsigned)div_up((i64)size, 256)), dim3(256), 0, s,
+                           (const u64 *)tab.p, size, (const u32 *)at.p, final_gen ? add : 0u, final_gen ? d_order : ord.p);
+        n_re = upto;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// (tests) hashes from the host, order back to the host
+extern "C" int catchhip_pyset_order_device(catchhip_ctx *ctx, const i64 *hashes, i64 n, i64 *order) {
+    ARG_CHECK(ctx && n >= 0 && n < ((i64)1 << 31) && (n == 0 || (hashes && order)));
+    PoolScope pool_scope(ctx);
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf<long long> d_hash;
+    DevBuf<u32> d_order;
+    TRY(d_hash.alloc((size_t)n));
+    TRY(d_order.alloc((size_t)n + 1));
+    HIP_TRY(hipMemcpyAsync(d_hash.p, hashes, sizeof(i64) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    TRY(pyset_order_device(ctx, d_hash.p, (u32)n, 0, d_order.p));
+    std::vector<u32> h((size_t)n);
+    HIP_TRY(hipMemcpyAsync(h.data(), d_order.p, sizeof(u32) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (i64 i = 0; i < n; ++i) order[i] = h[(size_t)i];
+    return 0;
+}
+
 // The kept candidates as the reference hands them on: `list(to_include)`, a set of probes
 // (near_duplicate_filter.py:76-103) -- per group (one _filter call each) the iteration order of a set
 // the kept probes were added to in inclusion order (chip_pyset_order).  kept / kgrp: the kept candidates
@@ -504,32 +625,54 @@ static int cand_set_order(catchhip_ctx *ctx, const catchhip_candidates *C, DevBu
     TRY(d_hash.alloc(nk));
     hipLaunchKernelGGL(cand_pyhash_kernel, dim3((unsigned)div_up((i64)nk, 256)), dim3(256), 0, s,
                        (const u8 *)C->T->bytes.p, (const u32 *)kept.p, nk, (u32)C->L, d_hash.p);
-    std::vector<i64> h_hash(nk), order(nk);
-    std::vector<u32> h_grp;
-    HIP_TRY(hipMemcpyAsync(h_hash.data(), d_hash.p, sizeof(i64) * nk, hipMemcpyDeviceToHost, s));
+    // groups: runs of kgrp.  Large ones are ordered on the device, the others by the host's emulation
+    std::vector<u32> h_grp, bounds{0};
     if (C->grouped) {
         h_grp.resize(nk);
         HIP_TRY(hipMemcpyAsync(h_grp.data(), kgrp.p, sizeof(u32) * nk, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (u32 i = 1; i < nk; ++i)
+            if (h_grp[i] != h_grp[i - 1]) bounds.push_back(i);
     }
-    HIP_TRY(hipStreamSynchronize(s));
-    for (u32 a = 0; a < nk;) {
-        u32 b = a + 1;
-        if (C->grouped) while (b < nk && h_grp[b] == h_grp[a]) ++b;
-        else b = nk;
-        chip_pyset_order(h_hash.data() + a, (i64)(b - a), order.data() + a);
-        for (u32 i = a; i < b; ++i) order[i] += a;
-        a = b;
+    bounds.push_back(nk);
+    static const u32 device_from = getenv("CATCHHIP_PYSET_DEVICE_FROM") ? (u32)atoll(getenv("CATCHHIP_PYSET_DEVICE_FROM")) : 8192u;
+    bool any_host = false;
+    for (size_t g = 0; g + 1 < bounds.size(); ++g) any_host |= bounds[g + 1] - bounds[g] < device_from;
+    std::vector<i64> h_hash, order;
+    std::vector<u32> o32;
+    if (any_host) {
+        h_hash.resize(nk);
+        order.resize(nk);
+        o32.resize(nk);
+        HIP_TRY(hipMemcpyAsync(h_hash.data(), d_hash.p, sizeof(i64) * nk, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
     }
-    std::vector<u32> o32(nk);
-    for (u32 i = 0; i < nk; ++i) o32[i] = (u32)order[i];
     DevBuf<u32> d_order, out;
     TRY(d_order.alloc(nk));
     TRY(out.alloc((size_t)nk + 1));
-    HIP_TRY(hipMemcpyAsync(d_order.p, o32.data(), sizeof(u32) * nk, hipMemcpyHostToDevice, s));
+    for (size_t g = 0; g + 1 < bounds.size(); ++g) {
+        const u32 a = bounds[g], b = bounds[g + 1];
+        if (b - a >= device_from) {
+            TRY(pyset_order_device(ctx, d_hash.p + a, b - a, a, d_order.p + a));
+            continue;
+        }
+        chip_pyset_order(h_hash.data() + a, (i64)(b - a), order.data() + a);
+        for (u32 i = a; i < b; ++i) o32[i] = (u32)(order[i] + a);
+    }
+    if (any_host) {       // the host-ordered runs, each to its place (usually all of them or none)
+        for (size_t g = 0; g + 1 < bounds.size();) {
+            if (bounds[g + 1] - bounds[g] >= device_from) { ++g; continue; }
+            size_t e = g;
+            while (e + 1 < bounds.size() && bounds[e + 1] - bounds[e] < device_from) ++e;
+            HIP_TRY(hipMemcpyAsync(d_order.p + bounds[g], o32.data() + bounds[g], sizeof(u32) * (bounds[e] - bounds[g]),
+                                   hipMemcpyHostToDevice, s));
+            g = e;
+        }
+    }
     hipLaunchKernelGGL(cand_permute_kernel, dim3((unsigned)div_up((i64)nk, 256)), dim3(256), 0, s,
                        (const u32 *)kept.p, (const u32 *)d_order.p, nk, out.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s));     // (o32 is read by the copy until here)
+    HIP_TRY(hipStreamSynchronize(s));     // (o32 is read by the copies until here)
     kept.swap(out);                       // groups: a permutation inside every group leaves kgrp as it is
     return 0;
 }

@@ -141,6 +141,13 @@ class Context:
                       "flat_owner_words"), (int(x) for x in sc)))
         return d
 
+    def pyset_order(self, hashes):
+        """catchhip_pyset_order_device: engine.pyset_order computed on the device."""
+        h = np.ascontiguousarray(hashes, dtype=np.int64)
+        out = np.zeros(max(h.size, 1), dtype=np.int64)
+        check(self._L.catchhip_pyset_order_device(self._h, _ptr(h, c_i64p), int(h.size), _ptr(out, c_i64p)))
+        return out[:h.size]
+
     def ndf_counters(self):
         """catchhip_ctx_last_ndf_counters -> dict (last Hamming filter)."""
         out = np.zeros(4, dtype=np.int64)

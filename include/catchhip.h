@@ -477,6 +477,11 @@ void catchhip_candidates_destroy(catchhip_candidates *cands);
 int catchhip_pyset_order(const int64_t *hashes, int64_t n, int64_t *order);
 int catchhip_pyset_order_strs(const uint8_t *bytes, const int64_t *off, int64_t n,
                               int64_t *order);
+/* The same order computed on the device (what the catchhip_candidates_ndf_* calls use for
+ * more than a few thousand kept probes): all insertions of one table generation at once,
+ * a slot claimed with atomicMin on (insertion rank, index) words and the displaced key
+ * walking on -- the fixed point is the sequential table.  hashes / order: host arrays. */
+int catchhip_pyset_order_device(catchhip_ctx *ctx, const int64_t *hashes, int64_t n, int64_t *order);
 int catchhip_candidates_rebind(catchhip_candidates *cands, catchhip_ctx *to);   /* see catchhip_targets_rebind */
 /* global_start[i] = position (in the targets' concatenated coordinate) of the
  * first occurrence of unique candidate ids[i] (ids == NULL: candidates 0..n-1) */

@@ -1072,6 +1072,32 @@ def test_ndf_then_scf_chains_equal_the_live_reference(ctx):
         assert sha(sorted(out)) == r["picks_sorted_sha256"], r
 
 
+@pytest.mark.parametrize("n", [1, 4, 5, 6, 19, 20, 77, 1000, 49999, 50001, 78643, 78644, 157286, 400000])
+def test_set_iteration_order_on_the_device(ctx, n):
+    """catchhip_pyset_order_device (all insertions of a table generation at once,
+    atomicMin on (rank, index) words) == the sequential emulation, at sizes on
+    both sides of every rebuild rule (8 slots rebuilt at 5 keys; x4 up to
+    50,000 keys, x2 beyond; a rebuild triggered by the very last key) -- and,
+    where the interpreter can, == list(set) of ints with those hashes."""
+    from catch_amd import engine
+    rng = np.random.RandomState(n)
+    for kind in ("random", "clustered"):
+        if kind == "random":
+            h = rng.randint(-2**62, 2**62, size=n, dtype=np.int64)
+        else:       # long collision chains: few distinct low bits, displaced keys displacing others
+            h = (rng.randint(0, 64, size=n).astype(np.int64) + (np.arange(n, dtype=np.int64) << 24))
+        want = engine.pyset_order(h)
+        got = ctx.pyset_order(h)
+        assert np.array_equal(got, want), (n, kind)
+    if n <= 50001:
+        keys = [int(x) for x in rng.permutation(4 * n)[:n] + 1]     # hash(i) == i for small positive ints
+        s = set()
+        for k in keys:
+            s.add(k)
+        order = ctx.pyset_order(np.asarray(keys, dtype=np.int64))
+        assert [keys[i] for i in order] == list(s)
+
+
 def test_selection_equals_live_reference_runs(ctx):
     """The inputs the LIVE reference was run on in the authoring container
     (tools/time_reference.py: S1, S2 in full, S3 and S4 scaled down to what the

@@ -5,16 +5,16 @@
 # (FETCH_SIZE / WRITE_SIZE in separate passes, as MI355X_MICROARCH.md says).
 #   tools/collect_profiles.sh <tag> [workload] [extra]   -> gpurun_out/profiles_<tag>/
 # extra = "all" also profiles the clustering pre-step and the device front end
-tag=${1:-r02}; wl=${2:-S4}; extra=${3:-}
+tag=${1:-r03}; wl=${2:-S4}; extra=${3:-}
 out=/root/repo/gpurun_out/profiles_$tag
 rm -rf $out
 mkdir -p $out
 cd /root/repo
 python bench.py --workload $wl > $out/bench.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python /root/repo/bench.py --workload $wl --no-cpu-baseline > $out/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python /root/repo/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python /root/repo/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python /root/repo/bench.py --workload $wl --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure > $out/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python /root/repo/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python /root/repo/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure > /dev/null 2>&1
 if [ "$extra" = "all" ]; then
   # the kernels outside the bench's hot path: clustering pre-step and the device front end
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cluster -- python /root/repo/tools/cluster_bench.py --scale 0.25 --cpu-sample 0 > $out/cluster_bench.json 2>/dev/null
@@ -58,6 +58,7 @@ def unit(names, per):
 seed = [k for k in kern if k.startswith("seed_") and not k.startswith("seed_verify")]
 rows = [k for k in kern if k.startswith(("scan1_", "bucket_", "rows_emit", "scan_tiles"))]
 solver = [k for k in kern if k.startswith(("gf_count_claim", "gf_check_apply", "gr_count", "gr_claim", "gr_check", "gr_apply"))]
+ndfk = [k for k in kern if k.startswith(("ndf_", "radix_", "mh_"))]
 verify = [k for k in kern if k.startswith("seed_verify")]
 rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
                "'python bench.py --workload %s --steps 2 --warmup 1 --no-cpu-baseline'; KB per launch averaged over "
@@ -70,7 +71,8 @@ rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                  "gr_claim": unit([k for k in solver if k.startswith("gr_claim")], [k for k in solver if k.startswith("gr_claim")]),
                  "seed_verify": unit(verify, verify),
                  "seed_table_lookup": unit(seed, [k for k in seed if k.startswith("seed_lookup")]),
-                 "rows_build": unit(rows, [k for k in rows if k.startswith("bucket_scatter")])},
+                 "rows_build": unit(rows, [k for k in rows if k.startswith("bucket_scatter")]),
+                 "ndf": unit(ndfk, [k for k in ndfk if k.startswith("ndf_key")][:1] or ndfk[:1])},
        "kernels": kern}
 json.dump(rec, open(out + "/pmc_traffic.json", "w"), indent=1)
 for i, r in enumerate(csv.DictReader(open(ks))):
