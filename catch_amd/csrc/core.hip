@@ -47,10 +47,29 @@ size_t pool_class(size_t b) {
         while (c < b) c <<= 1;
         return c;
     }
-    const size_t step = (size_t)1 << 26;  // 64 MiB granules above 64 MiB
+    // 64 MiB granules above 64 MiB; from 1 GiB an eighth of the power of two below the request (requests that
+    // differ by a few per cent -- the seed work lists of the chunks of a union instance: 28.6, 28.8, 28.7 GB --
+    // then share a class instead of each costing a hipFree + hipMalloc of tens of GB, seconds apiece)
+    size_t step = (size_t)1 << 26;
+    if (b >= ((size_t)1 << 30)) {
+        size_t p2 = (size_t)1 << 30;
+        while ((p2 << 1) <= b) p2 <<= 1;
+        step = p2 >> 3;
+    }
     return (b + step - 1) / step * step;
 }
 }  // namespace
+
+// what the library may hold before a request that misses the cache returns idle blocks to the driver
+static size_t pool_soft_limit() {
+    static size_t soft_limit = 0;
+    if (!soft_limit) {
+        size_t fr = 0, tot = 0;
+        soft_limit = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) ? (size_t)((double)tot * 0.72) : ~(size_t)0 >> 1;
+        if (const char *e = getenv("CATCHHIP_POOL_SOFT_LIMIT_GB")) soft_limit = (size_t)atof(e) << 30;
+    }
+    return soft_limit;
+}
 
 const void *chip_pool_set_owner(const void *owner) {
     const void *prev = g_pool_owner;
@@ -68,7 +87,11 @@ void *chip_pool_alloc(size_t bytes) {
         auto it = g_pool_free.find(std::make_pair(owner, cls));
         if (it == g_pool_free.end() && cls > POOL_BIG) {
             it = g_pool_free.lower_bound(std::make_pair(owner, cls));
-            if (it != g_pool_free.end() && (it->first.first != owner || it->first.second > 2 * cls))
+            // (at most twice the request -- unless a new block would take the library over its soft limit:
+            // then any idle block that is large enough beats returning the cache to the driver)
+            if (it != g_pool_free.end() &&
+                (it->first.first != owner ||
+                 (it->first.second > 2 * cls && (size_t)g_pool_stats[1] + cls <= pool_soft_limit())))
                 it = g_pool_free.end();
         }
         if (it != g_pool_free.end()) {
@@ -86,12 +109,7 @@ void *chip_pool_alloc(size_t bytes) {
     // allocations (kernel arguments, scratch) do not fail with the memory sitting unused in here.
     // (hipFree waits for the device, so blocks that queued work still reads are safe to return.)
     {
-        static size_t soft_limit = 0;
-        if (!soft_limit) {
-            size_t fr = 0, tot = 0;
-            soft_limit = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) ? (size_t)((double)tot * 0.72) : ~(size_t)0 >> 1;
-            if (const char *e = getenv("CATCHHIP_POOL_SOFT_LIMIT_GB")) soft_limit = (size_t)atof(e) << 30;
-        }
+        const size_t soft_limit = pool_soft_limit();
         std::lock_guard<std::mutex> lk(g_pool_mu);
         if ((size_t)g_pool_stats[1] + cls > soft_limit && g_pool_stats[2] > 0) {
             for (auto it = g_pool_free.begin(); it != g_pool_free.end();) {

@@ -19,6 +19,7 @@
 //      with a kept higher-priority neighbour, keep a probe whose
 //      higher-priority neighbours are all dropped.
 #include <algorithm>
+#include <chrono>
 
 #include "internal.h"
 
@@ -488,6 +489,93 @@ mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
     }
 }
 
+// Lazy resolution (round 3).  Appending EVERY near pair of a run and resolving afterwards costs the square of
+// the run length, and with hundreds or thousands of near-identical strains per species (S5) the runs are that
+// long: 89 of the 106 s of the filters at S5 x 1.0.  But a probe's fate only depends on higher-priority mates
+// that are KEPT (one of them near: dropped) or still UNDECIDED (one of them near: wait); dropped mates never
+// matter.  So every (table, sorted slot) keeps a cursor into its run, from the run's first (highest-priority)
+// slot upwards, and a round moves it on: past dropped mates without looking at them, past mates that are not
+// near (compared once, never again), and it stops at the first near mate that is not dropped -- kept: the
+// probe is dropped on the spot (final, whatever the other tables say); undecided: the probe waits, the cursor
+// remembers that this mate is near.  A probe none of whose cursors had to wait in a round, all of them at the
+// end of their runs' prefixes, is kept.  Decisions only ever rest on decided (final) states, so the fixed
+// point is the sequential pass of the reference.  In a run of near-identical probes every slot compares with
+// the run's head once and is dropped in the next round.  The tables of a round are launched one after the
+// other: a probe that already waits because of an earlier table is not looked at again in this round.
+#define MH_CUR_NEAR 0x80000000u
+#define MH_CUR_NONE 0xffffffffu
+__global__ void __launch_bounds__(256)
+mh_lazy_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, const u64 *__restrict__ id_hi,
+               const u64 *__restrict__ id_lo, const u32 *__restrict__ sig_all, int k, double thres, u32 n,
+               const u64 *__restrict__ keys_all, const u32 *__restrict__ vals_all, const u32 *__restrict__ grp,
+               u32 *__restrict__ cursor_all, u32 *__restrict__ status, u32 *__restrict__ flags,
+               unsigned long long *__restrict__ pairs, const u32 *__restrict__ list, u32 nlist,
+               u32 *__restrict__ next, u32 *__restrict__ next_count) {
+    // an entry = table * n + sorted slot; round 0 walks all of them (list == nullptr), table by table -- the
+    // blocks of a launch start roughly in order, so a probe that waits because of an early table is mostly
+    // not looked at again by the later ones -- and every round lists the entries that still have work to do
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    bool again = false;
+    u32 e = 0;
+    if (g < nlist) {
+        e = list ? list[g] : g;
+        const u32 t = e / n, x = e - t * n;
+        const u64 *keys = keys_all + (size_t)t * n;
+        const u32 *vals = vals_all + (size_t)t * n;
+        const u32 *sig = sig_all + (size_t)t * n * k;
+        const u32 i = vals[x];
+        const u32 cur = cursor_all[e];
+        if (status[i] == 0 && cur != x) {
+            again = true;
+            if (flags[i] == 0) {                     // (else: waiting already in this round)
+                const u64 key = keys[x];
+                bool near_known = false;
+                u32 y;
+                if (cur == MH_CUR_NONE) {            // first visit: the first slot of the run
+                    u32 lo = 0, hi = x;
+                    while (lo < hi) {
+                        const u32 mid = (lo + hi) >> 1;
+                        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+                    }
+                    y = lo;
+                } else {
+                    near_known = (cur & MH_CUR_NEAR) != 0;
+                    y = cur & ~MH_CUR_NEAR;
+                }
+                u32 compared = 0;
+                for (; y < x; ++y, near_known = false) {
+                    const u32 j = vals[y];   // j < i: stable sort keeps indices ascending in a run
+                    const u32 sj = status[j];
+                    if (sj == 2) continue;
+                    if (!near_known) {
+                        bool same = !grp || grp[i] == grp[j];    // same bucket = same group and signature (the key only groups)
+                        for (int f = 0; f < k; ++f) same = same && sig[(size_t)i * k + f] == sig[(size_t)j * k + f];
+                        if (!same) continue;
+                        ++compared;
+                        if (!mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j],
+                                     thres))
+                            continue;
+                    }
+                    if (sj == 1) { status[i] = 2; again = false; break; }   // a kept higher-priority near-duplicate
+                    flags[i] = 2;                     // an undecided one: wait for it
+                    break;
+                }
+                cursor_all[e] = y < x ? (y | MH_CUR_NEAR) : x;
+                if (y >= x) again = false;            // this table has nothing more to say about i
+                if (compared) atomicAdd(&pairs[(g >> 6) & (ES_SHARDS - 1)], (unsigned long long)compared);
+            }
+        }
+    }
+    const unsigned long long bal = __ballot(again);
+    if (bal) {
+        const u32 lane = threadIdx.x & 63;
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(next_count, (u32)__popcll(bal));
+        base = __shfl(base, 0, WAVE);
+        if (again) next[base + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = e;
+    }
+}
+
 // bytes_on_device: `bytes` already lives on the device (>= probe_off[n] + 16 bytes allocated)
 static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off, i64 n, const i64 *group_off,
                             i64 ngroups, i32 kmer_size, const i64 *ab, i32 ntables, i32 k, double dist_thres,
@@ -545,7 +633,7 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
     TRY(keys_all.alloc((size_t)tchunk * nn));
     TRY(keys.alloc(nn));
     TRY(vals.alloc(nn));
-    TRY(count.alloc(ES_WORDS));
+    TRY(count.alloc(ES_WORDS + 8));
     TRY(status.alloc(nn));
     TRY(flags.alloc(nn));
     if (!bytes_on_device) HIP_TRY(hipMemcpyAsync(d_bytes_own.p, bytes, total, hipMemcpyHostToDevice, s));
@@ -564,6 +652,80 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
                        (const u8 *)d_bytes.p, (const u32 *)d_off.p, (const u32 *)d_koff.p, nn, (int)kmer_size, xs.p,
                        id_hi.p, id_lo.p, nuniq.p);
     tm.launch(1);
+    ctx->ndf_counters[0] = n; ctx->ndf_counters[1] = ntables; ctx->ndf_counters[2] = ctx->ndf_counters[3] = 0;
+    if (tchunk >= ntables && (i64)ntables * n < ((i64)1 << 32) && !getenv("CATCHHIP_MH_ALL_PAIRS")) {
+        // lazy resolution (mh_lazy_kernel): all tables' sorted runs stay resident, one cursor per (table, slot)
+        DevBuf<u64> skeys, pairs;
+        DevBuf<u32> svals, cursor;
+        const size_t tn = (size_t)ntables * nn;
+        const bool timing = getenv("CATCHHIP_TIMING") != nullptr;
+        auto lap = [&](const char *what, std::chrono::steady_clock::time_point &t0) {
+            if (!timing) return;
+            (void)hipStreamSynchronize(s);
+            const auto t1 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[catchhip]   minhash filter, %u probes, %d tables: %s %.1f ms\n", nn, (int)ntables, what,
+                    std::chrono::duration<double, std::milli>(t1 - t0).count());
+            t0 = t1;
+        };
+        auto t_lap = std::chrono::steady_clock::now();
+        lap("k-mers", t_lap);
+        TRY(skeys.alloc(tn));
+        TRY(svals.alloc(tn));
+        TRY(cursor.alloc(tn));
+        TRY(pairs.alloc(ES_SHARDS));
+        HIP_TRY(hipMemsetAsync(cursor.p, 0xff, sizeof(u32) * tn, s));
+        HIP_TRY(hipMemsetAsync(pairs.p, 0, sizeof(u64) * ES_SHARDS, s));
+        hipLaunchKernelGGL(mh_keys_all_kernel, dim3((unsigned)div_up((i64)nn * 64, 256)), dim3(256), 0, s,
+                           (const u32 *)xs.p, (const u32 *)d_koff.p, nn, (const u64 *)d_ab.p, (int)k, (int)ntables, 0,
+                           (int)ntables, grp, sig.p, keys_all.p);
+        tm.launch(1);
+        for (int t = 0; t < ntables; ++t) {
+            hipLaunchKernelGGL(mh_table_kernel, dim3(nb), dim3(256), 0, s, (const u64 *)(keys_all.p + (size_t)t * nn), nn,
+                               keys.p, vals.p);
+            TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nn, 64));
+            HIP_TRY(hipMemcpyAsync(skeys.p + (size_t)t * nn, keys.p, sizeof(u64) * nn, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(svals.p + (size_t)t * nn, vals.p, sizeof(u32) * nn, hipMemcpyDeviceToDevice, s));
+            tm.launch(1 + 24 + 2);
+        }
+        lap("signatures + sorts", t_lap);
+        u32 *undecided = count.p + ES_SHARDS * ES_STRIDE;     // [0] undecided probes, [1] entries listed for the next round
+        DevBuf<u32> lists[2];
+        TRY(lists[0].alloc(tn));
+        TRY(lists[1].alloc(tn));
+        u32 left = nn, rounds_run = 0, nlist = (u32)tn;
+        for (u32 round = 0; left && round <= nn + 1; ++round, ++rounds_run) {
+            HIP_TRY(hipMemsetAsync(undecided, 0, 2 * sizeof(u32), s));
+            if (nlist)
+                hipLaunchKernelGGL(mh_lazy_kernel, dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s,
+                                   (const u32 *)d_koff.p, (const u32 *)nuniq.p, (const u64 *)id_hi.p, (const u64 *)id_lo.p,
+                                   (const u32 *)sig.p, (int)k, dist_thres, nn, (const u64 *)skeys.p, (const u32 *)svals.p, grp,
+                                   cursor.p, status.p, flags.p, (unsigned long long *)pairs.p,
+                                   round ? (const u32 *)lists[round & 1].p : (const u32 *)nullptr, nlist,
+                                   lists[(round & 1) ^ 1].p, undecided + 1);
+            hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, undecided);
+            tm.launch(2);
+            HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            left = ((volatile u32 *)ctx->h_pin)[0];
+            nlist = ((volatile u32 *)ctx->h_pin)[1];
+        }
+        HIP_TRY(hipGetLastError());
+        if (timing) fprintf(stderr, "[catchhip]   minhash filter: %u rounds\n", rounds_run);
+        lap("rounds", t_lap);
+        tm.stop();
+        std::vector<u32> h_status(nn);
+        std::vector<u64> h_pairs(ES_SHARDS);
+        HIP_TRY(hipMemcpyAsync(h_status.data(), status.p, sizeof(u32) * nn, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h_pairs.data(), pairs.p, sizeof(u64) * ES_SHARDS, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        tm.finish();
+        for (u64 v : h_pairs) ctx->ndf_counters[2] += (i64)v;
+        for (u32 i = 0; i < nn; ++i) {
+            if (h_status[i] == 0) { chip_set_error("ndf: unresolved probe"); return CATCHHIP_EINVAL; }
+            keep[i] = h_status[i] == 1 ? 1 : 0;
+        }
+        return 0;
+    }
     u32 cap = (u32)std::max<i64>((i64)1 << 14, std::min<i64>(n * 16, (i64)1 << 28) / ES_SHARDS);   // per shard
     u32 ne = 0;
     for (int attempt = 0;; ++attempt) {

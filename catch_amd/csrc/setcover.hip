@@ -1156,11 +1156,12 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         tm.launch(6);
     }
     int rc = 0;
-    // Lazy evaluation in one persistent workgroup (setcover_lazy.inc) from a few hundred thousand rows:
-    // the eager workgroup below re-counts everything a pick touches and is only cheaper on small instances
+    // Lazy evaluation in one persistent workgroup (setcover_lazy.inc), CATCHHIP_GREEDY_LAZY=1: exact, and on S4
+    // slower than the eager workgroup below (hundreds of re-evaluations per pick once thousands of sets hold
+    // the same stale gain)
     const u32 lz_n1 = (u32)div_up((i64)nsets, 64), lz_n2 = (u32)div_up((i64)lz_n1, 64);
     const bool use_lazy = !distributed && lz_n2 <= LZ_MAXT2 &&
-                          (getenv("CATCHHIP_GREEDY_LAZY") ? atoi(getenv("CATCHHIP_GREEDY_LAZY")) != 0 : nrows >= (1u << 18));
+                          (getenv("CATCHHIP_GREEDY_LAZY") && atoi(getenv("CATCHHIP_GREEDY_LAZY")) != 0);   // opt-in: measured slower
     if (use_lazy) {
         DevBuf<u32> segcnt, ub;
         DevBuf<uint4> lrow;

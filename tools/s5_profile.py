@@ -28,11 +28,12 @@ def step():
     print("cluster %.2f s, filters %.2f s (%s), %d clusters" % (t1 - t0, t2 - t1, mode, len(clusters)))
 
 
-step()
+if len(sys.argv) < 3 or sys.argv[2] != "once":
+    step()
 pr = cProfile.Profile()
 pr.enable()
 step()
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
-print(s.getvalue()[:9000])
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(60)
+print(s.getvalue()[:14000])
