@@ -293,6 +293,40 @@ __global__ __launch_bounds__(64) void sig_neigh_lds_kernel(const u32 *__restrict
     }
 }
 
+// The neighbour lists of several vertices in one launch (the search asks for the vertex it explores and for
+// those it is about to: the far neighbours it has just stacked): a workgroup stages its 64 target signatures
+// once -- reading the transposed signatures is what a single-vertex launch mostly does -- and walks them
+// against every query in turn.  Entry = query << 48 | index << 16 | common.
+#define NEIGH_MAXQ 32
+__global__ __launch_bounds__(64) void sig_neigh_many_kernel(const u32 *__restrict__ sig, const u32 *__restrict__ sigT,
+                                                            u32 nseq, u32 N, const u32 *__restrict__ js, u32 nq,
+                                                            u32 min_common, unsigned long long *__restrict__ out,
+                                                            u32 cap, u32 *__restrict__ count) {
+    extern __shared__ u32 s_mem[];
+    u32 *s_b = s_mem, *s_q = s_mem + (size_t)64 * N;   // s_b[i * 64 + lane], s_q[q * N + i]
+    const u32 kq = blockIdx.x * 64 + threadIdx.x;
+    const u32 kc = kq < nseq ? kq : nseq - 1;
+    for (u32 i = 0; i < N; ++i) s_b[i * 64 + threadIdx.x] = sigT[(size_t)i * nseq + kc];
+    for (u32 t = threadIdx.x; t < nq * N; t += 64) s_q[t] = sig[(size_t)js[t / N] * N + (t % N)];
+    __syncthreads();
+    for (u32 q = 0; q < nq; ++q) {
+        const u32 *a = s_q + (size_t)q * N;
+        u32 c = 0;
+        if (kq < nseq)
+            c = walk_common(N, [&](u32 i) { return a[i]; }, [&](u32 i) { return s_b[i * 64 + threadIdx.x]; });
+        const bool hit = kq < nseq && c >= min_common;
+        const unsigned long long b = __ballot(hit);
+        if (!b) continue;
+        u32 base = 0;
+        if (threadIdx.x == 0) base = atomicAdd(count, (u32)__popcll(b));
+        base = __shfl(base, 0, WAVE);
+        if (hit) {
+            const u32 pos = base + (u32)__popcll(b & ((1ull << threadIdx.x) - 1ull));
+            if (pos < cap) out[pos] = ((unsigned long long)q << 48) | ((unsigned long long)kq << 16) | (unsigned long long)c;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void sig_pairs_kernel(const u32 *__restrict__ sig, u32 nseq, u32 N, u32 T,
                                                         const float *__restrict__ lut, float *__restrict__ out) {
     extern __shared__ u32 s_ab[];
@@ -474,6 +508,47 @@ extern "C" int catchhip_sigs_neighbors(catchhip_ctx *ctx, const catchhip_sigs *S
     tm.finish();
     *count = n;
     if ((i64)n > cap) { chip_set_error("sigs_neighbors: %u neighbours, room for %lld", n, (long long)cap); return CATCHHIP_EINVAL; }
+    memcpy(out, h + 1, sizeof(unsigned long long) * (size_t)n);
+    return 0;
+}
+
+extern "C" int catchhip_sigs_neighbors_many(catchhip_ctx *ctx, const catchhip_sigs *S, const u32 *js, i64 nq,
+                                            u32 min_common, unsigned long long *out, i64 cap, i64 *count) {
+    ARG_CHECK(ctx && S && S->ctx == ctx && js && out && count && cap >= 0 && nq >= 1 && nq <= NEIGH_MAXQ);
+    ARG_CHECK(S->N <= 112);   // (64 + 32) * N * 4 bytes of LDS <= 43 KB
+    for (i64 q = 0; q < nq; ++q) ARG_CHECK(js[q] < S->nseq);
+    PoolScope pool_scope(ctx);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t dcap = (size_t)std::min<i64>(cap, (i64)S->nseq * nq);
+    DevBuf<unsigned long long> d;
+    DevBuf<u32> d_n, d_js;
+    TRY(d.alloc(dcap + 1));
+    TRY(d_n.alloc(1));
+    TRY(d_js.alloc(NEIGH_MAXQ));
+    const size_t first = 16384;
+    TRY(chip_pinned_reserve(ctx, sizeof(unsigned long long) * (dcap + 2)));
+    HIP_TRY(hipMemsetAsync(d_n.p, 0, sizeof(u32), st));
+    HIP_TRY(hipMemcpyAsync(d_js.p, js, sizeof(u32) * (size_t)nq, hipMemcpyHostToDevice, st));
+    PhaseTimer tm(ctx, PHASE_NDF);
+    hipLaunchKernelGGL(sig_neigh_many_kernel, dim3((S->nseq + 63) / 64), dim3(64), sizeof(u32) * (64 + (size_t)nq) * S->N, st,
+                       (const u32 *)S->sig.p, (const u32 *)S->sigT.p, S->nseq, S->N, (const u32 *)d_js.p, (u32)nq,
+                       min_common, d.p, (u32)std::min<size_t>(dcap, 0xffffffffu), d_n.p);
+    tm.launch(1);
+    HIP_TRY(hipGetLastError());
+    unsigned long long *h = (unsigned long long *)ctx->h_big;
+    const size_t n0 = std::min<size_t>(first, dcap);
+    HIP_TRY(hipMemcpyAsync(h, d_n.p, sizeof(u32), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h + 1, d.p, sizeof(unsigned long long) * n0, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));   // (js is read by its copy until here)
+    const u32 n = *(volatile u32 *)h;
+    *count = n;
+    if ((i64)n > cap) { tm.finish(); chip_set_error("sigs_neighbors_many: %u neighbours, room for %lld", n, (long long)cap); return CATCHHIP_EINVAL; }
+    if (n > n0) {
+        HIP_TRY(hipMemcpyAsync(h + 1 + n0, d.p + n0, sizeof(unsigned long long) * (n - n0), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    tm.finish();
     memcpy(out, h + 1, sizeof(unsigned long long) * (size_t)n);
     return 0;
 }

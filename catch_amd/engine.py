@@ -737,6 +737,31 @@ class Signatures:
         got = np.sort(self._nb_buf[:cnt.value])
         return (got >> np.uint64(16)).astype(np.int64), (got & np.uint64(0xffff)).astype(np.int64)
 
+    NEIGHBORS_MANY_MAX = 32        # queries per call (NEIGH_MAXQ), signatures of at most 112 values
+
+    def neighbors_many(self, js, min_common):
+        """catchhip_sigs_neighbors_many -> list of (indices ascending, their
+        common counts), one per vertex of js (at most NEIGHBORS_MANY_MAX)."""
+        js = np.ascontiguousarray(js, dtype=np.uint32)
+        if not hasattr(self, "_nbm_buf"):
+            self._nbm_buf = np.zeros(max(4 * self.n, 1 << 16), dtype=np.uint64)
+        cnt = ctypes.c_int64(0)
+        while True:
+            rc = self.ctx._L.catchhip_sigs_neighbors_many(
+                self.ctx._h, self._h, _ptr(js, c_u32p), int(js.size), int(min_common),
+                _ptr(self._nbm_buf, c_u64p), int(self._nbm_buf.size), ctypes.byref(cnt))
+            if rc != 0 and cnt.value > self._nbm_buf.size:      # more neighbours than room: grow and ask again
+                self._nbm_buf = np.zeros(int(cnt.value) + (1 << 16), dtype=np.uint64)
+                continue
+            check(rc)
+            break
+        got = np.sort(self._nbm_buf[:cnt.value])                # by query, then by index
+        q = (got >> np.uint64(48)).astype(np.int64)
+        bounds = np.searchsorted(q, np.arange(js.size + 1))
+        idx = ((got >> np.uint64(16)) & np.uint64(0xffffffff)).astype(np.int64)
+        com = (got & np.uint64(0xffff)).astype(np.int64)
+        return [(idx[bounds[i]:bounds[i + 1]], com[bounds[i]:bounds[i + 1]]) for i in range(js.size)]
+
     def condensed(self, lut):
         """float32[n(n-1)/2] in SciPy's condensed order; entry = lut[common]."""
         lut = np.ascontiguousarray(lut, dtype=np.float32)

@@ -117,9 +117,10 @@ _fast_order_ok = None
 
 
 def _fast_order_available():
-    """Whether this interpreter's sets behave as _diff_iterates_ascending
-    assumes (checked once on a few hundred differences; any surprise disables
-    the shortcut and every difference is built for real)."""
+    """Whether this interpreter's sets behave as _diff_iterates_ascending and
+    the copy shortcut of _components assume (checked once on a few hundred
+    differences; any surprise disables the shortcuts and every difference is
+    built for real)."""
     global _fast_order_ok
     if _fast_order_ok is None:
         import random as _random
@@ -138,12 +139,19 @@ def _fast_order_available():
                 if _diff_iterates_ascending(n, m, len(queued)):
                     d = list(remaining - queued)
                     ok = ok and d == sorted(d)
+                if (m >> 2) > len(queued):
+                    # the difference is a copy of `remaining` with the members of `queued` taken out
+                    ok = ok and list(remaining - queued) == [x for x in remaining.copy() if x not in queued]
                 remaining -= set(pool[:len(pool) // 2 + 1])
         _fast_order_ok = ok
     return _fast_order_ok
 
 
-def _components(n, row_fn, threshold, early_stop_threshold, neighbors_fn=None):
+_path_counts = {"ascending": 0, "copy rank": 0, "real difference": 0, "list calls": 0}   # (tests look at these)
+
+
+def _components(n, row_fn, threshold, early_stop_threshold, neighbors_fn=None, neighbors_many_fn=None,
+                batch=32):
     """Connected components by depth-first search with the reference's
     early-stop heuristic (:235-355): a neighbour within early_stop_threshold is
     absorbed into the component without being explored itself, so the result
@@ -152,18 +160,30 @@ def _components(n, row_fn, threshold, early_stop_threshold, neighbors_fn=None):
     applied to the same sets in the same sequence here, so CPython produces
     the same order.  row_fn(j, candidates as an int64 array) -> float64 distances.
     neighbors_fn(j) -> (indices ascending, distances) of ALL vertices within
-    `threshold` of j, or None: used while the difference is known to iterate in
-    ascending order (_diff_iterates_ascending -- the first two thirds of the
-    search or so), when the neighbours that count are simply those of them
-    still in `remaining` and not yet queued, in that order; the O(n) set
-    difference and distance row per explored vertex are then not needed."""
+    `threshold` of j, or None.  With it the O(n) set difference and distance
+    row per explored vertex are avoided in two situations:
+      * the difference is known to iterate in ascending order
+        (_diff_iterates_ascending -- about the first two thirds of a search):
+        the neighbours that count are those still in `remaining` and not yet
+        queued, in ascending order;
+      * CPython builds the difference as a COPY of `remaining` minus the
+        members of `queued` (len(remaining) // 4 > len(queued); the discards do
+        not move anything and are too few to trigger a rebuild): the order is
+        that of `remaining.copy()`, which changes only when `remaining` does --
+        once per component -- so one real copy per component ranks every
+        vertex and the neighbours are sorted by that rank.
+    Otherwise the difference is built for real.
+    neighbors_many_fn(list of vertices) -> list of such pairs: the lists of the
+    vertex being explored and of the vertices on top of the stack (the next to
+    be explored) in one device call."""
     remaining = set(range(n))
     done = set()
     components = []
-    fast = neighbors_fn is not None and _fast_order_available()
-    if fast:
+    lists = neighbors_fn is not None and _fast_order_available()
+    if lists:
         in_remaining = np.ones(n, dtype=bool)
         queued_in = np.zeros(n, dtype=np.int64)      # the component (1-based) that queued the vertex
+    cache = {}
     comp_no = 0
     for start in range(n):
         if start in done:
@@ -172,7 +192,9 @@ def _components(n, row_fn, threshold, early_stop_threshold, neighbors_fn=None):
         seen = set()
         stack = [start]
         queued = {start}
-        if fast:
+        copy_rank = None           # rank of every vertex in the iteration order of remaining.copy()
+        cache.clear()
+        if lists:
             queued_in[start] = comp_no
         while len(stack) > 0:
             j = stack.pop()
@@ -180,13 +202,42 @@ def _components(n, row_fn, threshold, early_stop_threshold, neighbors_fn=None):
                 continue
             seen.add(j)
             # (queued is a subset of remaining: its members come out of differences with it)
-            if len(remaining) == len(queued):
+            m, q = len(remaining), len(queued)
+            if m == q:
                 continue
-            if fast and _diff_iterates_ascending(n, len(remaining), len(queued)):
-                idx, dist = neighbors_fn(j)
+            ascending = lists and _diff_iterates_ascending(n, m, q)
+            if ascending or (lists and (m >> 2) > q):
+                hit = cache.pop(j, None)
+                if hit is None:
+                    _path_counts["list calls"] += 1
+                    if neighbors_many_fn is None:
+                        hit = neighbors_fn(j)
+                    else:
+                        ask = [j]
+                        for k in reversed(stack[-4 * batch:]):       # (a vertex is stacked at most once)
+                            if len(ask) >= batch:
+                                break
+                            if k not in seen and k not in cache:
+                                ask.append(k)
+                        got = neighbors_many_fn(ask)
+                        for k, r in zip(ask[1:], got[1:]):
+                            cache[k] = r
+                        hit = got[0]
+                idx, dist = hit
                 keep = in_remaining[idx] & (queued_in[idx] != comp_no)
-                ks, near = idx[keep], dist[keep] <= early_stop_threshold
+                ks, dk = idx[keep], dist[keep]
+                _path_counts["ascending" if ascending else "copy rank"] += 1
+                if not ascending and len(ks) > 1:
+                    if copy_rank is None:
+                        cp = remaining.copy()
+                        members = np.fromiter(cp, dtype=np.int64, count=len(cp))
+                        copy_rank = np.empty(n, dtype=np.int64)
+                        copy_rank[members] = np.arange(members.size)
+                    o = np.argsort(copy_rank[ks], kind="stable")
+                    ks, dk = ks[o], dk[o]
+                near = dk <= early_stop_threshold
             else:
+                _path_counts["real difference"] += 1
                 diff = remaining - queued
                 if not diff:
                     continue
@@ -195,17 +246,16 @@ def _components(n, row_fn, threshold, early_stop_threshold, neighbors_fn=None):
                 d = row_fn(j, cand)
                 adjacent = np.nonzero(d <= threshold)[0]
                 ks, near = cand[adjacent], d[adjacent] <= early_stop_threshold
-            for k, is_near in zip(ks.tolist(), near.tolist()):
-                if is_near:
-                    seen.add(k)
-                else:
-                    stack.append(k)
-                queued.add(k)
-            if fast and len(ks):
-                queued_in[ks] = comp_no
+            if len(ks):
+                # near ones are absorbed, the others explored later, in this order; all are queued
+                seen.update(ks[near].tolist())
+                stack.extend(ks[~near].tolist())
+                queued.update(ks.tolist())
+                if lists:
+                    queued_in[ks] = comp_no
         done.update(seen)
         remaining -= seen
-        if fast:
+        if lists:
             in_remaining[np.fromiter(seen, dtype=np.int64, count=len(seen))] = False
         components.append(sorted(seen))
     components.sort(key=len, reverse=True)
@@ -232,14 +282,18 @@ def _components_of_signatures(sigs, threshold,
     # the smallest number of shared values whose distance is within the threshold (the distance falls
     # as the number grows; evaluated with the expression above, so the comparison is the same)
     within = np.nonzero(1.0 - np.arange(sigs.N + 1, dtype=np.float64) / N <= threshold)[0]
-    neighbors = None
+    neighbors = neighbors_many = None
     if sigs.N <= 176 and len(within) and not os.environ.get("CATCHHIP_CLUSTER_ROWS_ONLY"):
         min_common = int(within[0])
 
         def neighbors(j):
             idx, common = sigs.neighbors(j, min_common)
             return idx, 1.0 - common.astype(np.float64) / N
-    return _components(sigs.n, row, threshold, early_stop_threshold, neighbors)
+        if sigs.N <= 112 and not os.environ.get("CATCHHIP_CLUSTER_ONE_BY_ONE"):
+            def neighbors_many(js):
+                return [(idx, 1.0 - common.astype(np.float64) / N) for idx, common in sigs.neighbors_many(js, min_common)]
+    return _components(sigs.n, row, threshold, early_stop_threshold, neighbors, neighbors_many,
+                       batch=getattr(sigs, "NEIGHBORS_MANY_MAX", 32))
 
 
 def cluster_with_minhash_signatures(seqs, k=12, N=100, threshold=0.1,

@@ -392,6 +392,13 @@ int catchhip_sigs_common_row(catchhip_ctx *ctx, const catchhip_sigs *sigs,
 int catchhip_sigs_neighbors(catchhip_ctx *ctx, const catchhip_sigs *sigs,
                             uint32_t j, uint32_t min_common,
                             unsigned long long *out, int64_t cap, int64_t *count);
+/* The lists of up to 32 vertices in one launch (the search asks for the vertex it
+ * explores together with those it has just stacked): out[i] = (q << 48 | k << 16 |
+ * common[k]) for query q = js[q].  Signatures of at most 112 values.  *count beyond cap is
+ * an error (CATCHHIP_EINVAL; nothing is written to out then). */
+int catchhip_sigs_neighbors_many(catchhip_ctx *ctx, const catchhip_sigs *sigs,
+                                 const uint32_t *js, int64_t nq, uint32_t min_common,
+                                 unsigned long long *out, int64_t cap, int64_t *count);
 /* cluster.create_condensed_dist_matrix (catch/utils/cluster.py:102-194) for the
  * signature distance: out[n(n-1)/2] float32 in SciPy's condensed order, entry
  * (i, j) = lut[common(i, j)] with lut[N+1] supplied by the caller (the float32

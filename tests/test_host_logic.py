@@ -424,8 +424,9 @@ def test_components_search_shortcut_equals_the_set_order():
             remaining -= set(members[:max(1, q // 2)])
     # whole searches: random geometric-ish graphs with near (absorbing) and far (explored) edges
     used_fast = 0
-    for trial in range(25):
-        n = int(rng.integers(30, 400))
+    before = dict(cluster._path_counts)
+    for trial in range(40):
+        n = int(rng.integers(30, 400)) if trial < 25 else int(rng.integers(1500, 5000))
         x = rng.random(n) * rng.choice([3.0, 10.0, 40.0])
         dist = np.abs(x[:, None] - x[None, :]) * rng.uniform(0.5, 1.5, size=(n, n))
         dist = np.minimum(dist, dist.T)
@@ -439,8 +440,19 @@ def test_components_search_shortcut_equals_the_set_order():
             calls.append(j)
             idx = np.nonzero(dist[j] <= thr)[0]
             return idx.astype(np.int64), dist[j, idx]
+        def neighbors_many(js):
+            assert 1 <= len(js) <= 8 and len(set(js)) == len(js)
+            return [neighbors(j) for j in js]
         slow = cluster._components(n, row, thr, early)
         fast = cluster._components(n, row, thr, early, neighbors)
         assert fast == slow, trial
         used_fast += len(calls)
+        # the lists of several vertices per call (the explored vertex + the top of the stack)
+        asked = cluster._path_counts["list calls"]
+        assert cluster._components(n, row, thr, early, neighbors, neighbors_many, batch=8) == slow, trial
+        asked = cluster._path_counts["list calls"] - asked
+        assert asked <= len(calls)
     assert used_fast > 1000
+    took = {k: cluster._path_counts[k] - before[k] for k in before}
+    # all three ways of ordering a vertex's neighbours were exercised
+    assert took["ascending"] > 1000 and took["copy rank"] > 200 and took["real difference"] > 1000, took

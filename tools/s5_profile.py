@@ -26,6 +26,8 @@ def step():
     chosen = run(clusters, 100, 50, None, ndf)
     t2 = time.perf_counter()
     print("cluster %.2f s, filters %.2f s (%s), %d clusters" % (t1 - t0, t2 - t1, mode, len(clusters)))
+    from catch_amd.utils import cluster as _c
+    print("components search:", _c._path_counts)
 
 
 if len(sys.argv) < 3 or sys.argv[2] != "once":
