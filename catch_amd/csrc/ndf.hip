@@ -149,6 +149,131 @@ ndf_node_round_kernel(u32 *__restrict__ status, u32 *__restrict__ flags, u32 n, 
     else atomicAdd(undecided, 1u);
 }
 
+// Lazy resolution (round 3; the long comment is at mh_lazy_kernel below): a cursor per (table, sorted slot)
+// over the higher-priority mates of its run, from the run's first slot upwards; dropped mates are skipped
+// unseen, mates that are not near are compared once, a near kept mate drops the probe on the spot, a near
+// undecided one makes it wait.  An entry = table * n + slot; round 0 walks all of them (list == nullptr).
+#define NDF_CUR_NEAR 0x80000000u
+#define NDF_CUR_NONE 0xffffffffu
+__global__ void __launch_bounds__(256)
+ndf_lazy_kernel(const u64 *__restrict__ padded, u32 n, int W, int d, const i32 *__restrict__ pos_all, int k,
+                const u64 *__restrict__ keys_all, const u32 *__restrict__ vals_all, const u32 *__restrict__ grp,
+                size_t pos_group_stride, u32 *__restrict__ cursor_all, u32 *__restrict__ status,
+                u32 *__restrict__ flags, unsigned long long *__restrict__ pairs, const u32 *__restrict__ list,
+                u32 nlist, u32 *__restrict__ next, u32 *__restrict__ next_count, int dedupe) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    bool again = false;
+    u32 e = 0;
+    if (g < nlist) {
+        e = list ? list[g] : g;
+        const u32 t = e / n, x = e - t * n;
+        const u64 *keys = keys_all + (size_t)t * n;
+        const u32 *vals = vals_all + (size_t)t * n;
+        const u32 i = vals[x];
+        const u32 cur = cursor_all[e];
+        if (status[i] == 0 && cur != x) {
+            again = true;
+            if (flags[i] == 0) {                     // (else: waiting already in this round)
+                const u64 key = keys[x];
+                const i32 *pos = pos_all + (size_t)t * k + (grp ? (size_t)grp[i] * pos_group_stride : 0);
+                const u64 *a = padded + (size_t)i * W;
+                bool near_known = false;
+                u32 y;
+                if (cur == NDF_CUR_NONE) {           // first visit: the first slot of the run
+                    u32 lo = 0, hi = x;
+                    while (lo < hi) {
+                        const u32 mid = (lo + hi) >> 1;
+                        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+                    }
+                    y = lo;
+                } else {
+                    near_known = (cur & NDF_CUR_NEAR) != 0;
+                    y = cur & ~NDF_CUR_NEAR;
+                }
+                u32 compared = 0, found = 0;
+                for (; y < x; ++y, near_known = false) {
+                    const u32 j = vals[y];   // j < i: stable sort keeps indices ascending in a run
+                    const u32 sj = status[j];
+                    if (sj == 2) continue;
+                    if (!near_known) {
+                        if (grp && grp[j] != grp[i]) continue;   // another group under the same key
+                        // (from four tables on: a pair that shares an earlier table's bucket belongs to that table's
+                        // cursor; with two or three the look at the earlier positions costs more than it saves)
+                        bool earlier = false;
+                        if (dedupe) {
+                            const u8 *ab = (const u8 *)a, *bb = (const u8 *)(padded + (size_t)j * W);
+                            for (u32 tp = 1; tp <= t && !earlier; ++tp) {
+                                const i32 *pe = pos - (size_t)tp * k;
+                                bool eq = true;
+                                for (int q = 0; q < k && eq; ++q) eq = ab[pe[q]] == bb[pe[q]];
+                                earlier = eq;
+                            }
+                        }
+                        if (earlier) continue;
+                        ++compared;
+                        if (!ndf_near(a, padded + (size_t)j * W, W, d, pos, k)) continue;
+                        ++found;
+                    }
+                    if (sj == 1) { status[i] = 2; again = false; break; }   // a kept higher-priority near-duplicate
+                    flags[i] = 2;                     // an undecided one: wait for it
+                    break;
+                }
+                cursor_all[e] = y < x ? (y | NDF_CUR_NEAR) : x;
+                if (y >= x) again = false;            // this table has nothing more to say about i
+                if (compared) atomicAdd(&pairs[(g >> 6) & (ES_SHARDS - 1)], (unsigned long long)compared);
+                if (found) atomicAdd(&pairs[ES_SHARDS + ((g >> 6) & (ES_SHARDS - 1))], (unsigned long long)found);
+            }
+        }
+    }
+    const unsigned long long bal = __ballot(again);
+    if (bal) {
+        const u32 lane = threadIdx.x & 63;
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(next_count, (u32)__popcll(bal));
+        base = __shfl(base, 0, WAVE);
+        if (again) next[base + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = e;
+    }
+}
+
+// the rounds of the lazy resolution and the read-back (both families): launch(list or nullptr, nlist, next,
+// next_count) queues one pass over the listed entries
+template <class Launch>
+static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &count, DevBuf<u32> &status, DevBuf<u32> &flags,
+                           DevBuf<u64> &pairs, PhaseTimer &tm, u8 *keep, Launch launch) {
+    hipStream_t s = ctx->stream;
+    const unsigned nb = (unsigned)div_up(nn, 256);
+    u32 *undecided = count.p + ES_SHARDS * ES_STRIDE;     // [0] undecided probes, [1] entries listed for the next round
+    DevBuf<u32> lists[2];
+    TRY(lists[0].alloc(tn));
+    TRY(lists[1].alloc(tn));
+    u32 left = nn, nlist = (u32)tn;
+    for (u32 round = 0; left && round <= nn + 1; ++round) {
+        HIP_TRY(hipMemsetAsync(undecided, 0, 2 * sizeof(u32), s));
+        if (nlist) launch(round ? (const u32 *)lists[round & 1].p : (const u32 *)nullptr, nlist, lists[(round & 1) ^ 1].p, undecided + 1);
+        hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, undecided);
+        tm.launch(2);
+        HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        left = ((volatile u32 *)ctx->h_pin)[0];
+        nlist = ((volatile u32 *)ctx->h_pin)[1];
+    }
+    HIP_TRY(hipGetLastError());
+    tm.stop();
+    std::vector<u32> h_status(nn);
+    std::vector<u64> h_pairs(2 * ES_SHARDS);
+    HIP_TRY(hipMemcpyAsync(h_status.data(), status.p, sizeof(u32) * nn, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h_pairs.data(), pairs.p, sizeof(u64) * 2 * ES_SHARDS, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    tm.finish();
+    // pairs compared / of them near (the all-pairs variant reports the length of its edge list there)
+    for (int sh = 0; sh < ES_SHARDS; ++sh) { ctx->ndf_counters[2] += (i64)h_pairs[sh]; ctx->ndf_counters[3] += (i64)h_pairs[ES_SHARDS + sh]; }
+    for (u32 i = 0; i < nn; ++i) {
+        if (h_status[i] == 0) { chip_set_error("ndf: unresolved probe"); return CATCHHIP_EINVAL; }
+        keep[i] = h_status[i] == 1 ? 1 : 0;
+    }
+    return 0;
+}
+
 // greedy resolution rounds over the edge list + read-back (shared by the two
 // LSH families)
 // edges in the fullest shard
@@ -222,7 +347,7 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
     TRY(d_pos.alloc((size_t)ngroups * ntables * k));
     TRY(keys.alloc(nn));
     TRY(vals.alloc(nn));
-    TRY(count.alloc(ES_WORDS));
+    TRY(count.alloc(ES_WORDS + 8));
     TRY(status.alloc(nn));
     TRY(flags.alloc(nn));
     HIP_TRY(hipMemcpyAsync(d_pos.p, positions, sizeof(i32) * (size_t)ngroups * ntables * k, hipMemcpyHostToDevice, s));
@@ -239,6 +364,33 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
     PhaseTimer tm(ctx, PHASE_NDF);
     ctx->ndf_counters[0] = n; ctx->ndf_counters[1] = ntables; ctx->ndf_counters[2] = ctx->ndf_counters[3] = 0;
     const unsigned nb = (unsigned)div_up(nn, 256);
+    if ((i64)ntables * n < ((i64)1 << 32) && !getenv("CATCHHIP_NDF_ALL_PAIRS")) {
+        // lazy resolution (ndf_lazy_kernel): all tables' sorted runs stay resident, one cursor per (table, slot)
+        DevBuf<u64> skeys, pairs;
+        DevBuf<u32> svals, cursor;
+        const size_t tn = (size_t)ntables * nn;
+        TRY(skeys.alloc(tn));
+        TRY(svals.alloc(tn));
+        TRY(cursor.alloc(tn));
+        TRY(pairs.alloc(2 * ES_SHARDS));
+        HIP_TRY(hipMemsetAsync(cursor.p, 0xff, sizeof(u32) * tn, s));
+        HIP_TRY(hipMemsetAsync(pairs.p, 0, sizeof(u64) * 2 * ES_SHARDS, s));
+        for (int t = 0; t < ntables; ++t) {
+            hipLaunchKernelGGL(ndf_key_kernel, dim3(nb), dim3(256), 0, s, d_bytes.p, nn, (int)L,
+                               d_pos.p + (size_t)t * k, (int)k, keys.p, vals.p, d_grp, pstride);
+            TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nn, 64));
+            HIP_TRY(hipMemcpyAsync(skeys.p + (size_t)t * nn, keys.p, sizeof(u64) * nn, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(svals.p + (size_t)t * nn, vals.p, sizeof(u32) * nn, hipMemcpyDeviceToDevice, s));
+            tm.launch(1 + 24 + 2);
+        }
+        return ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
+                               [&](const u32 *list, u32 nlist, u32 *next, u32 *next_count) {
+            hipLaunchKernelGGL(ndf_lazy_kernel, dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s,
+                               (const u64 *)padded.p, nn, W, (int)dist_thres, (const i32 *)d_pos.p, (int)k,
+                               (const u64 *)skeys.p, (const u32 *)svals.p, d_grp, pstride, cursor.p, status.p, flags.p,
+                               (unsigned long long *)pairs.p, list, nlist, next, next_count, ntables >= 4 ? 1 : 0);
+        });
+    }
     u32 cap = (u32)std::max<i64>((i64)1 << 14, std::min<i64>(n * 16, (i64)1 << 28) / ES_SHARDS);   // per shard
     u32 ne = 0;
     for (int attempt = 0;; ++attempt) {
@@ -463,6 +615,7 @@ mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
     if (x >= n) return;
     const u64 key = keys[x];
     const u32 i = vals[x];
+    u32 npairs = 0;
     for (u32 y = x; y-- > 0;) {
         if (keys[y] != key) break;
         const u32 j = vals[y];  // j < i: stable sort keeps indices ascending in a run
@@ -480,6 +633,7 @@ mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
             seen = eq;
         }
         if (seen) continue;
+        ++npairs;
         if (mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j],
                             thres)) {
             const u32 shard = (x >> 6) & (ES_SHARDS - 1);
@@ -487,6 +641,7 @@ mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
             if (slot < cap) { e_i[(size_t)shard * cap + slot] = i; e_j[(size_t)shard * cap + slot] = j; }
         }
     }
+    if (npairs) atomicAdd((unsigned long long *)(count + ((x >> 6) & (ES_SHARDS - 1)) * ES_STRIDE + 2), (unsigned long long)npairs);
 }
 
 // Lazy resolution (round 3).  Appending EVERY near pair of a run and resolving afterwards costs the square of
@@ -542,7 +697,7 @@ mh_lazy_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
                     near_known = (cur & MH_CUR_NEAR) != 0;
                     y = cur & ~MH_CUR_NEAR;
                 }
-                u32 compared = 0;
+                u32 compared = 0, found = 0;
                 for (; y < x; ++y, near_known = false) {
                     const u32 j = vals[y];   // j < i: stable sort keeps indices ascending in a run
                     const u32 sj = status[j];
@@ -551,10 +706,21 @@ mh_lazy_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
                         bool same = !grp || grp[i] == grp[j];    // same bucket = same group and signature (the key only groups)
                         for (int f = 0; f < k; ++f) same = same && sig[(size_t)i * k + f] == sig[(size_t)j * k + f];
                         if (!same) continue;
+                        // the pair shares a bucket in an earlier table too: it belongs to that table's cursor
+                        // (a probe is only kept once ALL its cursors have run out, so the pair is looked at there)
+                        bool earlier = false;
+                        for (u32 tp = 0; tp < t && !earlier; ++tp) {
+                            const u32 *si = sig_all + ((size_t)tp * n + i) * k, *sj2 = sig_all + ((size_t)tp * n + j) * k;
+                            bool eq = true;
+                            for (int f = 0; f < k; ++f) eq = eq && si[f] == sj2[f];
+                            earlier = eq;
+                        }
+                        if (earlier) continue;
                         ++compared;
                         if (!mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j],
                                      thres))
                             continue;
+                        ++found;
                     }
                     if (sj == 1) { status[i] = 2; again = false; break; }   // a kept higher-priority near-duplicate
                     flags[i] = 2;                     // an undecided one: wait for it
@@ -563,6 +729,7 @@ mh_lazy_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
                 cursor_all[e] = y < x ? (y | MH_CUR_NEAR) : x;
                 if (y >= x) again = false;            // this table has nothing more to say about i
                 if (compared) atomicAdd(&pairs[(g >> 6) & (ES_SHARDS - 1)], (unsigned long long)compared);
+                if (found) atomicAdd(&pairs[ES_SHARDS + ((g >> 6) & (ES_SHARDS - 1))], (unsigned long long)found);
             }
         }
     }
@@ -672,9 +839,9 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
         TRY(skeys.alloc(tn));
         TRY(svals.alloc(tn));
         TRY(cursor.alloc(tn));
-        TRY(pairs.alloc(ES_SHARDS));
+        TRY(pairs.alloc(2 * ES_SHARDS));
         HIP_TRY(hipMemsetAsync(cursor.p, 0xff, sizeof(u32) * tn, s));
-        HIP_TRY(hipMemsetAsync(pairs.p, 0, sizeof(u64) * ES_SHARDS, s));
+        HIP_TRY(hipMemsetAsync(pairs.p, 0, sizeof(u64) * 2 * ES_SHARDS, s));
         hipLaunchKernelGGL(mh_keys_all_kernel, dim3((unsigned)div_up((i64)nn * 64, 256)), dim3(256), 0, s,
                            (const u32 *)xs.p, (const u32 *)d_koff.p, nn, (const u64 *)d_ab.p, (int)k, (int)ntables, 0,
                            (int)ntables, grp, sig.p, keys_all.p);
@@ -688,43 +855,15 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
             tm.launch(1 + 24 + 2);
         }
         lap("signatures + sorts", t_lap);
-        u32 *undecided = count.p + ES_SHARDS * ES_STRIDE;     // [0] undecided probes, [1] entries listed for the next round
-        DevBuf<u32> lists[2];
-        TRY(lists[0].alloc(tn));
-        TRY(lists[1].alloc(tn));
-        u32 left = nn, rounds_run = 0, nlist = (u32)tn;
-        for (u32 round = 0; left && round <= nn + 1; ++round, ++rounds_run) {
-            HIP_TRY(hipMemsetAsync(undecided, 0, 2 * sizeof(u32), s));
-            if (nlist)
-                hipLaunchKernelGGL(mh_lazy_kernel, dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s,
-                                   (const u32 *)d_koff.p, (const u32 *)nuniq.p, (const u64 *)id_hi.p, (const u64 *)id_lo.p,
-                                   (const u32 *)sig.p, (int)k, dist_thres, nn, (const u64 *)skeys.p, (const u32 *)svals.p, grp,
-                                   cursor.p, status.p, flags.p, (unsigned long long *)pairs.p,
-                                   round ? (const u32 *)lists[round & 1].p : (const u32 *)nullptr, nlist,
-                                   lists[(round & 1) ^ 1].p, undecided + 1);
-            hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, undecided);
-            tm.launch(2);
-            HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            left = ((volatile u32 *)ctx->h_pin)[0];
-            nlist = ((volatile u32 *)ctx->h_pin)[1];
-        }
-        HIP_TRY(hipGetLastError());
-        if (timing) fprintf(stderr, "[catchhip]   minhash filter: %u rounds\n", rounds_run);
+        const int rc = ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
+                                       [&](const u32 *list, u32 nlist, u32 *next, u32 *next_count) {
+            hipLaunchKernelGGL(mh_lazy_kernel, dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s,
+                               (const u32 *)d_koff.p, (const u32 *)nuniq.p, (const u64 *)id_hi.p, (const u64 *)id_lo.p,
+                               (const u32 *)sig.p, (int)k, dist_thres, nn, (const u64 *)skeys.p, (const u32 *)svals.p, grp,
+                               cursor.p, status.p, flags.p, (unsigned long long *)pairs.p, list, nlist, next, next_count);
+        });
         lap("rounds", t_lap);
-        tm.stop();
-        std::vector<u32> h_status(nn);
-        std::vector<u64> h_pairs(ES_SHARDS);
-        HIP_TRY(hipMemcpyAsync(h_status.data(), status.p, sizeof(u32) * nn, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(h_pairs.data(), pairs.p, sizeof(u64) * ES_SHARDS, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        tm.finish();
-        for (u64 v : h_pairs) ctx->ndf_counters[2] += (i64)v;
-        for (u32 i = 0; i < nn; ++i) {
-            if (h_status[i] == 0) { chip_set_error("ndf: unresolved probe"); return CATCHHIP_EINVAL; }
-            keep[i] = h_status[i] == 1 ? 1 : 0;
-        }
-        return 0;
+        return rc;
     }
     u32 cap = (u32)std::max<i64>((i64)1 << 14, std::min<i64>(n * 16, (i64)1 << 28) / ES_SHARDS);   // per shard
     u32 ne = 0;

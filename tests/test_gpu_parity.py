@@ -1512,6 +1512,92 @@ def test_cluster_neighbor_lists_equal_full_rows(ctx, monkeypatch):
     assert 1 < len(fast) < len(seqs)
 
 
+def test_cluster_neighbor_lists_many_and_one_by_one(ctx, monkeypatch):
+    """catchhip_sigs_neighbors_many (the lists of up to 32 vertices per launch)
+    == catchhip_sigs_neighbors vertex by vertex == the full rows; and the search
+    that asks for the stack's top along with the explored vertex == the search
+    that asks one by one, on an input large enough for the tail of the search
+    (differences that are copies of `remaining`, ranked once per component)."""
+    from catch_amd.utils import cluster, lsh, synthetic
+    genomes = synthetic.dataset("S5", scale=0.02)[0]
+    seqs = dict(enumerate(s for g in genomes for s in g))
+    random.seed(6)
+    fam = lsh.MinHashFamily(12, N=100)
+    sigs = fam.signatures(list(seqs.values()))
+    try:
+        rng = np.random.RandomState(3)
+        for nq in (1, 2, 31, 32):
+            js = rng.choice(sigs.n, size=nq, replace=False)
+            many = sigs.neighbors_many(js, 20)
+            for j, (idx, com) in zip(js, many):
+                i1, c1 = sigs.neighbors(int(j), 20)
+                assert np.array_equal(idx, i1) and np.array_equal(com, c1)
+                row = sigs.common_row(int(j)).astype(np.int64)
+                assert np.array_equal(idx, np.nonzero(row >= 20)[0]) and np.array_equal(com, row[idx])
+    finally:
+        sigs.close()
+    before = dict(cluster._path_counts)
+    random.seed(5)
+    many = cluster.cluster_with_minhash_signatures(seqs, threshold=0.15, cluster_method="simple")
+    took = {k: cluster._path_counts[k] - before[k] for k in before}
+    assert took["copy rank"] > 100 and took["list calls"] < (took["ascending"] + took["copy rank"]) // 2, took
+    monkeypatch.setenv("CATCHHIP_CLUSTER_ONE_BY_ONE", "1")
+    random.seed(5)
+    one = cluster.cluster_with_minhash_signatures(seqs, threshold=0.15, cluster_method="simple")
+    monkeypatch.setenv("CATCHHIP_CLUSTER_ROWS_ONLY", "1")
+    random.seed(5)
+    rows = cluster.cluster_with_minhash_signatures(seqs, threshold=0.15, cluster_method="simple")
+    assert many == one == rows
+
+
+def test_minhash_filter_lazy_resolution_equals_all_pairs(ctx, monkeypatch):
+    """The MinHash filter's lazy resolution (a cursor per table and slot over
+    the higher-priority mates of its run; only kept and undecided mates are
+    ever compared) keeps exactly the probes the all-pairs edge list + rounds
+    keep (CATCHHIP_MH_ALL_PAIRS=1), on candidates with long runs of
+    near-identical probes (strains of one species) next to unrelated ones,
+    with and without groups."""
+    from catch_amd import engine
+    from catch_amd.filter import candidate_probes
+    from catch_amd.utils import synthetic
+    from catch_amd.filter.near_duplicate_filter import NearDuplicateFilterWithMinHash
+    groups = synthetic.dataset("S5m", scale=0.02)[0]
+    seqs = [s for g in groups for s in g]
+    cands = list(dict.fromkeys(candidate_probes.candidate_strings_from_sequences(seqs, 100, 50)))
+    assert len(cands) > 20000
+    out = {}
+    for mode in ("lazy", "all pairs"):
+        if mode == "all pairs":
+            monkeypatch.setenv("CATCHHIP_MH_ALL_PAIRS", "1")
+        random.seed(41)
+        ndf = NearDuplicateFilterWithMinHash(0.6)
+        kept = ndf._filter_strs(cands)
+        random.seed(41)
+        ndf = NearDuplicateFilterWithMinHash(0.6)
+        third = len(cands) // 3
+        many = ndf._filter_strs_many([cands[:third], cands[third:2 * third], cands[2 * third:]])
+        out[mode] = (kept, many, ctx.ndf_counters()["pairs_compared"])
+    assert out["lazy"][0] == out["all pairs"][0] and out["lazy"][1] == out["all pairs"][1]
+    assert 0 < len(out["lazy"][0]) < len(cands)
+    assert out["lazy"][2] < out["all pairs"][2]      # and with far fewer comparisons
+    # the Hamming family likewise (CATCHHIP_NDF_ALL_PAIRS=1), several tables
+    from catch_amd.filter.near_duplicate_filter import NearDuplicateFilterWithHammingDistance
+    monkeypatch.delenv("CATCHHIP_MH_ALL_PAIRS")
+    ham = {}
+    for mode in ("lazy", "all pairs"):
+        if mode == "all pairs":
+            monkeypatch.setenv("CATCHHIP_NDF_ALL_PAIRS", "1")
+        res = []
+        for thres in (2, 6):
+            random.seed(43)
+            res.append(NearDuplicateFilterWithHammingDistance(thres, 100)._filter_strs(cands))
+            res.append(ctx.ndf_counters()["pairs_compared"])
+        ham[mode] = res
+    assert ham["lazy"][0] == ham["all pairs"][0] and ham["lazy"][2] == ham["all pairs"][2]
+    assert 0 < len(ham["lazy"][2]) < len(ham["lazy"][0]) <= len(cands)
+    assert ham["lazy"][1] < ham["all pairs"][1] and ham["lazy"][3] < ham["all pairs"][3]
+
+
 def test_cluster_with_minhash_signatures_golden(ctx):
     """cluster.cluster_with_minhash_signatures (signatures + distances on the
     device, search / linkage on the host) == the reference's clusters, same
