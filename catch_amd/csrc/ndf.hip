@@ -149,37 +149,81 @@ ndf_node_round_kernel(u32 *__restrict__ status, u32 *__restrict__ flags, u32 n, 
     else atomicAdd(undecided, 1u);
 }
 
-// Lazy resolution (round 3; the long comment is at mh_lazy_kernel below): a cursor per (table, sorted slot)
-// over the higher-priority mates of its run, from the run's first slot upwards; dropped mates are skipped
-// unseen, mates that are not near are compared once, a near kept mate drops the probe on the spot, a near
-// undecided one makes it wait.  An entry = table * n + slot; round 0 walks all of them (list == nullptr).
+// Lazy resolution (round 3).  Appending EVERY near pair of a run and resolving afterwards costs the square of
+// the run length, and with hundreds or thousands of near-identical strains per species (S5) the runs are that
+// long: 89 of the 106 s of the filters at S5 x 1.0.  But a probe's fate only depends on higher-priority mates
+// that are KEPT (one of them near: the probe is dropped) or still UNDECIDED (one of them near: it has to wait);
+// dropped mates never matter.  So every (table, sorted slot) keeps a cursor into its run, from the run's first
+// (highest-priority) slot upwards, and a round moves it on: past dropped mates without looking at them, past
+// mates that are not near (compared once, never again), and it stops at the first near mate that is not
+// dropped -- kept: the probe is dropped on the spot (final, whatever the other tables say); undecided: the
+// probe waits, the cursor remembers that this mate is near.  A probe none of whose cursors had to wait in a
+// round, all of them at the end of their runs' prefixes, is kept (ndf_node_round_kernel).  Decisions only ever
+// rest on decided, hence final, states, so the fixed point is the reference's sequential pass.  In a run of
+// near-identical probes every slot compares with the run's head once and is dropped in the next round.
+// A pair that shares a bucket in several tables belongs to the first of them (Family::owned_earlier): a probe
+// is only kept once ALL its cursors have run out, so the pair is looked at there.
+// An entry = table * n + slot; round 0 walks all of them (list == nullptr), table by table -- the blocks of a
+// launch start roughly in order, so a probe that waits because of an early table is mostly not looked at
+// again by the later ones -- and every round lists the entries that still have work to do.
+// Long walks are shared: a slot deep in a run of thousands has thousands of dropped mates to pass, one
+// dependent load each -- tens of milliseconds for ONE lane while the launch waits
+// or, in a bucket of diverse probes, thousands of kept mates to compare with, microseconds each: tens of
+// milliseconds for ONE lane while the launch waits (measured: rounds of 3,000 entries took as long as rounds
+// of 900,000).  After a few steps of its own a lane therefore hands its walk to the wavefront: 64 mates per
+// step, every lane looks at one (state, bucket, distance), the first near one decides.
 #define NDF_CUR_NEAR 0x80000000u
 #define NDF_CUR_NONE 0xffffffffu
+#define NDF_OWN_STEPS 8
+
+struct HammingFamily {       // ndf_near on the padded rows; the earlier tables' sampled positions lie k entries apart
+    const u64 *padded;
+    int W, d, k;
+    const i32 *pos_all;
+    const u32 *grp;
+    size_t pos_group_stride;
+    int dedupe;              // from four tables on (with two or three the look at the earlier positions costs more than it saves)
+    __device__ __forceinline__ const i32 *pos(u32 t, u32 i) const { return pos_all + (size_t)t * k + (grp ? (size_t)grp[i] * pos_group_stride : 0); }
+    __device__ __forceinline__ bool same_bucket(u32, u32 i, u32 j) const { return !grp || grp[i] == grp[j]; }   // (ndf_near checks the sampled characters)
+    __device__ __forceinline__ bool owned_earlier(u32 t, u32 i, u32 j) const {
+        if (!dedupe) return false;
+        const u8 *ab = (const u8 *)(padded + (size_t)i * W), *bb = (const u8 *)(padded + (size_t)j * W);
+        for (u32 tp = 0; tp < t; ++tp) {
+            const i32 *pe = pos(tp, i);
+            bool eq = true;
+            for (int q = 0; q < k && eq; ++q) eq = ab[pe[q]] == bb[pe[q]];
+            if (eq) return true;
+        }
+        return false;
+    }
+    __device__ __forceinline__ bool near(u32 t, u32 i, u32 j) const {
+        return ndf_near(padded + (size_t)i * W, padded + (size_t)j * W, W, d, pos(t, i), k);
+    }
+};
+
+template <class Family>
 __global__ void __launch_bounds__(256)
-ndf_lazy_kernel(const u64 *__restrict__ padded, u32 n, int W, int d, const i32 *__restrict__ pos_all, int k,
-                const u64 *__restrict__ keys_all, const u32 *__restrict__ vals_all, const u32 *__restrict__ grp,
-                size_t pos_group_stride, u32 *__restrict__ cursor_all, u32 *__restrict__ status,
-                u32 *__restrict__ flags, unsigned long long *__restrict__ pairs, const u32 *__restrict__ list,
-                u32 nlist, u32 *__restrict__ next, u32 *__restrict__ next_count, int dedupe) {
-    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    bool again = false;
-    u32 e = 0;
+ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *__restrict__ vals_all,
+                u32 *__restrict__ cursor_all, u32 *status, u32 *flags, unsigned long long *__restrict__ pairs,
+                const u32 *__restrict__ list, u32 nlist, u32 *__restrict__ next, u32 *__restrict__ next_count) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const volatile u32 *st = status;
+    bool again = false, walking = false, near_known = false;
+    u32 e = 0, t = 0, x = 0, i = 0, y = 0, compared = 0, found = 0;
+    u32 verdict = 0;                                 // 1 run exhausted, 2 dropped, 3 waits at y
     if (g < nlist) {
         e = list ? list[g] : g;
-        const u32 t = e / n, x = e - t * n;
+        t = e / n;
+        x = e - t * n;
         const u64 *keys = keys_all + (size_t)t * n;
-        const u32 *vals = vals_all + (size_t)t * n;
-        const u32 i = vals[x];
+        i = vals_all[(size_t)t * n + x];
         const u32 cur = cursor_all[e];
-        if (status[i] == 0 && cur != x) {
+        if (st[i] == 0 && cur != x) {
             again = true;
-            if (flags[i] == 0) {                     // (else: waiting already in this round)
-                const u64 key = keys[x];
-                const i32 *pos = pos_all + (size_t)t * k + (grp ? (size_t)grp[i] * pos_group_stride : 0);
-                const u64 *a = padded + (size_t)i * W;
-                bool near_known = false;
-                u32 y;
+            if (((const volatile u32 *)flags)[i] == 0) {   // (else: waiting already in this round)
+                walking = true;
                 if (cur == NDF_CUR_NONE) {           // first visit: the first slot of the run
+                    const u64 key = keys[x];
                     u32 lo = 0, hi = x;
                     while (lo < hi) {
                         const u32 mid = (lo + hi) >> 1;
@@ -190,44 +234,81 @@ ndf_lazy_kernel(const u64 *__restrict__ padded, u32 n, int W, int d, const i32 *
                     near_known = (cur & NDF_CUR_NEAR) != 0;
                     y = cur & ~NDF_CUR_NEAR;
                 }
-                u32 compared = 0, found = 0;
-                for (; y < x; ++y, near_known = false) {
-                    const u32 j = vals[y];   // j < i: stable sort keeps indices ascending in a run
-                    const u32 sj = status[j];
-                    if (sj == 2) continue;
-                    if (!near_known) {
-                        if (grp && grp[j] != grp[i]) continue;   // another group under the same key
-                        // (from four tables on: a pair that shares an earlier table's bucket belongs to that table's
-                        // cursor; with two or three the look at the earlier positions costs more than it saves)
-                        bool earlier = false;
-                        if (dedupe) {
-                            const u8 *ab = (const u8 *)a, *bb = (const u8 *)(padded + (size_t)j * W);
-                            for (u32 tp = 1; tp <= t && !earlier; ++tp) {
-                                const i32 *pe = pos - (size_t)tp * k;
-                                bool eq = true;
-                                for (int q = 0; q < k && eq; ++q) eq = ab[pe[q]] == bb[pe[q]];
-                                earlier = eq;
-                            }
-                        }
-                        if (earlier) continue;
-                        ++compared;
-                        if (!ndf_near(a, padded + (size_t)j * W, W, d, pos, k)) continue;
-                        ++found;
-                    }
-                    if (sj == 1) { status[i] = 2; again = false; break; }   // a kept higher-priority near-duplicate
-                    flags[i] = 2;                     // an undecided one: wait for it
-                    break;
-                }
-                cursor_all[e] = y < x ? (y | NDF_CUR_NEAR) : x;
-                if (y >= x) again = false;            // this table has nothing more to say about i
-                if (compared) atomicAdd(&pairs[(g >> 6) & (ES_SHARDS - 1)], (unsigned long long)compared);
-                if (found) atomicAdd(&pairs[ES_SHARDS + ((g >> 6) & (ES_SHARDS - 1))], (unsigned long long)found);
             }
         }
     }
+    const u32 *vals = vals_all + (size_t)t * n;
+    // the mate at y (y < x): a verdict, or on to the next
+    auto examine = [&]() {
+        const u32 j = vals[y];                       // j < i: stable sort keeps indices ascending in a run
+        const u32 sj = st[j];
+        if (sj != 2) {
+            bool is_near = near_known;
+            if (!is_near && fam.same_bucket(t, i, j) && !fam.owned_earlier(t, i, j)) {
+                ++compared;
+                is_near = fam.near(t, i, j);
+                found += is_near ? 1u : 0u;
+            }
+            if (is_near) { verdict = sj == 1 ? 2u : 3u; return; }   // a kept higher-priority near-duplicate / an undecided one
+        }
+        ++y;
+        near_known = false;
+    };
+    for (int step = 0; walking && !verdict && step < NDF_OWN_STEPS; ++step) {
+        if (y >= x) verdict = 1; else examine();
+    }
+    for (;;) {                                       // the walks that are not over yet, one at a time, by the whole wavefront
+        const unsigned long long todo = __ballot(walking && !verdict);
+        if (!todo) break;
+        const int leader = __ffsll((long long)todo) - 1;
+        if (__shfl((int)near_known, leader, WAVE)) {  // (its blocker first: one look)
+            if ((int)lane == leader) examine();
+            continue;
+        }
+        const u32 ly = __shfl(y, leader, WAVE), lx = __shfl(x, leader, WAVE), lt = __shfl(t, leader, WAVE),
+                  li = __shfl(i, leader, WAVE);
+        const u32 *lvals = vals_all + (size_t)lt * n;
+        u32 ny = ly, hit_state = 0, ncmp = 0, nfound = 0;
+        for (;;) {                                   // 64 mates per step, each lane compares one
+            const u32 yy = ny + lane;
+            bool is_near = false;
+            u32 sj = 2;
+            if (yy < lx) {
+                const u32 j = lvals[yy];
+                sj = st[j];
+                if (sj != 2 && fam.same_bucket(lt, li, j) && !fam.owned_earlier(lt, li, j)) {
+                    ++ncmp;
+                    is_near = fam.near(lt, li, j);
+                    nfound += is_near ? 1u : 0u;
+                }
+            }
+            const unsigned long long m = __ballot(is_near);
+            if (m) {
+                const int first = __ffsll((long long)m) - 1;
+                ny += (u32)first;
+                hit_state = __shfl(sj, first, WAVE);
+                break;
+            }
+            ny += 64;
+            if (ny >= lx) { ny = lx; break; }
+        }
+        compared += ncmp;                            // (every lane counts what it compared)
+        found += nfound;
+        if ((int)lane == leader) {
+            y = ny;
+            verdict = y >= x ? 1u : (hit_state == 1 ? 2u : 3u);
+        }
+    }
+    if (walking) {
+        if (verdict == 2) { status[i] = 2; again = false; }
+        else if (verdict == 3) flags[i] = 2;         // wait for the undecided mate at y
+        else again = false;                          // this table has nothing more to say about i
+        cursor_all[e] = verdict == 1 ? x : (y | NDF_CUR_NEAR);
+    }
+    if (compared) atomicAdd(&pairs[(g >> 6) & (ES_SHARDS - 1)], (unsigned long long)compared);
+    if (found) atomicAdd(&pairs[ES_SHARDS + ((g >> 6) & (ES_SHARDS - 1))], (unsigned long long)found);
     const unsigned long long bal = __ballot(again);
     if (bal) {
-        const u32 lane = threadIdx.x & 63;
         u32 base = 0;
         if (lane == 0) base = atomicAdd(next_count, (u32)__popcll(bal));
         base = __shfl(base, 0, WAVE);
@@ -247,6 +328,8 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
     TRY(lists[0].alloc(tn));
     TRY(lists[1].alloc(tn));
     u32 left = nn, nlist = (u32)tn;
+    const bool trace = getenv("CATCHHIP_TIMING") && atoi(getenv("CATCHHIP_TIMING")) > 1;
+    auto t_round = std::chrono::steady_clock::now();
     for (u32 round = 0; left && round <= nn + 1; ++round) {
         HIP_TRY(hipMemsetAsync(undecided, 0, 2 * sizeof(u32), s));
         if (nlist) launch(round ? (const u32 *)lists[round & 1].p : (const u32 *)nullptr, nlist, lists[(round & 1) ^ 1].p, undecided + 1);
@@ -254,6 +337,16 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
         tm.launch(2);
         HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (trace) {
+            const auto t1 = std::chrono::steady_clock::now();
+            u64 hp[2 * ES_SHARDS], cmp = 0;
+            (void)hipMemcpy(hp, pairs.p, sizeof(hp), hipMemcpyDeviceToHost);
+            for (int sh = 0; sh < ES_SHARDS; ++sh) cmp += hp[sh];
+            fprintf(stderr, "[catchhip]     lazy round %u: %u entries -> %u undecided probes, %u entries next; %.2f ms, %llu pairs compared so far\n",
+                    round, nlist, ((volatile u32 *)ctx->h_pin)[0], ((volatile u32 *)ctx->h_pin)[1],
+                    std::chrono::duration<double, std::milli>(t1 - t_round).count(), (unsigned long long)cmp);
+            t_round = std::chrono::steady_clock::now();
+        }
         left = ((volatile u32 *)ctx->h_pin)[0];
         nlist = ((volatile u32 *)ctx->h_pin)[1];
     }
@@ -383,12 +476,12 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
             HIP_TRY(hipMemcpyAsync(svals.p + (size_t)t * nn, vals.p, sizeof(u32) * nn, hipMemcpyDeviceToDevice, s));
             tm.launch(1 + 24 + 2);
         }
+        HammingFamily fam{(const u64 *)padded.p, W, (int)dist_thres, (int)k, (const i32 *)d_pos.p, d_grp, pstride, ntables >= 4 ? 1 : 0};
         return ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
                                [&](const u32 *list, u32 nlist, u32 *next, u32 *next_count) {
-            hipLaunchKernelGGL(ndf_lazy_kernel, dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s,
-                               (const u64 *)padded.p, nn, W, (int)dist_thres, (const i32 *)d_pos.p, (int)k,
-                               (const u64 *)skeys.p, (const u32 *)svals.p, d_grp, pstride, cursor.p, status.p, flags.p,
-                               (unsigned long long *)pairs.p, list, nlist, next, next_count, ntables >= 4 ? 1 : 0);
+            hipLaunchKernelGGL(ndf_lazy_kernel<HammingFamily>, dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s, fam, nn,
+                               (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
+                               (unsigned long long *)pairs.p, list, nlist, next, next_count);
         });
     }
     u32 cap = (u32)std::max<i64>((i64)1 << 14, std::min<i64>(n * 16, (i64)1 << 28) / ES_SHARDS);   // per shard
@@ -644,104 +737,30 @@ mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
     if (npairs) atomicAdd((unsigned long long *)(count + ((x >> 6) & (ES_SHARDS - 1)) * ES_STRIDE + 2), (unsigned long long)npairs);
 }
 
-// Lazy resolution (round 3).  Appending EVERY near pair of a run and resolving afterwards costs the square of
-// the run length, and with hundreds or thousands of near-identical strains per species (S5) the runs are that
-// long: 89 of the 106 s of the filters at S5 x 1.0.  But a probe's fate only depends on higher-priority mates
-// that are KEPT (one of them near: dropped) or still UNDECIDED (one of them near: wait); dropped mates never
-// matter.  So every (table, sorted slot) keeps a cursor into its run, from the run's first (highest-priority)
-// slot upwards, and a round moves it on: past dropped mates without looking at them, past mates that are not
-// near (compared once, never again), and it stops at the first near mate that is not dropped -- kept: the
-// probe is dropped on the spot (final, whatever the other tables say); undecided: the probe waits, the cursor
-// remembers that this mate is near.  A probe none of whose cursors had to wait in a round, all of them at the
-// end of their runs' prefixes, is kept.  Decisions only ever rest on decided (final) states, so the fixed
-// point is the sequential pass of the reference.  In a run of near-identical probes every slot compares with
-// the run's head once and is dropped in the next round.  The tables of a round are launched one after the
-// other: a probe that already waits because of an earlier table is not looked at again in this round.
-#define MH_CUR_NEAR 0x80000000u
-#define MH_CUR_NONE 0xffffffffu
-__global__ void __launch_bounds__(256)
-mh_lazy_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, const u64 *__restrict__ id_hi,
-               const u64 *__restrict__ id_lo, const u32 *__restrict__ sig_all, int k, double thres, u32 n,
-               const u64 *__restrict__ keys_all, const u32 *__restrict__ vals_all, const u32 *__restrict__ grp,
-               u32 *__restrict__ cursor_all, u32 *__restrict__ status, u32 *__restrict__ flags,
-               unsigned long long *__restrict__ pairs, const u32 *__restrict__ list, u32 nlist,
-               u32 *__restrict__ next, u32 *__restrict__ next_count) {
-    // an entry = table * n + sorted slot; round 0 walks all of them (list == nullptr), table by table -- the
-    // blocks of a launch start roughly in order, so a probe that waits because of an early table is mostly
-    // not looked at again by the later ones -- and every round lists the entries that still have work to do
-    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    bool again = false;
-    u32 e = 0;
-    if (g < nlist) {
-        e = list ? list[g] : g;
-        const u32 t = e / n, x = e - t * n;
-        const u64 *keys = keys_all + (size_t)t * n;
-        const u32 *vals = vals_all + (size_t)t * n;
-        const u32 *sig = sig_all + (size_t)t * n * k;
-        const u32 i = vals[x];
-        const u32 cur = cursor_all[e];
-        if (status[i] == 0 && cur != x) {
-            again = true;
-            if (flags[i] == 0) {                     // (else: waiting already in this round)
-                const u64 key = keys[x];
-                bool near_known = false;
-                u32 y;
-                if (cur == MH_CUR_NONE) {            // first visit: the first slot of the run
-                    u32 lo = 0, hi = x;
-                    while (lo < hi) {
-                        const u32 mid = (lo + hi) >> 1;
-                        if (keys[mid] < key) lo = mid + 1; else hi = mid;
-                    }
-                    y = lo;
-                } else {
-                    near_known = (cur & MH_CUR_NEAR) != 0;
-                    y = cur & ~MH_CUR_NEAR;
-                }
-                u32 compared = 0, found = 0;
-                for (; y < x; ++y, near_known = false) {
-                    const u32 j = vals[y];   // j < i: stable sort keeps indices ascending in a run
-                    const u32 sj = status[j];
-                    if (sj == 2) continue;
-                    if (!near_known) {
-                        bool same = !grp || grp[i] == grp[j];    // same bucket = same group and signature (the key only groups)
-                        for (int f = 0; f < k; ++f) same = same && sig[(size_t)i * k + f] == sig[(size_t)j * k + f];
-                        if (!same) continue;
-                        // the pair shares a bucket in an earlier table too: it belongs to that table's cursor
-                        // (a probe is only kept once ALL its cursors have run out, so the pair is looked at there)
-                        bool earlier = false;
-                        for (u32 tp = 0; tp < t && !earlier; ++tp) {
-                            const u32 *si = sig_all + ((size_t)tp * n + i) * k, *sj2 = sig_all + ((size_t)tp * n + j) * k;
-                            bool eq = true;
-                            for (int f = 0; f < k; ++f) eq = eq && si[f] == sj2[f];
-                            earlier = eq;
-                        }
-                        if (earlier) continue;
-                        ++compared;
-                        if (!mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j],
-                                     thres))
-                            continue;
-                        ++found;
-                    }
-                    if (sj == 1) { status[i] = 2; again = false; break; }   // a kept higher-priority near-duplicate
-                    flags[i] = 2;                     // an undecided one: wait for it
-                    break;
-                }
-                cursor_all[e] = y < x ? (y | MH_CUR_NEAR) : x;
-                if (y >= x) again = false;            // this table has nothing more to say about i
-                if (compared) atomicAdd(&pairs[(g >> 6) & (ES_SHARDS - 1)], (unsigned long long)compared);
-                if (found) atomicAdd(&pairs[ES_SHARDS + ((g >> 6) & (ES_SHARDS - 1))], (unsigned long long)found);
-            }
-        }
+struct MinHashFamily {       // same signature in table t (the key only groups), exact Jaccard distance of the k-mer sets
+    const u32 *koff, *nuniq;
+    const u64 *id_hi, *id_lo;
+    const u32 *sig_all;      // [table][probe][k]
+    int k;
+    double thres;
+    u32 n;
+    const u32 *grp;
+    __device__ __forceinline__ bool same_sig(u32 t, u32 i, u32 j) const {
+        const u32 *si = sig_all + ((size_t)t * n + i) * k, *sj = sig_all + ((size_t)t * n + j) * k;
+        bool eq = true;
+        for (int f = 0; f < k; ++f) eq = eq && si[f] == sj[f];
+        return eq;
     }
-    const unsigned long long bal = __ballot(again);
-    if (bal) {
-        const u32 lane = threadIdx.x & 63;
-        u32 base = 0;
-        if (lane == 0) base = atomicAdd(next_count, (u32)__popcll(bal));
-        base = __shfl(base, 0, WAVE);
-        if (again) next[base + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = e;
+    __device__ __forceinline__ bool same_bucket(u32 t, u32 i, u32 j) const { return (!grp || grp[i] == grp[j]) && same_sig(t, i, j); }
+    __device__ __forceinline__ bool owned_earlier(u32 t, u32 i, u32 j) const {
+        for (u32 tp = 0; tp < t; ++tp)
+            if (same_sig(tp, i, j)) return true;
+        return false;
     }
-}
+    __device__ __forceinline__ bool near(u32, u32 i, u32 j) const {
+        return mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j], thres);
+    }
+};
 
 // bytes_on_device: `bytes` already lives on the device (>= probe_off[n] + 16 bytes allocated)
 static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off, i64 n, const i64 *group_off,
@@ -821,7 +840,7 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
     tm.launch(1);
     ctx->ndf_counters[0] = n; ctx->ndf_counters[1] = ntables; ctx->ndf_counters[2] = ctx->ndf_counters[3] = 0;
     if (tchunk >= ntables && (i64)ntables * n < ((i64)1 << 32) && !getenv("CATCHHIP_MH_ALL_PAIRS")) {
-        // lazy resolution (mh_lazy_kernel): all tables' sorted runs stay resident, one cursor per (table, slot)
+        // lazy resolution (ndf_lazy_kernel): all tables' sorted runs stay resident, one cursor per (table, slot)
         DevBuf<u64> skeys, pairs;
         DevBuf<u32> svals, cursor;
         const size_t tn = (size_t)ntables * nn;
@@ -855,12 +874,13 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
             tm.launch(1 + 24 + 2);
         }
         lap("signatures + sorts", t_lap);
+        MinHashFamily fam{(const u32 *)d_koff.p, (const u32 *)nuniq.p, (const u64 *)id_hi.p, (const u64 *)id_lo.p, (const u32 *)sig.p,
+                          (int)k, dist_thres, nn, grp};
         const int rc = ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
                                        [&](const u32 *list, u32 nlist, u32 *next, u32 *next_count) {
-            hipLaunchKernelGGL(mh_lazy_kernel, dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s,
-                               (const u32 *)d_koff.p, (const u32 *)nuniq.p, (const u64 *)id_hi.p, (const u64 *)id_lo.p,
-                               (const u32 *)sig.p, (int)k, dist_thres, nn, (const u64 *)skeys.p, (const u32 *)svals.p, grp,
-                               cursor.p, status.p, flags.p, (unsigned long long *)pairs.p, list, nlist, next, next_count);
+            hipLaunchKernelGGL(ndf_lazy_kernel<MinHashFamily>, dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s, fam, nn,
+                               (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
+                               (unsigned long long *)pairs.p, list, nlist, next, next_count);
         });
         lap("rounds", t_lap);
         return rc;
