@@ -35,6 +35,9 @@ struct catchhip_sigs {
     u32 nseq = 0, N = 0;
     DevBuf<u32> sig;    // [nseq][N], ascending
     DevBuf<u32> sigT;   // [N][nseq]
+    DevBuf<u64> fpT;    // 4,096-bit fingerprints of the signatures, [word][nseq] (catchhip_sigs_neighbors_many, on first use)
+    DevBuf<u32> fp_excess;
+    bool fp_ready = false;
 };
 
 #define MD5_P 0x7FFFFFFFu
@@ -294,27 +297,73 @@ __global__ __launch_bounds__(64) void sig_neigh_lds_kernel(const u32 *__restrict
 }
 
 // The neighbour lists of several vertices in one launch (the search asks for the vertex it explores and for
-// those it is about to: the far neighbours it has just stacked): a workgroup stages its 64 target signatures
-// once -- reading the transposed signatures is what a single-vertex launch mostly does -- and walks them
-// against every query in turn.  Entry = query << 48 | index << 16 | common.
+// those it is about to: the far neighbours it has just stacked).  Entry = query << 48 | index << 16 | common.
+// Almost every (query, target) pair is a pair of unrelated sequences, and finding that out by the walk costs
+// ~N dependent reads.  A fingerprint settles it first: every signature value sets one of 4,096 bits (64 words
+// per sequence, stored [word][sequence]); `excess` = N - the bits set (values that fell on a bit already set,
+// repeated values included).  The walk matches equal values pairwise, so
+//     common <= sum over values of min(multiplicity in A, in B) <= popcount(bits A & bits B) + min(excess A, excess B)
+// and a pair whose bound is below min_common cannot be a neighbour.  Unrelated signatures share two or three
+// bits by chance; only the workgroups that hold a survivor stage their 64 signatures in LDS and walk.
 #define NEIGH_MAXQ 32
+#define NEIGH_FPW 64          // 64-bit words of a fingerprint
+__device__ __forceinline__ u32 neigh_fp_bit(u32 v) { return (v * 2654435761u) >> 20; }   // 12 bits
+
+__global__ __launch_bounds__(256) void sig_fp_build_kernel(const u32 *__restrict__ sig, u32 nseq, u32 N,
+                                                           unsigned long long *__restrict__ fpT) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (u64)nseq * N) return;
+    const u32 seq = (u32)(t / N);
+    const u32 bit = neigh_fp_bit(sig[t]);
+    atomicOr(&fpT[(size_t)(bit >> 6) * nseq + seq], 1ull << (bit & 63u));
+}
+
+__global__ __launch_bounds__(256) void sig_fp_excess_kernel(const unsigned long long *__restrict__ fpT, u32 nseq, u32 N,
+                                                            u32 *__restrict__ excess) {
+    const u32 seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= nseq) return;
+    u32 set = 0;
+    for (u32 w = 0; w < NEIGH_FPW; ++w) set += (u32)__popcll(fpT[(size_t)w * nseq + seq]);
+    excess[seq] = N - set;
+}
+
 __global__ __launch_bounds__(64) void sig_neigh_many_kernel(const u32 *__restrict__ sig, const u32 *__restrict__ sigT,
-                                                            u32 nseq, u32 N, const u32 *__restrict__ js, u32 nq,
-                                                            u32 min_common, unsigned long long *__restrict__ out,
-                                                            u32 cap, u32 *__restrict__ count) {
+                                                            const unsigned long long *__restrict__ fpT,
+                                                            const u32 *__restrict__ excess, u32 nseq, u32 N,
+                                                            const u32 *__restrict__ js, u32 nq, u32 min_common,
+                                                            unsigned long long *__restrict__ out, u32 cap,
+                                                            u32 *__restrict__ count) {
     extern __shared__ u32 s_mem[];
     u32 *s_b = s_mem, *s_q = s_mem + (size_t)64 * N;   // s_b[i * 64 + lane], s_q[q * N + i]
+    __shared__ unsigned long long s_qfp[NEIGH_MAXQ][NEIGH_FPW];
+    __shared__ u32 s_qx[NEIGH_MAXQ];
     const u32 kq = blockIdx.x * 64 + threadIdx.x;
     const u32 kc = kq < nseq ? kq : nseq - 1;
+    for (u32 t = threadIdx.x; t < nq * NEIGH_FPW; t += 64) s_qfp[t / NEIGH_FPW][t % NEIGH_FPW] = fpT[(size_t)(t % NEIGH_FPW) * nseq + js[t / NEIGH_FPW]];
+    if (threadIdx.x < nq) s_qx[threadIdx.x] = excess[js[threadIdx.x]];
+    unsigned long long fp[NEIGH_FPW];
+#pragma unroll
+    for (int w = 0; w < NEIGH_FPW; ++w) fp[w] = fpT[(size_t)w * nseq + kc];
+    const u32 ex = excess[kc];
+    __syncthreads();
+    u32 need = 0;                                      // the queries this target may be a neighbour of
+    for (u32 q = 0; q < nq; ++q) {
+        u32 pc = 0;
+#pragma unroll
+        for (int w = 0; w < NEIGH_FPW; ++w) pc += (u32)__popcll(fp[w] & s_qfp[q][w]);
+        if (kq < nseq && pc + min(ex, s_qx[q]) >= min_common) need |= 1u << q;
+    }
+    if (!__ballot(need != 0)) return;                  // (one wavefront per workgroup)
     for (u32 i = 0; i < N; ++i) s_b[i * 64 + threadIdx.x] = sigT[(size_t)i * nseq + kc];
     for (u32 t = threadIdx.x; t < nq * N; t += 64) s_q[t] = sig[(size_t)js[t / N] * N + (t % N)];
     __syncthreads();
     for (u32 q = 0; q < nq; ++q) {
+        if (!__ballot((need >> q) & 1u)) continue;
         const u32 *a = s_q + (size_t)q * N;
         u32 c = 0;
-        if (kq < nseq)
+        if ((need >> q) & 1u)
             c = walk_common(N, [&](u32 i) { return a[i]; }, [&](u32 i) { return s_b[i * 64 + threadIdx.x]; });
-        const bool hit = kq < nseq && c >= min_common;
+        const bool hit = c >= min_common && ((need >> q) & 1u);
         const unsigned long long b = __ballot(hit);
         if (!b) continue;
         u32 base = 0;
@@ -531,8 +580,21 @@ extern "C" int catchhip_sigs_neighbors_many(catchhip_ctx *ctx, const catchhip_si
     HIP_TRY(hipMemsetAsync(d_n.p, 0, sizeof(u32), st));
     HIP_TRY(hipMemcpyAsync(d_js.p, js, sizeof(u32) * (size_t)nq, hipMemcpyHostToDevice, st));
     PhaseTimer tm(ctx, PHASE_NDF);
+    catchhip_sigs *Sm = const_cast<catchhip_sigs *>(S);
+    if (!Sm->fp_ready) {                               // the fingerprints, on first use
+        TRY(Sm->fpT.alloc((size_t)NEIGH_FPW * S->nseq));
+        TRY(Sm->fp_excess.alloc(S->nseq));
+        HIP_TRY(hipMemsetAsync(Sm->fpT.p, 0, sizeof(u64) * NEIGH_FPW * (size_t)S->nseq, st));
+        hipLaunchKernelGGL(sig_fp_build_kernel, dim3((unsigned)(((u64)S->nseq * S->N + 255) / 256)), dim3(256), 0, st,
+                           (const u32 *)S->sig.p, S->nseq, S->N, (unsigned long long *)Sm->fpT.p);
+        hipLaunchKernelGGL(sig_fp_excess_kernel, dim3((S->nseq + 255) / 256), dim3(256), 0, st,
+                           (const unsigned long long *)Sm->fpT.p, S->nseq, S->N, Sm->fp_excess.p);
+        tm.launch(2);
+        Sm->fp_ready = true;
+    }
     hipLaunchKernelGGL(sig_neigh_many_kernel, dim3((S->nseq + 63) / 64), dim3(64), sizeof(u32) * (64 + (size_t)nq) * S->N, st,
-                       (const u32 *)S->sig.p, (const u32 *)S->sigT.p, S->nseq, S->N, (const u32 *)d_js.p, (u32)nq,
+                       (const u32 *)S->sig.p, (const u32 *)S->sigT.p, (const unsigned long long *)Sm->fpT.p,
+                       (const u32 *)Sm->fp_excess.p, S->nseq, S->N, (const u32 *)d_js.p, (u32)nq,
                        min_common, d.p, (u32)std::min<size_t>(dcap, 0xffffffffu), d_n.p);
     tm.launch(1);
     HIP_TRY(hipGetLastError());
