@@ -107,19 +107,36 @@ struct SeedTable {
     u32 *cnt;                   // per slot: entries with this key (build time)
     u32 *ents;                  // entry ids (probe * nanchor + anchor) grouped by key
     u32 mask;                   // capacity - 1
-    // anchor-pair filter (seed_lookup_kernel; null when it does not apply): per entry (p, a) ONE 32-byte record
-    // {entry id, its anchor index, key of the probe's other anchors in anchor order (SEED_SIB of them; bit 62 = the anchor
-    // holds an N)} -- a position's entries are then one or two lines, not a line of ents plus two of keys
+    // anchor-pair filter (seed_lookup_kernel; null when it does not apply): per entry (p, a) ONE 16-byte record
+    // {entry id, table slot of the probe's other anchors in anchor order (SEED_SIB of them; bit 31 = the anchor holds
+    // an N)}.  Round 3: the slots, not the keys -- every anchor's k-mer has a slot (those that stay out of the
+    // table as a key without entries), a key has exactly one slot, so "the target's k-mer there equals that
+    // anchor" is a comparison of two slot numbers, and the record is half as long (28 of the look-up's bytes per
+    // table match were these records).
     const uint4 *sib;
+    // presence bits (round 3; null = off): 4 bits per slot, one of them set per key of the table (a second hash).
+    // 24 of 25 target positions hold no anchor k-mer, and each such miss used to cost a 64-byte sector of the
+    // 16-byte slots (half a gigabyte of them: HBM); the bits of the same table are 16 MB and stay in the
+    // memory-side cache.
+    u32 *present;
+    u32 pmask;                  // presence bits - 1
     __device__ __forceinline__ unsigned long long *key_at(u32 s) const { return (unsigned long long *)(slot + s); }
 };
 #define SEED_EMPTY 0xffffffffffffffffull
 #define SEED_DEAD 0xffffffffu   // work-list entry without a seed (the tail of a look-up workgroup's range)
 #define SEED_SIB 3              // other anchors per entry: the filter takes tables of <= 4 anchors per probe
 #define SEED_KEYBITS 0x3fffffffffffffffull
+#define SEED_SLOT_N 0x80000000u      // sibling / target slot word: the k-mer holds an N
+#define SEED_SLOT_BITS 0x7fffffffu
+#define SEED_SLOT_NONE 0x7fffffffu   // target: no such key in the table / no k-mer here
+#define SEED_SLOT_ABSENT 0x7ffffffeu // sibling: the probe has no such anchor
 
 __device__ __forceinline__ u32 seed_hash(unsigned long long k) {
     k ^= k >> 29; k *= 0xbf58476d1ce4e5b9ull; k ^= k >> 32;
+    return (u32)k;
+}
+__device__ __forceinline__ u32 seed_hash2(unsigned long long k) {
+    k ^= k >> 31; k *= 0x94d049bb133111ebull; k ^= k >> 29;
     return (u32)k;
 }
 
@@ -166,12 +183,12 @@ __device__ __forceinline__ unsigned long long plane_key_n(const u32 *__restrict_
 __global__ void __launch_bounds__(256)
 seed_count_kernel(const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent_probe,
                   const u32 *__restrict__ ent_pos, u32 nent, u32 pos_limit, int nanch, int k, int NW, int kb,
-                  SeedTable t, u32 *__restrict__ slot_of, unsigned long long *__restrict__ ekey) {
+                  SeedTable t, u32 *__restrict__ slot_of, u32 *__restrict__ aslot) {
     const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nent) return;
     const u32 p = nanch ? e / (u32)nanch : ent_probe[e];
     const u32 o = nanch ? (e % (u32)nanch) * (u32)k : ent_pos[e];
-    if (o >= pos_limit && !ekey) { slot_of[e] = SEED_SKIP; return; }
+    if (o >= pos_limit && !aslot) { slot_of[e] = SEED_SKIP; return; }
     // the probe image is [word][4]: planes 0/1 of the two words the k-mer starts in
     const u32 wi = o >> 5, sh = o & 31;
     const uint4 w0 = pplanes[(size_t)p * NW + wi];
@@ -179,16 +196,20 @@ seed_count_kernel(const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent
     const u32 m = kb >= 32 ? 0xffffffffu : ((1u << kb) - 1u);
     const unsigned long long key = ((unsigned long long)(__builtin_amdgcn_alignbit(w1.y, w0.y, sh) & m) << 32) |
                                    (__builtin_amdgcn_alignbit(w1.x, w0.x, sh) & m);
-    // (the anchor-pair filter wants the key of EVERY anchor, also of those that stay out of the table;
-    // bit 62: the anchor holds an N -- such a key equals no target key, whose N flag is bit 63)
-    if (ekey) ekey[e] = key | ((__builtin_amdgcn_alignbit(w1.z, w0.z, sh) & m) ? (1ull << 62) : 0ull);
-    if (o >= pos_limit) { slot_of[e] = SEED_SKIP; return; }
     u32 s = seed_hash(key) & t.mask;
     for (;;) {
         const unsigned long long prev = atomicCAS(t.key_at(s), SEED_EMPTY, key);
         if (prev == SEED_EMPTY || prev == key) break;
         s = (s + 1) & t.mask;
     }
+    if (t.present) {
+        const u32 b = seed_hash2(key) & t.pmask;
+        atomicOr(&t.present[b >> 5], 1u << (b & 31u));
+    }
+    // (the anchor-pair filter wants the slot of EVERY anchor's k-mer, also of those that stay out of the table
+    // -- a key without entries; bit 31: the anchor holds an N -- it then equals no target k-mer exactly)
+    if (aslot) aslot[e] = s | ((__builtin_amdgcn_alignbit(w1.z, w0.z, sh) & m) ? SEED_SLOT_N : 0u);
+    if (o >= pos_limit) { slot_of[e] = SEED_SKIP; return; }
     slot_of[e] = s;
     atomicAdd(&t.cnt[s], 1u);
 }
@@ -196,9 +217,10 @@ seed_count_kernel(const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent
 // one launch instead of five memsets
 __global__ void __launch_bounds__(256)
 seed_init_kernel(uint4 *__restrict__ slot, u32 *__restrict__ cnt, u32 capacity, u32 *__restrict__ ctr,
-                 u32 *__restrict__ bcnt, u32 nb, u32 *__restrict__ res) {
+                 u32 *__restrict__ bcnt, u32 nb, u32 *__restrict__ res, u32 *__restrict__ present, u32 npresent_words) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     for (u32 i = t; i < capacity; i += stride) { slot[i] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u); cnt[i] = 0; }
+    for (u32 i = t; i < npresent_words; i += stride) present[i] = 0u;
     for (u32 i = t; i < nb; i += stride) bcnt[i] = 0;
     if (t < 8) { ctr[t & 3] = 0; res[t] = 0; }
 }
@@ -239,7 +261,7 @@ seed_alloc_kernel(SeedTable t, u32 *__restrict__ cursor) {
 // table build 3/3: drop the entries into their slot's range
 __global__ void __launch_bounds__(256)
 seed_fill_kernel(u32 nent, SeedTable t, const u32 *__restrict__ slot_of, int nanch,
-                 const unsigned long long *__restrict__ ekey, uint4 *__restrict__ sib) {
+                 const u32 *__restrict__ aslot, uint4 *__restrict__ sib) {
     const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nent) return;
     const u32 s = slot_of[e];
@@ -249,13 +271,12 @@ seed_fill_kernel(u32 nent, SeedTable t, const u32 *__restrict__ slot_of, int nan
     t.ents[idx] = e;
     if (sib) {
         const u32 a = e % (u32)nanch, e0 = e - a;
-        unsigned long long kk[SEED_SIB];
+        u32 kk[SEED_SIB];
         u32 q = 0;
         for (u32 b = 0; b < (u32)nanch; ++b)
-            if (b != a && q < SEED_SIB) kk[q++] = ekey[e0 + b];
-        for (; q < SEED_SIB; ++q) kk[q] = SEED_EMPTY;
-        sib[2 * (size_t)idx] = make_uint4(e, a, (u32)kk[0], (u32)(kk[0] >> 32));
-        sib[2 * (size_t)idx + 1] = make_uint4((u32)kk[1], (u32)(kk[1] >> 32), (u32)kk[2], (u32)(kk[2] >> 32));
+            if (b != a && q < SEED_SIB) kk[q++] = aslot[e0 + b];
+        for (; q < SEED_SIB; ++q) kk[q] = SEED_SLOT_ABSENT;
+        sib[idx] = make_uint4(e, kk[0], kk[1], kk[2]);      // (a = e % nanch)
     }
 }
 
@@ -286,35 +307,53 @@ seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const
                    u32 *__restrict__ seed_ent, u32 *__restrict__ seed_seq, u32 *__restrict__ seed_count, u32 seed_cap,
                    uint2 *__restrict__ ranges) {
     __shared__ u32 s_off[SL_TILE + 1], s_rx[SL_TILE], s_sq[SL_TILE], s_part[SL_THREADS / 64], s_base;
-    __shared__ unsigned long long s_key[SL_TILE + 2 * SL_HALO];
+    __shared__ u32 s_slot[SL_TILE + 2 * SL_HALO];   // the table slot of every position's k-mer (filtered look-up)
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 tile0 = blockIdx.x * SL_TILE;
     // the tile's first sequence, found once (the same addresses for every lane); a
     // seeded position then walks on from there -- a tile rarely spans more than one
     // or two sequence ends -- instead of a binary search of its own
     const u32 sq0 = find_segment(seq_off, nseq, min(tile0, total - 1));
-    if (t.sib && tid < 2 * SL_HALO) {
+    // the slot of a k-mer (SEED_SLOT_NONE: not a key of the table), bit 31: it holds an N
+    auto slot_word = [&](u32 pos, u32 found) {
+        u32 w = found;
+        if (t_has_n && (plane_key_n(tplanes, nwords, pos, kb, 1) >> 63)) w |= SEED_SLOT_N;
+        return w;
+    };
+    auto find_slot = [&](unsigned long long key, uint2 *range) {
+        if (t.present) {
+            const u32 b = seed_hash2(key) & t.pmask;
+            if (!((t.present[b >> 5] >> (b & 31u)) & 1u)) return SEED_SLOT_NONE;
+        }
+        u32 sl_i = seed_hash(key) & t.mask;
+        for (;;) {
+            const uint4 sl = t.slot[sl_i];   // written by the table-build launches
+            const unsigned long long ks = ((unsigned long long)sl.y << 32) | sl.x;
+            if (ks == key) { if (range) *range = make_uint2(sl.z, sl.w); return sl_i; }
+            if (ks == SEED_EMPTY) return SEED_SLOT_NONE;
+            sl_i = (sl_i + 1) & t.mask;
+        }
+    };
+    if (t.sib && tid < 2 * SL_HALO) {                // the positions either side of the tile
         const long long pos = tid < SL_HALO ? (long long)tile0 - SL_HALO + tid : (long long)tile0 + SL_TILE + (tid - SL_HALO);
         const bool ok = pos >= 0 && pos + k <= (long long)total;
-        s_key[tid < SL_HALO ? tid : SL_TILE + tid] = ok ? plane_key_n(tplanes, nwords, (u32)pos, kb, t_has_n) : SEED_EMPTY;
+        u32 w = SEED_SLOT_NONE;
+        if (ok) {
+            const u32 f = find_slot(plane_key(tplanes, tplanes + nwords, (u32)pos, kb), nullptr);
+            w = f == SEED_SLOT_NONE ? f : slot_word((u32)pos, f);
+        }
+        s_slot[tid < SL_HALO ? tid : SL_TILE + tid] = w;
     }
     u32 cnt[SL_PPT], mine = 0;
 #pragma unroll
     for (int j = 0; j < SL_PPT; ++j) {
         const u32 q = tid * SL_PPT + j, i = tile0 + q;
         uint2 r = make_uint2(0, 0);
-        if (t.sib) s_key[SL_HALO + q] = SEED_EMPTY;
+        if (t.sib) s_slot[SL_HALO + q] = SEED_SLOT_NONE;
         if (i < total && i + (u32)k <= total) {
             const unsigned long long key = plane_key(tplanes, tplanes + nwords, i, kb);
-            if (t.sib) s_key[SL_HALO + q] = plane_key_n(tplanes, nwords, i, kb, t_has_n);
-            u32 s = seed_hash(key) & t.mask;
-            for (;;) {
-                const uint4 sl = t.slot[s];   // written by the table-build launches
-                const unsigned long long ks = ((unsigned long long)sl.y << 32) | sl.x;
-                if (ks == key) { r = make_uint2(sl.z, sl.w); break; }
-                if (ks == SEED_EMPTY) break;
-                s = (s + 1) & t.mask;
-            }
+            const u32 f = find_slot(key, &r);
+            if (t.sib && f != SEED_SLOT_NONE) s_slot[SL_HALO + q] = slot_word(i, f);
         }
         if (r.y) {
             u32 sq = sq0;
@@ -366,21 +405,22 @@ seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const
             u32 hi = SL_TILE;
             while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_off[mid] <= d) lo = mid; else hi = mid; }
             const u32 idx = s_rx[lo] + (d - s_off[lo]);
-            const uint4 r0 = t.sib[2 * (size_t)idx], r1 = t.sib[2 * (size_t)idx + 1];
+            const uint4 r0 = t.sib[idx];
             ent = r0.x;
-            const u32 a = r0.y;              // the entry's anchor index (= ent % nanch)
-            const unsigned long long sk[SEED_SIB] = {((unsigned long long)r0.w << 32) | r0.z, ((unsigned long long)r1.y << 32) | r1.x,
-                                                     ((unsigned long long)r1.w << 32) | r1.z};
+            const u32 a = ent % (u32)nanch;  // the entry's anchor index
+            const u32 sk[SEED_SIB] = {r0.y, r0.z, r0.w};
             bool lower_exact = false, higher = need2 == 0;
 #pragma unroll
             for (u32 j = 0; j < SEED_SIB; ++j) {
                 const u32 b = j < a ? j : j + 1;
                 if (b >= (u32)nanch) continue;
                 const int off = (int)lo + ((int)b - (int)a) * k + SL_HALO;
-                const unsigned long long tk = (off >= 0 && off < SL_TILE + 2 * SL_HALO) ? s_key[off] : SEED_EMPTY;
-                const unsigned long long pk = sk[j];
-                if (b < a) lower_exact = lower_exact || tk == pk;
-                else higher = higher || (tk != SEED_EMPTY && ((tk ^ pk) & SEED_KEYBITS) == 0ull);
+                const u32 tk = (off >= 0 && off < SL_TILE + 2 * SL_HALO) ? s_slot[off] : SEED_SLOT_NONE;
+                const u32 pk = sk[j];
+                // same slot = same k-mer on planes 0/1; exactly equal only if neither holds an N
+                const bool same = (tk & SEED_SLOT_BITS) != SEED_SLOT_NONE && ((tk ^ pk) & SEED_SLOT_BITS) == 0u;
+                if (b < a) lower_exact = lower_exact || (same && !((tk | pk) & SEED_SLOT_N));
+                else higher = higher || same;
             }
             keep = !lower_exact && higher;
         }
@@ -1191,7 +1231,8 @@ static u32 seed_capacity(const catchhip_probes *P, const catchhip_targets *T) {
 // into the bucketed row build as records indexed like the seeds.
 struct SeedRun {
     DevBuf<uint4> slot;
-    DevBuf<unsigned long long> ekey;
+    DevBuf<u32> aslot;       // filtered look-up: the table slot of every anchor's k-mer
+    DevBuf<u32> present;     // presence bits of the table's keys
     DevBuf<uint4> sib;
     DevBuf<uint2> ranges;    // filtered look-up: per look-up workgroup (first list entry, seeds kept)
     u32 nranges = 0;         // 0: unfiltered
@@ -1224,21 +1265,26 @@ static int seed_table_lookup_async(catchhip_ctx *ctx, const catchhip_probes *P, 
     const int need2 = filt && nanch_tab - mm >= 2 ? 1 : 0;
     const u32 nblk = (u32)div_up(T->total, SL_TILE);
     S.nranges = filt ? nblk : 0;
-    if (filt) { TRY(S.ekey.reserve(nent)); TRY(S.sib.reserve((size_t)nent * 2)); TRY(S.ranges.reserve(nblk)); }
+    if (filt) { TRY(S.aslot.reserve(nent)); TRY(S.sib.reserve((size_t)nent)); TRY(S.ranges.reserve(nblk)); }
     TRY(S.spos.reserve(S.scap));
     TRY(S.sent.reserve(S.scap));
     TRY(S.sseq.reserve(S.scap));
     if (!res) { TRY(S.dummy.reserve(8)); res = S.dummy.p; }
-    SeedTable t = {S.slot.p, S.cnt.p, S.ents.p, capacity - 1, filt ? (const uint4 *)S.sib.p : nullptr};
+    // presence bits: for the pigeonhole tables of a whole-genome scan (most positions miss); 4 per slot
+    const bool pres = P->pigeonhole && capacity >= (1u << 16) && capacity <= (1u << 29) && !getenv("CATCHHIP_SEED_NO_PRESENCE");
+    const u32 pwords = pres ? capacity / 8 : 0;      // 4 * capacity bits
+    if (pres) TRY(S.present.reserve(pwords));
+    SeedTable t = {S.slot.p, S.cnt.p, S.ents.p, capacity - 1, filt ? (const uint4 *)S.sib.p : nullptr,
+                   pres ? S.present.p : (u32 *)nullptr, pres ? 4 * capacity - 1 : 0u};
     const dim3 eb((unsigned)div_up((i64)nent, 256)), tb(256);
     hipLaunchKernelGGL(seed_init_kernel, dim3((unsigned)std::min<i64>(div_up((i64)capacity, 256), 2048)), tb, 0,
-                       ctx->stream, S.slot.p, S.cnt.p, capacity, S.ctr.p, bcnt, nb, res);
+                       ctx->stream, S.slot.p, S.cnt.p, capacity, S.ctr.p, bcnt, nb, res, pres ? S.present.p : (u32 *)nullptr, pwords);
     hipLaunchKernelGGL(seed_count_kernel, eb, tb, 0, ctx->stream, (const uint4 *)P->planes.p,
                        (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p, nent, pos_limit,
-                       nanch_tab, k, (int)P->pwords, kb, t, S.slot_of.p, filt ? S.ekey.p : nullptr);
+                       nanch_tab, k, (int)P->pwords, kb, t, S.slot_of.p, filt ? S.aslot.p : (u32 *)nullptr);
     hipLaunchKernelGGL(seed_alloc_kernel, dim3(capacity / SA_SLOTS), dim3(256), 0, ctx->stream, t, S.ctr.p);
     hipLaunchKernelGGL(seed_fill_kernel, eb, tb, 0, ctx->stream, nent, t, (const u32 *)S.slot_of.p, nanch_tab,
-                       (const unsigned long long *)S.ekey.p, filt ? S.sib.p : nullptr);
+                       (const u32 *)S.aslot.p, filt ? S.sib.p : nullptr);
     hipLaunchKernelGGL(seed_lookup_kernel, dim3((unsigned)div_up(T->total, SL_TILE)), dim3(SL_THREADS), 0, ctx->stream,
                        (const u32 *)T->planes.p, T->nwords, (u32)T->total, (const u32 *)T->seq_off.p,
                        (u32)T->nseq, k, kb, nanch_tab, need2, T->has_n ? 1 : 0, t, S.spos.p, S.sent.p, S.sseq.p,
