@@ -89,6 +89,7 @@ PROTOTYPES = {
     "catchhip_comm_init": (ctypes.c_int, [
         c_vp, c_u8p, ctypes.c_int32, ctypes.c_int32]),
     "catchhip_comm_destroy": (ctypes.c_int, [c_vp]),
+    "catchhip_comm_selftest": (ctypes.c_int, [c_vp, ctypes.c_int64]),
     "catchhip_comm_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64]),
     "catchhip_shard_create": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_i64p, c_vpp]),
     "catchhip_shard_destroy": (ctypes.c_int, [c_vp]),

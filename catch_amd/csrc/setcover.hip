@@ -842,6 +842,41 @@ extern "C" int catchhip_comm_init(catchhip_ctx *ctx, const u8 *id128, i32 nranks
     return 0;
 }
 
+// fills a buffer with (rank + 1), SUM all-reduce, checks every element against nranks (nranks + 1) / 2
+__global__ void __launch_bounds__(256)
+comm_selftest_fill_kernel(u32 *buf, u32 n, u32 v) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) buf[i] = v;
+}
+__global__ void __launch_bounds__(256)
+comm_selftest_check_kernel(const u32 *buf, u32 n, u32 want, u32 *bad) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && buf[i] != want) atomicAdd(bad, 1u);
+}
+
+extern "C" int catchhip_comm_selftest(catchhip_ctx *ctx, i64 nelem) {
+    ARG_CHECK(ctx && nelem >= 1 && nelem < ((i64)1 << 30));
+    if (!ctx->comm) { chip_set_error("comm_selftest: the context has no communicator"); return CATCHHIP_EINVAL; }
+    PoolScope pool_scope(ctx);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DevBuf<u32> buf, bad;
+    TRY(buf.alloc((size_t)nelem));
+    TRY(bad.alloc(1));
+    const u32 n = (u32)nelem;
+    HIP_TRY(hipMemsetAsync(bad.p, 0, sizeof(u32), s));
+    hipLaunchKernelGGL(comm_selftest_fill_kernel, dim3((unsigned)div_up((i64)n, 256)), dim3(256), 0, s, buf.p, n, (u32)ctx->rank + 1u);
+    const ncclResult_t r = rccl().AllReduce(buf.p, buf.p, (size_t)n, ncclUint32, ncclSum, (ncclComm_t)ctx->comm, s);
+    if (r != ncclSuccess) { chip_set_error("comm_selftest: ncclAllReduce: %s", rccl().GetErrorString(r)); return CATCHHIP_ECOMM; }
+    const u32 want = (u32)((i64)ctx->nranks * (ctx->nranks + 1) / 2);
+    hipLaunchKernelGGL(comm_selftest_check_kernel, dim3((unsigned)div_up((i64)n, 256)), dim3(256), 0, s, (const u32 *)buf.p, n, want, bad.p);
+    u32 h_bad = 0;
+    HIP_TRY(hipMemcpyAsync(&h_bad, bad.p, sizeof(u32), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h_bad) { chip_set_error("comm_selftest: %u of %u elements differ from %u after the SUM all-reduce", h_bad, n, want); return CATCHHIP_ECOMM; }
+    return 0;
+}
+
 extern "C" int catchhip_comm_destroy(catchhip_ctx *ctx) {
     if (ctx && ctx->comm) {
         (void)rccl().CommDestroy((ncclComm_t)ctx->comm);

@@ -190,6 +190,10 @@ class Context:
     def comm_destroy(self):
         check(self._L.catchhip_comm_destroy(self._h))
 
+    def comm_selftest(self, nelem=1 << 20):
+        """catchhip_comm_selftest: a checked SUM all-reduce on this context's communicator (collective)."""
+        check(self._L.catchhip_comm_selftest(self._h, int(nelem)))
+
     # -- near-duplicate filter --------------------------------------------
     def ndf_hamming(self, probe_strs, L, positions, dist_thres):
         n = len(probe_strs)

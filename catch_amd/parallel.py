@@ -236,6 +236,13 @@ def init_from_env():
             err = "%s: %s" % (type(exc).__name__, exc)
         errs = [None] * size
         dist.all_gather_object(errs, err)
+        if not any(e is not None for e in errs):
+            # every rank has a communicator: one checked all-reduce before anything depends on it
+            try:
+                comm_ctx.comm_selftest(1 << 20)
+            except Exception as exc:   # noqa: BLE001
+                err = "%s: %s" % (type(exc).__name__, exc)
+            dist.all_gather_object(errs, err)
         if any(e is not None for e in errs):
             if err is None:
                 comm_ctx.comm_destroy()

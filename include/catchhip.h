@@ -256,6 +256,12 @@ int catchhip_comm_unique_id(uint8_t *id128);
 int catchhip_comm_init(catchhip_ctx *ctx, const uint8_t *id128, int32_t nranks,
                        int32_t rank);
 int catchhip_comm_destroy(catchhip_ctx *ctx);
+/* Collective: every rank of the communicator fills nelem uint32 with rank + 1, SUM
+ * all-reduces them on the context's stream and checks every element against
+ * nranks (nranks + 1) / 2.  CATCHHIP_ECOMM with the RCCL error or the number of wrong
+ * elements.  catch_amd.parallel.init_from_env runs it once after catchhip_comm_init and
+ * falls back to the host exchange, by agreement of all ranks, if any rank fails. */
+int catchhip_comm_selftest(catchhip_ctx *ctx, int64_t nelem);
 /* Which RCCL the communicators of this library go through: "RCCL version code V
  * from <file> (<how it was chosen>)".  The library opens ONE copy by path
  * (CATCHHIP_RCCL_PATH, else /opt/rocm/lib/librccl.so) instead of whatever file of

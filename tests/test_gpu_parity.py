@@ -688,7 +688,11 @@ def test_greedy_rccl_solver_single_rank_matches(oracle):
     the same order as the oracle (and hence as the persistent solver)."""
     engine = _engine()
     c2 = engine.Context(0)
+    with pytest.raises(ValueError):
+        c2.comm_selftest()                    # no communicator yet
     c2.comm_init(engine.Context.comm_unique_id(), 1, 0)
+    c2.comm_selftest()                        # a checked SUM all-reduce through the pinned RCCL (1 rank: sum == 1)
+    c2.comm_selftest(3)
     rng = np.random.Generator(np.random.PCG64(321))
     for trial in range(6):
         P, U = int(rng.integers(5, 80)), int(rng.integers(1, 5))
