@@ -58,7 +58,7 @@ from catch_amd.utils import synthetic  # noqa: E402
 PROBE_LEN, STRIDE, MISMATCHES, EXT = 100, 50, 2, 50
 SCAN_MODE = int(os.environ.get("CATCHHIP_SCAN_MODE", "0"))   # 0 auto, 1 general, 2 fast
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
-CONFIG_OF = {"S1": 0, "S2": 1, "S3": 2, "S4": 3, "S5": 4}
+CONFIG_OF = {"S1": 0, "S2": 1, "S3": 2, "S4": 3, "S4i": 3, "S2i": 1, "S5": 4, "S5m": 4}
 
 
 class ResidentGroup:
@@ -927,7 +927,7 @@ def main():
             out["speedup_note"] = ("CPU seconds per pass over the sample's groups / GPU seconds for the same "
                                    "groups (resident inputs); `value` / cpu_baseline.value is NOT comparable: "
                                    "probe*bp grows quadratically with the group size")
-        if world == 1 and not args.no_partial and not Stepper.ndf and args.workload == "S4":
+        if world == 1 and not args.no_partial and not Stepper.ndf and args.workload in ("S4", "S4i"):
             # the same resident groups under -c 0.9 (partial coverage): frontier rounds with the universe
             # test; digests of the picks in order against the committed ones
             def c09_pass(collect):

@@ -926,9 +926,12 @@ def _digest_in_order(ids):
     return hashlib.sha256(np.asarray(ids, dtype="<i8").tobytes()).hexdigest()
 
 
-def test_full_size_config4_matches_oracle_digests(ctx):
+@pytest.mark.parametrize("name", ["S4", "S4i"])
+def test_full_size_config4_matches_oracle_digests(ctx, name):
     """BASELINE configs[3] at FULL size (S4: 20,755 genomes in 20 groups, 592
-    Mbp, 8.9 M candidates, 519 M cover rows): per group the number of
+    Mbp, 8.9 M candidates, 519 M cover rows; S4i: the same generator with
+    insertions and deletions between clades and strains, 20,169 genomes, 501
+    Mbp, 9.3 M candidates, 465 M rows): per group the number of
     candidates, the number of picks and the sha256 of the sorted pick ids equal
     what the pinned CPU oracle computed in the authoring container
     (tests/golden/make_full_size.py; the oracle needs ~20 minutes there) -- and
@@ -937,8 +940,8 @@ def test_full_size_config4_matches_oracle_digests(ctx):
     from catch_amd import probe
     from catch_amd.utils import synthetic
     engine = _engine()
-    gold = {g["group"]: g for g in _full_size("S4")["groups"]}
-    groups = synthetic.dataset("S4")
+    gold = {g["group"]: g for g in _full_size(name)["groups"]}
+    groups = synthetic.dataset(name)
     assert len(groups) == len(gold) == 20
     for gi, genomes in enumerate(groups):
         t = engine.Targets(ctx, genomes)
