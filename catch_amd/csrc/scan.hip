@@ -197,12 +197,14 @@ seed_count_kernel(const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent
     const unsigned long long key = ((unsigned long long)(__builtin_amdgcn_alignbit(w1.y, w0.y, sh) & m) << 32) |
                                    (__builtin_amdgcn_alignbit(w1.x, w0.x, sh) & m);
     u32 s = seed_hash(key) & t.mask;
+    bool fresh = false;
     for (;;) {
         const unsigned long long prev = atomicCAS(t.key_at(s), SEED_EMPTY, key);
-        if (prev == SEED_EMPTY || prev == key) break;
+        fresh = prev == SEED_EMPTY;
+        if (fresh || prev == key) break;
         s = (s + 1) & t.mask;
     }
-    if (t.present) {
+    if (t.present && fresh) {                        // (whoever creates the key's slot sets its presence bit)
         const u32 b = seed_hash2(key) & t.pmask;
         atomicOr(&t.present[b >> 5], 1u << (b & 31u));
     }
