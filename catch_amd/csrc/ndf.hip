@@ -457,8 +457,9 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
     PhaseTimer tm(ctx, PHASE_NDF);
     ctx->ndf_counters[0] = n; ctx->ndf_counters[1] = ntables; ctx->ndf_counters[2] = ctx->ndf_counters[3] = 0;
     const unsigned nb = (unsigned)div_up(nn, 256);
-    if ((i64)ntables * n < ((i64)1 << 32) && !getenv("CATCHHIP_NDF_ALL_PAIRS")) {
-        // lazy resolution (ndf_lazy_kernel): all tables' sorted runs stay resident, one cursor per (table, slot)
+    if ((i64)ntables * n <= ((i64)1 << 31) && !getenv("CATCHHIP_NDF_ALL_PAIRS")) {
+        // lazy resolution (ndf_lazy_kernel): all tables' sorted runs stay resident, one cursor per (table, slot) --
+        // 24 bytes per entry, at most 2^31 entries (48 GB); beyond that the edge-list variant below, table by table
         DevBuf<u64> skeys, pairs;
         DevBuf<u32> svals, cursor;
         const size_t tn = (size_t)ntables * nn;
@@ -839,8 +840,9 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
                        id_hi.p, id_lo.p, nuniq.p);
     tm.launch(1);
     ctx->ndf_counters[0] = n; ctx->ndf_counters[1] = ntables; ctx->ndf_counters[2] = ctx->ndf_counters[3] = 0;
-    if (tchunk >= ntables && (i64)ntables * n < ((i64)1 << 32) && !getenv("CATCHHIP_MH_ALL_PAIRS")) {
-        // lazy resolution (ndf_lazy_kernel): all tables' sorted runs stay resident, one cursor per (table, slot)
+    if (tchunk >= ntables && (i64)ntables * n <= ((i64)1 << 31) && !getenv("CATCHHIP_MH_ALL_PAIRS")) {
+        // lazy resolution (ndf_lazy_kernel): all tables' sorted runs stay resident, one cursor per (table, slot) --
+        // 24 bytes per entry, at most 2^31 entries (48 GB); beyond that the edge-list variant below, table by table
         DevBuf<u64> skeys, pairs;
         DevBuf<u32> svals, cursor;
         const size_t tn = (size_t)ntables * nn;
