@@ -108,6 +108,9 @@ PROTOTYPES = {
     "catchhip_sigs_create": (ctypes.c_int, [
         c_vp, c_u8p, c_u64p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_uint32,
         ctypes.c_uint32, ctypes.c_uint32, c_vpp]),
+    "catchhip_sigs_create_ptrs": (ctypes.c_int, [
+        c_vp, ctypes.c_void_p, c_i64p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_uint32,
+        ctypes.c_uint32, ctypes.c_uint32, c_vpp]),
     "catchhip_sigs_destroy": (None, [c_vp]),
     "catchhip_sigs_fetch": (ctypes.c_int, [c_vp, c_vp, c_u32p]),
     "catchhip_sigs_common_row": (ctypes.c_int, [

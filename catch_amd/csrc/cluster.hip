@@ -327,50 +327,57 @@ __global__ __launch_bounds__(256) void sig_fp_excess_kernel(const unsigned long 
     excess[seq] = N - set;
 }
 
-__global__ __launch_bounds__(64) void sig_neigh_many_kernel(const u32 *__restrict__ sig, const u32 *__restrict__ sigT,
-                                                            const unsigned long long *__restrict__ fpT,
-                                                            const u32 *__restrict__ excess, u32 nseq, u32 N,
-                                                            const u32 *__restrict__ js, u32 nq, u32 min_common,
-                                                            unsigned long long *__restrict__ out, u32 cap,
-                                                            u32 *__restrict__ count) {
+// 4 wavefronts per workgroup share its 64 targets: wavefront w takes the queries w, w + 4, ... (a target of a
+// large cluster is a neighbour of every query of a call, and the walks of one lane are a chain)
+#define NEIGH_WAVES 4
+__global__ __launch_bounds__(64 * NEIGH_WAVES) void sig_neigh_many_kernel(
+    const u32 *__restrict__ sig, const u32 *__restrict__ sigT, const unsigned long long *__restrict__ fpT,
+    const u32 *__restrict__ excess, u32 nseq, u32 N, const u32 *__restrict__ js, u32 nq, u32 min_common,
+    unsigned long long *__restrict__ out, u32 cap, u32 *__restrict__ count) {
     extern __shared__ u32 s_mem[];
     u32 *s_b = s_mem, *s_q = s_mem + (size_t)64 * N;   // s_b[i * 64 + lane], s_q[q * N + i]
     __shared__ unsigned long long s_qfp[NEIGH_MAXQ][NEIGH_FPW];
     __shared__ u32 s_qx[NEIGH_MAXQ];
-    const u32 kq = blockIdx.x * 64 + threadIdx.x;
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 kq = blockIdx.x * 64 + lane;
     const u32 kc = kq < nseq ? kq : nseq - 1;
-    for (u32 t = threadIdx.x; t < nq * NEIGH_FPW; t += 64) s_qfp[t / NEIGH_FPW][t % NEIGH_FPW] = fpT[(size_t)(t % NEIGH_FPW) * nseq + js[t / NEIGH_FPW]];
+    for (u32 t = threadIdx.x; t < nq * NEIGH_FPW; t += 64 * NEIGH_WAVES)
+        s_qfp[t / NEIGH_FPW][t % NEIGH_FPW] = fpT[(size_t)(t % NEIGH_FPW) * nseq + js[t / NEIGH_FPW]];
     if (threadIdx.x < nq) s_qx[threadIdx.x] = excess[js[threadIdx.x]];
     unsigned long long fp[NEIGH_FPW];
 #pragma unroll
     for (int w = 0; w < NEIGH_FPW; ++w) fp[w] = fpT[(size_t)w * nseq + kc];
     const u32 ex = excess[kc];
     __syncthreads();
-    u32 need = 0;                                      // the queries this target may be a neighbour of
-    for (u32 q = 0; q < nq; ++q) {
+    u32 need = 0;                                      // the queries (of this wavefront) this target may be a neighbour of
+    for (u32 q = wave; q < nq; q += NEIGH_WAVES) {
         u32 pc = 0;
 #pragma unroll
         for (int w = 0; w < NEIGH_FPW; ++w) pc += (u32)__popcll(fp[w] & s_qfp[q][w]);
         if (kq < nseq && pc + min(ex, s_qx[q]) >= min_common) need |= 1u << q;
     }
-    if (!__ballot(need != 0)) return;                  // (one wavefront per workgroup)
-    for (u32 i = 0; i < N; ++i) s_b[i * 64 + threadIdx.x] = sigT[(size_t)i * nseq + kc];
-    for (u32 t = threadIdx.x; t < nq * N; t += 64) s_q[t] = sig[(size_t)js[t / N] * N + (t % N)];
+    if (!__syncthreads_or(need != 0)) return;
+    for (u32 t = threadIdx.x; t < 64 * N; t += 64 * NEIGH_WAVES) {
+        const u32 i = t >> 6, l = t & 63;
+        const u32 kk = blockIdx.x * 64 + l;
+        s_b[t] = sigT[(size_t)i * nseq + (kk < nseq ? kk : nseq - 1)];
+    }
+    for (u32 t = threadIdx.x; t < nq * N; t += 64 * NEIGH_WAVES) s_q[t] = sig[(size_t)js[t / N] * N + (t % N)];
     __syncthreads();
-    for (u32 q = 0; q < nq; ++q) {
+    for (u32 q = wave; q < nq; q += NEIGH_WAVES) {
         if (!__ballot((need >> q) & 1u)) continue;
         const u32 *a = s_q + (size_t)q * N;
         u32 c = 0;
         if ((need >> q) & 1u)
-            c = walk_common(N, [&](u32 i) { return a[i]; }, [&](u32 i) { return s_b[i * 64 + threadIdx.x]; });
+            c = walk_common(N, [&](u32 i) { return a[i]; }, [&](u32 i) { return s_b[i * 64 + lane]; });
         const bool hit = c >= min_common && ((need >> q) & 1u);
         const unsigned long long b = __ballot(hit);
         if (!b) continue;
         u32 base = 0;
-        if (threadIdx.x == 0) base = atomicAdd(count, (u32)__popcll(b));
+        if (lane == 0) base = atomicAdd(count, (u32)__popcll(b));
         base = __shfl(base, 0, WAVE);
         if (hit) {
-            const u32 pos = base + (u32)__popcll(b & ((1ull << threadIdx.x) - 1ull));
+            const u32 pos = base + (u32)__popcll(b & ((1ull << lane) - 1ull));
             if (pos < cap) out[pos] = ((unsigned long long)q << 48) | ((unsigned long long)kq << 16) | (unsigned long long)c;
         }
     }
@@ -499,6 +506,43 @@ extern "C" int catchhip_sigs_fetch(catchhip_ctx *ctx, const catchhip_sigs *S, u3
     return 0;
 }
 
+// the sequences as one pointer per string (their own storage): gathered by host threads into pinned memory
+// instead of a multi-gigabyte join + encode in the interpreter (S5 x 1.0: 3.5 Gbases of fragments, 1.3 s)
+#include <memory>
+#include <new>
+#include <thread>
+extern "C" int catchhip_sigs_create_ptrs(catchhip_ctx *ctx, const u8 *const *seq_ptr, const i64 *seq_len, u32 nseq, i32 k,
+                                         u32 N, u32 a, u32 b, catchhip_sigs **out) {
+    ARG_CHECK(ctx && out && (nseq == 0 || (seq_ptr && seq_len)));
+    std::vector<u64> off((size_t)nseq + 1, 0);
+    for (u32 i = 0; i < nseq; ++i) {
+        ARG_CHECK(seq_len[i] >= 0 && (seq_len[i] == 0 || seq_ptr[i] != nullptr));
+        off[i + 1] = off[i] + (u64)seq_len[i];
+    }
+    const u64 total = off[nseq];
+    // (pageable: pinning gigabytes for one upload costs more than the staged copy does)
+    std::unique_ptr<u8[]> stage_mem(new (std::nothrow) u8[(size_t)total + 64]);
+    if (!stage_mem) { chip_set_error("signatures: no host memory for %llu bytes", (unsigned long long)total); return CATCHHIP_ENOMEM; }
+    u8 *stage = stage_mem.get();
+    const int nthreads = (int)std::max<u64>(1, std::min<u64>(16, total >> 21));
+    auto work = [&](int tix) {
+        const u64 lo = total * (u64)tix / (u64)nthreads, hi = total * (u64)(tix + 1) / (u64)nthreads;
+        size_t i = (size_t)(std::upper_bound(off.begin(), off.end(), lo) - off.begin());
+        i = i ? i - 1 : 0;
+        for (; i < nseq && off[i] < hi; ++i) {
+            if (off[i] < lo) continue;          // belongs to the previous slice
+            memcpy(stage + off[i], seq_ptr[i], (size_t)seq_len[i]);
+        }
+    };
+    if (nthreads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int tix = 0; tix < nthreads; ++tix) th.emplace_back(work, tix);
+        for (auto &t : th) t.join();
+    }
+    return catchhip_sigs_create(ctx, stage, off.data(), nseq, k, N, a, b, out);
+}
+
 extern "C" int catchhip_sigs_common_row(catchhip_ctx *ctx, const catchhip_sigs *S, u32 j, uint16_t *common) {
     ARG_CHECK(ctx && S && S->ctx == ctx && common && j < S->nseq);
     PoolScope pool_scope(ctx);
@@ -592,7 +636,7 @@ extern "C" int catchhip_sigs_neighbors_many(catchhip_ctx *ctx, const catchhip_si
         tm.launch(2);
         Sm->fp_ready = true;
     }
-    hipLaunchKernelGGL(sig_neigh_many_kernel, dim3((S->nseq + 63) / 64), dim3(64), sizeof(u32) * (64 + (size_t)nq) * S->N, st,
+    hipLaunchKernelGGL(sig_neigh_many_kernel, dim3((S->nseq + 63) / 64), dim3(64 * NEIGH_WAVES), sizeof(u32) * (64 + (size_t)nq) * S->N, st,
                        (const u32 *)S->sig.p, (const u32 *)S->sigT.p, (const unsigned long long *)Sm->fpT.p,
                        (const u32 *)Sm->fp_excess.p, S->nseq, S->N, (const u32 *)d_js.p, (u32)nq,
                        min_common, d.p, (u32)std::min<size_t>(dcap, 0xffffffffu), d_n.p);

@@ -686,6 +686,15 @@ class Signatures:
         self.ctx = ctx
         self.n = len(seqs)
         self.N = int(N)
+        self._h = ctypes.c_void_p()
+        ptrs = _str_pointers(seqs) if self.n else None
+        if ptrs is not None:
+            # one pointer per sequence: gathered by the library's host threads (no join + encode of gigabytes here)
+            arr, lens = ptrs
+            check(ctx._L.catchhip_sigs_create_ptrs(
+                ctx._h, ctypes.cast(arr, ctypes.c_void_p), _ptr(lens, c_i64p), self.n, int(kmer_size), self.N,
+                int(a), int(b), ctypes.byref(self._h)))
+            return
         try:
             raw = "".join(seqs).encode("ascii")
         except UnicodeEncodeError:

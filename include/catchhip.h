@@ -380,6 +380,11 @@ int catchhip_sigs_create(catchhip_ctx *ctx, const uint8_t *bytes,
                          const uint64_t *offsets, uint32_t nseq,
                          int32_t kmer_size, uint32_t N, uint32_t a, uint32_t b,
                          catchhip_sigs **out);
+/* The same with one pointer per sequence (the strings' own storage, e.g. CPython's ASCII str
+ * buffers): gathered by host threads into pinned memory -- no multi-gigabyte join on the caller's side. */
+int catchhip_sigs_create_ptrs(catchhip_ctx *ctx, const uint8_t *const *seq_ptr, const int64_t *seq_len,
+                              uint32_t nseq, int32_t k, uint32_t N, uint32_t a, uint32_t b,
+                              catchhip_sigs **out);
 void catchhip_sigs_destroy(catchhip_sigs *sigs);
 /* out[nseq * N]: signature of sequence s at out[s*N .. s*N+N) */
 int catchhip_sigs_fetch(catchhip_ctx *ctx, const catchhip_sigs *sigs,
