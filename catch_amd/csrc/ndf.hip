@@ -175,7 +175,6 @@ ndf_node_round_kernel(u32 *__restrict__ status, u32 *__restrict__ flags, u32 n, 
 #define NDF_CUR_NEAR 0x80000000u
 #define NDF_CUR_NONE 0xffffffffu
 #define NDF_OWN_STEPS 8
-#define NDF_SPINS 64         // looks of a waiting lane at its mate before the entry goes back to the list
 
 struct HammingFamily {       // ndf_near on the padded rows; the earlier tables' sampled positions lie k entries apart
     const u64 *padded;
@@ -206,15 +205,10 @@ template <class Family>
 __global__ void __launch_bounds__(256)
 ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *__restrict__ vals_all,
                 u32 *__restrict__ cursor_all, u32 *status, u32 *flags, unsigned long long *__restrict__ pairs,
-                const u32 *__restrict__ list, u32 nlist, u32 *__restrict__ next, u32 *__restrict__ next_count,
-                u32 *pending) {
-    // pending (or null): per probe the tables whose run prefix it has not exhausted yet.  With it nothing waits for
-    // a round to end: whoever exhausts a probe's last table keeps it on the spot, and a lane whose walk stops at
-    // an undecided near mate looks at that mate again a few times before it gives the entry back to the list --
-    // chains of decisions then resolve inside one launch as far as their links are resident at the same time.
+                const u32 *__restrict__ list, u32 nlist, u32 *__restrict__ next, u32 *__restrict__ next_count) {
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const volatile u32 *st = status;
-    bool again = false, walking = false, near_known = false, flagged = false;
+    bool again = false, walking = false, near_known = false;
     u32 e = 0, t = 0, x = 0, i = 0, y = 0, compared = 0, found = 0;
     u32 verdict = 0;                                 // 1 run exhausted, 2 dropped, 3 waits at y
     if (g < nlist) {
@@ -226,9 +220,7 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
         const u32 cur = cursor_all[e];
         if (st[i] == 0 && cur != x) {
             again = true;
-            const u32 fl = ((const volatile u32 *)flags)[i];
-            if (fl == 0 || (pending && fl == e + 1)) {   // (else: another table's cursor of this probe waits already)
-                flagged = pending && fl == e + 1;
+            if (((const volatile u32 *)flags)[i] == 0) {   // (else: waiting already in this round)
                 walking = true;
                 if (cur == NDF_CUR_NONE) {           // first visit: the first slot of the run
                     const u64 key = keys[x];
@@ -262,7 +254,6 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
         ++y;
         near_known = false;
     };
-  for (int spin = 0;; ++spin) {
     for (int step = 0; walking && !verdict && step < NDF_OWN_STEPS; ++step) {
         if (y >= x) verdict = 1; else examine();
     }
@@ -308,41 +299,12 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
             verdict = y >= x ? 1u : (hit_state == 1 ? 2u : 3u);
         }
     }
-    if (!pending) break;
-    // decisions are published at once ...
-    if (walking && verdict == 2) { status[i] = 2; __threadfence(); walking = false; again = false; }
-    if (walking && verdict == 1) {
-        cursor_all[e] = x;
-        if (atomicSub(&pending[i], 1u) == 1u) { status[i] = 1; __threadfence(); }   // its last table: kept
-        if (flagged) { (void)atomicCAS(&flags[i], e + 1, 0u); flagged = false; }    // (the probe's other cursors may walk now)
-        walking = false; again = false;
-    }
-    // ... and a waiting lane looks at its mate again: decided meanwhile -> the walk goes on
-    // (flags[i]: a cursor of probe i waits -- its other cursors leave their walks for later: most probes are
-    // dropped by the first near mate they meet, and what the other tables would have compared is never needed)
-    bool moved = false;
-    if (walking && verdict == 3) {
-        if (st[i] != 0) { walking = false; again = false; }                 // dropped through another table
-        else if (st[vals[y]] != 0) {
-            verdict = 0; near_known = true; moved = true;
-            if (flagged) { (void)atomicCAS(&flags[i], e + 1, 0u); flagged = false; }
-        } else if (!flagged && ((volatile u32 *)flags)[i] == 0) {
-            flagged = atomicCAS(&flags[i], 0u, e + 1) == 0u;                 // the one cursor of this probe that waits (it comes back as such)
-        }
-    }
-    if (!__ballot(walking)) break;                                          // nobody of this wavefront waits (or walks on)
-    if (!__ballot(moved)) {
-        if (spin >= NDF_SPINS) break;
-        __builtin_amdgcn_s_sleep(32);
-    }
-  }
-    if (walking && !pending) {
+    if (walking) {
         if (verdict == 2) { status[i] = 2; again = false; }
         else if (verdict == 3) flags[i] = 2;         // wait for the undecided mate at y
         else again = false;                          // this table has nothing more to say about i
         cursor_all[e] = verdict == 1 ? x : (y | NDF_CUR_NEAR);
     }
-    if (walking && pending) cursor_all[e] = y | NDF_CUR_NEAR;                // (still waiting at y)
     if (compared) atomicAdd(&pairs[(g >> 6) & (ES_SHARDS - 1)], (unsigned long long)compared);
     if (found) atomicAdd(&pairs[ES_SHARDS + ((g >> 6) & (ES_SHARDS - 1))], (unsigned long long)found);
     const unsigned long long bal = __ballot(again);
@@ -354,22 +316,11 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
     }
 }
 
-__global__ void __launch_bounds__(256)
-ndf_fill_kernel(u32 *p, u32 n, u32 v) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-static int chip_fill_u32(catchhip_ctx *ctx, u32 *p, u32 n, u32 v) {
-    hipLaunchKernelGGL(ndf_fill_kernel, dim3((unsigned)div_up((i64)n, 256)), dim3(256), 0, ctx->stream, p, n, v);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 // the rounds of the lazy resolution and the read-back (both families): launch(list or nullptr, nlist, next,
 // next_count) queues one pass over the listed entries
 template <class Launch>
 static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &count, DevBuf<u32> &status, DevBuf<u32> &flags,
-                           DevBuf<u64> &pairs, PhaseTimer &tm, u8 *keep, Launch launch, bool pending = false) {
+                           DevBuf<u64> &pairs, PhaseTimer &tm, u8 *keep, Launch launch) {
     hipStream_t s = ctx->stream;
     const unsigned nb = (unsigned)div_up(nn, 256);
     u32 *undecided = count.p + ES_SHARDS * ES_STRIDE;     // [0] undecided probes, [1] entries listed for the next round
@@ -379,10 +330,10 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
     u32 left = nn, nlist = (u32)tn;
     const bool trace = getenv("CATCHHIP_TIMING") && atoi(getenv("CATCHHIP_TIMING")) > 1;
     auto t_round = std::chrono::steady_clock::now();
-    for (u32 round = 0; (pending ? nlist : left) && round <= nn + 1; ++round) {
+    for (u32 round = 0; left && round <= nn + 1; ++round) {
         HIP_TRY(hipMemsetAsync(undecided, 0, 2 * sizeof(u32), s));
         if (nlist) launch(round ? (const u32 *)lists[round & 1].p : (const u32 *)nullptr, nlist, lists[(round & 1) ^ 1].p, undecided + 1);
-        if (!pending) hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, undecided);
+        hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, undecided);
         tm.launch(2);
         HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -527,16 +478,12 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
             tm.launch(1 + 24 + 2);
         }
         HammingFamily fam{(const u64 *)padded.p, W, (int)dist_thres, (int)k, (const i32 *)d_pos.p, d_grp, pstride, ntables >= 4 ? 1 : 0};
-        DevBuf<u32> pending;
-        const bool async = !getenv("CATCHHIP_NDF_SYNC_ROUNDS");
-        if (async) { TRY(pending.alloc(nn)); TRY(chip_fill_u32(ctx, pending.p, nn, (u32)ntables)); }
-        u32 *pend = async ? pending.p : (u32 *)nullptr;
         return ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
                                [&](const u32 *list, u32 nlist, u32 *next, u32 *next_count) {
             hipLaunchKernelGGL(ndf_lazy_kernel<HammingFamily>, dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s, fam, nn,
                                (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                               (unsigned long long *)pairs.p, list, nlist, next, next_count, pend);
-        }, async);
+                               (unsigned long long *)pairs.p, list, nlist, next, next_count);
+        });
     }
     u32 cap = (u32)std::max<i64>((i64)1 << 14, std::min<i64>(n * 16, (i64)1 << 28) / ES_SHARDS);   // per shard
     u32 ne = 0;
@@ -931,16 +878,12 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
         lap("signatures + sorts", t_lap);
         MinHashFamily fam{(const u32 *)d_koff.p, (const u32 *)nuniq.p, (const u64 *)id_hi.p, (const u64 *)id_lo.p, (const u32 *)sig.p,
                           (int)k, dist_thres, nn, grp};
-        DevBuf<u32> pending;
-        const bool async = !getenv("CATCHHIP_NDF_SYNC_ROUNDS");
-        if (async) { TRY(pending.alloc(nn)); TRY(chip_fill_u32(ctx, pending.p, nn, (u32)ntables)); }
-        u32 *pend = async ? pending.p : (u32 *)nullptr;
         const int rc = ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
                                        [&](const u32 *list, u32 nlist, u32 *next, u32 *next_count) {
             hipLaunchKernelGGL(ndf_lazy_kernel<MinHashFamily>, dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s, fam, nn,
                                (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                               (unsigned long long *)pairs.p, list, nlist, next, next_count, pend);
-        }, async);
+                               (unsigned long long *)pairs.p, list, nlist, next, next_count);
+        });
         lap("rounds", t_lap);
         return rc;
     }
