@@ -35,7 +35,8 @@
 
 __global__ void __launch_bounds__(256)
 ndf_key_kernel(const u8 *__restrict__ bytes, u32 n, int L, const i32 *__restrict__ pos, int k,
-               u64 *__restrict__ keys, u32 *__restrict__ vals, const u32 *__restrict__ grp, size_t pos_group_stride) {
+               u64 *__restrict__ keys, u32 *__restrict__ vals, const u32 *__restrict__ grp, size_t pos_group_stride,
+               int key_shift = 0) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u8 *p = bytes + (size_t)i * L;
@@ -45,7 +46,7 @@ ndf_key_kernel(const u8 *__restrict__ bytes, u32 n, int L, const i32 *__restrict
         h = (h ^ (u64)grp[i]) * 0x100000001b3ull;
     }
     for (int j = 0; j < k; ++j) h = (h ^ (u64)p[pos[j]]) * 0x100000001b3ull;
-    keys[i] = h;
+    keys[i] = h >> key_shift;     // (the key only groups: the lazy resolution sorts its upper 32 bits, half the radix passes)
     vals[i] = i;
 }
 
@@ -471,8 +472,8 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
         HIP_TRY(hipMemsetAsync(pairs.p, 0, sizeof(u64) * 2 * ES_SHARDS, s));
         for (int t = 0; t < ntables; ++t) {
             hipLaunchKernelGGL(ndf_key_kernel, dim3(nb), dim3(256), 0, s, d_bytes.p, nn, (int)L,
-                               d_pos.p + (size_t)t * k, (int)k, keys.p, vals.p, d_grp, pstride);
-            TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nn, 64));
+                               d_pos.p + (size_t)t * k, (int)k, keys.p, vals.p, d_grp, pstride, 32);
+            TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nn, 32));
             HIP_TRY(hipMemcpyAsync(skeys.p + (size_t)t * nn, keys.p, sizeof(u64) * nn, hipMemcpyDeviceToDevice, s));
             HIP_TRY(hipMemcpyAsync(svals.p + (size_t)t * nn, vals.p, sizeof(u32) * nn, hipMemcpyDeviceToDevice, s));
             tm.launch(1 + 24 + 2);
@@ -656,10 +657,10 @@ mh_keys_all_kernel(const u32 *__restrict__ xs, const u32 *__restrict__ koff, u32
 }
 
 __global__ void __launch_bounds__(256)
-mh_table_kernel(const u64 *__restrict__ keys_all, u32 n, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+mh_table_kernel(const u64 *__restrict__ keys_all, u32 n, u64 *__restrict__ keys, u32 *__restrict__ vals, int key_shift = 0) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    keys[i] = keys_all[i];
+    keys[i] = keys_all[i] >> key_shift;
     vals[i] = i;
 }
 
@@ -869,8 +870,8 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
         tm.launch(1);
         for (int t = 0; t < ntables; ++t) {
             hipLaunchKernelGGL(mh_table_kernel, dim3(nb), dim3(256), 0, s, (const u64 *)(keys_all.p + (size_t)t * nn), nn,
-                               keys.p, vals.p);
-            TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nn, 64));
+                               keys.p, vals.p, 32);
+            TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nn, 32));
             HIP_TRY(hipMemcpyAsync(skeys.p + (size_t)t * nn, keys.p, sizeof(u64) * nn, hipMemcpyDeviceToDevice, s));
             HIP_TRY(hipMemcpyAsync(svals.p + (size_t)t * nn, vals.p, sizeof(u32) * nn, hipMemcpyDeviceToDevice, s));
             tm.launch(1 + 24 + 2);
