@@ -87,6 +87,41 @@ class ResidentGroup:
         self.targets.close()
 
 
+class ResidentUnion:
+    """Several small groups as ONE instance: targets / candidates / probes that carry group numbers (duplicates are
+    removed inside a group only, the scan pairs a probe with its own group's genomes only, and one solve over the
+    disjoint union makes every group's own picks in its own order) -- what SetCoverFilter does for the clusters of
+    a clustered design and, in its default path, for groups below CATCHHIP_UNION_SMALL_BELOW_MBASES.  A group of a
+    few Mbases is a chain of ~60 launches of microseconds each; seventeen such groups one after the other are
+    seventeen chains, their union is one."""
+
+    def __init__(self, ctx, indices, groups):
+        self.ctx, self.indices = ctx, list(indices)
+        self.index = "union of groups %s" % self.indices
+        genomes = [g for i in self.indices for g in groups[i]]
+        self.targets = engine.Targets(ctx, genomes)
+        self.targets.set_groups(np.repeat(np.arange(len(self.indices)), [len(groups[i]) for i in self.indices]))
+        self.cands = engine.Candidates(ctx, self.targets, PROBE_LEN, STRIDE)
+        k, ep, eo = probe.anchor_entries_equal_length(self.cands.n, PROBE_LEN, MISMATCHES, PROBE_LEN)
+        self.probes = self.cands.probes(k, ep, eo)
+        self.n_sets = self.cands.n
+        self.cgrp = self.cands.groups()
+        self.first = np.concatenate([[0], np.cumsum(np.bincount(self.cgrp, minlength=len(self.indices)))])
+
+    def run(self):
+        """-> ({group index: its pick ids, counted from the group's first candidate}, rows)"""
+        ids, nrows = engine.setcover_filter(self.ctx, self.probes, self.targets, MISMATCHES, PROBE_LEN, 0, EXT,
+                                            self.n_sets, mode=SCAN_MODE)
+        ids = np.asarray(ids, dtype=np.int64)
+        grp = self.cgrp[ids]
+        return {gi: (ids[grp == m] - self.first[m]).tolist() for m, gi in enumerate(self.indices)}, nrows
+
+    def close(self):
+        self.probes.close()
+        self.cands.close()
+        self.targets.close()
+
+
 class NdfGroup(ResidentGroup):
     """configs[2] (`--filter-with-lsh-hamming 2`): the targets are resident; a
     step = device front end (candidate windows + exact de-duplication) ->
@@ -193,6 +228,7 @@ class Stepper:
     kernels of large groups only get in each other's way (seed_lookup went
     from 0.6-8 ms to 12 ms per launch with four S4 groups in flight)."""
     BIG_BASES = int(os.environ.get("CATCHHIP_BENCH_BIG_BASES", str(8_000_000)))
+    UNION_BELOW = int(float(os.environ.get("CATCHHIP_BENCH_UNION_BELOW_MBASES", "32")) * 1e6)
     ndf = False        # configs[2]: the Hamming near-duplicate filter is part of the step
 
     def __init__(self, device, groups, indices, width):
@@ -208,6 +244,14 @@ class Stepper:
         lanes = parallel.lpt_assign([sizes[i] for i in small], self.width)
         self.lanes = [[Group(self.ctxs[w], small[j], groups[small[j]])
                        for j in lane] for w, lane in enumerate(lanes)]
+        # the groups below UNION_BELOW bases as one instance (ResidentUnion); their own resident objects stay
+        # for the passes that go group by group (-c 0.9, the CPU sample, the overlapped-groups figure)
+        mid = [g for g in self.big if sizes[g.index] < self.UNION_BELOW]
+        members = sorted([g.index for g in mid] + small)
+        self.union = None
+        if not self.ndf and self.UNION_BELOW > 0 and len(members) >= 2:
+            self.union = ResidentUnion(self.ctxs[0], members, groups)
+            self.big_alone = [g for g in self.big if sizes[g.index] >= self.UNION_BELOW]
         for c in self.ctxs:
             c.sync()
         self.pool = (concurrent.futures.ThreadPoolExecutor(self.width)
@@ -225,6 +269,13 @@ class Stepper:
 
     def step(self, stats=None):
         """One pass over every group of this rank -> {group index: pick ids}."""
+        if self.union is not None:
+            out = dict(self._run_lane(self.big_alone, stats))
+            per_group, nrows = self.union.run()
+            out.update(per_group)
+            if stats is not None:
+                self._collect(self.union, [i for ids in per_group.values() for i in ids], nrows, stats)
+            return out
         out = dict(self._run_lane(self.big, stats))
         small = [g for lane in self.lanes for g in lane]
         if len(small) > 1 and len(small) <= self.width and not self.ndf:
@@ -277,6 +328,8 @@ class Stepper:
     def close(self):
         for g in self.resident:
             g.close()
+        if self.union is not None:
+            self.union.close()
         if self.pool is not None:
             self.pool.shutdown()
 
@@ -764,7 +817,8 @@ def main():
                                  launches=max(nlaunch["claim_launches"], 1) / K, pmc="gr_claim"),
             "rows_build": dict(kernel="bucketed row build (per group: scatter, merge, scans, emit)",
                                ms=ms["rows_ms"], bytes=rows_bytes,
-                               launches=float(len(stepper.resident)), pmc="rows_build"),
+                               launches=float(len(stepper.big_alone) + 1 if stepper.union is not None else len(stepper.resident)),
+                               pmc="rows_build"),
         }
         # The dominant KERNEL by its own HIP-event timer: the seed-verify launch (phase 5), the claim launches of
         # the row-parallel solver (phase 6: an event pair per launch), or -- several kernels, priced by the
@@ -803,7 +857,12 @@ def main():
                                 "ranks, longest first (no collective)",
                        "sharded_groups": list(sharded_idx),
                        "groups_on_rank0": [g.index for g in stepper.resident],
-                       "groups_in_flight": stepper.width, "scale": args.scale},
+                       "groups_in_flight": stepper.width, "scale": args.scale,
+                       "one_instance": (stepper.union.indices if stepper.union is not None else []),
+                       "one_instance_note": "the groups below %g Mbases are scanned and solved as ONE instance (targets / "
+                                            "candidates / probes that carry group numbers); every group's picks and "
+                                            "their order are its own and are checked against its own digests"
+                                            % (Stepper.UNION_BELOW / 1e6)},
             "setcoverfilter_ms": elapsed / K * 1e3,
             "picks": per.get("picks", 0), "rows": rows,
             "kernel_ms_per_step": {"k1_scan": ms["scan_ms"], "k1_seed_verify": ms["verify_ms"],
@@ -958,6 +1017,7 @@ def main():
                                        "note": "one pass over the resident groups, groups one after the other; digests "
                                                "are of the picks in pick order"}
         if world == 1 and not args.no_m2 and not Stepper.ndf:
+            engine.pool_trim()        # (the resident passes' cached blocks: the passes below allocate on other contexts)
             # M2: from host strings to ids on the host, nothing resident, through the
             # plugin's pipelined path; then one pass without the overlap for comparison
             tm2, picks_m2 = m2_passes(groups, args.m2_steps, 1, int(os.environ.get("CATCHHIP_PREFETCH_DEPTH", "2")))
@@ -979,7 +1039,9 @@ def main():
             # the line above keeps the large groups one after the other.
             stepper.close()
             stepper = None
+            engine.pool_trim()
             Stepper.BIG_BASES = 1 << 62
+            Stepper.UNION_BELOW = 0               # (every group on its own, three at a time)
             st2 = Stepper(device, groups, mine, 3)
             st2.sync()
             for _ in range(2):

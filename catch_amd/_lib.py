@@ -30,6 +30,7 @@ PROTOTYPES = {
     "catchhip_ctx_destroy": (ctypes.c_int, [c_vp]),
     "catchhip_ctx_sync": (ctypes.c_int, [c_vp]),
     "catchhip_pool_stats": (ctypes.c_int, [c_i64p]),
+    "catchhip_pool_trim": (ctypes.c_int, []),
     "catchhip_ctx_last_kernel_ms": (ctypes.c_int, [
         c_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), c_i64p]),
     "catchhip_ctx_last_counters": (ctypes.c_int, [c_vp, c_i64p]),

@@ -175,6 +175,19 @@ void chip_pool_release_owner(const void *owner) {
     }
 }
 
+// every idle block of every context back to the driver (after the device has finished: queued work may still
+// read them) -- between phases of a long-running process whose next phase allocates differently
+extern "C" int catchhip_pool_trim(void) {
+    HIP_TRY(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto it = g_pool_free.begin(); it != g_pool_free.end(); it = g_pool_free.erase(it)) {
+        (void)hipFree(it->second);
+        g_pool_stats[1] -= (long long)it->first.second;
+        g_pool_stats[2] -= (long long)it->first.second;
+    }
+    return 0;
+}
+
 extern "C" int catchhip_pool_stats(int64_t *out4) {
     ARG_CHECK(out4 != nullptr);
     std::lock_guard<std::mutex> lk(g_pool_mu);

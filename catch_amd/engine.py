@@ -86,6 +86,11 @@ def device_count():
     return n.value if rc == 0 else 0
 
 
+def pool_trim():
+    """catchhip_pool_trim: idle cached device blocks go back to the driver."""
+    check(_lib.lib().catchhip_pool_trim())
+
+
 def pool_stats():
     """catchhip_pool_stats -> dict (device-memory cache of the library)."""
     out = np.zeros(4, dtype=np.int64)

@@ -481,6 +481,33 @@ class SetCoverFilter(BaseFilter):
         # functions from `random` group after group)
         keep_input_order = not (near_duplicate_filter is None and not probe.anchors_use_random(
             ["A" * probe_length], self.mismatches, self.lcf_thres, self.kmer_probe_map_k))
+        # Small groups as ONE instance (as _filter_genomes_device_union does for the clusters of a clustered
+        # design): a group of a few Mbases is a chain of ~60 launches that the GPU finishes in microseconds
+        # each, and ten such groups one after the other are ten chains -- their union is one (S4 with resident inputs, the 17
+        # groups below 32 Mbases: 69.6 -> 60.4 ms; from host strings with three lanes the groups below 16 Mbases:
+        # 0.182 -> 0.178 s per pass, while a union of 247 Mbases unbalances the lanes: 0.30 s -- hence the default;
+        # every group's picks and their order are its own: test_union_of_groups_equals_per_group).  Only without random numbers in the building of a group
+        # (the draws of a union would come in another order than group by group).  An "item" below is a list of
+        # group numbers: one group, or the groups of a union.
+        union_below = int(float(os.environ.get("CATCHHIP_UNION_SMALL_BELOW_MBASES", "16")) * 1e6)
+        items = {}
+        if not keep_input_order and union_below > 0:
+            small = [i for i in todo if sizes[i] < union_below]
+            at = 0
+            while len(small) - at >= 2:
+                take, b = [], 0
+                while at < len(small) and (not take or b + sizes[small[at]] <= 300_000_000):
+                    take.append(small[at])
+                    b += sizes[small[at]]
+                    at += 1
+                if len(take) < 2:
+                    break
+                key = take[0]                         # an item goes by its first group's number
+                items[key] = take
+                sizes[key] = b
+                todo = [i for i in todo if i not in take[1:]]
+        for i in todo:
+            items.setdefault(i, [i])
         if not keep_input_order:
             todo.sort(key=lambda i: (-sizes[i], i))
             chunks = _chunks_by_size(todo, lambda gi: sizes[gi], width)
@@ -496,19 +523,31 @@ class SetCoverFilter(BaseFilter):
         depth = int(os.environ.get("CATCHHIP_PREFETCH_DEPTH", "2"))
         order = [gi for chunk in chunks for gi in chunk]
 
+        def genomes_of(gi):
+            return [g for member in items[gi] for g in target_genomes_grouped[member]]
+
+        def universe_p_of(gi):
+            return [p for member in items[gi] for p in self._make_universe_p(target_genomes_grouped[member])]
+
         def build(gi, ctx=None):
             uctx = ctx or engine.upload_context()
-            target_genomes = target_genomes_grouped[gi]
+            target_genomes = genomes_of(gi)
             made = []
             try:
                 targets = engine.Targets(uctx, [g.seqs for g in target_genomes])
                 made.append(targets)
+                if len(items[gi]) > 1:
+                    targets.set_groups(np.repeat(np.arange(len(items[gi])),
+                                                 [len(target_genomes_grouped[member]) for member in items[gi]]))
                 cands = engine.Candidates(uctx, targets, probe_length,
                                           probe_stride, seq_length_to_skip)
                 made.append(cands)
                 ncand, nuniq = cands.ncandidates, cands.n
                 if near_duplicate_filter is not None:
-                    near_duplicate_filter._apply_to_candidates(cands)
+                    if len(items[gi]) > 1:
+                        near_duplicate_filter._apply_to_grouped_candidates(cands, len(items[gi]))
+                    else:
+                        near_duplicate_filter._apply_to_candidates(cands)
                 k, ep, eo = probe.anchor_entries_equal_length(
                     cands.n, probe_length, self.mismatches, self.lcf_thres,
                     min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
@@ -543,25 +582,41 @@ class SetCoverFilter(BaseFilter):
             feed = iter(pre)
 
         def finish(ctx, gi, targets, cands, probes, ncand, nuniq, ids, nrows, lock=None):
-            """A group's result into out / timings (lock: several lanes finish groups at once)."""
-            target_genomes = target_genomes_grouped[gi]
+            """An item's result into out / timings (lock: several lanes finish groups at once)."""
+            members = items[gi]
+            target_genomes = genomes_of(gi)
+            ids_arr = np.asarray(ids, dtype=np.int64)
             if return_ids:
                 res = ids
             else:
                 seqs = [s for g in target_genomes for s in g.seqs]
-                pos = cands.positions(np.asarray(ids, dtype=np.int64))
+                pos = cands.positions(ids_arr)
                 which = np.searchsorted(targets.seq_off, pos, side="right") - 1
                 local = pos - targets.seq_off[which]
                 res = [seqs[q][o:o + probe_length]
                        for q, o in zip(which.tolist(), local.tolist())]
+            if len(members) > 1:
+                # a union: every group's own picks, in its own order; ids count from the group's first candidate
+                cgrp = cands.groups()
+                per_group = np.bincount(cgrp, minlength=len(members))
+                first = np.concatenate([[0], np.cumsum(per_group)])
+                pick_grp = cgrp[ids_arr] if ids_arr.size else np.zeros(0, dtype=np.int64)
+                parts, units = [], 0.0
+                for m, member in enumerate(members):
+                    sel = np.nonzero(pick_grp == m)[0]
+                    parts.append((ids_arr[sel] - first[m]).tolist() if return_ids else [res[q] for q in sel.tolist()])
+                    units += float(per_group[m]) * float(sum(g.size() for g in target_genomes_grouped[member]))
+            else:
+                parts = [res]
+                units = float(cands.n) * float(sum(g.size() for g in target_genomes))
             if lock is not None:
                 lock.acquire()
             try:
-                out[gi] = res
+                for member, part in zip(members, parts):
+                    out[member] = part
                 timings["candidates"] += ncand
                 timings["unique_candidates"] += nuniq
-                timings["probe_bp_units"] = timings.get("probe_bp_units", 0.0) + float(cands.n) * float(
-                    sum(g.size() for g in target_genomes))
+                timings["probe_bp_units"] = timings.get("probe_bp_units", 0.0) + units
                 _accumulate(timings, ctx, nrows, len(ids))
             finally:
                 if lock is not None:
@@ -628,7 +683,7 @@ class SetCoverFilter(BaseFilter):
                             ids, nrows = engine.setcover_filter(
                                 ctx, probes, targets, self.mismatches, self.lcf_thres,
                                 self.island_of_exact_match, self.cover_extension, cands.n, None,
-                                self._make_universe_p(target_genomes_grouped[gi]), self.scan_mode)
+                                universe_p_of(gi), self.scan_mode)
                             finish(ctx, gi, targets, cands, probes, ncand, nuniq, ids, nrows, res_lock)
                         except BaseException as exc:
                             with cv:
@@ -663,7 +718,6 @@ class SetCoverFilter(BaseFilter):
                     specs, held, built = [], [], []
                     try:
                         for ctx, gi in zip(ctxs, chunk):
-                            target_genomes = target_genomes_grouped[gi]
                             if feed is not None:
                                 got, res = next(feed)
                                 assert got == gi
@@ -678,8 +732,7 @@ class SetCoverFilter(BaseFilter):
                             if cands.n == 0:
                                 logger.warning("There are no candidate probes for a "
                                                "grouping of genomes")
-                            specs.append((ctx, probes, targets, cands.n, None,
-                                          self._make_universe_p(target_genomes)))
+                            specs.append((ctx, probes, targets, cands.n, None, universe_p_of(gi)))
                         results = engine.setcover_filter_many(
                             specs, self.mismatches, self.lcf_thres,
                             self.island_of_exact_match, self.cover_extension,

@@ -56,6 +56,10 @@ int catchhip_ctx_sync(catchhip_ctx *ctx);
  * counterpart (the reference keeps its working set in Python objects); the bench
  * reports it so that a step that allocates is visible. */
 int catchhip_pool_stats(int64_t *out4);
+/* Returns every idle cached block (of every context of the calling process's current device) to the
+ * driver, after a device synchronisation.  For the seams of a long-running process whose next
+ * phase allocates differently (the cache is keyed by context and size class). */
+int catchhip_pool_trim(void);
 /* Elapsed GPU milliseconds spent in the kernels of the most recent call of
  * the named phase (HIP events on the context's stream).  phase: 0 = cover
  * scan kernels (K1 hit search), 1 = row build (sort/merge), 2 = greedy
