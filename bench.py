@@ -990,11 +990,20 @@ def main():
             # the same resident groups under -c 0.9 (partial coverage): frontier rounds with the universe
             # test; digests of the picks in order against the committed ones
             def c09_pass(collect):
+                # (the same instances as the timed step: the large groups one by one, the small ones as their union)
                 out09, st09 = {}, dict(greedy_ms=0.0, rounds=0, picks=0)
-                for g in stepper.resident:
+                u = stepper.union
+                for g in (stepper.big_alone + [u] if u is not None else stepper.resident):
+                    ngen = g.n_genomes if g is not u else int(g.targets.ngenomes)
                     ids, _ = engine.setcover_filter(g.ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN, 0, EXT, g.n_sets,
-                                                    universe_p=[0.9] * g.n_genomes, mode=SCAN_MODE)
-                    out09[g.index] = ids
+                                                    universe_p=[0.9] * ngen, mode=SCAN_MODE)
+                    if g is u:
+                        ids_a = np.asarray(ids, dtype=np.int64)
+                        grp = u.cgrp[ids_a]
+                        for m, gi in enumerate(u.indices):
+                            out09[gi] = (ids_a[grp == m] - u.first[m]).tolist()
+                    else:
+                        out09[g.index] = ids
                     if collect:
                         st09["greedy_ms"] += g.ctx.kernel_ms(engine.PHASE_GREEDY)[0]
                         st09["rounds"] += g.ctx.counters()["greedy_iters"]
@@ -1014,8 +1023,9 @@ def main():
             out["partial_coverage"] = {"coverage": 0.9, "ms_per_step": el9 * 1e3, "k2_greedy_ms": st09["greedy_ms"],
                                        "k2_greedy_ms_full_coverage": ms["greedy_ms"], "rounds": st09["rounds"],
                                        "picks": st09["picks"], "parity_vs_golden_digests": ok9,
-                                       "note": "one pass over the resident groups, groups one after the other; digests "
-                                               "are of the picks in pick order"}
+                                       "note": "one pass over the resident instances of the timed step (large groups one after "
+                                               "the other, the small ones as one instance); digests are of every group's "
+                                               "picks in its own pick order"}
         if world == 1 and not args.no_m2 and not Stepper.ndf:
             engine.pool_trim()        # (the resident passes' cached blocks: the passes below allocate on other contexts)
             # M2: from host strings to ids on the host, nothing resident, through the
