@@ -112,9 +112,17 @@ class ResidentUnion:
         """-> ({group index: its pick ids, counted from the group's first candidate}, rows)"""
         ids, nrows = engine.setcover_filter(self.ctx, self.probes, self.targets, MISMATCHES, PROBE_LEN, 0, EXT,
                                             self.n_sets, mode=SCAN_MODE)
+        return self.split(ids), nrows
+
+    def split(self, ids):
+        """The union's picks -> {group index: that group's picks, in their order, counted from its first candidate}."""
         ids = np.asarray(ids, dtype=np.int64)
         grp = self.cgrp[ids]
-        return {gi: (ids[grp == m] - self.first[m]).tolist() for m, gi in enumerate(self.indices)}, nrows
+        order = np.argsort(grp, kind="stable")            # (one stable sort instead of a mask per group)
+        g_sorted = grp[order]
+        local = (ids[order] - self.first[g_sorted]).tolist()
+        bounds = np.searchsorted(g_sorted, np.arange(len(self.indices) + 1)).tolist()
+        return {gi: local[bounds[m]:bounds[m + 1]] for m, gi in enumerate(self.indices)}
 
     def close(self):
         self.probes.close()
@@ -998,10 +1006,7 @@ def main():
                     ids, _ = engine.setcover_filter(g.ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN, 0, EXT, g.n_sets,
                                                     universe_p=[0.9] * ngen, mode=SCAN_MODE)
                     if g is u:
-                        ids_a = np.asarray(ids, dtype=np.int64)
-                        grp = u.cgrp[ids_a]
-                        for m, gi in enumerate(u.indices):
-                            out09[gi] = (ids_a[grp == m] - u.first[m]).tolist()
+                        out09.update(u.split(ids))
                     else:
                         out09[g.index] = ids
                     if collect:

@@ -601,10 +601,13 @@ class SetCoverFilter(BaseFilter):
                 per_group = np.bincount(cgrp, minlength=len(members))
                 first = np.concatenate([[0], np.cumsum(per_group)])
                 pick_grp = cgrp[ids_arr] if ids_arr.size else np.zeros(0, dtype=np.int64)
+                sel = np.argsort(pick_grp, kind="stable")          # (every group's picks together, in their order)
+                g_sorted = pick_grp[sel]
+                bounds = np.searchsorted(g_sorted, np.arange(len(members) + 1)).tolist()
+                local = (ids_arr[sel] - first[g_sorted]).tolist() if return_ids else [res[q] for q in sel.tolist()]
                 parts, units = [], 0.0
                 for m, member in enumerate(members):
-                    sel = np.nonzero(pick_grp == m)[0]
-                    parts.append((ids_arr[sel] - first[m]).tolist() if return_ids else [res[q] for q in sel.tolist()])
+                    parts.append(local[bounds[m]:bounds[m + 1]])
                     units += float(per_group[m]) * float(sum(g.size() for g in target_genomes_grouped[member]))
             else:
                 parts = [res]
