@@ -1037,7 +1037,7 @@ def main():
             # plugin's pipelined path; then one pass without the overlap for comparison
             tm2, picks_m2 = m2_passes(groups, args.m2_steps, 1, int(os.environ.get("CATCHHIP_PREFETCH_DEPTH", "2")))
             m2 = sum(tm2) / len(tm2)
-            ts2, picks_s2 = m2_passes(groups, 1, 0, 0)
+            ts2, picks_s2 = m2_passes(groups, 1, 1, 0)     # (one warm pass: its contexts' blocks were returned by the trim above)
             out["m2_setcoverfilter_wall_s"] = m2
             out["m2_steps_s"] = tm2
             out["m2_serial_wall_s"] = ts2[0]
