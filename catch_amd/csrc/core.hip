@@ -279,7 +279,7 @@ extern "C" int catchhip_ctx_sync(catchhip_ctx *c) {
 
 extern "C" int catchhip_ctx_last_kernel_ms(catchhip_ctx *c, int phase, double *ms, i64 *launches) {
     ARG_CHECK(c != nullptr && phase >= 0 && phase < NPHASE);
-    if (phase == PHASE_VERIFY && c->phase_launches[phase]) chip_phase_collect(c, phase);   // recorded inside the scan phase
+    if ((phase == PHASE_VERIFY || phase == PHASE_VCOUNT) && c->phase_launches[phase]) chip_phase_collect(c, phase);   // recorded inside the scan phase
     if (ms) *ms = c->phase_ms[phase];
     if (launches) *launches = c->phase_launches[phase];
     return 0;

@@ -98,7 +98,7 @@ template <typename T> struct DevBuf {
 };
 
 enum { PHASE_SCAN = 0, PHASE_ROWS = 1, PHASE_GREEDY = 2, PHASE_NDF = 3, PHASE_GREEDY_ROUNDS = 4, PHASE_VERIFY = 5,
-       PHASE_CLAIM = 6, NPHASE = 7 };
+       PHASE_CLAIM = 6, PHASE_VCOUNT = 7, NPHASE = 8 };
 #define CHIP_EVX 16   // event pairs for per-launch timing inside a batch of solver rounds (PHASE_CLAIM)
 
 struct catchhip_ctx {
@@ -273,10 +273,10 @@ struct PhaseTimer {
 // if total != nullptr, *total (device u64) receives the grand total.
 int chip_exclusive_scan_u32(catchhip_ctx *ctx, const u32 *in, u32 *out, i64 n,
                             DevBuf<u32> &tmp);
-// LSD radix sort of (u64 key, u32 value) pairs on bits [0, key_bits).
+// Stable LSD radix sort of (u64 key, u32 value) pairs on bits [first_bit, first_bit + key_bits).
 // Result ends in keys/vals (the alt buffers are scratch of the same size).
 int chip_radix_sort_pairs(catchhip_ctx *ctx, DevBuf<u64> &keys, DevBuf<u64> &keys_alt,
-                          DevBuf<u32> &vals, DevBuf<u32> &vals_alt, i64 n, int key_bits);
+                          DevBuf<u32> &vals, DevBuf<u32> &vals_alt, i64 n, int key_bits, int first_bit = 0);
 
 // v mod (2^31 - 1) for v < 2^63 without a 64-bit division: 2^31 = 1 (mod p),
 // so the 31-bit digits of v add up (two folds leave at most p + 1)

@@ -178,7 +178,7 @@ radix_scatter(const u64 *__restrict__ keys_in, const u32 *__restrict__ vals_in,
 }
 
 int chip_radix_sort_pairs(catchhip_ctx *ctx, DevBuf<u64> &keys, DevBuf<u64> &keys_alt,
-                          DevBuf<u32> &vals, DevBuf<u32> &vals_alt, i64 n, int key_bits) {
+                          DevBuf<u32> &vals, DevBuf<u32> &vals_alt, i64 n, int key_bits, int first_bit) {
     if (n <= 1) return 0;
     if (n >= ((i64)1 << 32)) {
         chip_set_error("radix sort: n too large");
@@ -192,7 +192,7 @@ int chip_radix_sort_pairs(catchhip_ctx *ctx, DevBuf<u64> &keys, DevBuf<u64> &key
     int passes = (key_bits + 7) / 8;
     if (passes < 1) passes = 1;
     for (int p = 0; p < passes; ++p) {
-        int shift = 8 * p;
+        int shift = first_bit + 8 * p;
         hipLaunchKernelGGL(radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys.p, n,
                            shift, hist.p, nblocks);
         TRY(chip_exclusive_scan_u32(ctx, hist.p, hist.p, (i64)256 * nblocks, tmp));

@@ -715,6 +715,8 @@ static seed_verify4_fn pick_seed_verify4(int nw) {
     return nullptr;
 }
 
+#include "scan_join.inc"
+
 // The tiled scan kernel (see the comment above full_mismatches).
 __global__ void __launch_bounds__(SF2_THREADS)
 scan_fast3_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const u32 *__restrict__ seq_off,
@@ -1337,6 +1339,7 @@ static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const cat
                        (const u32 *)(S.ctr.p + 1), S.scap, sink);
     (void)hipEventRecord(ctx->ev[2 * PHASE_VERIFY + 1], ctx->stream);
     ctx->phase_launches[PHASE_VERIFY] = 1;
+    ctx->phase_launches[PHASE_VCOUNT] = 0; ctx->phase_ms[PHASE_VCOUNT] = 0.0;
     tm.launch(1);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1511,19 +1514,21 @@ static int bucket_scan(catchhip_ctx *ctx, BucketBuild &B, const u32 *in, u32 *ou
 // scan of the bucket sizes, scatter, per-bucket sort + merge, scan of the
 // merged counts.  nrec = hit records to look at (a device count, bounded by
 // B.cap, when nrec_dev is given).
+// grouped: the producer (run_join) has scanned the bucket sizes and written its records at their places in B.S.
 static int bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, const u32 *nrec_dev, bool want_sum,
-                               bool merge, PhaseTimer &tm, bool dedupe = false) {
+                               bool merge, PhaseTimer &tm, bool dedupe = false, bool grouped = false,
+                               const u32 *run_cnt = nullptr, int run_stride = 0, int nruns = 0) {
     hipStream_t s = ctx->stream;
-    TRY(bucket_scan(ctx, B, B.bcnt.p, B.bstart.p, B.nb, B.res.p + 2, nullptr, nullptr, tm));
+    if (!grouped) TRY(bucket_scan(ctx, B, B.bcnt.p, B.bstart.p, B.nb, B.res.p + 2, nullptr, nullptr, tm));
     if (!merge) return 0;   // radix build: only the bucket offsets are needed
-    if (nrec)
+    if (nrec && !grouped)
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)div_up((i64)nrec, 256)), dim3(256), 0, s,
                            (const uint4 *)B.rec.p, (const u32 *)B.rank.p, nrec, nrec_dev, (const u32 *)B.bstart.p,
                            B.S.p, B.compact ? (const u32 *)B.wcnt.p : (const u32 *)nullptr);
     unsigned long long *bsum = want_sum ? B.bsum.p : nullptr;
     hipLaunchKernelGGL((bucket_merge_kernel<64, BK_SMALL>), dim3((unsigned)std::min<i64>(B.nb, (i64)1 << 20)), dim3(64),
                        0, s, (const u32 *)B.bstart.p, B.nb, B.S.p, B.mcnt.p, B.blmax.p, bsum,
-                       dedupe ? 1 : 0);
+                       dedupe ? 1 : 0, run_cnt, run_stride, nruns);
     static bool big_attr_set = false;
     if (!big_attr_set) {
         (void)hipFuncSetAttribute((const void *)bucket_merge_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1535,6 +1540,159 @@ static int bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, cons
                        B.res.p + 1, dedupe ? 1 : 0);
     tm.launch(3);
     TRY(bucket_scan(ctx, B, B.mcnt.p, B.rstart.p, B.nb, B.res.p + 4, B.blmax.p, B.res.p + 5, tm));
+    return 0;
+}
+
+// ------------------------------------------------------------------------
+// K1d host side (scan_join.inc): table -> hit positions -> sort by slot -> count pass -> bucket offsets ->
+// write pass.  Leaves the hit records grouped by bucket in B.S with B.bstart / B.res[2] filled, i.e. where
+// bucket_finish_async's scatter would have left them.  Two host synchronisations (hit positions, hits): the
+// arrays are sized exactly.  Returns 1 when the inputs do not qualify (the caller takes the seed-list scan).
+// ------------------------------------------------------------------------
+struct JoinRun {
+    DevBuf<u64> stage_key, hkey, hkey_alt;
+    DevBuf<u32> stage_sq, hsq, hsq_alt, wg_cnt, wg_off, scan_tmp, ecnt, ebase, bcur, giant_n;
+    DevBuf<uint4> giant;
+    DevBuf<unsigned long long> pairs;
+    JoinArgs A;
+    kj_kernel_fn write_main = nullptr, write_giant = nullptr;
+    u32 nhit = 0, ngiant = 0;
+    bool used = false;
+};
+#define KJ_GIANT_CAP (1u << 20)
+
+static bool join_path_ok(const catchhip_probes *P, int mm) {
+    if (!P->pigeonhole || P->k <= 0 || P->pwords < 1 || P->pwords > 8) return false;
+    const int nanch = (int)(P->L / P->k);
+    const int ntab = (int)std::min<i64>(nanch, (i64)mm + 1);
+    return ntab >= 1 && ntab <= KJ_AMAX && !getenv("CATCHHIP_SEED_LIST");
+}
+
+// the write pass alone (again after a row build that fell back to the radix sort: the merge works in place)
+static void join_write_pass(catchhip_ctx *ctx, JoinRun &J) {
+    if (!J.nhit) return;
+    hipLaunchKernelGGL(J.write_main, dim3((unsigned)div_up((i64)J.nhit, 256)), dim3(256), 0, ctx->stream, J.A);
+    if (J.ngiant)
+        hipLaunchKernelGGL(J.write_giant, dim3((unsigned)std::min<i64>(div_up((i64)J.ngiant, 4), (i64)ctx->num_cus * 8)),
+                           dim3(256), 0, ctx->stream, J.A);
+}
+
+static int run_join(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_targets *T, int mm, SeedRun &S, JoinRun &J,
+                    const HitSink &sink, BucketBuild &B, u32 nb, PhaseTimer &tm) {
+    hipStream_t s = ctx->stream;
+    const int k = P->k, kb = std::min(k, 32), NW = (int)P->pwords;
+    const int nanch = (int)(P->L / k);
+    const u32 pos_limit = (u32)std::min<i64>((i64)(mm + 1) * k, P->L);
+    const int ntab = (int)std::min<i64>(nanch, div_up((i64)pos_limit, k));
+    const u64 nent64 = (u64)P->nent;
+    if (nent64 >= ((u64)1 << 31)) { chip_set_error("seed scan: too many anchors"); return CATCHHIP_EINVAL; }
+    const u32 nent = (u32)nent64;
+    // ---- table of the anchor k-mers (as the seed-list scan builds it, without the sibling records) ----------
+    u32 capacity = 1024;
+    while ((u64)capacity < 2 * nent64) capacity <<= 1;
+    TRY(S.slot.reserve(capacity));
+    TRY(S.cnt.reserve(capacity));
+    TRY(S.ents.reserve(nent));
+    TRY(S.slot_of.reserve(nent));
+    TRY(S.ctr.reserve(4));
+    const bool pres = capacity >= (1u << 16) && capacity <= (1u << 29) && !getenv("CATCHHIP_SEED_NO_PRESENCE");
+    const u32 pwords = pres ? capacity / 8 : 0;
+    if (pres) TRY(S.present.reserve(pwords));
+    SeedTable t = {S.slot.p, S.cnt.p, S.ents.p, capacity - 1, nullptr, pres ? S.present.p : (u32 *)nullptr,
+                   pres ? 4 * capacity - 1 : 0u};
+    const dim3 eb((unsigned)div_up((i64)nent, 256)), tb(256);
+    hipLaunchKernelGGL(seed_init_kernel, dim3((unsigned)std::min<i64>(div_up((i64)capacity, 256), 2048)), tb, 0, s,
+                       S.slot.p, S.cnt.p, capacity, S.ctr.p, B.bcnt.p, nb, B.res.p, pres ? S.present.p : (u32 *)nullptr, pwords);
+    hipLaunchKernelGGL(seed_count_kernel, eb, tb, 0, s, (const uint4 *)P->planes.p, (const u32 *)P->sent_probe.p,
+                       (const u32 *)P->sent_pos.p, nent, pos_limit, nanch, k, NW, kb, t, S.slot_of.p, (u32 *)nullptr);
+    hipLaunchKernelGGL(seed_alloc_kernel, dim3(capacity / SA_SLOTS), dim3(256), 0, s, t, S.ctr.p);
+    hipLaunchKernelGGL(seed_fill_kernel, eb, tb, 0, s, nent, t, (const u32 *)S.slot_of.p, nanch, (const u32 *)nullptr,
+                       (uint4 *)nullptr);
+    // ---- hit positions, in position order ------------------------------------------------------------------
+    const u32 nblk = (u32)div_up(T->total, KJ_TILE);
+    TRY(J.stage_key.reserve((size_t)nblk * KJ_TILE));
+    TRY(J.stage_sq.reserve((size_t)nblk * KJ_TILE));
+    TRY(J.wg_cnt.reserve((size_t)nblk + 1));
+    TRY(J.wg_off.reserve((size_t)nblk + 1));
+    hipLaunchKernelGGL(kj_hitpos_kernel, dim3(nblk), dim3(KJ_HT), 0, s, (const u32 *)T->planes.p, T->nwords, (u32)T->total,
+                       (const u32 *)T->seq_off.p, (u32)T->nseq, k, kb, t, (unsigned long long *)J.stage_key.p, J.stage_sq.p,
+                       J.wg_cnt.p);
+    TRY(chip_exclusive_scan_u32(ctx, J.wg_cnt.p, J.wg_off.p, (i64)nblk + 1, J.scan_tmp));
+    tm.launch(7);
+    TRY(read_count(ctx, J.wg_off.p + nblk, &J.nhit));
+    J.used = true;
+    J.ngiant = 0;
+    TRY(J.ecnt.reserve((size_t)nent + 1));
+    TRY(J.ebase.reserve((size_t)nent + 1));
+    TRY(J.giant.reserve(KJ_GIANT_CAP));
+    TRY(J.giant_n.reserve(4));
+    TRY(J.pairs.reserve(64));
+    HIP_TRY(hipMemsetAsync(J.ecnt.p, 0, sizeof(u32) * ((size_t)nent + 1), s));
+    HIP_TRY(hipMemsetAsync(J.giant_n.p, 0, sizeof(u32) * 4, s));
+    HIP_TRY(hipMemsetAsync(J.pairs.p, 0, sizeof(unsigned long long) * 64, s));
+    const bool cursor = sink.bucket_of != nullptr;   // several probes may share a bucket
+    if (cursor) { TRY(J.bcur.reserve((size_t)nb + 1)); HIP_TRY(hipMemsetAsync(J.bcur.p, 0, sizeof(u32) * ((size_t)nb + 1), s)); }
+    JoinArgs &A = J.A;
+    A.tq = (const uint4 *)T->tq.p; A.seq_off = (const u32 *)T->seq_off.p; A.pplanes = (const uint4 *)P->planes.p;
+    A.nanch = nanch; A.ntab = ntab; A.L = (int)P->L; A.k = k; A.mm = mm;
+    A.tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
+    A.nhit = J.nhit;
+    A.slot = (const uint4 *)S.slot.p; A.ents = (const u32 *)S.ents.p;
+    A.ecnt = J.ecnt.p; A.ebase = (const u32 *)J.ebase.p; A.S = nullptr;
+    A.bucket_of = sink.bucket_of; A.seq_genome = sink.seq_genome; A.ext = sink.ext;
+    A.probe_group = sink.probe_group; A.seq_group = sink.seq_group;
+    A.giant = J.giant.p; A.giant_n = J.giant_n.p; A.giant_cap = KJ_GIANT_CAP;
+    A.pairs = J.pairs.p;
+    J.write_main = pick_kj_verify<true>(NW);
+    J.write_giant = pick_kj_giant<true>(NW);
+    ctx->phase_launches[PHASE_VCOUNT] = 0; ctx->phase_ms[PHASE_VCOUNT] = 0.0;
+    if (J.nhit) {
+        TRY(J.hkey.reserve(J.nhit));
+        TRY(J.hsq.reserve(J.nhit));
+        hipLaunchKernelGGL(kj_compact_kernel, dim3(nblk), dim3(64), 0, s, (const unsigned long long *)J.stage_key.p,
+                           (const u32 *)J.stage_sq.p, (const u32 *)J.wg_off.p, (unsigned long long *)J.hkey.p, J.hsq.p);
+        // stable: the records of a slot stay in position order
+        TRY(chip_radix_sort_pairs(ctx, J.hkey, J.hkey_alt, J.hsq, J.hsq_alt, (i64)J.nhit, ceil_log2_u64((u64)capacity), 32));
+        A.hkey = (const unsigned long long *)J.hkey.p; A.hsq = (const u32 *)J.hsq.p;
+        (void)hipEventRecord(ctx->ev[2 * PHASE_VCOUNT], s);
+        hipLaunchKernelGGL(pick_kj_verify<false>(NW), dim3((unsigned)div_up((i64)J.nhit, 256)), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(pick_kj_giant<false>(NW), dim3((unsigned)ctx->num_cus * 2), dim3(256), 0, s, A);
+        (void)hipEventRecord(ctx->ev[2 * PHASE_VCOUNT + 1], s);
+        ctx->phase_launches[PHASE_VCOUNT] = 1;
+        tm.launch(3 + 5 * ((ceil_log2_u64((u64)capacity) + 7) / 8));
+    }
+    hipLaunchKernelGGL(kj_bucket_count_kernel, dim3((unsigned)div_up(P->nprobes, 256)), dim3(256), 0, s, (const u32 *)J.ecnt.p,
+                       (u32)P->nprobes, nanch, ntab, sink.bucket_of, B.bcnt.p);
+    tm.launch(1);
+    TRY(bucket_scan(ctx, B, B.bcnt.p, B.bstart.p, nb, B.res.p + 2, nullptr, nullptr, tm));
+    HIP_TRY(hipGetLastError());
+    u32 *h = (u32 *)ctx->h_pin;
+    HIP_TRY(hipMemcpyAsync(h, B.res.p + 2, sizeof(u32), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h + 1, J.giant_n.p, sizeof(u32), hipMemcpyDeviceToHost, s));
+    unsigned long long *hp = (unsigned long long *)(h + 2);
+    HIP_TRY(hipMemcpyAsync(hp, J.pairs.p, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost, s));   // (h_pin holds 64 words)
+    HIP_TRY(hipStreamSynchronize(s));
+    const u32 nhits = ((volatile u32 *)h)[0];
+    J.ngiant = ((volatile u32 *)h)[1];
+    unsigned long long pairs = 0, slots = 0;
+    for (int i = 0; i < 16; ++i) { pairs += ((volatile unsigned long long *)hp)[i]; slots += ((volatile unsigned long long *)hp)[16 + i]; }
+    if (getenv("CATCHHIP_TIMING"))
+        fprintf(stderr, "[catchhip]   join: %u hit positions, %llu pairs, %llu lane slots in wave-wide runs, %u hits, %u tasks of cut runs\n",
+                J.nhit, pairs, slots, nhits, J.ngiant);
+    if (J.ngiant > KJ_GIANT_CAP) return 1;   // absurdly repetitive input: the seed-list scan copes (slowly)
+    ctx->counters[1] = (i64)pairs;
+    ctx->seeds_dropped = 0;
+    TRY(B.S.reserve(std::max<size_t>(nhits, 1)));
+    A.S = B.S.p;
+    hipLaunchKernelGGL(kj_bases_kernel, dim3((unsigned)div_up(P->nprobes, 256)), dim3(256), 0, s, (const u32 *)J.ecnt.p,
+                       (u32)P->nprobes, nanch, ntab, sink.bucket_of, (const u32 *)B.bstart.p, cursor ? J.bcur.p : (u32 *)nullptr,
+                       J.ebase.p);
+    (void)hipEventRecord(ctx->ev[2 * PHASE_VERIFY], s);
+    join_write_pass(ctx, J);
+    (void)hipEventRecord(ctx->ev[2 * PHASE_VERIFY + 1], s);
+    ctx->phase_launches[PHASE_VERIFY] = 1;
+    tm.launch(2 + (J.ngiant ? 1 : 0));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -1564,19 +1722,38 @@ struct MergedRows {
     u32 nmerged = 0; // merged rows
 };
 
+// the same from records that are already grouped (key-grouped join: B.S, written again by its write pass)
+__global__ void __launch_bounds__(256)
+rec_keys_grouped_kernel(const uint4 *__restrict__ S, u32 n, const i32 *__restrict__ bucket_set, u64 *__restrict__ keys,
+                        u32 *__restrict__ vals) {
+    const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n) return;
+    const uint4 r = S[d];
+    keys[d] = ((u64)(bucket_set ? (u32)bucket_set[r.w] : r.w) << 32) | r.x;
+    vals[d] = r.y;
+}
+
 static int build_rows_radix(catchhip_ctx *ctx, const BucketBuild &B, u32 nrec, const u32 *nrec_dev, u32 nhits,
                             const i32 *bucket_set, const u32 *bounds, u32 nbounds, i64 max_set_id, MergedRows &M,
-                            PhaseTimer &tm) {
+                            PhaseTimer &tm, JoinRun *J = nullptr) {
     M.n = nhits;
     M.nmerged = 0;
     if (nhits == 0) return 0;
     const u32 n = nhits;
     TRY(M.keys.alloc(n));
     TRY(M.vals.alloc(n));
+    if (J) {
+        // the bucket merge works in place: have the join write its records again, then key them
+        join_write_pass(ctx, *J);
+        hipLaunchKernelGGL(rec_keys_grouped_kernel, dim3((unsigned)div_up((i64)n, 256)), dim3(256), 0, ctx->stream,
+                           (const uint4 *)B.S.p, n, bucket_set, M.keys.p, M.vals.p);
+        tm.launch(2);
+    } else {
     hipLaunchKernelGGL(rec_keys_kernel, dim3((unsigned)div_up((i64)nrec, 256)), dim3(256), 0, ctx->stream,
                        (const uint4 *)B.rec.p, (const u32 *)B.rank.p, nrec, nrec_dev, (const u32 *)B.bstart.p,
                        bucket_set, M.keys.p, M.vals.p, B.compact ? (const u32 *)B.wcnt.p : (const u32 *)nullptr);
     tm.launch();
+    }
     int bits = 32 + ceil_log2_u64((u64)max_set_id + 1);
     if (bits > 64) bits = 64;
     TRY(chip_radix_sort_pairs(ctx, M.keys, M.keys_alt, M.vals, M.vals_alt, n, bits));
@@ -1606,6 +1783,8 @@ struct ScanOut {
     SeedRun S;
     RawHits H;                 // general path (kept for the first-seen pass)
     bool from_seeds = false;   // records come from the seed work list (S), not from H
+    JoinRun J;                 // key-grouped join: hit list + what the write pass needs to run again
+    bool from_join = false;    // records were written grouped (B.S) by the join; there is no rec / rank
     u32 nrec = 0;              // records to look at (grid size)
     const u32 *nrec_dev = nullptr;
     u32 nhits = 0, nrows = 0, lmax = 0, maxbucket = 0;
@@ -1639,7 +1818,32 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
         if (P->has_groups) { sink.probe_group = P->group.p; sink.seq_group = T->seq_group.p; }
     }
     PhaseTimer ts(ctx, PHASE_SCAN), tr(ctx, PHASE_ROWS);
-    if (use_seed) {
+    bool use_join = use_seed && !want_first && join_path_ok(P, mismatches);
+    if (use_join) {
+        // key-grouped join (scan_join.inc): leaves the records grouped by bucket in O.B.S
+        TRY(bucket_prepare(O.B, nb, 1, by_sequence));
+        sink.rec = nullptr; sink.rank = nullptr; sink.bcnt = O.B.bcnt.p; sink.wcnt = nullptr;
+        ts.restart();
+        const int rc = run_join(ctx, P, T, mismatches, O.S, O.J, sink, O.B, nb, ts);
+        if (rc < 0) return rc;
+        if (rc > 0) use_join = false;       // did not qualify after all: the seed-list scan below
+        else {
+            ts.stop();
+            O.from_join = true;
+            O.nrec = 0; O.nrec_dev = nullptr;
+            tr.restart();
+            // (buckets = probes: every bucket is its probe's anchor runs side by side, each in position order)
+            const bool runs = sink.bucket_of == nullptr && O.J.A.ntab <= BK_RUNS_MAX && !getenv("CATCHHIP_MERGE_NO_RUNS");
+            TRY(bucket_finish_async(ctx, O.B, 0, nullptr, by_sequence, !force_radix, tr, dedupe, true,
+                                    runs ? (const u32 *)O.J.ecnt.p : (const u32 *)nullptr, O.J.A.nanch, O.J.A.ntab));
+            tr.stop();
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(ctx->h_pin, O.B.res.p, 8 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    if (use_join) {
+    } else if (use_seed) {
         O.from_seeds = true;
         O.S.scap = seed_capacity(P, T);
         if (const char *e = getenv("CATCHHIP_SEED_CAP")) O.S.scap = (u32)std::max(1, atoi(e));   // tests: force the retry
@@ -1906,7 +2110,7 @@ static int cover_scan_impl(catchhip_ctx *ctx, const catchhip_probes *P, const ca
         } else {
             MergedRows M;
             if ((rc = build_rows_radix(ctx, O.B, O.nrec, O.nrec_dev, O.nhits, P->bucket_set.p, T->genome_off.p,
-                                       (u32)T->ngenomes, P->max_set_id, M, tm))) break;
+                                       (u32)T->ngenomes, P->max_set_id, M, tm, O.from_join ? &O.J : nullptr))) break;
             R->n = M.nmerged;
             if ((rc = R->set_id.alloc(R->n))) break;
             if ((rc = R->univ.alloc(R->n))) break;
@@ -2029,7 +2233,7 @@ extern "C" int catchhip_tolerant_bp(catchhip_ctx *ctx, const catchhip_probes *P,
         MergedRows M;
         PhaseTimer tm(ctx, PHASE_ROWS, true);
         TRY(build_rows_radix(ctx, O.B, O.nrec, O.nrec_dev, O.nhits, nullptr, T->seq_off.p, (u32)T->nseq, P->nprobes,
-                             M, tm));
+                             M, tm, O.from_join ? &O.J : nullptr));
         DevBuf<unsigned long long> bp;
         TRY(bp.alloc((size_t)P->nprobes));
         HIP_TRY(hipMemsetAsync(bp.p, 0, sizeof(unsigned long long) * P->nprobes, ctx->stream));

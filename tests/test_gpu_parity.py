@@ -1136,6 +1136,39 @@ def test_selection_equals_live_reference_runs(ctx):
         assert dig == r["picks_sha256"], (r["input"], r["scale"])
 
 
+def test_selection_equals_live_reference_on_real_ebola_genomes(ctx):
+    """Real sequences: the first 30 / 100 records of the Ebola FASTA of the reference's own tests
+    (tests/golden/ebola_zaire_100.fasta.gz: real composition, low-complexity runs, indels, N runs).
+    The GPU filter selects exactly what the LIVE reference selected (tests/golden/real_runs.json,
+    made by tests/golden/make_real_golden.py): pigeonhole anchors at -pl 100 and -pl 75, random
+    anchors + truncated alignments (-l 60, np.random seeded as there), partial coverage."""
+    import hashlib
+    import json
+    from catch_amd import genome
+    from catch_amd.filter import candidate_probes
+    from catch_amd.filter.set_cover_filter import SetCoverFilter
+    from catch_amd.utils import seq_io
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "real_runs.json")) as f:
+        d = json.load(f)
+    genomes_all = seq_io.read_genomes_from_fasta(os.path.join(here, d["fasta"]))
+    assert len(d["runs"]) >= 4
+    for r in d["runs"]:
+        gen = genomes_all[:r["records"]]
+        pl = r["probe_length"]
+        cands = list(dict.fromkeys(candidate_probes.candidate_strings_from_sequences(
+            [s for g in gen for s in g.seqs], pl, pl // 2)))
+        assert len(cands) == r["P"]
+        if r["np_random_seed"] is not None:
+            np.random.seed(r["np_random_seed"])
+        f = SetCoverFilter(mismatches=r["mismatches"], lcf_thres=r["lcf_thres"], coverage=r["coverage"],
+                           cover_extension=r["cover_extension"])
+        ids = f._filter_strs([cands], [gen], assume_unique=True)[0]
+        sel = sorted(cands[i] for i in ids)
+        assert len(sel) == r["probes_out"], r
+        assert hashlib.sha256(",".join(sel).encode()).hexdigest() == r["picks_sha256"], r
+
+
 # ---------------------------------------------------------------- front end
 def test_design_cli_end_to_end(ctx, oracle, tmp_path, capsys):
     """python -m catch_amd.design on two FASTA datasets: the written probe set

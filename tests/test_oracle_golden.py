@@ -375,6 +375,51 @@ def test_oracle_selects_what_the_live_reference_selected_on_indel_input(oracle):
     assert hashlib.sha256("\n".join(",".join(g) for g in sel).encode()).hexdigest() == run["picks_sha256"]
 
 
+def _real_runs():
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "real_runs.json")) as f:
+        d = json.load(f)
+    return os.path.join(here, d["fasta"]), d["runs"]
+
+
+def test_oracle_selects_what_the_live_reference_selected_on_real_ebola_genomes(oracle):
+    """Real viral sequences (the first 30 records of the Ebola FASTA the reference's own
+    tests hold: low-complexity runs, repeats, real indels, N runs -- what the synthetic
+    genomes lack), four parameter sets incl. random anchors with truncated alignments
+    (`-l 60`, np.random seeded) and partial coverage: the oracle's selection == the LIVE
+    reference's (tests/golden/real_runs.json, recorded by tests/golden/make_real_golden.py).
+    The 100-record runs are asserted on the GPU only (minutes of CPU here)."""
+    import hashlib
+    from catch_amd.filter import candidate_probes
+    from catch_amd.utils import seq_io
+    fasta, runs = _real_runs()
+    genomes_all = [list(g.seqs) for g in seq_io.read_genomes_from_fasta(fasta)]
+    assert len(genomes_all) == 100
+    checked = 0
+    oracle.set_threads(oracle.hw_threads())
+    try:
+        for r in runs:
+            if r["records"] > 30:
+                continue
+            genomes = genomes_all[:r["records"]]
+            pl = r["probe_length"]
+            cands = list(dict.fromkeys(candidate_probes.candidate_strings_from_sequences(
+                [s for g in genomes for s in g], pl, pl // 2)))
+            assert len(cands) == r["P"] and sum(len(s) for g in genomes for s in g) == r["G"]
+            if r["np_random_seed"] is not None:
+                np.random.seed(r["np_random_seed"])
+            ids = oracle.set_cover_filter([cands], [genomes], r["mismatches"], r["lcf_thres"], coverage=r["coverage"],
+                                          cover_extension=r["cover_extension"], lazy=True)[0]
+            sel = sorted(cands[i] for i in ids)
+            assert len(sel) == r["probes_out"], r
+            assert hashlib.sha256(",".join(sel).encode()).hexdigest() == r["picks_sha256"], r
+            checked += 1
+    finally:
+        oracle.set_threads(1)
+    assert checked >= 4
+
+
 def _chain_runs():
     import json
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ndf_scf_chains.json")) as f:
