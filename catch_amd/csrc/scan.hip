@@ -1572,6 +1572,7 @@ static bool join_path_ok(const catchhip_probes *P, int mm) {
 static void join_write_pass(catchhip_ctx *ctx, JoinRun &J) {
     if (!J.nhit) return;
     hipLaunchKernelGGL(J.write_main, dim3((unsigned)div_up((i64)J.nhit, 256)), dim3(256), 0, ctx->stream, J.A);
+    if (J.ngiant) (void)hipMemsetAsync(J.giant_n.p + 2, 0, sizeof(u32), ctx->stream);   // the write pass's task cursor
     if (J.ngiant)
         hipLaunchKernelGGL(J.write_giant, dim3((unsigned)std::min<i64>(div_up((i64)J.ngiant, 4), (i64)ctx->num_cus * 8)),
                            dim3(256), 0, ctx->stream, J.A);
@@ -1596,10 +1597,15 @@ static int run_join(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
     TRY(S.slot_of.reserve(nent));
     TRY(S.ctr.reserve(4));
     const bool pres = capacity >= (1u << 16) && capacity <= (1u << 29) && !getenv("CATCHHIP_SEED_NO_PRESENCE");
-    const u32 pwords = pres ? capacity / 8 : 0;
+    // One presence bit per slot (4 MB for the 32 M slots of S4's largest group: mostly L2 hits; the seed-list scan's
+    // 4 bits per slot are 16 MB: every probe a trip to the memory-side cache).  Measured on S4, whole scan phase:
+    // 4 bits 33.8 ms, 1 bit 30.5, half a bit 30.4, a quarter 30.8 (more false positives go on to the slot array).
+    static const int pshift = getenv("CATCHHIP_PRESENCE_SHIFT") ? atoi(getenv("CATCHHIP_PRESENCE_SHIFT")) : 2;
+    const u32 pbits = pres ? std::max<u32>((4u * capacity) >> pshift, 1u << 16) : 0;
+    const u32 pwords = pbits / 32;
     if (pres) TRY(S.present.reserve(pwords));
     SeedTable t = {S.slot.p, S.cnt.p, S.ents.p, capacity - 1, nullptr, pres ? S.present.p : (u32 *)nullptr,
-                   pres ? 4 * capacity - 1 : 0u};
+                   pres ? pbits - 1 : 0u};
     const dim3 eb((unsigned)div_up((i64)nent, 256)), tb(256);
     hipLaunchKernelGGL(seed_init_kernel, dim3((unsigned)std::min<i64>(div_up((i64)capacity, 256), 2048)), tb, 0, s,
                        S.slot.p, S.cnt.p, capacity, S.ctr.p, B.bcnt.p, nb, B.res.p, pres ? S.present.p : (u32 *)nullptr, pwords);
