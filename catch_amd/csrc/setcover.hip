@@ -1117,14 +1117,14 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     // Measured on S4 (rows: rounds of the fused vs the flat kernels): 272 M: 65 vs
     // 30 ms; 44 M: 9.9 vs 6.7; 29 M: 6.6 vs 4.5; 19 M: 4.0 vs 3.4; 4 M: 1.5 vs 1.5.
     const i64 flat_min_rows = getenv("CATCHHIP_FLAT_MIN_ROWS") ? atoll(getenv("CATCHHIP_FLAT_MIN_ROWS")) : (i64)1 << 22;
-    if (batched && R->lmax <= 257 && (i64)nrows >= flat_min_rows)
+    if (batched && R->lmax <= 257 && (i64)nrows >= flat_min_rows && nsets <= GR_MAX_SETS)
         return greedy_flat(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out);
     if (batched) return greedy_frontier(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out, &no_retry);
     // Partial coverage (some universe_p < 1) with rows of at most 257 bases: frontier rounds of the
     // row-parallel kernels with the universe test (setcover_flat.inc, "PARTIAL") whatever the size --
     // the one-workgroup solvers below take 3.9 ms per pick on S4's largest group (54.6 s for S4 under
     // -c 0.9 against 0.17 s under -c 1.0)
-    if (universe_p && !distributed && R->lmax <= 257 && !getenv("CATCHHIP_GREEDY_SEQUENTIAL") &&
+    if (universe_p && !distributed && R->lmax <= 257 && nsets <= GR_MAX_SETS && !getenv("CATCHHIP_GREEDY_SEQUENTIAL") &&
         !getenv("CATCHHIP_PARTIAL_SEQUENTIAL") && (i64)nrows >= (getenv("CATCHHIP_PARTIAL_MIN_ROWS") ? atoll(getenv("CATCHHIP_PARTIAL_MIN_ROWS")) : 0))
         return greedy_flat(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out, universe_p);
 

@@ -369,14 +369,14 @@ def test_greedy_batched_rounds_restore_sequential_order(ctx, oracle, monkeypatch
     with and without ranks): the frontier solver -- set-parallel fused kernels
     and, forced here on these small instances, the row-parallel kernels large
     instances take -- must return the oracle's sequential pick order, and so
-    must the one-pick-per-iteration solver.  The row-parallel kernels count a
-    row again only when one of its bitmap words changed (cached counts): run
-    with the changed bits read from global memory and staged in LDS, with
-    striped and with contiguous tiles."""
+    must the one-pick-per-iteration solver.  The row-parallel kernels run with
+    striped and with contiguous tiles, and ("lds" variants, named for the
+    round-3 cache they replaced) with the E_dirty statistics collected -- the
+    changed-word bits the apply launch then marks and the count launch reads."""
     engine = _engine()
     monkeypatch.setenv("CATCHHIP_FLAT_MIN_ROWS", "0" if flat else str(1 << 40))
     if flat in ("lds", "contiguous-lds"):
-        monkeypatch.setenv("CATCHHIP_FLAT_CHG_FORCE_LDS", "1")
+        monkeypatch.setenv("CATCHHIP_FLAT_COUNT_DIRTY", "1")
     if flat in ("contiguous", "contiguous-lds"):
         monkeypatch.setenv("CATCHHIP_FLAT_TILE_SHIFT", "16")
     rng = np.random.Generator(np.random.PCG64(321))
@@ -467,7 +467,7 @@ def test_partial_cover_frontier_rounds_match_oracle(ctx, oracle, monkeypatch, ti
     engine = _engine()
     if tiles == "contiguous":
         monkeypatch.setenv("CATCHHIP_FLAT_TILE_SHIFT", "16")
-        monkeypatch.setenv("CATCHHIP_FLAT_CHG_FORCE_LDS", "1")
+        monkeypatch.setenv("CATCHHIP_FLAT_COUNT_DIRTY", "1")
     rng = np.random.Generator(np.random.PCG64(4242))
     for trial in range(6):
         U = int(rng.integers(20, 90))
