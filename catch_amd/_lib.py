@@ -150,6 +150,8 @@ PROTOTYPES = {
         c_vp, c_vp, ctypes.c_int64, c_i64p, c_i64p, c_i64p]),
     "catchhip_rows_stats": (ctypes.c_int, [
         c_vp, c_vp, c_i64p, c_i64p, ctypes.c_int64, c_i64p]),
+    "catchhip_rows_cover_check": (ctypes.c_int, [
+        c_vp, c_vp, ctypes.c_int64, c_i64p, ctypes.c_int64, c_f64p, c_i64p]),
     "catchhip_probes_set_groups": (ctypes.c_int, [c_vp, c_vp, c_i32p]),
     "catchhip_targets_set_groups": (ctypes.c_int, [c_vp, c_vp, c_i32p]),
 }

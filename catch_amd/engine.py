@@ -537,6 +537,19 @@ class Rows:
             int(num_sets), _ptr(ps, c_i64p)))
         return tl[:ngenomes], ul[:ngenomes], ps[:num_sets]
 
+    def cover_check(self, num_sets, picks, universe_p=None):
+        """catchhip_rows_cover_check: replays `picks` (set ids in pick order) over these rows with kernels that
+        share nothing with the solvers -> dict(picks_without_gain, universes_short, bad_pick_ids, universe_bases,
+        covered_bases); a correct solution has the first three at zero."""
+        pk = np.ascontiguousarray(picks, dtype=np.int64)
+        up = None if universe_p is None else np.ascontiguousarray(universe_p, dtype=np.float64)
+        out = np.zeros(5, dtype=np.int64)
+        check(self.ctx._L.catchhip_rows_cover_check(
+            self.ctx._h, self._h, int(num_sets), _ptr(pk, c_i64p) if pk.size else None, int(pk.size),
+            None if up is None else _ptr(up, c_f64p), _ptr(out, c_i64p)))
+        return dict(picks_without_gain=int(out[0]), universes_short=int(out[1]), bad_pick_ids=int(out[2]),
+                    universe_bases=int(out[3]), covered_bases=int(out[4]))
+
     def fetch_first_seen(self):
         """uint64[n]: (k-mer position in the universe << 32) | anchor order."""
         out = np.zeros(max(self.n, 1), dtype=np.uint64)
@@ -843,7 +856,28 @@ def setcover_filter_many(groups, mismatches, lcf_thres, island,
             n, ctxs, prs, tgs, int(mismatches), int(lcf_thres), int(island),
             int(cover_extension), int(mode), _ptr(nsets, c_i64p), rk_p, up_p,
             out_p, _ptr(n_out, c_i64p), _ptr(nrows, c_i64p)))
-    return [(outs[g][:n_out[g]].tolist(), int(nrows[g])) for g in range(n)]
+    res = [(outs[g][:n_out[g]].tolist(), int(nrows[g])) for g in range(n)]
+    if _solution_checks is not None:
+        # bench / tests: every instance's picks replayed by the independent check kernels (one more scan, untimed)
+        for g, (ids, _) in zip(groups, res):
+            rows = Rows.scan(g[0], g[1], g[2], mismatches, lcf_thres, island, cover_extension, mode)
+            try:
+                r = rows.cover_check(g[3], ids, g[5])
+                r.update(picks=len(ids), rows=rows.n, universes=int(g[2].ngenomes))
+                _solution_checks.append(r)
+            finally:
+                rows.close()
+    return res
+
+
+_solution_checks = None
+
+
+def collect_solution_checks(sink):
+    """sink: a list -- from now on every fused scan + solve (setcover_filter / _many) is followed by
+    catchhip_rows_cover_check on a second scan of the same instance and its verdict is appended; None: off."""
+    global _solution_checks
+    _solution_checks = sink
 
 
 class Prefetch:

@@ -558,6 +558,16 @@ int catchhip_rows_stats(catchhip_ctx *ctx, const catchhip_rows *rows,
                         int64_t *total_len, int64_t *union_len,
                         int64_t num_sets, int64_t *universes_per_set);
 
+/* Property checks of a set-cover solution by kernels independent of the solvers (csrc/check.hip), usable at any
+ * scale: `picks` are set ids IN THE ORDER they were picked, `rows` the instance's row table (not a deferred one),
+ * universe_p per universe or NULL (every universe fully covered).  out5[0] = picks that covered no new position
+ * when their turn came (catch/utils/set_cover.py:448-550 only picks a set with a positive gain), out5[1] =
+ * universes covered short of |U| - int(|U| - p |U|) (set_cover.py:362-373, U = union of all rows of the universe),
+ * out5[2] = pick ids out of range or repeated, out5[3] = bases in the universes, out5[4] = of them covered.
+ * A correct solution has out5[0] == out5[1] == out5[2] == 0. */
+int catchhip_rows_cover_check(catchhip_ctx *ctx, const catchhip_rows *rows, int64_t num_sets, const int64_t *picks,
+                              int64_t npicks, const double *universe_p, int64_t *out5);
+
 /* AdapterFilter._make_votes_across_target_genomes (catch/filter/adapter_filter.py
  * :299-361) on rows from catchhip_cover_scan_first_seen with one universe per
  * sequence: per sequence, in order, the greedy interval schedule over its

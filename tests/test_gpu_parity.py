@@ -1032,6 +1032,108 @@ def test_full_size_config5_design_large_matches_oracle_digest(ctx, tmp_path, cap
     assert hashlib.sha256("\n".join(got).encode()).hexdigest() == g["probes_sha256"]
 
 
+def _np_cover_check(set_id, univ, start, end, genome_len, picks, p=None):
+    """numpy restatement of catchhip_rows_cover_check (small instances)."""
+    off = np.concatenate([[0], np.cumsum(genome_len)])
+    U = np.zeros(int(off[-1]), dtype=bool)
+    for u, s0, e0 in zip(univ, start, end):
+        U[off[u] + s0: off[u] + e0] = True
+    C = np.zeros_like(U)
+    nogain = 0
+    for s in picks:
+        fresh = 0
+        for r in np.nonzero(set_id == s)[0]:
+            seg = slice(int(off[univ[r]] + start[r]), int(off[univ[r]] + end[r]))
+            fresh += int((~C[seg]).sum())
+            C[seg] = True
+        nogain += fresh == 0
+    short = 0
+    for u in range(len(genome_len)):
+        n = int(U[off[u]:off[u + 1]].sum())
+        pu = 1.0 if p is None else p[u]
+        need = n - int(n - pu * n)
+        short += int((C & U)[off[u]:off[u + 1]].sum()) < need
+    return nogain, short, int(U.sum()), int((C & U).sum())
+
+
+def test_cover_check_kernels_equal_a_numpy_replay(ctx):
+    """catchhip_rows_cover_check (csrc/check.hip: the picks replayed per universe in pick order over a covered-
+    positions bitmap; shares no code with the solvers) against a numpy replay: solved instances pass with every
+    counter at zero; a dropped pick leaves universes short; a pick moved behind the sets that cover all of it is
+    reported as a pick without gain; repeated / out-of-range ids are counted."""
+    engine = _engine()
+    rng = np.random.Generator(np.random.PCG64(77))
+    for trial in range(8):
+        U = int(rng.integers(3, 30))
+        glen = rng.integers(300, 3000, size=U)
+        P = int(rng.integers(40, 400))
+        rows = []
+        for s in range(P):
+            for u in rng.choice(U, size=int(rng.integers(1, min(U, 6) + 1)), replace=False):
+                a = int(rng.integers(0, glen[u] - 60))
+                rows.append((s, int(u), a, a + int(rng.integers(20, 257))))
+        rows = sorted(set((s, u, a, min(e, int(glen[u]))) for s, u, a, e in rows))
+        # one row per (set, universe) start: merge nothing, the table only has to be sorted
+        sid = np.array([r[0] for r in rows], np.int32); un = np.array([r[1] for r in rows], np.int32)
+        st = np.array([r[2] for r in rows], np.int64); en = np.array([r[3] for r in rows], np.int64)
+        R = engine.Rows.from_host(ctx, sid, un, st, en, glen)
+        p = None if trial % 2 == 0 else rng.choice([1.0, 0.9, 0.5], size=U)
+        ids = R.greedy(P, universe_p=p)
+        got = R.cover_check(P, ids, p)
+        want = _np_cover_check(sid, un, st, en, glen, ids, p)
+        assert (got["picks_without_gain"], got["universes_short"], got["universe_bases"], got["covered_bases"]) == want
+        assert got["picks_without_gain"] == 0 and got["universes_short"] == 0 and got["bad_pick_ids"] == 0
+        if len(ids) > 1:
+            # the first pick covers something nobody else needs to: without it a universe stays short (p = 1)
+            bad = R.cover_check(P, ids[1:], p)
+            want = _np_cover_check(sid, un, st, en, glen, ids[1:], p)
+            assert (bad["picks_without_gain"], bad["universes_short"]) == want[:2]
+            if p is None:
+                assert bad["universes_short"] >= 1
+            # a set replayed twice in spirit: the last pick first and again last -> counted as repeated
+            rep = R.cover_check(P, list(ids) + [ids[0]], p)
+            assert rep["bad_pick_ids"] == 1
+            # under full coverage everything is covered in the end: one more set has nothing left to gain
+            rest = sorted(set(sid.tolist()) - set(ids))
+            if p is None and rest:
+                m = R.cover_check(P, list(ids) + [rest[0]], None)
+                assert (m["picks_without_gain"], m["universes_short"], m["bad_pick_ids"]) == (1, 0, 0)
+        assert R.cover_check(P, [P + 3], p)["bad_pick_ids"] == 1
+        R.close()
+
+
+def test_property_checks_at_scale_config5(ctx):
+    """BASELINE configs[4] through the design_large chain at S5 x 0.25 (47,514 genomes, 0.9 Gbases, 20 M candidate
+    windows, 640 k probes): no oracle can solve this, so every set-cover instance the plugin solves is checked by
+    the independent replay kernels (engine.collect_solution_checks -> catchhip_rows_cover_check on a second scan):
+    every pick covered something new at its turn, every universe is covered to its requirement."""
+    from catch_amd import engine as eng, genome
+    from catch_amd.filter import near_duplicate_filter, probe_designer, set_cover_filter
+    from catch_amd.utils import synthetic
+    genomes = synthetic.dataset("S5", scale=0.25)[0]
+    gobjs = [[genome.Genome.from_one_seq(g[0]) for g in genomes]]
+    random.seed(21)
+    np.random.seed(22)
+    ndf = near_duplicate_filter.NearDuplicateFilterWithMinHash(0.6)
+    scf = set_cover_filter.SetCoverFilter(mismatches=5, lcf_thres=100, coverage=1.0, cover_extension=50,
+                                          kmer_probe_map_k=20)
+    pd = probe_designer.ProbeDesigner(gobjs, [ndf, scf], probe_length=100, probe_stride=50, cluster_threshold=0.15,
+                                      cluster_merge_after=scf, cluster_method="choose", cluster_fragment_length=50000)
+    clusters = pd._cluster_genomes()
+    mode = pd._device_front_end_mode(clusters, ndf, scf)
+    run = scf._filter_genomes_device if mode == "per group" else scf._filter_genomes_device_union
+    checks = []
+    eng.collect_solution_checks(checks)
+    try:
+        chosen = run(clusters, 100, 50, None, ndf)
+    finally:
+        eng.collect_solution_checks(None)
+    assert sum(len(c) for c in chosen) > 500000
+    assert len(checks) >= 1 and sum(c["picks"] for c in checks) > 500000
+    assert all(c["picks_without_gain"] == 0 and c["universes_short"] == 0 and c["bad_pick_ids"] == 0 for c in checks)
+    assert all(c["covered_bases"] == c["universe_bases"] for c in checks)      # -c 1.0
+
+
 def test_ndf_then_scf_chains_equal_the_live_reference(ctx):
     """Near-duplicate filter -> set cover filter, recorded from the LIVE
     reference under PYTHONHASHSEED=0 (tests/golden/ndf_scf_chains.json): the
