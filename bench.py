@@ -315,6 +315,7 @@ class Stepper:
         st = dict(rows=nrows, picks=len(ids))
         for name, ph in (("scan_ms", engine.PHASE_SCAN),
                          ("verify_ms", engine.PHASE_VERIFY),
+                         ("vcount_ms", engine.PHASE_VCOUNT),
                          ("rows_ms", engine.PHASE_ROWS),
                          ("greedy_ms", engine.PHASE_GREEDY),
                          ("rounds_ms", engine.PHASE_GREEDY_ROUNDS),
@@ -324,9 +325,9 @@ class Stepper:
             st[name.replace("_ms", "_launches")] = nl
         st.update(c.counters())
         st.update(getattr(g, "ndf_stats", {}))
-        # the claim kernel of the row-parallel solver streams every alive record (12 B) and looks at the
-        # owner word (8 B) of every flagged word of it
-        st["claim_bytes"] = (12.0 * st["flat_rows_streamed"] + 8.0 * st["flat_owner_words"]) if st["claim_launches"] else 0.0
+        # the claim kernel of the row-parallel solver streams every alive record (8 B since round 4) and looks at
+        # the owner word (8 B) of every flagged word of it
+        st["claim_bytes"] = (8.0 * st["flat_rows_streamed"] + 8.0 * st["flat_owner_words"]) if st["claim_launches"] else 0.0
         stats.append(st)
 
     def sync(self):
@@ -342,26 +343,91 @@ class Stepper:
             self.pool.shutdown()
 
 
+def _pmc_record(workload, scale):
+    """The committed rocprofv3 PMC passes of this same command (profiles/r04_pmc_traffic_<workload>.json, made by
+    tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in separate runs); None when there is none for this
+    workload at this scale: counters cannot be collected from inside the timed run."""
+    for rnd in ("r04", "r03", "r02"):
+        path = os.path.join(REPO, "profiles", "%s_pmc_traffic_%s.json" % (rnd, workload))
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get("workload") == workload and scale == 1.0:
+            rec["_file"] = os.path.relpath(path, REPO)
+            return rec
+    return None
+
+
 def pmc_traffic(unit, workload, scale):
-    """HBM bytes per launch of `unit` from the committed rocprofv3 PMC passes of
-    this same command (profiles/r03_pmc_traffic_<workload>.json, else the round-2 file: FETCH_SIZE and
-    WRITE_SIZE collected in separate runs, tools/collect_profiles.sh;
-    FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes).  None
-    when no matching record exists: counters cannot be collected from inside
-    the timed run."""
-    path = os.path.join(REPO, "profiles", "r03_pmc_traffic_%s.json" % workload)
-    if not os.path.exists(path):
-        path = os.path.join(REPO, "profiles", "r02_pmc_traffic_%s.json" % workload)
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-        if rec.get("workload") != workload or scale != 1.0:
-            return None
-        k = rec["units"].get(unit) or rec["kernels"][unit + "_kernel"]   # a unit, or one kernel by name
-        return (2.0 * k["FETCH_SIZE_KB_per_launch"]
-                + k["WRITE_SIZE_KB_per_launch"]) * 1024.0
-    except (OSError, KeyError, ValueError):
+    """HBM-side bytes per launch of `unit` (a unit of the record, or one kernel by name): 2 x FETCH_SIZE +
+    WRITE_SIZE -- FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes."""
+    rec = _pmc_record(workload, scale)
+    if rec is None:
         return None
+    try:
+        k = rec["units"].get(unit) or rec["kernels"][unit + "_kernel"]
+        return (2.0 * k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024.0
+    except KeyError:
+        return None
+
+
+def traffic_per_step(workload, scale):
+    """GB of counted traffic per step and unit (2 x FETCH_SIZE + WRITE_SIZE), from the same record."""
+    rec = _pmc_record(workload, scale)
+    if rec is None or "steps_in_run" not in rec:
+        return None
+    out = {"source": rec["_file"], "formula": "(2 x FETCH_SIZE + WRITE_SIZE) summed over the unit's launches / steps of the run"}
+    tot = 0.0
+    for name, u in rec["units"].items():
+        gb = (2.0 * u["FETCH_SIZE_KB_per_launch"] + u["WRITE_SIZE_KB_per_launch"]) * 1024.0 * u["launches"] / rec["steps_in_run"] / 1e9
+        out[name + "_GB"] = gb
+        if name in rec.get("disjoint_units", []):
+            tot += gb
+    out["total_GB"] = tot
+    return out
+
+
+def summarize_checks(checks):
+    """Verdicts of catchhip_rows_cover_check (csrc/check.hip: the picks replayed per universe in pick order by
+    kernels that share nothing with the solvers) over the instances of one step."""
+    if not checks:
+        return None
+    tot = {k: int(sum(c[k] for c in checks)) for k in ("picks", "rows", "universes", "picks_without_gain", "universes_short",
+                                                         "bad_pick_ids", "universe_bases", "covered_bases")}
+    tot["instances"] = len(checks)
+    tot["ok"] = tot["picks_without_gain"] == 0 and tot["universes_short"] == 0 and tot["bad_pick_ids"] == 0
+    tot["what"] = ("independent replay of every instance's picks in pick order: every pick covered a new position at its "
+                   "turn, every universe is covered to |U| - int(|U| - p |U|)")
+    return tot
+
+
+def ndf_bucket_independence(kept, positions, dist_thres):
+    """The Hamming near-duplicate filter's guarantee, checked with numpy: no two KEPT probes that share a bucket
+    (equal characters at a table's sampled positions; catch/utils/lsh.py:289-320) are within dist_thres of each other.
+    kept: uint8 array [n, L].  -> (pairs compared, violations)."""
+    n = kept.shape[0]
+    pairs = bad = 0
+    for pos in positions:
+        key = np.ascontiguousarray(kept[:, pos])
+        v = key.view(np.dtype((np.void, key.shape[1]))).ravel()
+        order = np.argsort(v, kind="stable")
+        sv = v[order]
+        head = np.ones(n, dtype=bool)
+        head[1:] = sv[1:] != sv[:-1]
+        run = np.cumsum(head) - 1
+        size = np.bincount(run)
+        mx = int(size.max()) if n else 0
+        for d in range(1, mx):
+            i = np.nonzero(run[d:] == run[:-d])[0]
+            if i.size == 0:
+                break
+            a, b = kept[order[i]], kept[order[i + d]]
+            dist = (a != b).sum(axis=1)
+            pairs += int(i.size)
+            bad += int((dist <= dist_thres).sum())
+    return pairs, bad
 
 
 def digest(ids):
@@ -385,12 +451,15 @@ def golden_digests(workload, scale):
         return None
 
 
-def cpu_baseline(groups, sample, budget_s=20.0):
+def cpu_baseline(groups, sample, budget_s=20.0, mid=None):
     """The CPU oracle (oracle/, plain C) timed on a bounded sample of the
     workload's groups: per group the threaded per-sequence scans (all host
     cores, like the reference's process pool) and then the line-by-line greedy
     restatement (one core, like the reference's one process per instance).
-    Reported beside the GPU number, never part of it."""
+    mid: one mid-size group (25-40 Mbases) on top, once, with the oracle's
+    lazy-evaluation greedy (pinned to the line-by-line one; that one would take
+    minutes there) -- so that the like-for-like ratio is not taken on the
+    smallest groups alone.  Reported beside the GPU number, never part of it."""
     from catch_amd.filter import candidate_probes
     from oracle import oracle as orc
     orc.build()
@@ -415,17 +484,32 @@ def cpu_baseline(groups, sample, budget_s=20.0):
         el = time.perf_counter() - t0 - cand_s
         if el >= budget_s / 2 or reps >= 50:
             break
-    orc.set_threads(1)
     el = time.perf_counter() - t0 - cand_s
+    mid_rec = None
+    if mid is not None:
+        genomes = groups[mid]
+        seqs = [s for g in genomes for s in g]
+        cands = list(dict.fromkeys(candidate_probes.candidate_strings_from_sequences(seqs, PROBE_LEN, STRIDE)))
+        tm = time.perf_counter()
+        ids = orc.set_cover_filter([cands], [genomes], MISMATCHES, PROBE_LEN, coverage=1.0, cover_extension=EXT,
+                                   lazy=True)[0]
+        mid_s = time.perf_counter() - tm
+        sel[mid] = ids
+        mid_rec = dict(group=mid, bases=sum(len(s) for s in seqs), candidates=len(cands), seconds=mid_s,
+                       value=len(cands) * sum(len(s) for s in seqs) / mid_s, unit="probe*bp/s",
+                       greedy="lazy evaluation over bitmaps (oracle.orc_lazy_greedy, pinned to the line-by-line "
+                              "restatement; ~40 x faster than it)")
+    orc.set_threads(1)
     return dict(value=units / el, unit="probe*bp/s", cores=cores, kind="port",
-                seconds=el, passes=reps,
+                seconds=el, passes=reps, mid_group=mid_rec,
                 sample="groups %s of the bench workload (the smallest by bases, "
                        "%d of %d groups), %d pass%s through the plain-C oracle: "
                        "seed-and-extend scan on %d OpenMP threads, interval-set "
                        "greedy on 1 (as the reference: pool for the scans, one "
-                       "process per instance for the solve)"
+                       "process per instance for the solve)%s"
                        % (sample, len(sample), len(groups), reps,
-                          "" if reps == 1 else "es", cores)), sel
+                          "" if reps == 1 else "es", cores,
+                          "" if mid_rec is None else "; plus group %d (%.1f Mbases) once, see mid_group" % (mid, mid_rec["bases"] / 1e6))), sel
 
 
 def cpu_baseline_s3(ctx, scale=0.03):
@@ -641,7 +725,15 @@ def bench_design_large(args):
         # property check where no oracle digest exists: the two kernel families of the frontier solver
         # (set-parallel fused / row-parallel flat) must select the same probes
         cur_flat = per.get("flat_rows_streamed", 0) > 0
-        p2, tm2 = one_step({"CATCHHIP_FLAT_MIN_ROWS": str(1 << 40) if cur_flat else "0"})
+        checks = [] if not args.no_property_checks else None
+        engine.collect_solution_checks(checks)
+        try:
+            p2, tm2 = one_step({"CATCHHIP_FLAT_MIN_ROWS": str(1 << 40) if cur_flat else "0"})
+        finally:
+            engine.collect_solution_checks(None)
+        if checks is not None:
+            # (the solutions replayed are those of this pass, the other solver family's; the digest below ties them to the timed ones)
+            out["property_checks"] = summarize_checks(checks)
         out["solver_families_agree"] = probes_digest(p2) == dg
         out["solver_family_timed"] = "flat (row-parallel)" if cur_flat else "fused (set-parallel)"
         out["other_family_wall_s"] = tm2["wall_s"]
@@ -667,6 +759,11 @@ def main():
                     help="one untimed-quality step on every rank: asserts the digests and prints per-rank "
                          "pack / scan / rows / solve / exchange times and the RCCL copy in use -- what to look "
                          "at first when a multi-GPU run misbehaves")
+    ap.add_argument("--no-property-checks", action="store_true",
+                    help="skip the extra step whose solutions are replayed by the independent check kernels")
+    ap.add_argument("--no-also", action="store_true",
+                    help="default S4 run: do not run configs[2] (S3) and configs[4] (S5) afterwards")
+    ap.add_argument("--also-s5-scale", type=float, default=1.0)
     ap.add_argument("--no-solver-check", action="store_true",
                     help="S5: skip the extra pass through the other solver family")
     args = ap.parse_args()
@@ -730,6 +827,37 @@ def main():
     pool1 = engine.pool_stats()
     my_elapsed = elapsed
 
+    # one extra, untimed step with the E_dirty statistics on (SURVEY 8(d) K2's byte formula wants them), and one
+    # whose solutions are replayed by the independent check kernels
+    dirty_stats, prop = None, None
+    if world == 1 and not args.preflight:
+        os.environ["CATCHHIP_FLAT_COUNT_DIRTY"] = "1"
+        try:
+            st_d = []
+            run_step(st_d)
+            dirty_stats = {"rows_recounted": float(sum(st.get("rows_recounted", 0) for st in st_d))}
+        finally:
+            os.environ.pop("CATCHHIP_FLAT_COUNT_DIRTY", None)
+        if not args.no_property_checks:
+            checks = []
+            engine.collect_solution_checks(checks)
+            try:
+                run_step()
+            finally:
+                engine.collect_solution_checks(None)
+            prop = summarize_checks(checks)
+            if Stepper.ndf:
+                import random
+                from catch_amd.filter.near_duplicate_filter import NearDuplicateFilterWithHammingDistance
+                g0 = stepper.resident[0]
+                random.seed(7)
+                tabs = NearDuplicateFilterWithHammingDistance(NdfGroup.HAMMING, PROBE_LEN)._draw_positions()
+                flat = np.frombuffer("".join(s_ for g in groups[g0.index] for s_ in g).encode(), dtype=np.uint8)
+                at = np.asarray(g0.cands.positions(), dtype=np.int64)
+                kept = flat[at[:, None] + np.arange(PROBE_LEN)[None, :]]
+                npairs, nbad = ndf_bucket_independence(kept, tabs, NdfGroup.HAMMING)
+                prop = dict(prop or {}, ndf_kept=int(at.size), ndf_pairs_sharing_a_bucket=npairs, ndf_pairs_too_close=nbad)
+                prop["ok"] = bool(prop.get("ok", True) and nbad == 0)
     # identical picks whatever N: every group against the committed digests
     gold = golden_digests(args.workload, args.scale)
     gold_ok, gold_n = True, 0
@@ -787,60 +915,70 @@ def main():
         per = {k: v / K for k, v in tot.items()}        # per step, this rank
         seeds, hits, rows = per.get("seed_hits", 0), per.get("raw_hits", 0), per.get("rows", 0)
         # ---- bytes per step ("Roofline accounting") ----
-        # seed_verify, per seed: 12 B work item + 0.375 B/base of a (L+32)-base
-        #   target window and of the L-base probe + 4 B rank; per hit a 16 B record
-        #   (a list entry the look-up's anchor-pair filter left empty is a 4-B read and nothing else)
+        # K1 since round 4 = the key-grouped join (csrc/scan_join.inc).  H = target positions whose k-mer is in the
+        # anchor table, pairs = (position, entry) pairs verified, E = anchor entries in the table (m + 1 per candidate).
+        H, pairs = per.get("join_hit_positions", 0), per.get("join_pairs", 0)
+        E = float(MISMATCHES + 1) * P
         dropped = per.get("seeds_dropped", 0)
         live = seeds - dropped
-        verify_bytes = live * (12 + 0.375 * (PROBE_LEN + 32) + 0.375 * PROBE_LEN + 4) + 4.0 * dropped + 16.0 * hits
+        # one pass of kj_verify: per hit position a 12-B record + two sequence bounds + (m + 1) windows of
+        # (NW + 1) 16-byte words; per table entry its id, 64-byte probe image, bucket and offset; the counting pass
+        # writes 4 B per entry, the writing pass a 16-B record per hit
+        nw = -(-PROBE_LEN // 32)
+        pass_bytes = H * (12 + 8 + (MISMATCHES + 1) * 16.0 * (nw + 1)) + E * (4 + 16.0 * nw + 8)
+        verify_bytes = 2 * pass_bytes + 4.0 * E + 16.0 * hits
         # SURVEY 8(d) K1 (brute-force tiles, T_p = 1024) for the same groups
         survey_k1 = sum(0.375 * g.G * -(-g.n_sets // 1024) + 0.375 * PROBE_LEN * g.n_sets
                         for g in stepper.resident) + 16.0 * rows
-        # whole seed scan as implemented: planes 0/1 + a 16 B table probe per
-        # position, per seed 24 B list + 60 B window + 64 B probe image + 20 B record
-        # (+ the 24 B of sibling-anchor keys the look-up reads per table match)
-        k1_impl = 16.25 * G + 28.0 * seeds + 4.0 * dropped + 168.0 * live
-        rows_bytes = 44.0 * hits + 40.0 * rows
-        # 12 B per (set, universe, interval) row re-counted + 8 B
-        #   per bitmap word read for the popcounts
-        #   per bitmap word read for the popcounts -- E_dirty pricing: only rows whose words changed
-        k2_bytes = 12.0 * per.get("rows_recounted", 0) + 8.0 * per.get("bitmap_words_read", 0)
-        # what the rounds move as implemented: the row-parallel solver also streams the rows that are NOT
-        # counted again (12 B read by the count launch, 12 B written for every survivor, 12 B read by the
-        # claim launch) and looks at one owner word per flagged word
+        # whole scan phase as implemented: table build (per entry: 64-B image read, 16-B slot, 4-B list entry, twice
+        # its slot number), hit positions (planes 0/1 = 0.25 B per base + a presence bit; 12 B staged, read and
+        # written again per hit position), 4 radix passes of 12 B in and out, the two verify passes
+        k1_impl = 100.0 * E + 0.25 * G + 36.0 * H + 4 * 24.0 * H + verify_bytes
+        rows_bytes = 32.0 * hits + 32.0 * rows      # merge: records in, merged rows out; emit: 16 B in, 16 B out
+        # 12 B per (set, universe, interval) row of E_dirty + 8 B per bitmap word read for the
+        # popcounts.  E_dirty (rows that hold a word the previous picks changed) is counted in one extra, untimed
+        # step (CATCHHIP_FLAT_COUNT_DIRTY); the rows the launches actually count again are all alive ones.
+        edirty = dirty_stats.get("rows_recounted") if dirty_stats else None
+        k2_bytes = 12.0 * (edirty if edirty is not None else per.get("rows_recounted", 0)) + 8.0 * per.get("bitmap_words_read", 0)
+        k2_full = 12.0 * per.get("rows_recounted", 0) + 8.0 * per.get("bitmap_words_read", 0)
+        # what the rounds move as implemented: every alive record read by the count launch (8 B), written for every
+        # survivor (8 B), read again by the claim launch (8 B), one bitmap word per flagged word and one owner word
         streamed = per.get("flat_rows_streamed", 0)
-        k2_impl = (k2_bytes + 12.0 * (streamed - per.get("flat_rows_recounted", 0)) + 24.0 * streamed
-                   + 8.0 * per.get("flat_owner_words", 0))
-        ms = {k: per.get(k, 0.0) for k in ("scan_ms", "verify_ms", "rows_ms", "greedy_ms", "rounds_ms", "claim_ms")}
-        nlaunch = {k: tot.get(k, 0) for k in ("verify_launches", "rounds_launches", "scan_launches", "claim_launches")}
+        k2_impl = 24.0 * streamed + 8.0 * per.get("bitmap_words_read", 0) + 8.0 * per.get("flat_owner_words", 0)
+        ms = {k: per.get(k, 0.0) for k in ("scan_ms", "verify_ms", "vcount_ms", "rows_ms", "greedy_ms", "rounds_ms", "claim_ms")}
+        nlaunch = {k: tot.get(k, 0) for k in ("verify_launches", "vcount_launches", "rounds_launches", "scan_launches", "claim_launches")}
 
         def gbs(b, t_ms):
             return b / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+        ninst = float(len(stepper.big_alone) + 1 if stepper.union is not None else len(stepper.resident))
         units_roof = {
-            "seed_verify": dict(kernel="seed_verify4_kernel<%d>" % -(-PROBE_LEN // 32),
-                                ms=ms["verify_ms"], bytes=verify_bytes,
-                                launches=nlaunch["verify_launches"] / K, pmc="seed_verify"),
+            "join_verify": dict(kernel="kj_verify_kernel<%d, true/false> + kj_giant_kernel (key-grouped join: counting + writing pass)" % nw,
+                                ms=ms["verify_ms"] + ms["vcount_ms"], bytes=verify_bytes,
+                                launches=(nlaunch["verify_launches"] + nlaunch["vcount_launches"]) / K, pmc="join_verify"),
             "solver_claim": dict(kernel="gr_claim_kernel (row-parallel solver, groups of >= 4 M rows)",
                                  ms=ms["claim_ms"], bytes=per.get("claim_bytes", 0.0),
                                  launches=max(nlaunch["claim_launches"], 1) / K, pmc="gr_claim"),
-            "rows_build": dict(kernel="bucketed row build (per group: scatter, merge, scans, emit)",
-                               ms=ms["rows_ms"], bytes=rows_bytes,
-                               launches=float(len(stepper.big_alone) + 1 if stepper.union is not None else len(stepper.resident)),
-                               pmc="rows_build"),
+            "rows_build": dict(kernel="bucketed row build (per group: merge, scans, emit)",
+                               ms=ms["rows_ms"], bytes=rows_bytes, launches=ninst, pmc="rows_build"),
         }
-        # The dominant KERNEL by its own HIP-event timer: the seed-verify launch (phase 5), the claim launches of
-        # the row-parallel solver (phase 6: an event pair per launch), or -- several kernels, priced by the
-        # scatter's share of them in rocprofv3's summary -- the row build.
-        share = {"seed_verify": 1.0, "solver_claim": 1.0, "rows_build": 0.55}
-        dom = max(units_roof, key=lambda k: units_roof[k]["ms"] * share[k])
+        # The dominant KERNEL by its own HIP-event timer: the join's verify launches (phases 5 + 7), the claim
+        # launches of the row-parallel solver (phase 6: an event pair per launch), or the row build.
+        dom = max(units_roof, key=lambda k: units_roof[k]["ms"])
         d = units_roof[dom]
         avg_ms = d["ms"] / max(d["launches"], 1)
-        roof = dict(bound="hbm", kernel=d["kernel"], achieved=gbs(d["bytes"], d["ms"]),
-                    peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs(d["bytes"], d["ms"]) / HBM_PEAK_GBS,
-                    traffic=pmc_traffic(d["pmc"], args.workload, args.scale),
-                    algorithmic_bytes_per_launch=d["bytes"] / max(d["launches"], 1),
+        traffic = pmc_traffic(d["pmc"], args.workload, args.scale)
+        alg_pl = d["bytes"] / max(d["launches"], 1)
+        # `achieved` never prices more bytes than were counted on the memory side: min(model, PMC traffic)
+        priced = alg_pl if traffic is None else min(alg_pl, traffic)
+        roof = dict(bound="hbm", kernel=d["kernel"], achieved=gbs(priced, avg_ms),
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs(priced, avg_ms) / HBM_PEAK_GBS,
+                    traffic=traffic,
+                    algorithmic_bytes_per_launch=alg_pl,
+                    priced_bytes_per_launch=priced,
                     avg_launch_ms=avg_ms, launches_per_step=d["launches"],
-                    device_ms_per_step=d["ms"])
+                    device_ms_per_step=d["ms"],
+                    note="frac = min(algorithmic bytes of the kernel's model, PMC traffic) / HIP-event time / peak; "
+                         "the K2 round as a whole against SURVEY 8(d)'s formula: roofline_k2")
         out = {
             "metric": "candidate-probe x target-bp / s through SetCoverFilter "
                       "(K1 scan + K2 greedy)",
@@ -873,46 +1011,56 @@ def main():
                                             % (Stepper.UNION_BELOW / 1e6)},
             "setcoverfilter_ms": elapsed / K * 1e3,
             "picks": per.get("picks", 0), "rows": rows,
-            "kernel_ms_per_step": {"k1_scan": ms["scan_ms"], "k1_seed_verify": ms["verify_ms"],
+            "kernel_ms_per_step": {"k1_scan": ms["scan_ms"], "k1_join_verify_count": ms["vcount_ms"],
+                                   "k1_join_verify_write": ms["verify_ms"],
                                    "rows_build": ms["rows_ms"], "k2_greedy": ms["greedy_ms"],
-                                   "k2_greedy_rounds_only": ms["rounds_ms"],
+                                   "k2_greedy_rounds_only": ms["rounds_ms"], "k2_claim_launches": ms["claim_ms"],
                                    "note": "HIP-event device time summed over the groups of rank 0; "
                                            "groups in flight overlap, so the sum can exceed ms_per_step"},
             "roofline": roof,
-            "roofline_k1_verify": dict(bound="hbm", achieved=gbs(verify_bytes, ms["verify_ms"]),
+            "roofline_k1_verify": dict(bound="hbm", achieved=gbs(verify_bytes, ms["verify_ms"] + ms["vcount_ms"]),
                                        peak=HBM_PEAK_GBS, unit="GB/s",
-                                       frac=gbs(verify_bytes, ms["verify_ms"]) / HBM_PEAK_GBS,
-                                       traffic=pmc_traffic("seed_verify", args.workload, args.scale)),
+                                       frac=gbs(verify_bytes, ms["verify_ms"] + ms["vcount_ms"]) / HBM_PEAK_GBS,
+                                       implementation_bytes=verify_bytes,
+                                       traffic=pmc_traffic("join_verify", args.workload, args.scale),
+                                       valu_note="the verify passes are integer-issue work, not bandwidth: %.3g pairs x ~45 "
+                                                 "lane-ops per pass" % pairs,
+                                       lane_utilisation=(pairs / per["join_lane_slots"]) if per.get("join_lane_slots") else None),
             "roofline_k1_scan": dict(bound="hbm", implementation_bytes=k1_impl,
                                      achieved_implementation=gbs(k1_impl, ms["scan_ms"]),
+                                     frac_implementation=gbs(k1_impl, ms["scan_ms"]) / HBM_PEAK_GBS,
                                      survey_8d_formula_bytes=survey_k1,
                                      achieved_survey_formula=gbs(survey_k1, ms["scan_ms"]),
                                      peak=HBM_PEAK_GBS, unit="GB/s",
                                      note="SURVEY 8(d)'s K1 bytes price a brute-force tiled scan "
-                                          "(every probe tile re-reads the targets); the seeded scan "
+                                          "(every probe tile re-reads the targets); the join "
                                           "does not do that work, so that figure is an upper "
                                           "courtesy, not an achievement"),
             "roofline_rows": dict(bound="hbm", achieved=gbs(rows_bytes, ms["rows_ms"]),
                                   peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=gbs(rows_bytes, ms["rows_ms"]) / HBM_PEAK_GBS,
+                                  implementation_bytes=rows_bytes,
                                   traffic=pmc_traffic("rows_build", args.workload, args.scale)),
             "roofline_k2": dict(bound="hbm", achieved=gbs(k2_bytes, ms["rounds_ms"]),
                                 peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=gbs(k2_bytes, ms["rounds_ms"]) / HBM_PEAK_GBS,
+                                algorithmic_bytes=k2_bytes, e_dirty_rows=edirty,
+                                full_recompute_bytes=k2_full,
                                 traffic=pmc_traffic("solver_round", args.workload, args.scale),
                                 implementation_bytes=k2_impl,
                                 achieved_implementation=gbs(k2_impl, ms["rounds_ms"]),
-                                note="bytes = SURVEY 8(d) K2: 12 B per row counted again (a word of it changed) + "
-                                     "8 B per bitmap word read; implementation_bytes adds the record streams of "
-                                     "the row-parallel solver (count, compaction, claim) and the owner words",
+                                note="algorithmic_bytes = SURVEY 8(d) K2: 12 B per row of E_dirty (a word of it changed since "
+                                     "the last round; counted in one extra untimed step) + 8 B per bitmap word read; "
+                                     "full_recompute_bytes prices every alive row (what the count launches do since round 4); "
+                                     "implementation_bytes adds the record streams (count in and out, claim in) and the owner words",
                                 us_per_pick=ms["rounds_ms"] * 1e3 / max(per.get("picks", 0), 1),
                                 rounds_per_step=per.get("greedy_iters", 0)),
             "roofline_k3": None,
-            "work_per_step": {"table_matches": seeds, "seeds_verified": live, "hits": hits, "rows": rows,
-                              "rows_recounted": per.get("rows_recounted", 0),
+            "traffic_per_step": traffic_per_step(args.workload, args.scale),
+            "work_per_step": {"hit_positions": H, "table_matches": pairs, "pairs_verified": pairs, "hits": hits, "rows": rows,
+                              "rows_recounted": per.get("rows_recounted", 0), "e_dirty_rows": edirty,
                               "bitmap_words_read": per.get("bitmap_words_read", 0),
                               "flat_rows_streamed": streamed,
-                              "flat_rows_recounted": per.get("flat_rows_recounted", 0),
                               "flat_owner_words": per.get("flat_owner_words", 0)},
             "dataset_generation_s": gen_s,
             "first_upload_s": upload_s,
@@ -922,6 +1070,7 @@ def main():
                 pool1["hipmalloc_calls"] - pool0["hipmalloc_calls"])),
             "parity_vs_golden_digests": (gold_ok if gold_n else None),
             "groups_checked_against_digests": gold_n,
+            "property_checks": prop,
             "rccl": engine.Context.comm_info() if world > 1 else None,
         }
         if preflight is not None:
@@ -941,7 +1090,7 @@ def main():
                                       kept=per.get("ndf_kept", 0), windows=per.get("windows", 0),
                                       front_end_ms=per.get("front_end_ms", 0.0))
             out["config"]["workload"] += "; step = device front end + --filter-with-lsh-hamming 2 (K3) + scan + solve, targets resident"
-            if per.get("ndf_ms", 0.0) > d["ms"] * share[dom]:
+            if per.get("ndf_ms", 0.0) > d["ms"]:
                 # configs[2]: the filter is the dominant unit of the step (one filter call per group = one "launch")
                 nf = float(len(stepper.resident))
                 k3 = out["roofline_k3"]
@@ -960,37 +1109,47 @@ def main():
             out["speedup_vs_cpu_oracle"] = base["seconds"] / gpu_s
         elif world == 1 and not args.no_cpu_baseline:
             order = sorted(range(len(groups)), key=lambda i: bases[i])
+            by_idx_ok = set(g.index for g in stepper.resident)
             sample, acc = [], 0
             for i in order:
                 if sample and acc + bases[i] > 13_000_000:
                     break
                 sample.append(i)
                 acc += bases[i]
-            base, sel = cpu_baseline(groups, sample)
+            mids = [i for i in range(len(groups)) if 20_000_000 <= bases[i] <= 40_000_000 and i in by_idx_ok]
+            mid = min(mids, key=lambda i: abs(bases[i] - 30_000_000)) if mids else None
+            base, sel = cpu_baseline(groups, sample, mid=mid)
             out["cpu_baseline"] = base
+            checked = sample + ([mid] if mid is not None else [])
             # the timed GPU result must equal the oracle's (parity guard)
             out["parity_vs_oracle"] = all(sorted(picks[gi]) == sorted(sel[gi])
-                                          for gi in sample)
+                                          for gi in checked)
             # like for like: the GPU on exactly the CPU sample's groups (resident inputs, one
             # after the other), against the CPU's time per pass over the same groups
             by_index = {g.index: g for g in stepper.resident}
-            reps = 5
-            for _ in range(2):
-                for gi in sample:
-                    g = by_index[gi]
-                    engine.setcover_filter(g.ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN, 0, EXT,
-                                           g.n_sets, mode=SCAN_MODE)
-            stepper.sync()
-            tg = time.perf_counter()
-            for _ in range(reps):
-                for gi in sample:
-                    g = by_index[gi]
-                    engine.setcover_filter(g.ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN, 0, EXT,
-                                           g.n_sets, mode=SCAN_MODE)
-            stepper.sync()
-            gpu_sample_s = (time.perf_counter() - tg) / reps
+
+            def gpu_seconds(gis, reps=5):
+                for _ in range(2):
+                    for gi in gis:
+                        g = by_index[gi]
+                        engine.setcover_filter(g.ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN, 0, EXT,
+                                               g.n_sets, mode=SCAN_MODE)
+                stepper.sync()
+                tg = time.perf_counter()
+                for _ in range(reps):
+                    for gi in gis:
+                        g = by_index[gi]
+                        engine.setcover_filter(g.ctx, g.probes, g.targets, MISMATCHES, PROBE_LEN, 0, EXT,
+                                               g.n_sets, mode=SCAN_MODE)
+                stepper.sync()
+                return (time.perf_counter() - tg) / reps
+            gpu_sample_s = gpu_seconds(sample)
             out["gpu_ms_on_cpu_sample"] = gpu_sample_s * 1e3
             out["speedup_vs_cpu_oracle"] = (base["seconds"] / base["passes"]) / gpu_sample_s
+            if mid is not None:
+                gm = gpu_seconds([mid], reps=3)
+                base["mid_group"]["gpu_ms"] = gm * 1e3
+                base["mid_group"]["speedup_vs_cpu_oracle"] = base["mid_group"]["seconds"] / gm
             out["speedup_note"] = ("CPU seconds per pass over the sample's groups / GPU seconds for the same "
                                    "groups (resident inputs); `value` / cpu_baseline.value is NOT comparable: "
                                    "probe*bp grows quadratically with the group size")
@@ -1076,6 +1235,36 @@ def main():
                                         "note": "not the headline: per-kernel times (roofline) are only "
                                                 "meaningful when kernels run alone"}
             st2.close()
+        if (world == 1 and args.workload == "S4" and args.scale == 1.0 and not args.no_also and not args.no_cpu_baseline
+                and not args.preflight):
+            # BASELINE configs[2] (S3: --filter-with-lsh-hamming in the step) and configs[4] (S5: the design_large chain)
+            # in the same driver-run line: each in a process of its own, after this one has given its memory back
+            import subprocess
+            if stepper is not None:
+                stepper.close()
+                stepper = None
+            engine.pool_trim()
+            keep = ("ms_per_step", "value", "unit", "steps", "warmup", "kernel_ms_per_step", "roofline", "roofline_k3",
+                    "wall_s_per_step", "parity_vs_golden_digests", "property_checks", "solver_families_agree",
+                    "work_per_step", "dataset_generation_s", "probes_sha256", "m2_setcoverfilter_wall_s")
+            also = {}
+            for name, extra in (("S3", ["--workload", "S3", "--steps", "3", "--warmup", "1"]),
+                                ("S5", ["--workload", "S5", "--scale", "%g" % args.also_s5_scale, "--steps", "1", "--warmup", "0"])):
+                ta = time.perf_counter()
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra +
+                                       ["--no-cpu-baseline", "--no-m2", "--no-partial", "--no-overlap-figure", "--no-also"],
+                                       capture_output=True, text=True, timeout=1200)
+                    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+                    sub = json.loads(line)
+                    rec = {k: sub[k] for k in keep if k in sub}
+                    rec["workload"] = sub["config"]["workload"]
+                    rec["bytes_held"] = sub.get("device_memory", {}).get("bytes_held")
+                except Exception as e:      # noqa: BLE001 -- the S4 line must not be lost to a failure here
+                    rec = {"error": "%s: %s" % (type(e).__name__, e)}
+                rec["wall_s"] = time.perf_counter() - ta
+                also[name] = rec
+            out["also"] = also
         print(json.dumps(out))
     for g in sharded:
         g.close()

@@ -35,6 +35,7 @@ PROTOTYPES = {
         c_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), c_i64p]),
     "catchhip_ctx_last_counters": (ctypes.c_int, [c_vp, c_i64p]),
     "catchhip_ctx_last_seeds_dropped": (ctypes.c_int, [c_vp, c_i64p]),
+    "catchhip_ctx_last_join_counters": (ctypes.c_int, [c_vp, c_i64p]),
     "catchhip_ctx_last_solver_counters": (ctypes.c_int, [c_vp, c_i64p]),
     "catchhip_ctx_last_ndf_counters": (ctypes.c_int, [c_vp, c_i64p]),
     "catchhip_targets_create": (ctypes.c_int, [

@@ -303,6 +303,12 @@ extern "C" int catchhip_ctx_last_ndf_counters(catchhip_ctx *c, i64 *out4) {
     return 0;
 }
 
+extern "C" int catchhip_ctx_last_join_counters(catchhip_ctx *c, i64 *out4) {
+    ARG_CHECK(c != nullptr && out4 != nullptr);
+    for (int i = 0; i < 4; ++i) out4[i] = c->join_counters[i];
+    return 0;
+}
+
 extern "C" int catchhip_ctx_last_seeds_dropped(catchhip_ctx *c, i64 *out) {
     ARG_CHECK(c != nullptr && out != nullptr);
     *out = c->seeds_dropped;

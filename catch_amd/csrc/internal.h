@@ -112,6 +112,7 @@ struct catchhip_ctx {
     i64 ndf_counters[4] = {};      // last Hamming near-duplicate filter: probes, tables, pairs compared, edges
     i64 solver_counters[4] = {};   // row-parallel solver: records streamed, rows counted again, bitmap words read, owner words looked at
     i64 seeds_dropped = 0;   // of counters[1]: work-list entries the seed look-up's anchor-pair filter left empty
+    i64 join_counters[4] = {};     // last key-grouped join: hit positions, pairs verified, lane slots of wave-wide runs, tasks of cut runs
     // pinned staging word(s) for small device->host reads
     u64 *h_pin = nullptr;
     // larger pinned staging area (grown on demand) so that result read-backs are

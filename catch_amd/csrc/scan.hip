@@ -1688,6 +1688,7 @@ static int run_join(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
     if (J.ngiant > KJ_GIANT_CAP) return 1;   // absurdly repetitive input: the seed-list scan copes (slowly)
     ctx->counters[1] = (i64)pairs;
     ctx->seeds_dropped = 0;
+    ctx->join_counters[0] = J.nhit; ctx->join_counters[1] = (i64)pairs; ctx->join_counters[2] = (i64)slots; ctx->join_counters[3] = J.ngiant;
     TRY(B.S.reserve(std::max<size_t>(nhits, 1)));
     A.S = B.S.p;
     hipLaunchKernelGGL(kj_bases_kernel, dim3((unsigned)div_up(P->nprobes, 256)), dim3(256), 0, s, (const u32 *)J.ecnt.p,
@@ -1882,6 +1883,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
                 continue;
             }
             ctx->counters[1] = nseeds;
+            for (int q = 0; q < 4; ++q) ctx->join_counters[q] = 0;
             ctx->seeds_dropped = (i64)nseeds - (i64)((volatile u32 *)h)[10];   // list entries without a seed
             P->seed_ratio_hint = std::max(P->seed_ratio_hint, (double)nseeds / (double)std::max<i64>(T->total, 1));   // see seed_capacity
             break;

@@ -15,6 +15,7 @@ SCAN_AUTO, SCAN_GENERAL, SCAN_FAST, SCAN_SEED = 0, 1, 2, 3
 PHASE_SCAN, PHASE_ROWS, PHASE_GREEDY, PHASE_NDF, PHASE_GREEDY_ROUNDS = 0, 1, 2, 3, 4
 PHASE_VERIFY = 5
 PHASE_CLAIM = 6
+PHASE_VCOUNT = 7      # key-grouped join: the counting pass (PHASE_VERIFY: the writing pass)
 
 
 def _ptr(a, t):
@@ -140,6 +141,9 @@ class Context:
         dropped = np.zeros(1, dtype=np.int64)
         check(self._L.catchhip_ctx_last_seeds_dropped(self._h, _ptr(dropped, c_i64p)))
         d["seeds_dropped"] = int(dropped[0])   # of seed_hits: left without a seed by the look-up's filter
+        jc = np.zeros(4, dtype=np.int64)
+        check(self._L.catchhip_ctx_last_join_counters(self._h, _ptr(jc, c_i64p)))
+        d.update(zip(("join_hit_positions", "join_pairs", "join_lane_slots", "join_cut_tasks"), (int(x) for x in jc)))
         sc = np.zeros(4, dtype=np.int64)
         check(self._L.catchhip_ctx_last_solver_counters(self._h, _ptr(sc, c_i64p)))
         d.update(zip(("flat_rows_streamed", "flat_rows_recounted", "flat_bitmap_words",

@@ -79,6 +79,12 @@ int catchhip_ctx_last_kernel_ms(catchhip_ctx *ctx, int phase, double *ms,
  * words read while re-counting, [7] cover rows of the last fused
  * catchhip_setcover_filter call. */
 int catchhip_ctx_last_counters(catchhip_ctx *ctx, int64_t *out8);
+/* Work of the last key-grouped join (the seed scan of pigeonhole tables, csrc/scan_join.inc): out4[0] = target
+ * positions whose k-mer is in the anchor table, [1] = (position, entry) pairs verified (the table matches of
+ * catch/probe.py:1062-1069), [2] = lane slots the wave-wide runs occupied (64 per window chunk and entry; pairs /
+ * slots = lane utilisation), [3] = tasks of runs that were cut by entries.  Zeros after a seed-list scan. */
+int catchhip_ctx_last_join_counters(catchhip_ctx *ctx, int64_t *out4);
+
 /* Of counter [1] (entries of the last seed scan's work list): those the
  * look-up's anchor-pair filter left without a seed -- a lower anchor of the same
  * probe is exact at the same window (the pair is reported from that anchor's

@@ -5,16 +5,16 @@
 # (FETCH_SIZE / WRITE_SIZE in separate passes, as MI355X_MICROARCH.md says).
 #   tools/collect_profiles.sh <tag> [workload] [extra]   -> gpurun_out/profiles_<tag>/
 # extra = "all" also profiles the clustering pre-step and the device front end
-tag=${1:-r03}; wl=${2:-S4}; extra=${3:-}
+tag=${1:-r04}; wl=${2:-S4}; extra=${3:-}
 out=/root/repo/gpurun_out/profiles_$tag
 rm -rf $out
 mkdir -p $out
 cd /root/repo
 python bench.py --workload $wl > $out/bench.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python /root/repo/bench.py --workload $wl --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure > $out/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python /root/repo/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python /root/repo/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python /root/repo/bench.py --workload $wl --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure --no-property-checks > $out/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python /root/repo/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure --no-property-checks > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python /root/repo/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure --no-property-checks > /dev/null 2>&1
 if [ "$extra" = "all" ]; then
   # the kernels outside the bench's hot path: clustering pre-step and the device front end
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cluster -- python /root/repo/tools/cluster_bench.py --scale 0.25 --cpu-sample 0 > $out/cluster_bench.json 2>/dev/null
@@ -55,23 +55,28 @@ def unit(names, per):
     return {"kernels": names, "per_launch_of": per, "launches": launches,
             "FETCH_SIZE_KB_per_launch": sum(kern[n]["FETCH_SIZE_KB_per_launch"] * kern[n]["launches"] for n in names) / launches,
             "WRITE_SIZE_KB_per_launch": sum(kern[n]["WRITE_SIZE_KB_per_launch"] * kern[n]["launches"] for n in names) / launches}
-seed = [k for k in kern if k.startswith("seed_") and not k.startswith("seed_verify")]
-rows = [k for k in kern if k.startswith(("scan1_", "bucket_", "rows_emit", "scan_tiles"))]
+k1a = [k for k in kern if k.startswith(("seed_init", "seed_count", "seed_alloc", "seed_fill", "seed_lookup", "kj_hitpos", "kj_compact",
+                                        "radix_hist", "radix_scatter", "scan_tile_"))]
+verify = [k for k in kern if k.startswith(("kj_verify", "kj_giant", "seed_verify"))]
+rows = [k for k in kern if k.startswith(("scan1_", "bucket_", "rows_emit", "scan_tiles", "kj_bucket_count", "kj_bases"))]
+setup = [k for k in kern if k.startswith(("gr_tile_", "set_ptr", "gr_bitmap"))]
 solver = [k for k in kern if k.startswith(("gf_count_claim", "gf_check_apply", "gr_count", "gr_claim", "gr_check", "gr_apply"))]
-ndfk = [k for k in kern if k.startswith(("ndf_", "radix_", "mh_"))]
-verify = [k for k in kern if k.startswith("seed_verify")]
+ndfk = [k for k in kern if k.startswith(("ndf_", "mh_"))]
 rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
-               "'python bench.py --workload %s --steps 2 --warmup 1 --no-cpu-baseline'; KB per launch averaged over "
+               "'python bench.py --workload %s --steps 2 --warmup 1 --no-cpu-baseline --no-property-checks' (3 steps + the "
+               "untimed step with the E_dirty statistics = 4 steps in the run); KB per launch averaged over "
                "the launches of the run (all groups, all rounds); a unit = total KB of its kernels / launches of its "
                "leading kernel(s) (a solver round = one count launch with its claim / apply launches); on "
                "gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md), bench.py doubles it; "
                "other widths and WRITE_SIZE are uncalibrated" % wl,
-       "workload": wl,
+       "workload": wl, "steps_in_run": 4,
+       "disjoint_units": ["k1_table_hitpos_sort", "join_verify", "rows_build", "solver_setup", "solver_round", "ndf"],
        "units": {"solver_round": unit(solver, [k for k in solver if k.startswith(("gf_count_claim", "gr_count"))]),
                  "gr_claim": unit([k for k in solver if k.startswith("gr_claim")], [k for k in solver if k.startswith("gr_claim")]),
-                 "seed_verify": unit(verify, verify),
-                 "seed_table_lookup": unit(seed, [k for k in seed if k.startswith("seed_lookup")]),
-                 "rows_build": unit(rows, [k for k in rows if k.startswith("bucket_scatter")]),
+                 "join_verify": unit(verify, [k for k in verify if k.startswith(("kj_verify", "seed_verify"))]),
+                 "k1_table_hitpos_sort": unit(k1a, [k for k in k1a if k.startswith(("kj_hitpos", "seed_lookup"))]),
+                 "rows_build": unit(rows, [k for k in rows if k.startswith("rows_emit")]),
+                 "solver_setup": unit(setup, [k for k in setup if k.startswith("gr_tile_scatter")]),
                  "ndf": unit(ndfk, [k for k in ndfk if k.startswith("ndf_key")][:1] or ndfk[:1])},
        "kernels": kern}
 json.dump(rec, open(out + "/pmc_traffic.json", "w"), indent=1)
