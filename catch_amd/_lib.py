@@ -10,6 +10,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CATCHHIP_LIB: another build of the same ABI (A/B runs of two kernel versions)
 LIB_PATH = os.environ.get("CATCHHIP_LIB") or os.path.join(_HERE, "libcatchhip.so")
 
+
+
+def test_env(name, default=None):
+    """A TEST HOOK of the Python side (a switch that forces one of several exact code paths so that tests can
+    compare them): only honoured under CATCHHIP_TEST_HOOKS=1, like the C library's (csrc/internal.h).  The
+    supported settings are read with os.environ directly and listed in README.md."""
+    if os.environ.get("CATCHHIP_TEST_HOOKS", "0") in ("", "0"):
+        return default
+    return os.environ.get(name, default)
+
+
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
 c_u8p = ctypes.POINTER(ctypes.c_uint8)

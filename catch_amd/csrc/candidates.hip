@@ -314,7 +314,7 @@ static int candidates_build(catchhip_ctx *ctx, const catchhip_targets *T, u32 L,
     // CATCHHIP_CAND_HASH_BITS (tests): keep only that many bits of the hash, so that
     // different windows collide and the byte-wise resolution is exercised
     u64 hash_mask = ~0ull;
-    if (const char *e = getenv("CATCHHIP_CAND_HASH_BITS")) {
+    if (const char *e = chip_test_env("CATCHHIP_CAND_HASH_BITS")) {
         const int b = atoi(e);
         if (b >= 0 && b < 64) hash_mask = ((u64)1 << b) - 1;
     }
@@ -635,7 +635,7 @@ static int cand_set_order(catchhip_ctx *ctx, const catchhip_candidates *C, DevBu
             if (h_grp[i] != h_grp[i - 1]) bounds.push_back(i);
     }
     bounds.push_back(nk);
-    static const u32 device_from = getenv("CATCHHIP_PYSET_DEVICE_FROM") ? (u32)atoll(getenv("CATCHHIP_PYSET_DEVICE_FROM")) : 8192u;
+    static const u32 device_from = chip_test_env("CATCHHIP_PYSET_DEVICE_FROM") ? (u32)atoll(chip_test_env("CATCHHIP_PYSET_DEVICE_FROM")) : 8192u;
     bool any_host = false;
     for (size_t g = 0; g + 1 < bounds.size(); ++g) any_host |= bounds[g + 1] - bounds[g] < device_from;
     std::vector<i64> h_hash, order;
@@ -701,7 +701,7 @@ static int cand_apply_keep(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<u32
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
-    if (!getenv("CATCHHIP_NDF_INCLUSION_ORDER")) TRY(cand_set_order(ctx, C, out, gout, nk));
+    if (!chip_test_env("CATCHHIP_NDF_INCLUSION_ORDER")) TRY(cand_set_order(ctx, C, out, gout, nk));
     C->upos.swap(out);
     if (C->grouped) C->ugrp.swap(gout);
     C->nuniq = nk;

@@ -25,7 +25,7 @@ extern "C" int catchhip_setcover_filter(catchhip_ctx *ctx, const catchhip_probes
     // single host synchronisation; the solver checks on the device that the scan
     // did not overflow and the rows fit its 5-word path, otherwise the group is
     // redone through the two synchronous calls below.
-    bool full = ctx->comm == nullptr && !getenv("CATCHHIP_GREEDY_SEQUENTIAL") && num_sets > 0 && out_ids;
+    bool full = ctx->comm == nullptr && !chip_test_env("CATCHHIP_GREEDY_SEQUENTIAL") && num_sets > 0 && out_ids;
     if (universe_p)
         for (i32 u = 0; u < T->ngenomes && full; ++u) full = universe_p[u] == 1.0;
     const auto t_in = std::chrono::steady_clock::now();

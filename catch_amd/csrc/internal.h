@@ -47,6 +47,16 @@ void chip_set_error(const char *fmt, ...);
         }                                                                     \
     } while (0)
 
+// Environment switches.  Four are part of the product and read with getenv(): CATCHHIP_TIMING (host-side wall
+// times on stderr), CATCHHIP_RCCL_PATH, CATCHHIP_POOL_SOFT_LIMIT_GB, CATCHHIP_GATHER_THREADS (README.md lists them
+// with the Python side's).  Everything else is a TEST HOOK -- it forces one of several exact code paths (the radix
+// row build, the set-parallel solver on a large instance, striped tiles ...) so that tests/ and bench.py can
+// compare them -- and is only honoured when CATCHHIP_TEST_HOOKS=1 is set (tests/conftest.py and bench.py do).
+static inline const char *chip_test_env(const char *name) {
+    static const bool on = [] { const char *e = getenv("CATCHHIP_TEST_HOOKS"); return e && atoi(e) != 0; }();
+    return on ? getenv(name) : nullptr;
+}
+
 // Caching device allocator (core.hip): hipMalloc/hipFree cost tens of
 // microseconds and hipFree synchronises the device, which would dominate the
 // millisecond-scale calls of this library.  Blocks are rounded up to a size

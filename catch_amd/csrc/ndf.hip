@@ -458,7 +458,7 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
     PhaseTimer tm(ctx, PHASE_NDF);
     ctx->ndf_counters[0] = n; ctx->ndf_counters[1] = ntables; ctx->ndf_counters[2] = ctx->ndf_counters[3] = 0;
     const unsigned nb = (unsigned)div_up(nn, 256);
-    if ((i64)ntables * n <= ((i64)1 << 31) && !getenv("CATCHHIP_NDF_ALL_PAIRS")) {
+    if ((i64)ntables * n <= ((i64)1 << 31) && !chip_test_env("CATCHHIP_NDF_ALL_PAIRS")) {
         // lazy resolution (ndf_lazy_kernel): all tables' sorted runs stay resident, one cursor per (table, slot) --
         // 24 bytes per entry, at most 2^31 entries (48 GB); beyond that the edge-list variant below, table by table
         DevBuf<u64> skeys, pairs;
@@ -501,7 +501,7 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
                                e_j.p, count.p, cap, d_grp, pstride,
                                // (with two or three tables the look at the earlier tables' positions costs more than
                                // the comparisons it saves: S3, 2 tables, 15.1 -> 18.0 ms)
-                               (ntables < 4 || getenv("CATCHHIP_MH_NO_DEDUPE")) ? 0 : t);
+                               (ntables < 4 || chip_test_env("CATCHHIP_MH_NO_DEDUPE")) ? 0 : t);
             tm.launch(2 + 24);
         }
         HIP_TRY(hipGetLastError());
@@ -841,7 +841,7 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
                        id_hi.p, id_lo.p, nuniq.p);
     tm.launch(1);
     ctx->ndf_counters[0] = n; ctx->ndf_counters[1] = ntables; ctx->ndf_counters[2] = ctx->ndf_counters[3] = 0;
-    if (tchunk >= ntables && (i64)ntables * n <= ((i64)1 << 31) && !getenv("CATCHHIP_MH_ALL_PAIRS")) {
+    if (tchunk >= ntables && (i64)ntables * n <= ((i64)1 << 31) && !chip_test_env("CATCHHIP_MH_ALL_PAIRS")) {
         // lazy resolution (ndf_lazy_kernel): all tables' sorted runs stay resident, one cursor per (table, slot) --
         // 24 bytes per entry, at most 2^31 entries (48 GB); beyond that the edge-list variant below, table by table
         DevBuf<u64> skeys, pairs;
@@ -909,7 +909,7 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
                                (const u64 *)id_hi.p, (const u64 *)id_lo.p,
                                (const u32 *)(sig.p + (size_t)tc * nn * k), (int)k, dist_thres, nn,
                                (const u64 *)keys.p, (const u32 *)vals.p, grp, e_i.p, e_j.p, count.p, cap,
-                               (const u32 *)sig.p, getenv("CATCHHIP_MH_NO_DEDUPE") ? 0 : tc);
+                               (const u32 *)sig.p, chip_test_env("CATCHHIP_MH_NO_DEDUPE") ? 0 : tc);
             tm.launch(2 + 24);
         }
         HIP_TRY(hipGetLastError());

@@ -1265,7 +1265,7 @@ static int seed_table_lookup_async(catchhip_ctx *ctx, const catchhip_probes *P, 
     // whose keys are whole k-mers with room for the N flags
     const int nanch_tab = P->pigeonhole ? (int)(P->L / k) : 0;
     const bool filt = allow_filter && nanch_tab >= 2 && nanch_tab <= SEED_SIB + 1 && pos_limit != 0xffffffffu && k <= 30 &&
-                      (nanch_tab - 1) * k <= SL_HALO && !getenv("CATCHHIP_SEED_KEEP_ALL");
+                      (nanch_tab - 1) * k <= SL_HALO && !chip_test_env("CATCHHIP_SEED_KEEP_ALL");
     const int need2 = filt && nanch_tab - mm >= 2 ? 1 : 0;
     const u32 nblk = (u32)div_up(T->total, SL_TILE);
     S.nranges = filt ? nblk : 0;
@@ -1275,7 +1275,7 @@ static int seed_table_lookup_async(catchhip_ctx *ctx, const catchhip_probes *P, 
     TRY(S.sseq.reserve(S.scap));
     if (!res) { TRY(S.dummy.reserve(8)); res = S.dummy.p; }
     // presence bits: for the pigeonhole tables of a whole-genome scan (most positions miss); 4 per slot
-    const bool pres = P->pigeonhole && capacity >= (1u << 16) && capacity <= (1u << 29) && !getenv("CATCHHIP_SEED_NO_PRESENCE");
+    const bool pres = P->pigeonhole && capacity >= (1u << 16) && capacity <= (1u << 29) && !chip_test_env("CATCHHIP_SEED_NO_PRESENCE");
     const u32 pwords = pres ? capacity / 8 : 0;      // 4 * capacity bits
     if (pres) TRY(S.present.reserve(pwords));
     SeedTable t = {S.slot.p, S.cnt.p, S.ents.p, capacity - 1, filt ? (const uint4 *)S.sib.p : nullptr,
@@ -1309,7 +1309,7 @@ static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     const u32 pos_limit = P->pigeonhole ? (u32)std::min<i64>((i64)(mm + 1) * k, P->L) : 0xffffffffu;
     seed_verify_fn verify = pick_seed_verify((int)P->pwords);
     if (!verify) { chip_set_error("seed scan: unsupported probe length"); return CATCHHIP_EINVAL; }
-    seed_verify4_fn verify4 = getenv("CATCHHIP_VERIFY_V1") ? nullptr : pick_seed_verify4((int)P->pwords);
+    seed_verify4_fn verify4 = pick_seed_verify4((int)P->pwords);
     // anchors per probe in the table (pigeonhole: those below pos_limit), <= 31 for the bit set
     const int nanch = P->pigeonhole ? (int)(P->L / k) : 0;
     const int ntab = nanch ? (int)std::min<i64>(nanch, div_up((i64)pos_limit, k)) : 0;
@@ -1340,6 +1340,7 @@ static int run_seed_async(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     (void)hipEventRecord(ctx->ev[2 * PHASE_VERIFY + 1], ctx->stream);
     ctx->phase_launches[PHASE_VERIFY] = 1;
     ctx->phase_launches[PHASE_VCOUNT] = 0; ctx->phase_ms[PHASE_VCOUNT] = 0.0;
+    for (int q = 0; q < 4; ++q) ctx->join_counters[q] = 0;   // (no join in this scan)
     tm.launch(1);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1357,7 +1358,7 @@ static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchh
     // every target position does one look-up (the extension below re-checks the
     // k-mer on the bytes).  Anything else is joined through a sort of byte hashes.
     const bool table = P->dna5 && T->dna5 && P->L > 0 && P->L <= 256 && P->pwords >= 1 && P->k <= P->L &&
-                       !getenv("CATCHHIP_GENERAL_SORTJOIN");
+                       !chip_test_env("CATCHHIP_GENERAL_SORTJOIN");
     SeedRun S;
     DevBuf<u64> keys, keys_alt;
     DevBuf<u32> vals, vals_alt, sa, sb, scount;
@@ -1417,7 +1418,7 @@ static int run_general(catchhip_ctx *ctx, const catchhip_probes *P, const catchh
     }
     HitBuf ob = {H.a.p, H.b.p, H.c.p, H.count.p, nseeds, H.want_seed ? H.d.p : nullptr,
                  H.want_seed ? H.e.p : nullptr};
-    extend_planes_fn planes = table && !getenv("CATCHHIP_EXTEND_BYTES") ? pick_extend_planes((int)P->pwords) : nullptr;
+    extend_planes_fn planes = table && !chip_test_env("CATCHHIP_EXTEND_BYTES") ? pick_extend_planes((int)P->pwords) : nullptr;
     DevBuf<u32> cut;
     const u32 cut_cap = 1u << 22;
     if (planes) {
@@ -1494,7 +1495,7 @@ static int bucket_scan(catchhip_ctx *ctx, BucketBuild &B, const u32 *in, u32 *ou
                        const u32 *aux, u32 *auxmax_out, PhaseTimer &tm) {
     hipStream_t s = ctx->stream;
     if (n <= 16384) {
-        static const int s1t = getenv("CATCHHIP_SCAN1_THREADS") ? atoi(getenv("CATCHHIP_SCAN1_THREADS")) : 1024;
+        static const int s1t = chip_test_env("CATCHHIP_SCAN1_THREADS") ? atoi(chip_test_env("CATCHHIP_SCAN1_THREADS")) : 1024;
         hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(s1t), 0, s, in, out, n, total_out, (u32 *)nullptr, aux,
                            auxmax_out);
         tm.launch(1);
@@ -1565,7 +1566,7 @@ static bool join_path_ok(const catchhip_probes *P, int mm) {
     if (!P->pigeonhole || P->k <= 0 || P->pwords < 1 || P->pwords > 8) return false;
     const int nanch = (int)(P->L / P->k);
     const int ntab = (int)std::min<i64>(nanch, (i64)mm + 1);
-    return ntab >= 1 && ntab <= KJ_AMAX && !getenv("CATCHHIP_SEED_LIST");
+    return ntab >= 1 && ntab <= KJ_AMAX && !chip_test_env("CATCHHIP_SEED_LIST");
 }
 
 // the write pass alone (again after a row build that fell back to the radix sort: the merge works in place)
@@ -1596,11 +1597,11 @@ static int run_join(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
     TRY(S.ents.reserve(nent));
     TRY(S.slot_of.reserve(nent));
     TRY(S.ctr.reserve(4));
-    const bool pres = capacity >= (1u << 16) && capacity <= (1u << 29) && !getenv("CATCHHIP_SEED_NO_PRESENCE");
+    const bool pres = capacity >= (1u << 16) && capacity <= (1u << 29) && !chip_test_env("CATCHHIP_SEED_NO_PRESENCE");
     // One presence bit per slot (4 MB for the 32 M slots of S4's largest group: mostly L2 hits; the seed-list scan's
     // 4 bits per slot are 16 MB: every probe a trip to the memory-side cache).  Measured on S4, whole scan phase:
     // 4 bits 33.8 ms, 1 bit 30.5, half a bit 30.4, a quarter 30.8 (more false positives go on to the slot array).
-    static const int pshift = getenv("CATCHHIP_PRESENCE_SHIFT") ? atoi(getenv("CATCHHIP_PRESENCE_SHIFT")) : 2;
+    static const int pshift = chip_test_env("CATCHHIP_PRESENCE_SHIFT") ? atoi(chip_test_env("CATCHHIP_PRESENCE_SHIFT")) : 2;
     const u32 pbits = pres ? std::max<u32>((4u * capacity) >> pshift, 1u << 16) : 0;
     const u32 pwords = pbits / 32;
     if (pres) TRY(S.present.reserve(pwords));
@@ -1803,7 +1804,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
                           bool dedupe = false, bool want_first = false) {
     const bool seed_ok = seed_path_ok(P, T, mismatches, lcf_thres, island);
     const bool tiled_ok = fast_path_ok(P, T, mismatches, lcf_thres, island);
-    const bool want_tiled = mode == CATCHHIP_SCAN_FAST || (mode == CATCHHIP_SCAN_AUTO && getenv("CATCHHIP_SCAN_TILED"));
+    const bool want_tiled = mode == CATCHHIP_SCAN_FAST || (mode == CATCHHIP_SCAN_AUTO && chip_test_env("CATCHHIP_SCAN_TILED"));
     const bool use_fast = tiled_ok && want_tiled && !(want_first && mode == CATCHHIP_SCAN_AUTO);
     if (use_fast && want_first) {
         chip_set_error("cover_scan_first_seen: the tiled scan does not know which anchor seeded a hit");
@@ -1812,7 +1813,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     O.from_seeds = false;
     const bool use_seed = seed_ok && !use_fast && mode != CATCHHIP_SCAN_GENERAL && mode != CATCHHIP_SCAN_FAST;
     const u32 nb = by_sequence ? (u32)P->nprobes : (u32)P->nbuckets;
-    const bool force_radix = getenv("CATCHHIP_ROWS_RADIX") != nullptr && !dedupe;
+    const bool force_radix = chip_test_env("CATCHHIP_ROWS_RADIX") != nullptr && !dedupe;
     HitSink sink;
     sink.bucket_of = by_sequence || P->bucket_identity ? nullptr : P->bucket_of.p;   // (null: the probe index itself)
     sink.seq_genome = by_sequence ? nullptr : T->seq_genome.p;
@@ -1840,7 +1841,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
             O.nrec = 0; O.nrec_dev = nullptr;
             tr.restart();
             // (buckets = probes: every bucket is its probe's anchor runs side by side, each in position order)
-            const bool runs = sink.bucket_of == nullptr && O.J.A.ntab <= BK_RUNS_MAX && !getenv("CATCHHIP_MERGE_NO_RUNS");
+            const bool runs = sink.bucket_of == nullptr && O.J.A.ntab <= BK_RUNS_MAX && !chip_test_env("CATCHHIP_MERGE_NO_RUNS");
             TRY(bucket_finish_async(ctx, O.B, 0, nullptr, by_sequence, !force_radix, tr, dedupe, true,
                                     runs ? (const u32 *)O.J.ecnt.p : (const u32 *)nullptr, O.J.A.nanch, O.J.A.ntab));
             tr.stop();
@@ -1853,13 +1854,13 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     } else if (use_seed) {
         O.from_seeds = true;
         O.S.scap = seed_capacity(P, T);
-        if (const char *e = getenv("CATCHHIP_SEED_CAP")) O.S.scap = (u32)std::max(1, atoi(e));   // tests: force the retry
+        if (const char *e = chip_test_env("CATCHHIP_SEED_CAP")) O.S.scap = (u32)std::max(1, atoi(e));   // tests: force the retry
         for (int attempt = 0;; ++attempt) {
             const auto dbg0 = std::chrono::steady_clock::now();
             TRY(bucket_prepare(O.B, nb, O.S.scap, by_sequence));
             sink.rec = O.B.rec.p; sink.rank = O.B.rank.p; sink.bcnt = O.B.bcnt.p;
             // (the first-discovery keys pair record d with seed d: not compact then)
-            O.B.compact = !want_first && !getenv("CATCHHIP_HITS_SPARSE");
+            O.B.compact = !want_first && !chip_test_env("CATCHHIP_HITS_SPARSE");
             sink.wcnt = O.B.compact ? O.B.wcnt.p : nullptr;
             ts.restart();
             TRY(run_seed_async(ctx, P, T, mismatches, O.S, sink, nb, O.B.res.p, ts));
@@ -1938,8 +1939,8 @@ int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const ca
     *out = nullptr;
     if (P->nprobes == 0 || T->total == 0) return 1;
     if (!seed_path_ok(P, T, mismatches, lcf_thres, island)) return 1;
-    if (!(mode == CATCHHIP_SCAN_SEED || (mode == CATCHHIP_SCAN_AUTO && !getenv("CATCHHIP_SCAN_TILED")))) return 1;
-    if (getenv("CATCHHIP_ROWS_RADIX") || getenv("CATCHHIP_SEED_CAP") || getenv("CATCHHIP_FUSED_SYNC")) return 1;
+    if (!(mode == CATCHHIP_SCAN_SEED || (mode == CATCHHIP_SCAN_AUTO && !chip_test_env("CATCHHIP_SCAN_TILED")))) return 1;
+    if (chip_test_env("CATCHHIP_ROWS_RADIX") || chip_test_env("CATCHHIP_SEED_CAP") || chip_test_env("CATCHHIP_FUSED_SYNC")) return 1;
     const i64 scap64 = seed_capacity(P, T);
     if (scap64 > ((i64)1 << 26)) return 1;   // keep the capacity-sized row arrays small
     HIP_TRY(hipSetDevice(ctx->device));

@@ -659,7 +659,6 @@ greedy_wg_kernel(GreedyArgs a) {
 
 #include "setcover_batched.inc"
 #include "setcover_flat.inc"
-#include "setcover_lazy.inc"
 
 // ------------------------------------------------------------------------
 // multi-launch solver (one gain launch + one apply launch per pick); used when
@@ -902,7 +901,7 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
     const bool wide = d_info ? nuniv >= 256 : (i64)nrows >= 32 * (i64)nsets;
     // rows of more than 5 bitmap words take the lane-per-word kernels (a deferred
     // scan with such rows stops itself, info[5], and comes back through here)
-    const bool long_rows = (!d_info && R->lmax > 257) || getenv("CATCHHIP_GF_LONG") != nullptr;
+    const bool long_rows = (!d_info && R->lmax > 257) || chip_test_env("CATCHHIP_GF_LONG") != nullptr;
     const u32 sets_per_wg = GF_THREADS / (wide ? 64 : 16);
     const unsigned gblocks = (unsigned)std::min<i64>(div_up(nsets, sets_per_wg), (i64)ctx->num_cus * 16);
     // arena: the zero-initialised part first
@@ -917,7 +916,7 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
                  o_setptr = take(4 * ((size_t)nsets + 1)), o_frow = take(8 * (size_t)nrows),
                  o_flag = take(nrows), o_picks = take(4 * (size_t)nsets), o_keys = take(8 * (size_t)nsets);
     // live-set lists only where walking every set each round would dominate
-    const bool use_list = nsets > 65536 && !getenv("CATCHHIP_GF_NOLIST");
+    const bool use_list = nsets > 65536 && !chip_test_env("CATCHHIP_GF_NOLIST");
     const size_t o_live0 = use_list ? take(4 * (size_t)nsets) : 0, o_live1 = use_list ? take(4 * (size_t)nsets) : 0;
     DevBuf<u8> arena;
     TRY(arena.alloc(off));
@@ -1108,7 +1107,7 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
 
     // every universe fully covered: batched rounds (many independent picks per
     // round); otherwise one pick per iteration
-    bool batched = !distributed && !getenv("CATCHHIP_GREEDY_SEQUENTIAL");
+    bool batched = !distributed && !chip_test_env("CATCHHIP_GREEDY_SEQUENTIAL");
     if (universe_p)
         for (u32 u = 0; u < nuniv && batched; ++u) batched = universe_p[u] == 1.0;
 
@@ -1116,7 +1115,7 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     // large instances: the row-parallel, tile-ordered kernels (setcover_flat.inc).
     // Measured on S4 (rows: rounds of the fused vs the flat kernels): 272 M: 65 vs
     // 30 ms; 44 M: 9.9 vs 6.7; 29 M: 6.6 vs 4.5; 19 M: 4.0 vs 3.4; 4 M: 1.5 vs 1.5.
-    const i64 flat_min_rows = getenv("CATCHHIP_FLAT_MIN_ROWS") ? atoll(getenv("CATCHHIP_FLAT_MIN_ROWS")) : (i64)1 << 22;
+    const i64 flat_min_rows = chip_test_env("CATCHHIP_FLAT_MIN_ROWS") ? atoll(chip_test_env("CATCHHIP_FLAT_MIN_ROWS")) : (i64)1 << 22;
     if (batched && R->lmax <= 257 && (i64)nrows >= flat_min_rows && nsets <= GR_MAX_SETS)
         return greedy_flat(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out);
     if (batched) return greedy_frontier(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out, &no_retry);
@@ -1124,8 +1123,8 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
     // row-parallel kernels with the universe test (setcover_flat.inc, "PARTIAL") whatever the size --
     // the one-workgroup solvers below take 3.9 ms per pick on S4's largest group (54.6 s for S4 under
     // -c 0.9 against 0.17 s under -c 1.0)
-    if (universe_p && !distributed && R->lmax <= 257 && nsets <= GR_MAX_SETS && !getenv("CATCHHIP_GREEDY_SEQUENTIAL") &&
-        !getenv("CATCHHIP_PARTIAL_SEQUENTIAL") && (i64)nrows >= (getenv("CATCHHIP_PARTIAL_MIN_ROWS") ? atoll(getenv("CATCHHIP_PARTIAL_MIN_ROWS")) : 0))
+    if (universe_p && !distributed && R->lmax <= 257 && nsets <= GR_MAX_SETS && !chip_test_env("CATCHHIP_GREEDY_SEQUENTIAL") &&
+        !chip_test_env("CATCHHIP_PARTIAL_SEQUENTIAL") && (i64)nrows >= (chip_test_env("CATCHHIP_PARTIAL_MIN_ROWS") ? atoll(chip_test_env("CATCHHIP_PARTIAL_MIN_ROWS")) : 0))
         return greedy_flat(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out, universe_p);
 
     DevBuf<u32> set_ptr, flag, idx, tmp, seg_row, seg_univ, seg_set, row_seg, set_seg_ptr, usize, can, left, rank,
@@ -1191,54 +1190,7 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         tm.launch(6);
     }
     int rc = 0;
-    // Lazy evaluation in one persistent workgroup (setcover_lazy.inc), CATCHHIP_GREEDY_LAZY=1: exact, and on S4
-    // slower than the eager workgroup below (hundreds of re-evaluations per pick once thousands of sets hold
-    // the same stale gain)
-    const u32 lz_n1 = (u32)div_up((i64)nsets, 64), lz_n2 = (u32)div_up((i64)lz_n1, 64);
-    const bool use_lazy = !distributed && lz_n2 <= LZ_MAXT2 &&
-                          (getenv("CATCHHIP_GREEDY_LAZY") && atoi(getenv("CATCHHIP_GREEDY_LAZY")) != 0);   // opt-in: measured slower
-    if (use_lazy) {
-        DevBuf<u32> segcnt, ub;
-        DevBuf<uint4> lrow;
-        DevBuf<unsigned long long> t1, t2;
-        TRY(segcnt.alloc(nseg));
-        TRY(ub.alloc(nsets));
-        TRY(lrow.alloc(nrows));
-        TRY(t1.alloc(lz_n1));
-        TRY(t2.alloc(lz_n2));
-        HIP_TRY(hipMemsetAsync(segcnt.p, 0, sizeof(u32) * nseg, s));
-        hipLaunchKernelGGL(rowcnt_init_kernel, dim3(rb), dim3(256), 0, s, R->gs.p, R->ge.p, row_seg.p, nrows, segcnt.p);
-        hipLaunchKernelGGL(lazy_gain_init_kernel, dim3(sb), dim3(256), 0, s, (const u32 *)segcnt.p, (const u32 *)seg_univ.p,
-                           (const u32 *)left.p, (const u32 *)set_seg_ptr.p, nsets, ub.p);
-        hipLaunchKernelGGL(lrow_fill_kernel, dim3(rb), dim3(256), 0, s, R->gs.p, R->ge.p, R->univ.p, (const u32 *)row_seg.p,
-                           nrows, lrow.p);
-        hipLaunchKernelGGL(lazy_t1_kernel, dim3((unsigned)div_up((i64)lz_n1, 4)), dim3(256), 0, s, (const u32 *)ub.p,
-                           (const u32 *)rank.p, 0u, nsets, lz_n1, t1.p);
-        hipLaunchKernelGGL(lazy_t2_kernel, dim3((unsigned)div_up((i64)lz_n2, 4)), dim3(256), 0, s,
-                           (const unsigned long long *)t1.p, lz_n1, lz_n2, t2.p);
-        static bool lz_attr_set = false;
-        if (!lz_attr_set) {
-            (void)hipFuncSetAttribute((const void *)lazy_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      LZ_MAXT2 * (int)sizeof(unsigned long long));
-            lz_attr_set = true;
-        }
-        LazyArgs a;
-        a.bm = bm.p; a.lrow = lrow.p; a.set_ptr = set_ptr.p; a.set_seg_ptr = set_seg_ptr.p; a.seg_row = seg_row.p;
-        a.can = can.p; a.rank = rank.p; a.usize = usize.p; a.left = left.p; a.ub = ub.p; a.t1 = t1.p; a.t2g = t2.p;
-        a.picks = picks.p; a.st = st.p;
-        a.nsets = nsets; a.n1 = lz_n1; a.n2 = lz_n2; a.nuniv = nuniv;
-        hipLaunchKernelGGL(lazy_wg_kernel, dim3(1), dim3(LZ_THREADS), (size_t)lz_n2 * sizeof(unsigned long long), s, a);
-        tm.launch(6);
-        tm.stop();
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(&h_st, st.p, sizeof(h_st), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        tm.finish();
-        ctx->phase_launches[PHASE_GREEDY] = h_st.iters;
-        // [2] iterations (evaluations + rank changes), [4] rows walked, [5] sets evaluated
-        ctx->counters[2] = h_st.iters; ctx->counters[3] = h_st.npicks; ctx->counters[4] = (i64)h_st.n_wrows;
-        ctx->counters[5] = (i64)h_st.n_recount; ctx->counters[6] = 0;
-    } else if (!distributed) {
+    if (!distributed) {
         // ---- persistent single-workgroup solver ---------------------------
         DevBuf<u32> prowcnt, segcnt, segcontrib, gain, dirty, pos_row, pos_row_alt, useg, useg_alt, useg_ptr,
             bucket;
@@ -1294,7 +1246,7 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         ctx->counters[2] = h_st.iters; ctx->counters[3] = h_st.npicks; ctx->counters[4] = (i64)h_st.n_wrows;
         ctx->counters[5] = (i64)h_st.n_recount; ctx->counters[6] = (i64)h_st.n_words;
 #ifdef CATCHHIP_PROFILE
-        if (getenv("CATCHHIP_PROF")) {
+        if (chip_test_env("CATCHHIP_PROF")) {
             fprintf(stderr, "[catchhip] greedy wg: iters=%u picks=%u ms=%.3f ticks/iter:", h_st.iters, h_st.npicks,
                     ctx->phase_ms[PHASE_GREEDY]);
             for (int i = 0; i < 4; ++i) fprintf(stderr, " p%d=%.0f", i, (double)h_st.prof[i] / (h_st.iters ? h_st.iters : 1));

@@ -21,6 +21,7 @@ import operator
 import random
 from collections import defaultdict
 
+from catch_amd import _lib
 from catch_amd import engine
 from catch_amd.filter.base_filter import BaseFilter
 
@@ -54,7 +55,7 @@ def _as_the_reference_returns_them(kept, key=None):
     computed here is the one of PYTHONHASHSEED=0 on CPython <= 3.10
     (engine.pyset_order_strs emulates the set), whatever this process' own hash
     seed is -- the same stance as for the MinHash family's hash."""
-    if len(kept) < 2 or os.environ.get("CATCHHIP_NDF_INCLUSION_ORDER"):
+    if len(kept) < 2 or _lib.test_env("CATCHHIP_NDF_INCLUSION_ORDER"):
         return list(kept)
     order = engine.pyset_order_strs([k if key is None else key(k) for k in kept])
     return [kept[i] for i in order.tolist()]

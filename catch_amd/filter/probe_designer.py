@@ -5,6 +5,7 @@ _cluster_genomes :78-184, _pass_through_filters :186-228, _design_for_genomes
 import itertools
 import logging
 
+from catch_amd import _lib
 from catch_amd import genome
 from catch_amd import probe
 from catch_amd.filter import candidate_probes
@@ -200,7 +201,7 @@ class ProbeDesigner:
         # a set cover over one long genome is a chain of ties (its picks come one per round), and in a
         # union the chains of all clusters advance in the same rounds (S5 x 0.25, 2,293 clusters of
         # 0.4 Mbases: 164,418 rounds one cluster at a time)
-        if ngroups < 8 or total >= int(os.environ.get("CATCHHIP_UNION_MAX_MEAN_BASES", "4000000")) * ngroups:
+        if ngroups < 8 or total >= int(_lib.test_env("CATCHHIP_UNION_MAX_MEAN_BASES", "4000000")) * ngroups:
             return "per group"
         return "union"
 

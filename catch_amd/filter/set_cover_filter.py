@@ -15,6 +15,7 @@ import logging
 
 import numpy as np
 
+from catch_amd import _lib
 from catch_amd import engine
 from catch_amd import probe
 from catch_amd.filter.base_filter import BaseFilter
@@ -245,9 +246,9 @@ class SetCoverFilter(BaseFilter):
         # candidates each) overlap better as separate instances in flight
         if (only is None and tables is None
                 and assume_unique and not self.identify and not self.avoided_genomes
-                and len(todo) >= int(os.environ.get("CATCHHIP_UNION_MIN_GROUPS", "8"))
+                and len(todo) >= int(_lib.test_env("CATCHHIP_UNION_MIN_GROUPS", "8"))
                 and sum(len(input_strs[gi]) for gi in todo) <= len(todo) * int(
-                    os.environ.get("CATCHHIP_UNION_MAX_MEAN_CANDIDATES", "8192"))
+                    _lib.test_env("CATCHHIP_UNION_MAX_MEAN_CANDIDATES", "8192"))
                 and len({len(s) for gi in todo for s in input_strs[gi]}) == 1):
             self._filter_strs_union(input_strs, target_genomes_grouped, todo,
                                     selected, timings)

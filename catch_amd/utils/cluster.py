@@ -16,6 +16,7 @@ import os
 
 import numpy as np
 
+from catch_amd import _lib
 from catch_amd.utils import lsh
 
 logger = logging.getLogger(__name__)
@@ -283,13 +284,13 @@ def _components_of_signatures(sigs, threshold,
     # as the number grows; evaluated with the expression above, so the comparison is the same)
     within = np.nonzero(1.0 - np.arange(sigs.N + 1, dtype=np.float64) / N <= threshold)[0]
     neighbors = neighbors_many = None
-    if sigs.N <= 176 and len(within) and not os.environ.get("CATCHHIP_CLUSTER_ROWS_ONLY"):
+    if sigs.N <= 176 and len(within) and not _lib.test_env("CATCHHIP_CLUSTER_ROWS_ONLY"):
         min_common = int(within[0])
 
         def neighbors(j):
             idx, common = sigs.neighbors(j, min_common)
             return idx, 1.0 - common.astype(np.float64) / N
-        if sigs.N <= 112 and not os.environ.get("CATCHHIP_CLUSTER_ONE_BY_ONE"):
+        if sigs.N <= 112 and not _lib.test_env("CATCHHIP_CLUSTER_ONE_BY_ONE"):
             def neighbors_many(js):
                 return [(idx, 1.0 - common.astype(np.float64) / N) for idx, common in sigs.neighbors_many(js, min_common)]
     return _components(sigs.n, row, threshold, early_stop_threshold, neighbors, neighbors_many,

@@ -6,6 +6,7 @@ without duplicate candidates; compares the cover rows and the selected probe
 sets, and the near-duplicate filters.  Not part of the pytest suite: run by
 hand after kernel changes; every failure prints the seed that reproduces it."""
 import os
+os.environ.setdefault("CATCHHIP_TEST_HOOKS", "1")
 import random
 import sys
 import time
@@ -44,7 +45,7 @@ def rand_group(rnd):
     return genomes
 
 
-SOLVER_ENV = ("CATCHHIP_FLAT_MIN_ROWS", "CATCHHIP_FLAT_STRIPED", "CATCHHIP_GF_LONG", "CATCHHIP_VERIFY_V1",
+SOLVER_ENV = ("CATCHHIP_FLAT_MIN_ROWS", "CATCHHIP_FLAT_STRIPED", "CATCHHIP_GF_LONG", "CATCHHIP_SEED_LIST",
               "CATCHHIP_SHARD_FLAT")
 
 
@@ -53,7 +54,7 @@ def one_case(seed, ctx):
     # which of the equivalent kernel families run (all must give the oracle's result)
     for name in SOLVER_ENV:
         os.environ.pop(name, None)
-    variant = random.Random(seed * 7919 + 13).choice(["default", "flat", "flat_striped", "long", "verify_v1"])
+    variant = random.Random(seed * 7919 + 13).choice(["default", "flat", "flat_striped", "long", "seed_list"])
     os.environ["CATCHHIP_SHARD_FLAT"] = "1" if seed % 2 else "0"
     if variant.startswith("flat"):
         os.environ["CATCHHIP_FLAT_MIN_ROWS"] = "0"
@@ -61,8 +62,8 @@ def one_case(seed, ctx):
             os.environ["CATCHHIP_FLAT_STRIPED"] = "1"
     elif variant == "long":
         os.environ["CATCHHIP_GF_LONG"] = "1"
-    elif variant == "verify_v1":
-        os.environ["CATCHHIP_VERIFY_V1"] = "1"
+    elif variant == "seed_list":
+        os.environ["CATCHHIP_SEED_LIST"] = "1"      # the seed-list scan of rounds 1-3 instead of the key-grouped join
     L = rnd.choice([40, 60, 75, 100, 120])
     stride = rnd.choice([L // 4, L // 2, L])
     m = rnd.choice([0, 1, 2, 3, 5])

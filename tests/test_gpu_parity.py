@@ -70,9 +70,18 @@ def test_scan_fast_matches_oracle(ctx, oracle, L, stride, m, ext):
     # the seed-join + extension path must agree with the tiled Hamming kernel
     got_g = _scan_rows(ctx, probes, genomes, m, L, 0, ext, engine.SCAN_GENERAL)
     assert got_g == exp
-    # ... and so must the hash-seeded Hamming kernel (K1c)
+    # ... and so must the seed scan: the key-grouped join (K1d, round 4) and, forced, the seed-list scan it replaced
+    # for pigeonhole tables (K1c: still what random anchor tables and the first-seen scans take)
     got_s = _scan_rows(ctx, probes, genomes, m, L, 0, ext, engine.SCAN_SEED)
     assert got_s == exp
+    assert ctx.counters()["join_hit_positions"] > 0
+    os.environ["CATCHHIP_SEED_LIST"] = "1"
+    try:
+        got_l = _scan_rows(ctx, probes, genomes, m, L, 0, ext, engine.SCAN_SEED)
+        assert ctx.counters()["join_hit_positions"] == 0
+    finally:
+        del os.environ["CATCHHIP_SEED_LIST"]
+    assert got_l == exp
 
 
 def test_seed_lookup_anchor_pair_filter_edge_cases(ctx, oracle):
@@ -116,14 +125,17 @@ def test_seed_lookup_anchor_pair_filter_edge_cases(ctx, oracle):
     exp = _oracle_rows(oracle, probes, genomes, 2, 100, 0, 10)
     assert len(exp) > 30
     for mode in (engine.SCAN_SEED, engine.SCAN_GENERAL):
-        assert _scan_rows(ctx, probes, genomes, 2, 100, 0, 10, mode) == exp, mode
-    # the same through the unfiltered look-up (CATCHHIP_SEED_KEEP_ALL) -- the filter must not change a row
-    import os
-    os.environ["CATCHHIP_SEED_KEEP_ALL"] = "1"
+        assert _scan_rows(ctx, probes, genomes, 2, 100, 0, 10, mode) == exp, mode      # (SCAN_SEED: the join)
+    # the seed-list scan with its anchor-pair filter, and through the unfiltered look-up (CATCHHIP_SEED_KEEP_ALL) --
+    # the filter must not change a row
+    os.environ["CATCHHIP_SEED_LIST"] = "1"
     try:
         assert _scan_rows(ctx, probes, genomes, 2, 100, 0, 10, engine.SCAN_SEED) == exp
+        os.environ["CATCHHIP_SEED_KEEP_ALL"] = "1"
+        assert _scan_rows(ctx, probes, genomes, 2, 100, 0, 10, engine.SCAN_SEED) == exp
     finally:
-        del os.environ["CATCHHIP_SEED_KEEP_ALL"]
+        os.environ.pop("CATCHHIP_SEED_KEEP_ALL", None)
+        del os.environ["CATCHHIP_SEED_LIST"]
 
 
 def test_scan_fast_no_n_two_planes(ctx, oracle):
@@ -294,14 +306,14 @@ def test_scan_empty_inputs(ctx):
 # ---------------------------------------------------------------- K2
 def _partial_solver(monkeypatch, solver):
     """Which solver takes instances with universe_p < 1: the frontier rounds of
-    the row-parallel kernels with the universe test (default), or one of the
-    two persistent-workgroup solvers (eager re-count / lazy evaluation)."""
+    the row-parallel kernels with the universe test (default), or the
+    persistent-workgroup solver (eager re-count; the lazy-evaluation variant of
+    round 3 was a measured dead end and is gone)."""
     if solver != "frontier":
         monkeypatch.setenv("CATCHHIP_PARTIAL_SEQUENTIAL", "1")
-        monkeypatch.setenv("CATCHHIP_GREEDY_LAZY", "1" if solver == "lazy" else "0")
 
 
-@pytest.mark.parametrize("solver", ["frontier", "eager", "lazy"])
+@pytest.mark.parametrize("solver", ["frontier", "eager"])
 def test_greedy_reference_test_vectors(ctx, monkeypatch, solver):
     """set_cover.approx_multiuniverse known answers
     (catch/utils/tests/test_set_cover.py), unit-cost instances; partial
@@ -327,7 +339,7 @@ def test_greedy_reference_test_vectors(ctx, monkeypatch, solver):
     assert n >= 20
 
 
-@pytest.mark.parametrize("solver", ["frontier", "eager", "lazy"])
+@pytest.mark.parametrize("solver", ["frontier", "eager"])
 def test_greedy_random_instances_match_oracle(ctx, oracle, monkeypatch, solver):
     engine = _engine()
     _partial_solver(monkeypatch, solver)
@@ -404,34 +416,27 @@ def test_greedy_batched_rounds_restore_sequential_order(ctx, oracle, monkeypatch
         cn = ctx.counters()
         rounds = cn["greedy_iters"]
         if flat:
-            assert 0 < cn["flat_rows_recounted"] < cn["flat_rows_streamed"]
+            assert 0 < cn["flat_rows_recounted"] <= cn["flat_rows_streamed"]
         else:
             assert cn["flat_rows_streamed"] == 0
         os.environ["CATCHHIP_GREEDY_SEQUENTIAL"] = "1"
         try:
-            os.environ["CATCHHIP_GREEDY_LAZY"] = "0"
             got_seq = dev.greedy(P, ranks, None)
-            os.environ["CATCHHIP_GREEDY_LAZY"] = "1"      # lazy evaluation in the persistent workgroup
-            got_lazy = dev.greedy(P, ranks, None)
-            evals = ctx.counters()["rows_recounted"]
         finally:
             del os.environ["CATCHHIP_GREEDY_SEQUENTIAL"]
-            del os.environ["CATCHHIP_GREEDY_LAZY"]
         dev.close()
         assert got == exp, trial
         assert got_seq == exp, trial
-        assert got_lazy == exp, trial
-        assert evals >= len(exp)           # every pick is evaluated at least once
         assert rounds < len(exp)      # really batched
 
 
-def test_lazy_solver_partial_cover_many_universes(ctx, oracle, monkeypatch):
-    """The lazy persistent workgroup on sets that touch more universes than
-    its LDS accumulators hold at once (> 4,096 segments per set), with partial
-    coverage (min(left, count) binds at the end of every universe), ranks, and
-    rows longer than five bitmap words: the oracle's picks in its order."""
+def test_sequential_solver_partial_cover_many_universes(ctx, oracle, monkeypatch):
+    """The persistent-workgroup solver on sets that touch thousands of universes,
+    with partial coverage (min(left, count) binds at the end of every universe),
+    ranks, and rows longer than five bitmap words (which the frontier rounds do
+    not take under partial coverage): the oracle's picks in its order."""
     engine = _engine()
-    _partial_solver(monkeypatch, "lazy")
+    _partial_solver(monkeypatch, "eager")
     rng = np.random.Generator(np.random.PCG64(2024))
     for trial in range(3):
         P, U = 40, 4500 + 700 * trial

@@ -3,6 +3,7 @@
 wall time per group as a function of CATCHHIP_GROUPS_IN_FLIGHT.
     python tools/many_groups_bench.py [scale]"""
 import os
+os.environ.setdefault("CATCHHIP_TEST_HOOKS", "1")   # (the tools below switch code paths through test hooks)
 import sys
 import time
 
