@@ -578,7 +578,9 @@ class SetCoverFilter(BaseFilter):
         lanes = depth > 0 and lane_env != 0 and len(order) > 1
         lane_count = 3 if lane_env == 1 else lane_env
         pre = feed = None
-        if depth > 0 and not lanes:
+        # (several devices, CATCHHIP_DEVICES: the chunks' contexts sit on different GPUs and an object built on the one
+        # upload context cannot change hands across devices -- every group is then built on its own context)
+        if depth > 0 and not lanes and len(set(_devices())) == 1:
             pre = engine.Prefetch(order, build, depth, discard)
             feed = iter(pre)
 
@@ -658,7 +660,9 @@ class SetCoverFilter(BaseFilter):
                         if errors:
                             return
                         try:
-                            res = build(gi)
+                            # built on the upload context of the DEVICE whose lane will consume it: with CATCHHIP_DEVICES
+                            # the lanes sit on several GPUs, and an object cannot change hands across devices
+                            res = build(gi, engine.upload_context(ctxs[lane_of[gi]].device))
                         except BaseException as exc:
                             with cv:
                                 errors.append(exc)
@@ -694,6 +698,10 @@ class SetCoverFilter(BaseFilter):
                                 errors.append(exc)
                                 cv.notify_all()
                             slots.release()          # (the producer may be waiting for a slot)
+                            try:
+                                ctx.sync()           # kernels of this lane may still read the objects closed below
+                            except Exception:        # noqa: BLE001 -- the first error is the one to report
+                                pass
                         finally:
                             for h in (probes, cands, targets):
                                 h.close()
