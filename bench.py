@@ -778,7 +778,7 @@ def main():
             raise SystemExit("--workload S5 runs on one GPU (the clustered design is one process)")
         return bench_design_large(args)
 
-    W = parallel.init_from_env()          # gloo plumbing + RCCL communicator when WORLD_SIZE > 1
+    W = parallel.init_from_env()          # TCP process group (catch_amd.netstore) + RCCL communicator when WORLD_SIZE > 1
     rank, world, dist = W.rank, W.size, W.dist
     device = engine.default_context().device
 
@@ -892,19 +892,15 @@ def main():
                   rccl=engine.Context.comm_info(), digests_ok=bool(gold_ok), groups_checked=gold_n)
         preflight = W.allgather(me)
     if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        u = torch.tensor([float(units), float(gold_n), 0.0 if gold_ok else 1.0,
-                          float(n_cands)], dtype=torch.float64)
-        dist.all_reduce(u, op=dist.ReduceOp.SUM)
-        total_units, gold_n, gold_ok = float(u[0]), int(u[1]), float(u[2]) == 0.0
-        n_cands = int(u[3])
-        gathered = [None] * world
-        dist.all_gather_object(gathered, my_elapsed)
-        all_elapsed = gathered
-        dist.barrier()
+        # (host objects over the process group: catch_amd.netstore -- no torch)
+        parts = W.allgather((my_elapsed, float(units), float(gold_n), 0.0 if gold_ok else 1.0, float(n_cands)))
+        elapsed = max(p_[0] for p_ in parts)
+        total_units = sum(p_[1] for p_ in parts)
+        gold_n = int(sum(p_[2] for p_ in parts))
+        gold_ok = all(p_[3] == 0.0 for p_ in parts)
+        n_cands = int(sum(p_[4] for p_ in parts))
+        all_elapsed = [p_[0] for p_ in parts]
+        W.barrier()
 
     if rank == 0:
         K = args.steps
@@ -1273,8 +1269,7 @@ def main():
         g.close()
     if stepper is not None:
         stepper.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    W.close()
 
 
 if __name__ == "__main__":

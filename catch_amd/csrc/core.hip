@@ -62,12 +62,19 @@ size_t pool_class(size_t b) {
 
 // what the library may hold before a request that misses the cache returns idle blocks to the driver
 static size_t pool_soft_limit() {
+    // (initialised once, under call_once: lanes and the prefetch thread allocate concurrently; a fractional
+    // CATCHHIP_POOL_SOFT_LIMIT_GB is scaled before it is truncated, and at least one byte so that "0.0001" is not
+    // mistaken for "no limit")
+    static std::once_flag once;
     static size_t soft_limit = 0;
-    if (!soft_limit) {
+    std::call_once(once, [] {
         size_t fr = 0, tot = 0;
         soft_limit = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) ? (size_t)((double)tot * 0.72) : ~(size_t)0 >> 1;
-        if (const char *e = getenv("CATCHHIP_POOL_SOFT_LIMIT_GB")) soft_limit = (size_t)atof(e) << 30;
-    }
+        if (const char *e = getenv("CATCHHIP_POOL_SOFT_LIMIT_GB")) {
+            const double gb = atof(e);
+            if (gb > 0.0) soft_limit = std::max<size_t>((size_t)(gb * (double)((size_t)1 << 30)), 1);
+        }
+    });
     return soft_limit;
 }
 

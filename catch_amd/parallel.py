@@ -129,37 +129,39 @@ def plan_with_sharding(group_costs, world, min_cost=0, slack=1.08, eligible=None
 
 
 # ---------------------------------------------------------------------------
-# run time: one process per GPU (torch.distributed.run / torchrun).  torch is
-# plumbing only -- rendezvous, barriers and small host objects over gloo; the
-# data path's exchanges are RCCL all-reduces on device buffers
-# (catchhip_shard_allreduce) over a communicator attached to a context of its
-# own (a context with a communicator switches catchhip_setcover_greedy to the
-# per-pick sharded form, which the whole-group solves must not take).
+# run time: one process per GPU (launched by torch.distributed.run / torchrun or anything else that sets RANK /
+# WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT).  The plumbing -- rendezvous, barriers, small host objects --
+# goes over catch_amd.netstore.TcpGroup (plain sockets; no torch in the product since round 4), or, with
+# CATCHHIP_RENDEZVOUS=gloo, over torch.distributed's gloo backend (netstore.GlooGroup); the data path's exchanges
+# are RCCL all-reduces on device buffers (catchhip_shard_allreduce) over a communicator attached to a context of
+# its own (a context with a communicator switches catchhip_setcover_greedy to the per-pick sharded form, which
+# the whole-group solves must not take).
 # ---------------------------------------------------------------------------
 class World:
-    def __init__(self, rank=0, size=1, dist=None, comm_ctx=None, rccl=False):
-        self.rank, self.size, self.dist, self.comm_ctx = rank, size, dist, comm_ctx
+    def __init__(self, rank=0, size=1, group=None, comm_ctx=None, rccl=False):
+        self.rank, self.size, self.group, self.comm_ctx = rank, size, group, comm_ctx
         self.rccl = rccl
 
+    @property
+    def dist(self):
+        """None for a single process (what callers test), else the group."""
+        return self.group
+
     def barrier(self):
-        if self.dist is not None:
-            self.dist.barrier()
+        if self.group is not None:
+            self.group.barrier()
 
     def allgather(self, obj):
-        """Every rank's host object, in rank order (gloo)."""
-        if self.dist is None:
+        """Every rank's host object, in rank order."""
+        if self.group is None:
             return [obj]
-        out = [None] * self.size
-        self.dist.all_gather_object(out, obj)
-        return out
+        return self.group.allgather(obj)
 
     def broadcast(self, obj, src=0):
-        """Rank src's host object on every rank (gloo)."""
-        if self.dist is None:
+        """Rank src's host object on every rank."""
+        if self.group is None:
             return obj
-        box = [obj if self.rank == src else None]
-        self.dist.broadcast_object_list(box, src=src)
-        return box[0]
+        return self.group.broadcast(obj, src)
 
     def agree(self, error):
         """Collective error check: every rank passes its own failure (a string)
@@ -173,14 +175,19 @@ class World:
 
     def exchange_for(self, shards):
         """The exchange callable sharded_solve wants: RCCL on the device buffers,
-        or -- CATCHHIP_EXCHANGE=gloo, for boxes where RCCL cannot span the ranks
-        (e.g. several ranks on ONE GPU) -- through the host over gloo."""
+        or -- CATCHHIP_EXCHANGE=gloo (any value but "rccl"), for boxes where RCCL cannot span the ranks
+        (e.g. several ranks on ONE GPU) -- through host memory over the group."""
         if self.rccl:
             def exchange(which):
                 for sh in shards:
                     sh.allreduce(which)
             return exchange
-        return lambda which: host_exchange(self.dist, shards, which)
+        return lambda which: host_exchange(self.group, shards, which)
+
+    def close(self):
+        if self.group is not None:
+            self.group.close()
+            self.group = None
 
 
 _world = World()
@@ -192,9 +199,9 @@ def world():
 
 
 def init_from_env():
-    """Under torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*):
-    gloo process group for the plumbing and an RCCL communicator on a dedicated
-    context of this rank's GPU.  Idempotent; a no-op for WORLD_SIZE <= 1."""
+    """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in the environment (torch.distributed.run sets them): a TCP group
+    for the plumbing and an RCCL communicator on a dedicated context of this rank's GPU.  Idempotent; a no-op for
+    WORLD_SIZE <= 1."""
     global _world
     import os
     import sys
@@ -204,17 +211,21 @@ def init_from_env():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import ctypes
-    import torch.distributed as dist
-    from catch_amd import engine
+    from catch_amd import engine, netstore
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    # gloo and RCCL announce themselves on stdout; callers print machine-readable lines
+    # RCCL (and gloo) announce themselves on stdout; callers print machine-readable lines
     sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(2, 1)
     try:
-        if not dist.is_initialized():
-            dist.init_process_group("gloo", rank=rank, world_size=size)
-        dist.barrier()
+        if os.environ.get("CATCHHIP_RENDEZVOUS", "tcp") == "gloo":
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group("gloo", rank=rank, world_size=size)
+            group = netstore.GlooGroup(dist)
+        else:
+            group = netstore.TcpGroup(rank, size, os.environ["MASTER_ADDR"], os.environ.get("CATCHHIP_STORE_PORT"))
+        group.barrier()
         ctypes.CDLL(None).fflush(None)
     finally:
         os.dup2(saved, 1)
@@ -222,52 +233,51 @@ def init_from_env():
     ndev = max(1, engine.device_count())
     device = local_rank % ndev
     os.environ.setdefault("CATCHHIP_DEVICE", str(device))   # engine.default_context()
-    ids = [engine.Context.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(ids, src=0)
+    uid = group.broadcast(engine.Context.comm_unique_id() if rank == 0 else None, 0)
     comm_ctx = engine.Context(device)
-    rccl = os.environ.get("CATCHHIP_EXCHANGE", "rccl") != "gloo"
+    rccl = os.environ.get("CATCHHIP_EXCHANGE", "rccl") == "rccl"
     if rccl:
-        # RCCL refuses e.g. two ranks on one device; the ranks then agree (over gloo)
+        # RCCL refuses e.g. two ranks on one device; the ranks then agree (over the group)
         # to exchange through the host instead of dying one by one
         err = None
         try:
-            comm_ctx.comm_init(ids[0], size, rank)
+            comm_ctx.comm_init(uid, size, rank)
         except Exception as exc:   # noqa: BLE001 -- whatever the C ABI maps the RCCL error to
             err = "%s: %s" % (type(exc).__name__, exc)
-        errs = [None] * size
-        dist.all_gather_object(errs, err)
+        errs = group.allgather(err)
         if not any(e is not None for e in errs):
             # every rank has a communicator: one checked all-reduce before anything depends on it
             try:
                 comm_ctx.comm_selftest(1 << 20)
             except Exception as exc:   # noqa: BLE001
                 err = "%s: %s" % (type(exc).__name__, exc)
-            dist.all_gather_object(errs, err)
+            errs = group.allgather(err)
         if any(e is not None for e in errs):
             if err is None:
                 comm_ctx.comm_destroy()
             if rank == 0:
                 print("catch_amd.parallel: RCCL communicator not available (%s); the solver rounds "
-                      "exchange through host memory over gloo" % next(e for e in errs if e is not None),
+                      "exchange through host memory over the process group" % next(e for e in errs if e is not None),
                       file=sys.stderr)
             rccl = False
-    _world = World(rank, size, dist, comm_ctx, rccl)
+    _world = World(rank, size, group, comm_ctx, rccl)
     return _world
 
 
-def host_exchange(dist, shards, which):
+def host_exchange(group, shards, which):
     """All-reduce of the shards' gain (SUM) or lost (MAX) buffers through host
     memory: over the shards of this process first, then over the process group
-    (None: single process).  Fallback transport and the one the CPU tests use."""
+    (None: single process; a netstore group, or a raw torch.distributed module as the gloo test passes it).
+    Fallback transport and the one the CPU tests use."""
     import numpy as np
     bufs = [sh.buffer_to_host(which) for sh in shards]
     acc = bufs[0].astype(np.int64)
     for b in bufs[1:]:
         acc = acc + b if which == 0 else np.maximum(acc, b)
-    if dist is not None and acc.size:      # (the size is the same on every rank)
-        import torch
-        t = torch.from_numpy(acc)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM if which == 0 else dist.ReduceOp.MAX)
-        acc = t.numpy()
+    if group is not None and acc.size:      # (the size is the same on every rank)
+        if not hasattr(group, "allreduce"):
+            from catch_amd import netstore
+            group = netstore.GlooGroup(group)          # torch.distributed itself
+        acc = group.allreduce(acc, "sum" if which == 0 else "max")
     for sh in shards:
         sh.buffer_from_host(which, acc)

@@ -43,7 +43,7 @@ def main():
     res = W.allgather(ok)
     if W.rank == 0:
         print("MULTIRANK_PLUGIN_OK" if all(res) else "MULTIRANK_PLUGIN_MISMATCH %s" % res)
-    W.dist.destroy_process_group()
+    W.close()
 
 
 if __name__ == "__main__":

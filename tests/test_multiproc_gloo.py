@@ -148,12 +148,27 @@ def _instance(seed, P, U, with_ranks):
     return sorted(rows), [int(x) for x in glen], ranks
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, transport="gloo"):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from catch_amd import parallel
+    from catch_amd import netstore, parallel
+    if transport == "gloo":
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        group = dist                      # host_exchange wraps the raw torch module itself
+        coll = netstore.GlooGroup(dist)
+    else:
+        # the product's own process group (catch_amd.netstore: plain TCP through rank 0, no torch)
+        group = coll = netstore.TcpGroup(rank, world, "127.0.0.1", port)
+        ok0 = coll.allgather(("r", rank)) == [("r", i) for i in range(world)]
+        ok0 = ok0 and coll.broadcast({"x": rank}, src=world - 1) == {"x": world - 1}
+        a = np.arange(5, dtype=np.int64) * (rank + 1)
+        ok0 = ok0 and coll.allreduce(a, "sum").tolist() == (np.arange(5) * sum(range(1, world + 1))).tolist()
+        ok0 = ok0 and coll.allreduce(a, "max").tolist() == (np.arange(5) * world).tolist()
+        coll.barrier()
+        if not ok0:
+            q.put((rank, False))
+            return
     from oracle import oracle as orc
     orc.build()
     ok = True
@@ -168,7 +183,7 @@ def _worker(rank, world, port, q):
         local = [(s, u - g0, a, e) for s, u, a, e in rows if g0 <= u < g1]
         shard = NumpyShard(local, P, glen[g0:g1], ranks)
         got = parallel.sharded_solve(
-            [shard], lambda which: parallel.host_exchange(dist, [shard], which))
+            [shard], lambda which: parallel.host_exchange(group, [shard], which))
         ok = ok and got == exp and len(exp) > 3
     # ---- level 1 + 2 together: a plan over several groups ------------------
     costs = [900, 40, 35, 30, 20, 10]
@@ -181,8 +196,7 @@ def _worker(rank, world, port, q):
         rows, glen, ranks = _instance(100 + gi, 30, 3, False)
         r = np.array(rows, dtype=np.int64)
         mine[gi] = orc.lazy_greedy(r[:, 0], r[:, 1], r[:, 2], r[:, 3], 30, glen)
-    gathered = [None] * world
-    dist.all_gather_object(gathered, mine)
+    gathered = coll.allgather(mine)
     merged = {}
     for part in gathered:
         merged.update(part)
@@ -192,7 +206,7 @@ def _worker(rank, world, port, q):
         r = np.array(rows, dtype=np.int64)
         ok = ok and merged[gi] == orc.lazy_greedy(r[:, 0], r[:, 1], r[:, 2], r[:, 3], 30, glen)
     q.put((rank, ok))
-    dist.destroy_process_group()
+    coll.close()
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -203,6 +217,23 @@ def test_sharded_solve_and_plan_over_gloo(world):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_solve_and_plan_over_the_tcp_group(world):
+    """The same over catch_amd.netstore.TcpGroup -- the transport the product uses since round 4 (rendezvous,
+    barriers, host objects, and the fallback exchange of the solver rounds): its collectives, then the sharded
+    round loop and the two-level plan."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "tcp")) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=300) for _ in range(world))
