@@ -1554,7 +1554,8 @@ struct JoinRun {
     DevBuf<u64> stage_key, hkey, hkey_alt;
     DevBuf<u32> stage_sq, hsq, hsq_alt, wg_cnt, wg_off, scan_tmp, ecnt, ebase, bcur, giant_n;
     DevBuf<uint4> giant;
-    DevBuf<unsigned long long> pairs;
+    DevBuf<unsigned long long> pairs, masks;
+    DevBuf<u32> mbase, gmbase;
     JoinArgs A;
     kj_kernel_fn write_main = nullptr, write_giant = nullptr;
     u32 nhit = 0, ngiant = 0;
@@ -1633,7 +1634,7 @@ static int run_join(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
     TRY(J.ebase.reserve((size_t)nent + 1));
     TRY(J.giant.reserve(KJ_GIANT_CAP));
     TRY(J.giant_n.reserve(4));
-    TRY(J.pairs.reserve(64));
+    TRY(J.pairs.reserve(64));   // [0..32) statistics, [32] the mask store's cursor
     HIP_TRY(hipMemsetAsync(J.ecnt.p, 0, sizeof(u32) * ((size_t)nent + 1), s));
     HIP_TRY(hipMemsetAsync(J.giant_n.p, 0, sizeof(u32) * 4, s));
     HIP_TRY(hipMemsetAsync(J.pairs.p, 0, sizeof(unsigned long long) * 64, s));
@@ -1649,6 +1650,16 @@ static int run_join(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
     A.bucket_of = sink.bucket_of; A.seq_genome = sink.seq_genome; A.ext = sink.ext;
     A.probe_group = sink.probe_group; A.seq_group = sink.seq_group;
     A.giant = J.giant.p; A.giant_n = J.giant_n.p; A.giant_cap = KJ_GIANT_CAP;
+    // hit masks of the counting pass for the writing pass (scan_join.inc): 6 words per hit position hold S4's
+    // (2 per position there); a run that finds the store full is simply verified again
+    A.masks = nullptr; A.mbase = A.gmbase = nullptr; A.mcursor = J.pairs.p + 32; A.mask_cap = 0;   // (pairs[32]: zeroed with the statistics)
+    if (J.nhit && !chip_test_env("CATCHHIP_JOIN_NO_MASKS")) {
+        const size_t mcap = (size_t)std::min<u64>((u64)1 << 26, std::max<u64>((u64)1 << 20, 6ull * J.nhit));
+        TRY(J.masks.reserve(mcap));
+        TRY(J.mbase.reserve(J.nhit));
+        TRY(J.gmbase.reserve(KJ_GIANT_CAP));
+        A.masks = J.masks.p; A.mbase = J.mbase.p; A.gmbase = J.gmbase.p; A.mask_cap = (u32)mcap;
+    }
     A.pairs = J.pairs.p;
     J.write_main = pick_kj_verify<true>(NW);
     J.write_giant = pick_kj_giant<true>(NW);
