@@ -838,7 +838,8 @@ def main():
         try:
             st_d = []
             run_step(st_d)
-            dirty_stats = {"rows_recounted": float(sum(st.get("rows_recounted", 0) for st in st_d))}
+            dirty_stats = {"rows_recounted": float(sum(st.get("rows_recounted", 0) for st in st_d)),
+                           "bitmap_words_read": float(sum(st.get("bitmap_words_read", 0) for st in st_d))}
         finally:
             os.environ.pop("CATCHHIP_FLAT_COUNT_DIRTY", None)
         if not args.no_property_checks:
@@ -938,7 +939,9 @@ def main():
         # popcounts.  E_dirty (rows that hold a word the previous picks changed) is counted in one extra, untimed
         # step (CATCHHIP_FLAT_COUNT_DIRTY); the rows the launches actually count again are all alive ones.
         edirty = dirty_stats.get("rows_recounted") if dirty_stats else None
-        k2_bytes = 12.0 * (edirty if edirty is not None else per.get("rows_recounted", 0)) + 8.0 * per.get("bitmap_words_read", 0)
+        ewords = dirty_stats.get("bitmap_words_read") if dirty_stats else None
+        k2_bytes = (12.0 * (edirty if edirty is not None else per.get("rows_recounted", 0))
+                    + 8.0 * (ewords if ewords is not None else per.get("bitmap_words_read", 0)))
         k2_full = 12.0 * per.get("rows_recounted", 0) + 8.0 * per.get("bitmap_words_read", 0)
         # what the rounds move as implemented: every alive record read by the count launch (8 B), written for every
         # survivor (8 B), read again by the claim launch (8 B), one bitmap word per flagged word and one owner word
@@ -1043,7 +1046,7 @@ def main():
             "roofline_k2": dict(bound="hbm", achieved=gbs(k2_bytes, ms["rounds_ms"]),
                                 peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=gbs(k2_bytes, ms["rounds_ms"]) / HBM_PEAK_GBS,
-                                algorithmic_bytes=k2_bytes, e_dirty_rows=edirty,
+                                algorithmic_bytes=k2_bytes, e_dirty_rows=edirty, e_dirty_words=ewords,
                                 full_recompute_bytes=k2_full,
                                 traffic=pmc_traffic("solver_round", args.workload, args.scale),
                                 implementation_bytes=k2_impl,
