@@ -12,6 +12,7 @@ loaded from a Python file (`custom_cover_range_fn`, :288-299) -- an arbitrary
 Python callable cannot run inside a kernel.
 """
 import logging
+import os
 
 import numpy as np
 
@@ -782,7 +783,7 @@ class SetCoverFilter(BaseFilter):
                        rows=0, scan_launches=0, greedy_launches=0,
                        candidates=0, unique_candidates=0)
         ctx = engine.default_context()
-        at = 0
+        chunks, at = [], 0
         while at < ngroups:
             chunk, bases = [], 0
             while at < ngroups:
@@ -792,49 +793,87 @@ class SetCoverFilter(BaseFilter):
                 chunk.append(at)
                 bases += b
                 at += 1
-            logger.info("Groups %d..%d of %d as one instance", chunk[0] + 1,
-                        chunk[-1] + 1, ngroups)
+            chunks.append(chunk)
+
+        # Two stages, one chunk apart (CATCHHIP_PREFETCH_DEPTH, 0 = one after the other): a helper thread packs the
+        # NEXT chunk's targets, enumerates and de-duplicates its candidates and runs the near-duplicate filter on the
+        # upload context (the MinHash filter is ~45 dependent rounds per call: the GPU is mostly waiting), while this
+        # thread draws the current chunk's anchors (NumPy, seconds at this scale), scans and solves on the compute
+        # context.  The filter's hash functions / sampled positions come from `random`, the anchors from `np.random`:
+        # each generator is only ever used by one of the two threads, in chunk order -- the same draws as one after
+        # the other.
+        depth = int(os.environ.get("CATCHHIP_PREFETCH_DEPTH", "2"))
+
+        def build(chunk, bctx=None):
+            bctx = bctx or engine.upload_context()
             genomes = [g.seqs for gi in chunk for g in target_genomes_grouped[gi]]
             ngen = [len(target_genomes_grouped[gi]) for gi in chunk]
-            seqs = [s for gs in genomes for s in gs]
-            universe_p = [p for gi in chunk
-                          for p in self._make_universe_p(target_genomes_grouped[gi])]
-            targets = engine.Targets(ctx, genomes)
-            cands = probes = None
+            targets = engine.Targets(bctx, genomes)
+            cands = None
             try:
                 targets.set_groups(np.repeat(np.arange(len(chunk)), ngen))
-                cands = engine.Candidates(ctx, targets, probe_length,
-                                          probe_stride, seq_length_to_skip)
-                timings["candidates"] += cands.ncandidates
-                timings["unique_candidates"] += cands.n
+                cands = engine.Candidates(bctx, targets, probe_length, probe_stride, seq_length_to_skip)
+                ncand, nuniq = cands.ncandidates, cands.n
                 if near_duplicate_filter is not None:
-                    near_duplicate_filter._apply_to_grouped_candidates(
-                        cands, len(chunk))
-                k, ep, eo = probe.anchor_entries_equal_length(
-                    cands.n, probe_length, self.mismatches, self.lcf_thres,
-                    min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
-                probes = cands.probes(k, ep, eo)
-                ids, nrows = engine.setcover_filter(
-                    ctx, probes, targets, self.mismatches, self.lcf_thres,
-                    self.island_of_exact_match, self.cover_extension, cands.n,
-                    None, universe_p, self.scan_mode)
-                ids = np.asarray(ids, dtype=np.int64)
-                # candidate-probe x target-bp of the chunk: every cluster's own candidates x its bases
-                per_group = np.bincount(cands.groups(), minlength=len(chunk)) if cands.n else np.zeros(len(chunk), np.int64)
-                gbases = np.array([sum(g.size() for g in target_genomes_grouped[gi]) for gi in chunk], dtype=np.float64)
-                timings["probe_bp_units"] = timings.get("probe_bp_units", 0.0) + float(np.dot(per_group[:len(chunk)], gbases))
-                if ids.size:
-                    grp = cands.groups()[ids]
-                    pos = cands.positions(ids)
-                    which = np.searchsorted(targets.seq_off, pos, side="right") - 1
-                    local = pos - targets.seq_off[which]
-                    for g, q, o in zip(grp.tolist(), which.tolist(), local.tolist()):
-                        out[chunk[g]].append(seqs[q][o:o + probe_length])
-            finally:
-                for h in (probes, cands, targets):
+                    near_duplicate_filter._apply_to_grouped_candidates(cands, len(chunk))
+                bctx.sync()
+            except BaseException:
+                for h in (cands, targets):
                     if h is not None:
                         h.close()
-            _accumulate(timings, ctx, nrows, int(ids.size))
+                raise
+            return targets, cands, ncand, nuniq
+
+        def discard(res):
+            for h in (res[1], res[0]):
+                h.close()
+
+        pre = engine.Prefetch(chunks, build, 1, discard) if depth > 0 and len(chunks) > 1 else None
+        feed = iter(pre) if pre is not None else ((c, build(c, ctx)) for c in chunks)
+        try:
+            for chunk, (targets, cands, ncand, nuniq) in feed:
+                logger.info("Groups %d..%d of %d as one instance", chunk[0] + 1, chunk[-1] + 1, ngroups)
+                probes = None
+                nrows, ids = 0, np.zeros(0, dtype=np.int64)
+                try:
+                    if pre is not None:
+                        for h in (targets, cands):
+                            h.rebind(ctx)
+                    seqs = [s for gi in chunk for g in target_genomes_grouped[gi] for s in g.seqs]
+                    universe_p = [p for gi in chunk
+                                  for p in self._make_universe_p(target_genomes_grouped[gi])]
+                    timings["candidates"] += ncand
+                    timings["unique_candidates"] += nuniq
+                    k, ep, eo = probe.anchor_entries_equal_length(
+                        cands.n, probe_length, self.mismatches, self.lcf_thres,
+                        min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
+                    probes = cands.probes(k, ep, eo)
+                    ids, nrows = engine.setcover_filter(
+                        ctx, probes, targets, self.mismatches, self.lcf_thres,
+                        self.island_of_exact_match, self.cover_extension, cands.n,
+                        None, universe_p, self.scan_mode)
+                    ids = np.asarray(ids, dtype=np.int64)
+                    # candidate-probe x target-bp of the chunk: every cluster's own candidates x its bases
+                    per_group = np.bincount(cands.groups(), minlength=len(chunk)) if cands.n else np.zeros(len(chunk), np.int64)
+                    gbases = np.array([sum(g.size() for g in target_genomes_grouped[gi]) for gi in chunk], dtype=np.float64)
+                    timings["probe_bp_units"] = timings.get("probe_bp_units", 0.0) + float(np.dot(per_group[:len(chunk)], gbases))
+                    if ids.size:
+                        grp = cands.groups()[ids]
+                        pos = cands.positions(ids)
+                        which = np.searchsorted(targets.seq_off, pos, side="right") - 1
+                        local = pos - targets.seq_off[which]
+                        for g, q, o in zip(grp.tolist(), which.tolist(), local.tolist()):
+                            out[chunk[g]].append(seqs[q][o:o + probe_length])
+                finally:
+                    if pre is not None:
+                        ctx.sync()          # (objects built on the upload context go back to its cache: nothing may still read them)
+                    for h in (probes, cands, targets):
+                        if h is not None:
+                            h.close()
+                _accumulate(timings, ctx, nrows, int(ids.size))
+        finally:
+            if pre is not None:
+                pre.close()
         self.last_timings = timings
         return out
 
