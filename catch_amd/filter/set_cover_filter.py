@@ -347,8 +347,9 @@ class SetCoverFilter(BaseFilter):
         universes: every rank scans the group's candidates against its own
         range of genomes and the frontier solver's rounds exchange the
         per-candidate gains (RCCL all-reduce, catch_amd/parallel.py).  Sharding
-        needs full coverage and no ranks (identify / avoided genomes); such
-        groups stay whole.  Every rank returns every group's selection."""
+        needs full coverage; groups under partial coverage stay whole.  Ranks
+        (identify / avoided genomes) are computed by every rank for the groups
+        it shares.  Every rank returns every group's selection."""
         import os
         from catch_amd import parallel
         n = len(input_strs)
@@ -361,8 +362,9 @@ class SetCoverFilter(BaseFilter):
                                      only=set(range(n)))
         costs = [sum(g.size() for g in target_genomes_grouped[i]) if len(input_strs[i]) else 0
                  for i in range(n)]
-        eligible = (not self.identify and not self.avoided_genomes
-                    and self.coverage == 1.0)
+        # (full coverage only: the sharded rounds have no universe test yet; ranks -- identify / avoided genomes -- are
+        # fine since round 4: every rank computes the sharded group's ranks itself, they only gate which sets may claim)
+        eligible = self.coverage == 1.0
         # (a group with fewer genomes than ranks is not sharded: some rank would hold an empty shard)
         sharded, whole = parallel.plan_with_sharding(
             costs, W.size,
@@ -404,8 +406,10 @@ class SetCoverFilter(BaseFilter):
                     rows = engine.Rows.scan(ctx, probes, targets, self.mismatches,
                                             self.lcf_thres, self.island_of_exact_match,
                                             self.cover_extension, self.scan_mode)
+                    ranks = (self._make_ranks_strs(strs, target_genomes_grouped, ctx)
+                             if (self.identify or self.avoided_genomes) else None)
                     try:
-                        shard = engine.Shard(rows, len(strs))
+                        shard = engine.Shard(rows, len(strs), ranks)
                         qualifies = True
                     except ValueError as exc:
                         # the one expected refusal: rows too long for the sharded kernels -> whole group

@@ -40,6 +40,14 @@ def main():
         got = [sorted(p.seq_str for p in g) for g in out]
         want = [sorted(c[i] for i in ids) for c, ids in zip(cands, exp)]
         ok = ok and got == want and f.last_timings.get("sharded_groups") == [1]
+    # --identify: the sharded group's ranks (a tolerant scan of its candidates over ALL groups and their reverse
+    # complements) are computed on every rank and gate the sharded rounds' claims
+    exp = orc.set_cover_filter(cands, groups, 2, 100, coverage=1.0, cover_extension=50, identify=True)
+    f = SetCoverFilter(mismatches=2, lcf_thres=100, coverage=1.0, cover_extension=50, identify=True)
+    out = f.filter([[probe.Probe.from_str(s) for s in c] for c in cands], gen, input_is_grouped=True)
+    got = [sorted(p.seq_str for p in g) for g in out]
+    want = [sorted(c[i] for i in ids) for c, ids in zip(cands, exp)]
+    ok = ok and got == want and f.last_timings.get("sharded_groups") == [1]
     res = W.allgather(ok)
     if W.rank == 0:
         print("MULTIRANK_PLUGIN_OK" if all(res) else "MULTIRANK_PLUGIN_MISMATCH %s" % res)
