@@ -82,7 +82,7 @@ class ResidentGroup:
 
     def run(self):
         return engine.setcover_filter(self.ctx, self.probes, self.targets, MISMATCHES, PROBE_LEN, 0, EXT,
-                                      self.n_sets, mode=SCAN_MODE)
+                                      self.n_sets, mode=SCAN_MODE, as_array=True)
 
     def close(self):
         self.probes.close()
@@ -114,16 +114,17 @@ class ResidentUnion:
     def run(self):
         """-> ({group index: its pick ids, counted from the group's first candidate}, rows)"""
         ids, nrows = engine.setcover_filter(self.ctx, self.probes, self.targets, MISMATCHES, PROBE_LEN, 0, EXT,
-                                            self.n_sets, mode=SCAN_MODE)
+                                            self.n_sets, mode=SCAN_MODE, as_array=True)
         return self.split(ids), nrows
 
     def split(self, ids):
-        """The union's picks -> {group index: that group's picks, in their order, counted from its first candidate}."""
+        """The union's picks -> {group index: that group's picks, in their order, counted from its first candidate}
+        (int64 arrays: the ~10^5 picks never become Python lists in the timed step)."""
         ids = np.asarray(ids, dtype=np.int64)
         grp = self.cgrp[ids]
         order = np.argsort(grp, kind="stable")            # (one stable sort instead of a mask per group)
         g_sorted = grp[order]
-        local = (ids[order] - self.first[g_sorted]).tolist()
+        local = ids[order] - self.first[g_sorted]
         bounds = np.searchsorted(g_sorted, np.arange(len(self.indices) + 1)).tolist()
         return {gi: local[bounds[m]:bounds[m + 1]] for m, gi in enumerate(self.indices)}
 
@@ -285,7 +286,7 @@ class Stepper:
             per_group, nrows = self.union.run()
             out.update(per_group)
             if stats is not None:
-                self._collect(self.union, [i for ids in per_group.values() for i in ids], nrows, stats)
+                self._collect(self.union, range(sum(len(ids) for ids in per_group.values())), nrows, stats)
             return out
         out = dict(self._run_lane(self.big, stats))
         small = [g for lane in self.lanes for g in lane]
@@ -1124,7 +1125,7 @@ def main():
             out["cpu_baseline"] = base
             checked = sample + ([mid] if mid is not None else [])
             # the timed GPU result must equal the oracle's (parity guard)
-            out["parity_vs_oracle"] = all(sorted(picks[gi]) == sorted(sel[gi])
+            out["parity_vs_oracle"] = all(sorted(int(x) for x in picks[gi]) == sorted(sel[gi])
                                           for gi in checked)
             # like for like: the GPU on exactly the CPU sample's groups (resident inputs, one
             # after the other), against the CPU's time per pass over the same groups

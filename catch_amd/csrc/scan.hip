@@ -1650,6 +1650,7 @@ static int run_join(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
     A.bucket_of = sink.bucket_of; A.seq_genome = sink.seq_genome; A.ext = sink.ext;
     A.probe_group = sink.probe_group; A.seq_group = sink.seq_group;
     A.giant = J.giant.p; A.giant_n = J.giant_n.p; A.giant_cap = KJ_GIANT_CAP;
+    A.giant_pairs = chip_test_env("CATCHHIP_JOIN_GIANT_PAIRS") ? (u32)atoi(chip_test_env("CATCHHIP_JOIN_GIANT_PAIRS")) : KJ_GIANT_PAIRS;
     // hit masks of the counting pass for the writing pass (scan_join.inc): 6 words per hit position hold S4's
     // (2 per position there); a run that finds the store full is simply verified again
     A.masks = nullptr; A.mbase = A.gmbase = nullptr; A.mcursor = J.pairs.p + 32; A.mask_cap = 0;   // (pairs[32]: zeroed with the statistics)

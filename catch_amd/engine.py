@@ -817,16 +817,18 @@ def tolerant_bp(ctx, probes, targets, mismatches, lcf_thres, island, out):
 
 def setcover_filter(ctx, probes, targets, mismatches, lcf_thres, island,
                     cover_extension, num_sets, ranks=None, universe_p=None,
-                    mode=SCAN_AUTO):
+                    mode=SCAN_AUTO, as_array=False):
     """catchhip_setcover_filter: scan + greedy in one call.
-    Returns (picked set ids in pick order, number of cover rows)."""
+    Returns (picked set ids in pick order, number of cover rows); as_array: the
+    ids as an int64 array instead of a list (a union instance makes 10^5 picks:
+    list conversions there and back were 8 ms of a 100-ms step)."""
     return setcover_filter_many([(ctx, probes, targets, num_sets, ranks,
                                   universe_p)], mismatches, lcf_thres, island,
-                                cover_extension, mode)[0]
+                                cover_extension, mode, as_array)[0]
 
 
 def setcover_filter_many(groups, mismatches, lcf_thres, island,
-                         cover_extension, mode=SCAN_AUTO):
+                         cover_extension, mode=SCAN_AUTO, as_array=False):
     """catchhip_setcover_filter_many over independent groups, each a tuple
     (ctx, probes, targets, num_sets, ranks or None, universe_p or None) with
     its own Context.  Returns [(ids, nrows)] per group."""
@@ -860,7 +862,7 @@ def setcover_filter_many(groups, mismatches, lcf_thres, island,
             n, ctxs, prs, tgs, int(mismatches), int(lcf_thres), int(island),
             int(cover_extension), int(mode), _ptr(nsets, c_i64p), rk_p, up_p,
             out_p, _ptr(n_out, c_i64p), _ptr(nrows, c_i64p)))
-    res = [(outs[g][:n_out[g]].tolist(), int(nrows[g])) for g in range(n)]
+    res = [((outs[g][:n_out[g]].copy() if as_array else outs[g][:n_out[g]].tolist()), int(nrows[g])) for g in range(n)]
     if _solution_checks is not None:
         # bench / tests: every instance's picks replayed by the independent check kernels (one more scan, untimed)
         for g, (ids, _) in zip(groups, res):

@@ -855,8 +855,7 @@ class SetCoverFilter(BaseFilter):
                     ids, nrows = engine.setcover_filter(
                         ctx, probes, targets, self.mismatches, self.lcf_thres,
                         self.island_of_exact_match, self.cover_extension, cands.n,
-                        None, universe_p, self.scan_mode)
-                    ids = np.asarray(ids, dtype=np.int64)
+                        None, universe_p, self.scan_mode, as_array=True)
                     # candidate-probe x target-bp of the chunk: every cluster's own candidates x its bases
                     per_group = np.bincount(cands.groups(), minlength=len(chunk)) if cands.n else np.zeros(len(chunk), np.int64)
                     gbases = np.array([sum(g.size() for g in target_genomes_grouped[gi]) for gi in chunk], dtype=np.float64)
