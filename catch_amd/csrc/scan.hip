@@ -1634,15 +1634,16 @@ static int run_join(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
     TRY(J.ebase.reserve((size_t)nent + 1));
     TRY(J.giant.reserve(KJ_GIANT_CAP));
     TRY(J.giant_n.reserve(4));
-    TRY(J.pairs.reserve(64));   // [0..32) statistics, [32] the mask store's cursor
+    TRY(J.pairs.reserve(192));   // [0..128) statistics (sharded), [128..192) the mask store's cursors
     HIP_TRY(hipMemsetAsync(J.ecnt.p, 0, sizeof(u32) * ((size_t)nent + 1), s));
     HIP_TRY(hipMemsetAsync(J.giant_n.p, 0, sizeof(u32) * 4, s));
-    HIP_TRY(hipMemsetAsync(J.pairs.p, 0, sizeof(unsigned long long) * 64, s));
+    HIP_TRY(hipMemsetAsync(J.pairs.p, 0, sizeof(unsigned long long) * 192, s));
     const bool cursor = sink.bucket_of != nullptr;   // several probes may share a bucket
     if (cursor) { TRY(J.bcur.reserve((size_t)nb + 1)); HIP_TRY(hipMemsetAsync(J.bcur.p, 0, sizeof(u32) * ((size_t)nb + 1), s)); }
     JoinArgs &A = J.A;
     A.tq = (const uint4 *)T->tq.p; A.seq_off = (const u32 *)T->seq_off.p; A.pplanes = (const uint4 *)P->planes.p;
     A.nanch = nanch; A.ntab = ntab; A.L = (int)P->L; A.k = k; A.mm = mm;
+    A.div_magic = (((unsigned long long)1 << 34) + (unsigned long long)nanch - 1ull) / (unsigned long long)nanch;
     A.tailmask = (P->L & 31) ? ((1u << (P->L & 31)) - 1u) : 0xffffffffu;
     A.nhit = J.nhit;
     A.slot = (const uint4 *)S.slot.p; A.ents = (const u32 *)S.ents.p;
@@ -1653,7 +1654,7 @@ static int run_join(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
     A.giant_pairs = chip_test_env("CATCHHIP_JOIN_GIANT_PAIRS") ? (u32)atoi(chip_test_env("CATCHHIP_JOIN_GIANT_PAIRS")) : KJ_GIANT_PAIRS;
     // hit masks of the counting pass for the writing pass (scan_join.inc): 6 words per hit position hold S4's
     // (2 per position there); a run that finds the store full is simply verified again
-    A.masks = nullptr; A.mbase = A.gmbase = nullptr; A.mcursor = J.pairs.p + 32; A.mask_cap = 0;   // (pairs[32]: zeroed with the statistics)
+    A.masks = nullptr; A.mbase = A.gmbase = nullptr; A.mcursor = J.pairs.p + 128; A.mask_cap = 0;   // (zeroed with the statistics)
     if (J.nhit && !chip_test_env("CATCHHIP_JOIN_NO_MASKS")) {
         const size_t mcap = (size_t)std::min<u64>((u64)1 << 26, std::max<u64>((u64)1 << 20, 6ull * J.nhit));
         TRY(J.masks.reserve(mcap));
@@ -1688,13 +1689,14 @@ static int run_join(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
     u32 *h = (u32 *)ctx->h_pin;
     HIP_TRY(hipMemcpyAsync(h, B.res.p + 2, sizeof(u32), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(h + 1, J.giant_n.p, sizeof(u32), hipMemcpyDeviceToHost, s));
-    unsigned long long *hp = (unsigned long long *)(h + 2);
-    HIP_TRY(hipMemcpyAsync(hp, J.pairs.p, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost, s));   // (h_pin holds 64 words)
+    TRY(chip_pinned_reserve(ctx, sizeof(unsigned long long) * 128));
+    unsigned long long *hp = (unsigned long long *)ctx->h_big;
+    HIP_TRY(hipMemcpyAsync(hp, J.pairs.p, sizeof(unsigned long long) * 128, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const u32 nhits = ((volatile u32 *)h)[0];
     J.ngiant = ((volatile u32 *)h)[1];
     unsigned long long pairs = 0, slots = 0;
-    for (int i = 0; i < 16; ++i) { pairs += ((volatile unsigned long long *)hp)[i]; slots += ((volatile unsigned long long *)hp)[16 + i]; }
+    for (int i = 0; i < 64; ++i) { pairs += ((volatile unsigned long long *)hp)[i]; slots += ((volatile unsigned long long *)hp)[64 + i]; }
     if (getenv("CATCHHIP_TIMING"))
         fprintf(stderr, "[catchhip]   join: %u hit positions, %llu pairs, %llu lane slots in wave-wide runs, %u hits, %u tasks of cut runs\n",
                 J.nhit, pairs, slots, nhits, J.ngiant);
