@@ -133,6 +133,8 @@ PROTOTYPES = {
         c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_u64p, ctypes.c_int64, c_i64p]),
     "catchhip_sigs_neighbors_many": (ctypes.c_int, [
         c_vp, c_vp, c_u32p, ctypes.c_int64, ctypes.c_uint32, c_u64p, ctypes.c_int64, c_i64p]),
+    "catchhip_sigs_graph": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_int64, c_i64p]),
+    "catchhip_sigs_graph_fetch": (ctypes.c_int, [c_vp, c_vp, c_i64p, c_u32p, c_u32p]),
     "catchhip_cover_scan_first_seen": (ctypes.c_int, [
         c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_int32, c_u32p, c_vpp, c_i64p]),

@@ -38,7 +38,14 @@ struct catchhip_sigs {
     DevBuf<u64> fpT;    // 4,096-bit fingerprints of the signatures, [word][nseq] (catchhip_sigs_neighbors_many, on first use)
     DevBuf<u32> fp_excess;
     bool fp_ready = false;
+    // the neighbour graph (catchhip_sigs_graph): rows of g_idx / g_com delimited by g_ptr
+    DevBuf<u64> g_ptr;
+    DevBuf<u32> g_idx, g_com;
+    u64 g_edges = 0;
+    bool g_ready = false;
 };
+
+static int sigs_fingerprints(catchhip_ctx *ctx, catchhip_sigs *Sm, PhaseTimer &tm);
 
 #define MD5_P 0x7FFFFFFFu
 #define KM_THREADS 256
@@ -383,6 +390,103 @@ __global__ __launch_bounds__(64 * NEIGH_WAVES) void sig_neigh_many_kernel(
     }
 }
 
+// The WHOLE neighbour graph in one launch (round 4): every pair (q, t), q < t, whose walk finds at least min_common
+// values, emitted in both directions as key = q << 32 | t, value = common.  The search then reads its lists from a
+// CSR copy on the host instead of asking the device 11,000 times (S5 x 1.0: 224 k vertices; the calls were 3.3 of the
+// 7 s of the search, and they compared 7.9e10 pairs where the triangle has 2.5e10).  Same two stages as above: the
+// fingerprint bound settles almost every pair; workgroups that hold survivors stage signatures in LDS and walk.
+// Workgroup (x, y): the 64 targets of block x against the SG_TILES tiles of SG_QT queries of group y.
+#define SG_QT 32
+#define SG_TILES 16
+__global__ __launch_bounds__(64 * NEIGH_WAVES) void sig_graph_kernel(
+    const u32 *__restrict__ sig, const u32 *__restrict__ sigT, const unsigned long long *__restrict__ fpT,
+    const u32 *__restrict__ excess, u32 nseq, u32 N, u32 min_common,
+    unsigned long long *__restrict__ out_key, u32 *__restrict__ out_val, unsigned long long cap,
+    unsigned long long *__restrict__ count) {
+    const u32 t0 = blockIdx.x * 64, q00 = blockIdx.y * (SG_QT * SG_TILES);
+    if (q00 >= t0 + 63 || q00 >= nseq) return;             // only pairs with q < t
+    extern __shared__ u32 s_mem[];
+    u32 *s_b = s_mem, *s_q = s_mem + (size_t)64 * N;       // s_b[i * 64 + lane], s_q[q * N + i]
+    __shared__ unsigned long long s_qfp[SG_QT][NEIGH_FPW + 1];
+    __shared__ u32 s_qx[SG_QT];
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 kq = t0 + lane;
+    const u32 kc = kq < nseq ? kq : nseq - 1;
+    unsigned long long fp[NEIGH_FPW];
+#pragma unroll
+    for (int w = 0; w < NEIGH_FPW; ++w) fp[w] = fpT[(size_t)w * nseq + kc];
+    const u32 ex = excess[kc];
+    bool staged = false;
+    for (u32 tile = 0; tile < SG_TILES; ++tile) {
+        const u32 q0 = q00 + tile * SG_QT;
+        if (q0 >= t0 + 63 || q0 >= nseq) break;            // (uniform)
+        __syncthreads();                                    // the previous tile's walks are done with s_qfp / s_q
+        for (u32 t = threadIdx.x; t < SG_QT * NEIGH_FPW; t += 64 * NEIGH_WAVES) {
+            const u32 q = t % SG_QT, w = t / SG_QT;
+            s_qfp[q][w] = fpT[(size_t)w * nseq + min(q0 + q, nseq - 1)];
+        }
+        if (threadIdx.x < SG_QT) s_qx[threadIdx.x] = excess[min(q0 + threadIdx.x, nseq - 1)];
+        __syncthreads();
+        u32 need = 0;
+        for (u32 q = wave; q < SG_QT; q += NEIGH_WAVES) {
+            u32 pc = 0;
+#pragma unroll
+            for (int w = 0; w < NEIGH_FPW; ++w) pc += (u32)__popcll(fp[w] & s_qfp[q][w]);
+            if (kq < nseq && q0 + q < kq && pc + min(ex, s_qx[q]) >= min_common) need |= 1u << q;
+        }
+        if (!__syncthreads_or(need != 0)) continue;
+        if (!staged) {
+            for (u32 t = threadIdx.x; t < 64 * N; t += 64 * NEIGH_WAVES) {
+                const u32 i = t >> 6, l = t & 63;
+                s_b[t] = sigT[(size_t)i * nseq + min(t0 + l, nseq - 1)];
+            }
+            staged = true;
+        }
+        for (u32 t = threadIdx.x; t < SG_QT * N; t += 64 * NEIGH_WAVES) s_q[t] = sig[(size_t)min(q0 + t / N, nseq - 1) * N + (t % N)];
+        __syncthreads();
+        for (u32 q = wave; q < SG_QT; q += NEIGH_WAVES) {
+            if (!__ballot((need >> q) & 1u)) continue;
+            const u32 *a = s_q + (size_t)q * N;
+            u32 c = 0;
+            if ((need >> q) & 1u)
+                c = walk_common(N, [&](u32 i) { return a[i]; }, [&](u32 i) { return s_b[i * 64 + lane]; });
+            const bool hit = c >= min_common && ((need >> q) & 1u);
+            const unsigned long long b = __ballot(hit);
+            if (!b) continue;
+            const u32 nh = (u32)__popcll(b);
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(count, 2ull * nh);
+            base = __shfl(base, 0, WAVE);
+            if (hit) {
+                const unsigned long long pos = base + 2ull * (u32)__popcll(b & ((1ull << lane) - 1ull));
+                if (pos + 1 < cap) {
+                    out_key[pos] = ((unsigned long long)(q0 + q) << 32) | kq; out_val[pos] = c;
+                    out_key[pos + 1] = ((unsigned long long)kq << 32) | (q0 + q); out_val[pos + 1] = c;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sig_graph_ptr_kernel(const unsigned long long *__restrict__ key, u64 nedges, u32 nseq,
+                                                            unsigned long long *__restrict__ ptr) {
+    const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > nseq) return;
+    const unsigned long long want = (unsigned long long)v << 32;
+    u64 lo = 0, hi = nedges;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (key[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    ptr[v] = lo;
+}
+
+__global__ __launch_bounds__(256) void sig_graph_idx_kernel(const unsigned long long *__restrict__ key, u64 nedges,
+                                                            u32 *__restrict__ idx) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nedges) idx[e] = (u32)key[e];
+}
+
 __global__ __launch_bounds__(256) void sig_pairs_kernel(const u32 *__restrict__ sig, u32 nseq, u32 N, u32 T,
                                                         const float *__restrict__ lut, float *__restrict__ out) {
     extern __shared__ u32 s_ab[];
@@ -625,17 +729,7 @@ extern "C" int catchhip_sigs_neighbors_many(catchhip_ctx *ctx, const catchhip_si
     HIP_TRY(hipMemcpyAsync(d_js.p, js, sizeof(u32) * (size_t)nq, hipMemcpyHostToDevice, st));
     PhaseTimer tm(ctx, PHASE_NDF);
     catchhip_sigs *Sm = const_cast<catchhip_sigs *>(S);
-    if (!Sm->fp_ready) {                               // the fingerprints, on first use
-        TRY(Sm->fpT.alloc((size_t)NEIGH_FPW * S->nseq));
-        TRY(Sm->fp_excess.alloc(S->nseq));
-        HIP_TRY(hipMemsetAsync(Sm->fpT.p, 0, sizeof(u64) * NEIGH_FPW * (size_t)S->nseq, st));
-        hipLaunchKernelGGL(sig_fp_build_kernel, dim3((unsigned)(((u64)S->nseq * S->N + 255) / 256)), dim3(256), 0, st,
-                           (const u32 *)S->sig.p, S->nseq, S->N, (unsigned long long *)Sm->fpT.p);
-        hipLaunchKernelGGL(sig_fp_excess_kernel, dim3((S->nseq + 255) / 256), dim3(256), 0, st,
-                           (const unsigned long long *)Sm->fpT.p, S->nseq, S->N, Sm->fp_excess.p);
-        tm.launch(2);
-        Sm->fp_ready = true;
-    }
+    TRY(sigs_fingerprints(ctx, Sm, tm));                // on first use
     hipLaunchKernelGGL(sig_neigh_many_kernel, dim3((S->nseq + 63) / 64), dim3(64 * NEIGH_WAVES), sizeof(u32) * (64 + (size_t)nq) * S->N, st,
                        (const u32 *)S->sig.p, (const u32 *)S->sigT.p, (const unsigned long long *)Sm->fpT.p,
                        (const u32 *)Sm->fp_excess.p, S->nseq, S->N, (const u32 *)d_js.p, (u32)nq,
@@ -656,6 +750,97 @@ extern "C" int catchhip_sigs_neighbors_many(catchhip_ctx *ctx, const catchhip_si
     }
     tm.finish();
     memcpy(out, h + 1, sizeof(unsigned long long) * (size_t)n);
+    return 0;
+}
+
+static int sigs_fingerprints(catchhip_ctx *ctx, catchhip_sigs *Sm, PhaseTimer &tm) {
+    hipStream_t st = ctx->stream;
+    if (Sm->fp_ready) return 0;
+    TRY(Sm->fpT.alloc((size_t)NEIGH_FPW * Sm->nseq));
+    TRY(Sm->fp_excess.alloc(Sm->nseq));
+    HIP_TRY(hipMemsetAsync(Sm->fpT.p, 0, sizeof(u64) * NEIGH_FPW * (size_t)Sm->nseq, st));
+    hipLaunchKernelGGL(sig_fp_build_kernel, dim3((unsigned)(((u64)Sm->nseq * Sm->N + 255) / 256)), dim3(256), 0, st,
+                       (const u32 *)Sm->sig.p, Sm->nseq, Sm->N, (unsigned long long *)Sm->fpT.p);
+    hipLaunchKernelGGL(sig_fp_excess_kernel, dim3((Sm->nseq + 255) / 256), dim3(256), 0, st,
+                       (const unsigned long long *)Sm->fpT.p, Sm->nseq, Sm->N, Sm->fp_excess.p);
+    tm.launch(2);
+    Sm->fp_ready = true;
+    return 0;
+}
+
+static int ceil_log2_u32(u32 v) { int b = 0; while (((u64)1 << b) < (u64)v) ++b; return b; }
+
+extern "C" int catchhip_sigs_graph(catchhip_ctx *ctx, catchhip_sigs *S, u32 min_common, i64 max_edges, i64 *nedges) {
+    ARG_CHECK(ctx && S && S->ctx == ctx && nedges && max_edges >= 0);
+    ARG_CHECK(S->N <= 112 && S->nseq >= 1 && S->nseq < (1u << 31));
+    PoolScope pool_scope(ctx);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    PhaseTimer tm(ctx, PHASE_NDF);
+    TRY(sigs_fingerprints(ctx, S, tm));
+    S->g_ready = false;
+    DevBuf<u64> key, key_alt, d_n;
+    DevBuf<u32> val, val_alt;
+    TRY(d_n.alloc(1));
+    TRY(chip_pinned_reserve(ctx, 64));
+    u64 cap = std::max<u64>((u64)1 << 24, (u64)128 * S->nseq);
+    if (max_edges && cap > (u64)max_edges) cap = (u64)max_edges;
+    u64 n = 0;
+    const dim3 grid((S->nseq + 63) / 64, (S->nseq + SG_QT * SG_TILES - 1) / (SG_QT * SG_TILES));
+    ARG_CHECK(grid.y <= 65535);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        TRY(key.alloc(cap + 2));
+        TRY(val.alloc(cap + 2));
+        HIP_TRY(hipMemsetAsync(d_n.p, 0, sizeof(u64), st));
+        hipLaunchKernelGGL(sig_graph_kernel, grid, dim3(64 * NEIGH_WAVES), sizeof(u32) * (64 + (size_t)SG_QT) * S->N, st,
+                           (const u32 *)S->sig.p, (const u32 *)S->sigT.p, (const unsigned long long *)S->fpT.p,
+                           (const u32 *)S->fp_excess.p, S->nseq, S->N, min_common, (unsigned long long *)key.p, val.p,
+                           (unsigned long long)cap, (unsigned long long *)d_n.p);
+        tm.launch(1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ctx->h_pin, d_n.p, sizeof(u64), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n = *(volatile u64 *)ctx->h_pin;
+        if (n + 1 < cap || n == 0) break;
+        if (max_edges && n > (u64)max_edges) { tm.finish(); *nedges = (i64)n; return 0; }   // too many: the caller asks list by list
+        if (attempt == 1) { chip_set_error("sigs_graph: edge count changed between two passes"); return CATCHHIP_EINVAL; }
+        key.release(); val.release();
+        cap = n + 2;
+    }
+    *nedges = (i64)n;
+    if (n) {
+        TRY(key_alt.alloc(cap + 2));
+        TRY(val_alt.alloc(cap + 2));
+        const int bits = std::max(1, ceil_log2_u32(S->nseq));
+        TRY(chip_radix_sort_pairs(ctx, key, key_alt, val, val_alt, (i64)n, bits, 0));
+        TRY(chip_radix_sort_pairs(ctx, key, key_alt, val, val_alt, (i64)n, bits, 32));
+    }
+    TRY(S->g_ptr.alloc((size_t)S->nseq + 1));
+    TRY(S->g_idx.alloc(std::max<u64>(n, 1)));
+    hipLaunchKernelGGL(sig_graph_ptr_kernel, dim3((S->nseq + 256) / 256), dim3(256), 0, st,
+                       (const unsigned long long *)key.p, n, S->nseq, (unsigned long long *)S->g_ptr.p);
+    if (n) hipLaunchKernelGGL(sig_graph_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                              (const unsigned long long *)key.p, n, S->g_idx.p);
+    tm.launch(2);
+    HIP_TRY(hipGetLastError());
+    S->g_com.swap(val);
+    HIP_TRY(hipStreamSynchronize(st));
+    tm.finish();
+    S->g_edges = n;
+    S->g_ready = true;
+    return 0;
+}
+
+extern "C" int catchhip_sigs_graph_fetch(catchhip_ctx *ctx, const catchhip_sigs *S, i64 *ptr, u32 *idx, u32 *common) {
+    ARG_CHECK(ctx && S && S->ctx == ctx && ptr && S->g_ready && (S->g_edges == 0 || (idx && common)));
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ptr, S->g_ptr.p, sizeof(u64) * ((size_t)S->nseq + 1), hipMemcpyDeviceToHost, st));
+    if (S->g_edges) {
+        HIP_TRY(hipMemcpyAsync(idx, S->g_idx.p, sizeof(u32) * (size_t)S->g_edges, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(common, S->g_com.p, sizeof(u32) * (size_t)S->g_edges, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
 

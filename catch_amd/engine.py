@@ -797,6 +797,25 @@ class Signatures:
         com = (got & np.uint64(0xffff)).astype(np.int64)
         return [(idx[bounds[i]:bounds[i + 1]], com[bounds[i]:bounds[i + 1]]) for i in range(js.size)]
 
+    GRAPH_MAX_EDGES = 1 << 29      # ordered pairs kept as a graph (6 GB on the device while sorting, 4 GB on the host)
+
+    def graph(self, min_common):
+        """catchhip_sigs_graph + fetch -> (ptr int64[n + 1], idx uint32[E] ascending inside a row, common
+        uint32[E]): the neighbour lists of every vertex in one device pass, or None when there are more than
+        GRAPH_MAX_EDGES ordered pairs (the caller then asks list by list).  Signatures of at most 112 values."""
+        cnt = ctypes.c_int64(0)
+        check(self.ctx._L.catchhip_sigs_graph(self.ctx._h, self._h, int(min_common), int(self.GRAPH_MAX_EDGES),
+                                              ctypes.byref(cnt)))
+        e = int(cnt.value)
+        if e > self.GRAPH_MAX_EDGES:
+            return None
+        ptr = np.zeros(self.n + 1, dtype=np.int64)
+        idx = np.empty(max(e, 1), dtype=np.uint32)
+        com = np.empty(max(e, 1), dtype=np.uint32)
+        check(self.ctx._L.catchhip_sigs_graph_fetch(self.ctx._h, self._h, _ptr(ptr, c_i64p), _ptr(idx, c_u32p),
+                                                    _ptr(com, c_u32p)))
+        return ptr, idx[:e], com[:e]
+
     def condensed(self, lut):
         """float32[n(n-1)/2] in SciPy's condensed order; entry = lut[common]."""
         lut = np.ascontiguousarray(lut, dtype=np.float32)

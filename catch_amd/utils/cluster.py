@@ -148,11 +148,11 @@ def _fast_order_available():
     return _fast_order_ok
 
 
-_path_counts = {"ascending": 0, "copy rank": 0, "real difference": 0, "list calls": 0}   # (tests look at these)
+_path_counts = {"ascending": 0, "copy rank": 0, "real difference": 0, "list calls": 0, "graphs": 0}   # (tests look at these)
 
 
 def _components(n, row_fn, threshold, early_stop_threshold, neighbors_fn=None, neighbors_many_fn=None,
-                batch=32):
+                batch=32, local_lists=False):
     """Connected components by depth-first search with the reference's
     early-stop heuristic (:235-355): a neighbour within early_stop_threshold is
     absorbed into the component without being explored itself, so the result
@@ -176,7 +176,8 @@ def _components(n, row_fn, threshold, early_stop_threshold, neighbors_fn=None, n
     Otherwise the difference is built for real.
     neighbors_many_fn(list of vertices) -> list of such pairs: the lists of the
     vertex being explored and of the vertices on top of the stack (the next to
-    be explored) in one device call."""
+    be explored) in one device call.  local_lists: neighbors_fn slices a graph
+    that is already on the host (one device pass made all the lists)."""
     remaining = set(range(n))
     done = set()
     components = []
@@ -210,7 +211,8 @@ def _components(n, row_fn, threshold, early_stop_threshold, neighbors_fn=None, n
             if ascending or (lists and (m >> 2) > q):
                 hit = cache.pop(j, None)
                 if hit is None:
-                    _path_counts["list calls"] += 1
+                    if not local_lists:                      # (local: slices of a graph held on the host)
+                        _path_counts["list calls"] += 1
                     if neighbors_many_fn is None:
                         hit = neighbors_fn(j)
                     else:
@@ -284,6 +286,30 @@ def _components_of_signatures(sigs, threshold,
     # as the number grows; evaluated with the expression above, so the comparison is the same)
     within = np.nonzero(1.0 - np.arange(sigs.N + 1, dtype=np.float64) / N <= threshold)[0]
     neighbors = neighbors_many = None
+    if sigs.N <= 112 and len(within) and not _lib.test_env("CATCHHIP_CLUSTER_ROWS_ONLY") \
+            and not _lib.test_env("CATCHHIP_CLUSTER_NO_GRAPH") and not _lib.test_env("CATCHHIP_CLUSTER_ONE_BY_ONE") \
+            and hasattr(sigs, "graph"):
+        # the whole neighbour graph in one device pass (round 4): the search reads its lists from the CSR
+        # copy, and the distance rows of the real differences come from it too
+        g = sigs.graph(int(within[0]))
+        if g is not None:
+            ptr, gidx, gcom = g
+            lut = 1.0 - np.arange(sigs.N + 1, dtype=np.float64) / N
+            far = np.full(sigs.n, 2.0, dtype=np.float64)        # scratch: 2.0 = not a neighbour
+
+            def neighbors_g(j):
+                a, b = ptr[j], ptr[j + 1]
+                return gidx[a:b], lut[gcom[a:b]]
+
+            def row_g(j, cand):
+                a, b = ptr[j], ptr[j + 1]
+                nb = gidx[a:b]
+                far[nb] = lut[gcom[a:b]]
+                d = far[cand]
+                far[nb] = 2.0
+                return d
+            _path_counts["graphs"] += 1
+            return _components(sigs.n, row_g, threshold, early_stop_threshold, neighbors_g, None, local_lists=True)
     if sigs.N <= 176 and len(within) and not _lib.test_env("CATCHHIP_CLUSTER_ROWS_ONLY"):
         min_common = int(within[0])
 

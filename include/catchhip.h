@@ -420,6 +420,15 @@ int catchhip_sigs_neighbors(catchhip_ctx *ctx, const catchhip_sigs *sigs,
 int catchhip_sigs_neighbors_many(catchhip_ctx *ctx, const catchhip_sigs *sigs,
                                  const uint32_t *js, int64_t nq, uint32_t min_common,
                                  unsigned long long *out, int64_t cap, int64_t *count);
+/* The neighbour lists of ALL vertices at once (the graph the connected-components search of
+ * catch/utils/cluster.py:235-355 walks): every ordered pair (j, k), j != k, with common(j, k) >= min_common.
+ * Built and kept on the device; *nedges = how many.  max_edges > 0: when the graph has more, nothing is kept
+ * (the caller falls back to catchhip_sigs_neighbors_many).  Signatures of at most 112 values. */
+int catchhip_sigs_graph(catchhip_ctx *ctx, catchhip_sigs *sigs, uint32_t min_common,
+                        int64_t max_edges, int64_t *nedges);
+/* ... copied out in CSR form: the neighbours of j are idx[ptr[j] .. ptr[j + 1]) ascending, common[] beside them. */
+int catchhip_sigs_graph_fetch(catchhip_ctx *ctx, const catchhip_sigs *sigs, int64_t *ptr,
+                              uint32_t *idx, uint32_t *common);
 /* cluster.create_condensed_dist_matrix (catch/utils/cluster.py:102-194) for the
  * signature distance: out[n(n-1)/2] float32 in SciPy's condensed order, entry
  * (i, j) = lut[common(i, j)] with lut[N+1] supplied by the caller (the float32

@@ -1660,7 +1660,8 @@ def test_cluster_neighbor_lists_equal_full_rows(ctx, monkeypatch):
 
 
 def test_cluster_neighbor_lists_many_and_one_by_one(ctx, monkeypatch):
-    """catchhip_sigs_neighbors_many (the lists of up to 32 vertices per launch)
+    """catchhip_sigs_graph (all lists in one pass) == catchhip_sigs_neighbors_many
+    (the lists of up to 32 vertices per launch)
     == catchhip_sigs_neighbors vertex by vertex == the full rows; and the search
     that asks for the stack's top along with the explored vertex == the search
     that asks one by one, on an input large enough for the tail of the search
@@ -1681,13 +1682,35 @@ def test_cluster_neighbor_lists_many_and_one_by_one(ctx, monkeypatch):
                 assert np.array_equal(idx, i1) and np.array_equal(com, c1)
                 row = sigs.common_row(int(j)).astype(np.int64)
                 assert np.array_equal(idx, np.nonzero(row >= 20)[0]) and np.array_equal(com, row[idx])
+        # the whole graph in one pass (catchhip_sigs_graph): every row == the vertex's own list without itself
+        ptr, gidx, gcom = sigs.graph(20)
+        assert ptr[0] == 0 and ptr[-1] == gidx.size and np.all(np.diff(ptr) >= 0)
+        for j in list(rng.choice(sigs.n, size=40, replace=False)) + [0, sigs.n - 1]:
+            i1, c1 = sigs.neighbors(int(j), 20)
+            keep = i1 != j
+            assert np.array_equal(gidx[ptr[j]:ptr[j + 1]], i1[keep]) and np.array_equal(gcom[ptr[j]:ptr[j + 1]], c1[keep])
+        # symmetric, and no more edges than it has room for when asked to give up early
+        deg = np.diff(ptr)
+        src = np.repeat(np.arange(sigs.n), deg)
+        fwd = set(zip(src[:5000].tolist(), gidx[:5000].tolist()))
+        assert all((gidx[a + int(np.searchsorted(gidx[a:b], q))] == q) for q, k in fwd for a, b in [(ptr[k], ptr[k + 1])])
+        sigs.GRAPH_MAX_EDGES = max(int(gidx.size) // 2, 1)
+        assert sigs.graph(20) is None
+        del sigs.GRAPH_MAX_EDGES
     finally:
         sigs.close()
+    before = dict(cluster._path_counts)
+    random.seed(5)
+    graph = cluster.cluster_with_minhash_signatures(seqs, threshold=0.15, cluster_method="simple")
+    took = {k: cluster._path_counts[k] - before[k] for k in before}
+    assert took["graphs"] == 1 and took["copy rank"] > 100 and took["list calls"] == 0, took
+    monkeypatch.setenv("CATCHHIP_CLUSTER_NO_GRAPH", "1")
     before = dict(cluster._path_counts)
     random.seed(5)
     many = cluster.cluster_with_minhash_signatures(seqs, threshold=0.15, cluster_method="simple")
     took = {k: cluster._path_counts[k] - before[k] for k in before}
     assert took["copy rank"] > 100 and took["list calls"] < (took["ascending"] + took["copy rank"]) // 2, took
+    assert graph == many
     monkeypatch.setenv("CATCHHIP_CLUSTER_ONE_BY_ONE", "1")
     random.seed(5)
     one = cluster.cluster_with_minhash_signatures(seqs, threshold=0.15, cluster_method="simple")
