@@ -135,6 +135,14 @@ PROTOTYPES = {
         c_vp, c_vp, c_u32p, ctypes.c_int64, ctypes.c_uint32, c_u64p, ctypes.c_int64, c_i64p]),
     "catchhip_sigs_graph": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_int64, c_i64p]),
     "catchhip_sigs_graph_fetch": (ctypes.c_int, [c_vp, c_vp, c_i64p, c_u32p, c_u32p]),
+    "catchhip_dfs_create": (ctypes.c_int, [ctypes.c_uint32, c_i64p, c_u32p, c_u32p, ctypes.c_uint32, c_vpp]),
+    "catchhip_dfs_destroy": (None, [c_vp]),
+    "catchhip_dfs_run": (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), c_i64p]),
+    "catchhip_dfs_seen": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32p), c_i64p]),
+    "catchhip_dfs_new_queued": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32p), c_i64p]),
+    "catchhip_dfs_set_copy_rank": (ctypes.c_int, [c_vp, c_i64p]),
+    "catchhip_dfs_push": (ctypes.c_int, [c_vp, c_i64p, c_u8p, ctypes.c_int64]),
+    "catchhip_dfs_counts": (ctypes.c_int, [c_vp, c_i64p]),
     "catchhip_cover_scan_first_seen": (ctypes.c_int, [
         c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_int32, c_u32p, c_vpp, c_i64p]),

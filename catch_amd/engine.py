@@ -967,17 +967,89 @@ class Prefetch:
                 self._discard(res)
 
 
+class PrefetchPool:
+    """Prefetch with several helper threads: build(item, worker) runs on `workers`
+    threads, items are taken in order and results are handed to the consumer in
+    order; at most workers + depth items are built or waiting at any time.  For
+    stages whose calls leave the device idle much of the time (the MinHash
+    filter's ~45 dependent rounds): two of them on two streams overlap."""
+
+    def __init__(self, items, build, workers=2, depth=1, discard=None):
+        import threading
+        self._items = list(items)
+        n = len(self._items)
+        self._res = [None] * n
+        self._ready = [threading.Event() for _ in range(n)]
+        self._stop = threading.Event()
+        self._discard = discard
+        self._lock = threading.Lock()
+        self._next = 0
+        self._taken = 0                       # results the consumer has taken
+        self._room = threading.Semaphore(max(1, int(workers)) + max(0, int(depth)))
+
+        def run(w):
+            while not self._stop.is_set():
+                if not self._room.acquire(timeout=0.05):
+                    continue
+                with self._lock:
+                    i = self._next
+                    self._next += 1
+                if i >= n or self._stop.is_set():
+                    self._room.release()
+                    return
+                try:
+                    res, err = build(self._items[i], w), None
+                except BaseException as e:      # handed to the consumer
+                    res, err = None, e
+                self._res[i] = (res, err)
+                self._ready[i].set()
+                if err is not None:
+                    self._stop.set()
+                    return
+
+        self._threads = [threading.Thread(target=run, args=(w,), name="catchhip-prefetch-%d" % w, daemon=True)
+                         for w in range(max(1, int(workers)))]
+        for t in self._threads:
+            t.start()
+
+    def __iter__(self):
+        for i in range(len(self._items)):
+            while not self._ready[i].wait(0.05):
+                if self._stop.is_set() and not self._ready[i].is_set():
+                    # a later item failed before this one was built: report that failure
+                    for r in self._res:
+                        if r is not None and r[1] is not None:
+                            raise r[1]
+            res, err = self._res[i]
+            self._res[i] = None
+            self._taken = i + 1
+            self._room.release()
+            if err is not None:
+                raise err
+            yield self._items[i], res
+
+    def close(self):
+        self._stop.set()
+        for t in self._threads:
+            t.join()
+        for i in range(self._taken, len(self._items)):
+            r, self._res[i] = self._res[i], None
+            if r is not None and r[0] is not None and self._discard:
+                self._discard(r[0])
+
+
 _upload_ctxs = {}
 
 
-def upload_context(device=None):
+def upload_context(device=None, index=0):
     """The context whose stream packs and uploads the NEXT group's inputs while
-    the compute context works (one per device, made on first use)."""
+    the compute context works (made on first use; index: further ones for
+    stages that run several builders side by side)."""
     if device is None:
         device = default_context().device
-    if device not in _upload_ctxs:
-        _upload_ctxs[device] = Context(device)
-    return _upload_ctxs[device]
+    if (device, index) not in _upload_ctxs:
+        _upload_ctxs[(device, index)] = Context(device)
+    return _upload_ctxs[(device, index)]
 
 
 _default_ctx = None

@@ -115,10 +115,15 @@ class NearDuplicateFilterWithHammingDistance(NearDuplicateFilter):
                                                     self.dist_thres)
         return _as_the_reference_returns_them([s for s, kp in zip(order, keep) if kp])
 
-    def _apply_to_grouped_candidates(self, cands, ngroups):
+    def _draw_for_groups(self, ngroups):
+        """The draws of _apply_to_grouped_candidates for ngroups groups, made ahead (callers that run several
+        chunks' filters side by side draw for every chunk first, in chunk order: the same stream of draws)."""
+        return [self._draw_positions() for _ in range(ngroups)]
+
+    def _apply_to_grouped_candidates(self, cands, ngroups, drawn=None):
         """The same on candidates of grouped targets: sampled positions drawn
         per group in group order, as one _filter call per group would."""
-        positions = [self._draw_positions() for _ in range(ngroups)]
+        positions = drawn if drawn is not None else self._draw_for_groups(ngroups)
         if cands.n == 0:
             return
         if cands.L != self.dim:
@@ -219,10 +224,14 @@ class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
                                                     self.dist_thres)
         return _as_the_reference_returns_them([s for s, kp in zip(order, keep) if kp])
 
-    def _apply_to_grouped_candidates(self, cands, ngroups):
+    def _draw_for_groups(self, ngroups):
+        """See NearDuplicateFilterWithHammingDistance._draw_for_groups."""
+        return [self._draw_params() for _ in range(ngroups)]
+
+    def _apply_to_grouped_candidates(self, cands, ngroups, drawn=None):
         """The same on candidates of grouped targets: hash functions drawn per
         group in group order, as one _filter call per group would."""
-        params = [self._draw_params() for _ in range(ngroups)]
+        params = drawn if drawn is not None else self._draw_for_groups(ngroups)
         if cands.n == 0:
             return
         if cands.L < self.kmer_size:

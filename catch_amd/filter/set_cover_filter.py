@@ -808,19 +808,49 @@ class SetCoverFilter(BaseFilter):
         # the other.
         depth = int(os.environ.get("CATCHHIP_PREFETCH_DEPTH", "2"))
 
-        def build(chunk, bctx=None):
-            bctx = bctx or engine.upload_context()
+        import time as _time
+        stage_s = dict(pack_s=0.0, candidates_s=0.0, near_duplicates_s=0.0, anchors_s=0.0, solve_s=0.0)
+
+        # The front end runs on `workers` threads, each with its own stream (CATCHHIP_FRONT_END_WORKERS; the
+        # MinHash filter is ~45 dependent rounds of mostly small launches per chunk, 5.3 of the 6.8 s of
+        # S5 x 1.0's filters: two of them side by side overlap).  The filter's draws from `random` are made for
+        # every chunk first, in chunk order -- the stream of draws one chunk after the other would make.
+        workers = max(1, int(os.environ.get("CATCHHIP_FRONT_END_WORKERS", "2")))
+        piped = depth > 0 and len(chunks) > 1
+        drawn_ndf = {}
+        if piped and near_duplicate_filter is not None and hasattr(near_duplicate_filter, "_draw_for_groups"):
+            for ci, chunk in enumerate(chunks):
+                drawn_ndf[ci] = near_duplicate_filter._draw_for_groups(len(chunk))
+        chunk_no = {id(c): ci for ci, c in enumerate(chunks)}
+
+        def build(chunk, worker=None):
+            bctx = ctx if worker is None else engine.upload_context(index=worker)
+            t0 = _time.perf_counter()
             genomes = [g.seqs for gi in chunk for g in target_genomes_grouped[gi]]
             ngen = [len(target_genomes_grouped[gi]) for gi in chunk]
             targets = engine.Targets(bctx, genomes)
             cands = None
             try:
                 targets.set_groups(np.repeat(np.arange(len(chunk)), ngen))
+                t1 = _time.perf_counter()
                 cands = engine.Candidates(bctx, targets, probe_length, probe_stride, seq_length_to_skip)
                 ncand, nuniq = cands.ncandidates, cands.n
+                t2 = _time.perf_counter()
                 if near_duplicate_filter is not None:
-                    near_duplicate_filter._apply_to_grouped_candidates(cands, len(chunk))
+                    if chunk_no[id(chunk)] in drawn_ndf:
+                        near_duplicate_filter._apply_to_grouped_candidates(cands, len(chunk), drawn_ndf[chunk_no[id(chunk)]])
+                    else:
+                        near_duplicate_filter._apply_to_grouped_candidates(cands, len(chunk))
                 bctx.sync()
+                if bctx is not ctx:
+                    # handed over here, while this stream is idle: a rebind later would wait for the NEXT chunk's
+                    # filter rounds, which this thread queues on the same stream (1.1 s of S5 x 1.0)
+                    for h in (targets, cands):
+                        h.rebind(ctx)
+                t3 = _time.perf_counter()
+                stage_s["pack_s"] += t1 - t0
+                stage_s["candidates_s"] += t2 - t1
+                stage_s["near_duplicates_s"] += t3 - t2
             except BaseException:
                 for h in (cands, targets):
                     if h is not None:
@@ -832,30 +862,54 @@ class SetCoverFilter(BaseFilter):
             for h in (res[1], res[0]):
                 h.close()
 
-        pre = engine.Prefetch(chunks, build, 1, discard) if depth > 0 and len(chunks) > 1 else None
-        feed = iter(pre) if pre is not None else ((c, build(c, ctx)) for c in chunks)
+        def anchors(n):
+            t0 = _time.perf_counter()
+            got = probe.anchor_entries_equal_length(n, probe_length, self.mismatches, self.lcf_thres,
+                                                    min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
+            stage_s["anchors_s"] += _time.perf_counter() - t0
+            return got
+
+        # Three stages since round 4 (depth >= 2): front end of chunk i + 2 | anchors of chunk i + 1 | scan and solve
+        # of chunk i.  The anchors are NumPy draws and array work (2 s of S5 x 1.0), which release the interpreter
+        # lock; np.random is still used by one thread only, in chunk order.
+        pre = engine.PrefetchPool(chunks, build, workers, 1, discard) if piped else None
+        pre2 = None
+        if pre is not None and depth >= 2:
+            first = iter(pre)
+
+            def draw(_chunk):
+                _c, res = next(first)
+                try:
+                    return res + (anchors(res[1].n),)
+                except BaseException:
+                    discard(res)
+                    raise
+            pre2 = engine.Prefetch(chunks, draw, 1, discard)
+        if pre2 is not None:
+            feed = iter(pre2)
+        elif pre is not None:
+            feed = ((c, res + (None,)) for c, res in pre)
+        else:
+            feed = ((c, build(c) + (None,)) for c in chunks)
         try:
-            for chunk, (targets, cands, ncand, nuniq) in feed:
+            for chunk, (targets, cands, ncand, nuniq, drawn) in feed:
                 logger.info("Groups %d..%d of %d as one instance", chunk[0] + 1, chunk[-1] + 1, ngroups)
                 probes = None
                 nrows, ids = 0, np.zeros(0, dtype=np.int64)
                 try:
-                    if pre is not None:
-                        for h in (targets, cands):
-                            h.rebind(ctx)
                     seqs = [s for gi in chunk for g in target_genomes_grouped[gi] for s in g.seqs]
                     universe_p = [p for gi in chunk
                                   for p in self._make_universe_p(target_genomes_grouped[gi])]
                     timings["candidates"] += ncand
                     timings["unique_candidates"] += nuniq
-                    k, ep, eo = probe.anchor_entries_equal_length(
-                        cands.n, probe_length, self.mismatches, self.lcf_thres,
-                        min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
+                    k, ep, eo = drawn if drawn is not None else anchors(cands.n)
+                    t0 = _time.perf_counter()
                     probes = cands.probes(k, ep, eo)
                     ids, nrows = engine.setcover_filter(
                         ctx, probes, targets, self.mismatches, self.lcf_thres,
                         self.island_of_exact_match, self.cover_extension, cands.n,
                         None, universe_p, self.scan_mode, as_array=True)
+                    stage_s["solve_s"] += _time.perf_counter() - t0
                     # candidate-probe x target-bp of the chunk: every cluster's own candidates x its bases
                     per_group = np.bincount(cands.groups(), minlength=len(chunk)) if cands.n else np.zeros(len(chunk), np.int64)
                     gbases = np.array([sum(g.size() for g in target_genomes_grouped[gi]) for gi in chunk], dtype=np.float64)
@@ -875,8 +929,10 @@ class SetCoverFilter(BaseFilter):
                             h.close()
                 _accumulate(timings, ctx, nrows, int(ids.size))
         finally:
-            if pre is not None:
-                pre.close()
+            for p in (pre2, pre):
+                if p is not None:
+                    p.close()
+        timings.update(stage_s)
         self.last_timings = timings
         return out
 

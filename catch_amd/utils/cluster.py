@@ -265,6 +265,67 @@ def _components(n, row_fn, threshold, early_stop_threshold, neighbors_fn=None, n
     return components
 
 
+def _components_over_graph(n, ptr, gidx, gcom, near_common, row_fn, threshold, early_stop_threshold):
+    """_components with the neighbour lists of every vertex on the host (CSR) and the explored vertices whose
+    neighbour order is known without a set difference run natively (catch_amd/csrc/components.hip,
+    catchhip_dfs_*): the same search, the same real `remaining` set -- whose layout decides which case an
+    explored vertex is -- and the real differences and copies built here exactly as _components builds them."""
+    import ctypes
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+    gidx = np.ascontiguousarray(gidx, dtype=np.uint32)
+    gcom = np.ascontiguousarray(gcom, dtype=np.uint32)
+    _lib.check(L.catchhip_dfs_create(n, ptr.ctypes.data_as(_lib.c_i64p), gidx.ctypes.data_as(_lib.c_u32p),
+                                     gcom.ctypes.data_as(_lib.c_u32p), int(near_common), ctypes.byref(h)))
+    remaining = set(range(n))
+    queued = set()
+    components = []
+    status, vertex, cnt = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    p32 = _lib.c_u32p()
+
+    def listed(fn):
+        _lib.check(fn(h, ctypes.byref(p32), ctypes.byref(cnt)))
+        return np.ctypeslib.as_array(p32, shape=(cnt.value,)).copy() if cnt.value else np.zeros(0, dtype=np.uint32)
+    try:
+        while True:
+            _lib.check(L.catchhip_dfs_run(h, len(remaining), ctypes.byref(status), ctypes.byref(vertex)))
+            if status.value == 0:
+                break
+            if status.value == 1:
+                seen = listed(L.catchhip_dfs_seen)
+                remaining -= set(seen.tolist())
+                seen.sort()
+                components.append(seen.tolist())
+                queued = set()
+            elif status.value == 2:
+                cp = remaining.copy()
+                members = np.fromiter(cp, dtype=np.int64, count=len(cp))
+                copy_rank = np.zeros(n, dtype=np.int64)
+                copy_rank[members] = np.arange(members.size)
+                _lib.check(L.catchhip_dfs_set_copy_rank(h, copy_rank.ctypes.data_as(_lib.c_i64p)))
+            else:
+                j = int(vertex.value)
+                queued.update(listed(L.catchhip_dfs_new_queued).tolist())
+                diff = remaining - queued
+                if not diff:
+                    continue
+                cand = np.fromiter(diff, dtype=np.int64, count=len(diff))
+                d = row_fn(j, cand)
+                adjacent = np.nonzero(d <= threshold)[0]
+                ks = np.ascontiguousarray(cand[adjacent])
+                near = np.ascontiguousarray(d[adjacent] <= early_stop_threshold, dtype=np.uint8)
+                _lib.check(L.catchhip_dfs_push(h, ks.ctypes.data_as(_lib.c_i64p), near.ctypes.data_as(_lib.c_u8p), int(ks.size)))
+        got = (ctypes.c_int64 * 3)()
+        _lib.check(L.catchhip_dfs_counts(h, got))
+        for k, v in zip(("ascending", "copy rank", "real difference"), got):
+            _path_counts[k] += int(v)
+    finally:
+        L.catchhip_dfs_destroy(h)
+    components.sort(key=len, reverse=True)
+    return components
+
+
 def find_connected_components(n, dist_fn, threshold,
                               early_stop_threshold=_jaccard_dist_from_mash_dist(0.02, 12)):
     """Components under an arbitrary Python distance function (:235-355)."""
@@ -309,6 +370,11 @@ def _components_of_signatures(sigs, threshold,
                 far[nb] = 2.0
                 return d
             _path_counts["graphs"] += 1
+            if _fast_order_available() and not _lib.test_env("CATCHHIP_CLUSTER_PYTHON_SEARCH"):
+                # common counts whose distance is within the early-stop threshold (same expression, same comparison)
+                near = np.nonzero(lut <= early_stop_threshold)[0]
+                near_common = int(near[0]) if len(near) else sigs.N + 1
+                return _components_over_graph(sigs.n, ptr, gidx, gcom, near_common, row_g, threshold, early_stop_threshold)
             return _components(sigs.n, row_g, threshold, early_stop_threshold, neighbors_g, None, local_lists=True)
     if sigs.N <= 176 and len(within) and not _lib.test_env("CATCHHIP_CLUSTER_ROWS_ONLY"):
         min_common = int(within[0])

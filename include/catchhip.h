@@ -429,6 +429,25 @@ int catchhip_sigs_graph(catchhip_ctx *ctx, catchhip_sigs *sigs, uint32_t min_com
 /* ... copied out in CSR form: the neighbours of j are idx[ptr[j] .. ptr[j + 1]) ascending, common[] beside them. */
 int catchhip_sigs_graph_fetch(catchhip_ctx *ctx, const catchhip_sigs *sigs, int64_t *ptr,
                               uint32_t *idx, uint32_t *common);
+/* The connected-components search of catch/utils/cluster.py:235-355 over such a graph, host side (no kernel):
+ * runs the explored vertices whose neighbour order is known without building a Python set (catch_amd/utils/
+ * cluster.py says when) and hands the others back.  ptr / idx / common are borrowed until catchhip_dfs_destroy;
+ * a neighbour with common >= near_common is absorbed without being explored (the early-stop rule, :313-330).
+ * catchhip_dfs_run(m = len(remaining)): *status 0 = finished; 1 = a component ended (catchhip_dfs_seen lists it;
+ * remove it from `remaining`, run again); 2 = catchhip_dfs_set_copy_rank is needed (rank of every vertex in the
+ * iteration order of remaining.copy()), run again; 3 = *vertex needs a real `remaining - queued`
+ * (catchhip_dfs_new_queued lists what was queued since the last call; catchhip_dfs_push files the vertex's
+ * neighbours in that set's order), run again.  catchhip_dfs_counts: explored vertices by case. */
+typedef struct catchhip_dfs catchhip_dfs;
+int catchhip_dfs_create(uint32_t n, const int64_t *ptr, const uint32_t *idx, const uint32_t *common,
+                        uint32_t near_common, catchhip_dfs **out);
+void catchhip_dfs_destroy(catchhip_dfs *dfs);
+int catchhip_dfs_run(catchhip_dfs *dfs, int64_t m, int32_t *status, int64_t *vertex);
+int catchhip_dfs_seen(catchhip_dfs *dfs, const uint32_t **p, int64_t *count);
+int catchhip_dfs_new_queued(catchhip_dfs *dfs, const uint32_t **p, int64_t *count);
+int catchhip_dfs_set_copy_rank(catchhip_dfs *dfs, const int64_t *rank);
+int catchhip_dfs_push(catchhip_dfs *dfs, const int64_t *ks, const uint8_t *near, int64_t count);
+int catchhip_dfs_counts(const catchhip_dfs *dfs, int64_t *out3);
 /* cluster.create_condensed_dist_matrix (catch/utils/cluster.py:102-194) for the
  * signature distance: out[n(n-1)/2] float32 in SciPy's condensed order, entry
  * (i, j) = lut[common(i, j)] with lut[N+1] supplied by the caller (the float32

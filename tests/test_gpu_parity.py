@@ -1704,6 +1704,14 @@ def test_cluster_neighbor_lists_many_and_one_by_one(ctx, monkeypatch):
     graph = cluster.cluster_with_minhash_signatures(seqs, threshold=0.15, cluster_method="simple")
     took = {k: cluster._path_counts[k] - before[k] for k in before}
     assert took["graphs"] == 1 and took["copy rank"] > 100 and took["list calls"] == 0, took
+    # ... the same graph walked by the interpreter instead of catchhip_dfs_*: same components, same cases
+    monkeypatch.setenv("CATCHHIP_CLUSTER_PYTHON_SEARCH", "1")
+    before = dict(cluster._path_counts)
+    random.seed(5)
+    graph_py = cluster.cluster_with_minhash_signatures(seqs, threshold=0.15, cluster_method="simple")
+    took_py = {k: cluster._path_counts[k] - before[k] for k in before}
+    assert graph_py == graph and took_py == took, (took_py, took)
+    monkeypatch.delenv("CATCHHIP_CLUSTER_PYTHON_SEARCH")
     monkeypatch.setenv("CATCHHIP_CLUSTER_NO_GRAPH", "1")
     before = dict(cluster._path_counts)
     random.seed(5)

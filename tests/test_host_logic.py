@@ -456,3 +456,100 @@ def test_components_search_shortcut_equals_the_set_order():
     took = {k: cluster._path_counts[k] - before[k] for k in before}
     # all three ways of ordering a vertex's neighbours were exercised
     assert took["ascending"] > 1000 and took["copy rank"] > 200 and took["real difference"] > 1000, took
+
+
+def test_native_components_search_equals_the_interpreter_on_random_graphs():
+    """catchhip_dfs_* (catch_amd/csrc/components.hip: the explored vertices whose neighbour order is known without
+    a set difference, run natively) == _components (the same search in the interpreter) on planted-cluster graphs
+    large enough for all three cases -- ascending differences, differences that are copies of `remaining`, real
+    differences -- with early-stop absorption; components and case counts.  No GPU: host code only."""
+    from catch_amd.utils import cluster
+    assert cluster._fast_order_available()
+    for seed, n, ncl in ((1, 2500, 40), (2, 9000, 300), (3, 700, 3), (4, 1, 1), (5, 4000, 4000)):
+        rng = np.random.RandomState(seed)
+        label = rng.randint(0, ncl, size=n)
+        rows, cols, com = [], [], []
+        for c in range(ncl):
+            mem = np.nonzero(label == c)[0]
+            if mem.size < 2:
+                continue
+            a, b = np.meshgrid(mem, mem, indexing="ij")
+            keep = (a < b) & (rng.random_sample(a.shape) < 0.5)
+            aa, bb = a[keep], b[keep]
+            cc = rng.randint(9, 101, size=aa.size)
+            rows += [aa, bb]; cols += [bb, aa]; com += [cc, cc]
+        if rows:
+            rows, cols, com = np.concatenate(rows), np.concatenate(cols), np.concatenate(com)
+            o = np.lexsort((cols, rows))
+            rows, cols, com = rows[o], cols[o], com[o]
+        else:
+            rows = cols = com = np.zeros(0, dtype=np.int64)
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rows, minlength=n), out=ptr[1:])
+        gidx, gcom = cols.astype(np.uint32), com.astype(np.uint32)
+        N = 100.0
+        lut = 1.0 - np.arange(101, dtype=np.float64) / N
+        threshold, early = lut[9], lut[60]
+        far = np.full(n, 2.0)
+
+        def neighbors(j):
+            return gidx[ptr[j]:ptr[j + 1]], lut[gcom[ptr[j]:ptr[j + 1]]]
+
+        def row(j, cand):
+            nb = gidx[ptr[j]:ptr[j + 1]]
+            far[nb] = lut[gcom[ptr[j]:ptr[j + 1]]]
+            d = far[cand]
+            far[nb] = 2.0
+            return d
+        before = dict(cluster._path_counts)
+        want = cluster._components(n, row, threshold, early, neighbors, None, local_lists=True)
+        took_py = {k: cluster._path_counts[k] - before[k] for k in before}
+        before = dict(cluster._path_counts)
+        got = cluster._components_over_graph(n, ptr, gidx, gcom, 60, row, threshold, early)
+        took = {k: cluster._path_counts[k] - before[k] for k in before}
+        assert got == want
+        assert took == took_py, (took, took_py)
+        if n >= 2500 and ncl < n:
+            assert took["copy rank"] > 0 and took["real difference"] > 0 and took["ascending"] > 0, took
+
+
+def test_prefetch_pool_hands_results_over_in_order_and_discards_what_is_left():
+    """engine.PrefetchPool: several builders, results in item order, bounded run-ahead, an exception of a
+    builder re-raised at the consumer, built-but-unconsumed results handed to `discard` on close."""
+    import threading
+    import time
+    from catch_amd import engine
+    lock, running, peak, built = threading.Lock(), [0], [0], []
+
+    def build(item, worker):
+        with lock:
+            running[0] += 1
+            peak[0] = max(peak[0], running[0])
+        time.sleep(0.002 * ((item * 7) % 5))
+        with lock:
+            running[0] -= 1
+            built.append(item)
+        if item == 13:
+            raise KeyError("thirteen")
+        return ("built", item, worker)
+    gone = []
+    pool = engine.PrefetchPool(range(10), build, workers=3, depth=1, discard=gone.append)
+    got = [(it, res[1]) for it, res in pool]
+    pool.close()
+    assert got == [(i, i) for i in range(10)] and gone == [] and 1 <= peak[0] <= 3
+    # run-ahead is bounded: a consumer that stops early leaves at most workers + depth results behind
+    built.clear()
+    pool = engine.PrefetchPool(range(100), build, workers=2, depth=1, discard=gone.append)
+    it = iter(pool)
+    first = [next(it)[0] for _ in range(4)]
+    time.sleep(0.1)
+    pool.close()
+    assert first == [0, 1, 2, 3] and len(built) <= 4 + 3 and sorted(g[1] for g in gone) == sorted(set(built) - set(first))
+    # a builder's exception reaches the consumer
+    pool = engine.PrefetchPool(range(10, 20), build, workers=2, depth=1, discard=gone.append)
+    seen = []
+    with pytest.raises(KeyError):
+        for it_, res in pool:
+            seen.append(it_)
+    pool.close()
+    assert seen == [10, 11, 12]

@@ -1,7 +1,8 @@
-"""cProfile of one design_large step on S5 x scale (GPU box): where the host time of the clustering
-and of the union filter goes."""
-import cProfile, io, os, pstats, random, sys, time
+"""Wall time of the design_large step on S5 x scale per environment setting (GPU box):
+   tools/s5_time.py 1.0 "" "CATCHHIP_FRONT_END_WORKERS=1" ...   -> best of 2 after a warm-up, cluster / filters split."""
+import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("CATCHHIP_TEST_HOOKS", "1")
 import numpy as np
 from catch_amd import genome
 from catch_amd.filter import near_duplicate_filter, probe_designer, set_cover_filter
@@ -25,18 +26,30 @@ def step():
     run = scf._filter_genomes_device if mode == "per group" else scf._filter_genomes_device_union
     chosen = run(clusters, 100, 50, None, ndf)
     t2 = time.perf_counter()
-    print("cluster %.2f s, filters %.2f s (%s), %d clusters" % (t1 - t0, t2 - t1, mode, len(clusters)))
-    print("stages (thread seconds):", {k: round(v, 2) for k, v in scf.last_timings.items() if k.endswith("_s")})
-    from catch_amd.utils import cluster as _c
-    print("components search:", _c._path_counts)
+    import hashlib
+    h = hashlib.sha256()
+    for c in chosen:
+        for p in c:
+            h.update(p.encode()); h.update(b"\n")
+        h.update(b"|")
+    return t1 - t0, t2 - t1, h.hexdigest()[:12], {k: round(v, 2) for k, v in scf.last_timings.items() if k.endswith("_s")}
 
 
-if len(sys.argv) < 3 or sys.argv[2] != "once":
-    step()
-pr = cProfile.Profile()
-pr.enable()
 step()
-pr.disable()
-s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(60)
-print(s.getvalue()[:14000])
+for setting in (sys.argv[2:] or [""]):
+    saved = {}
+    for kv in setting.split():
+        k, v = kv.split("=", 1)
+        saved[k] = os.environ.get(k)
+        os.environ[k] = v
+    best = None
+    for _ in range(2):
+        r = step()
+        if best is None or r[0] + r[1] < best[0] + best[1]:
+            best = r
+    print("%-40s cluster %.2f s  filters %.2f s  total %.2f s  digest %s  %s" % (setting or "-", best[0], best[1], best[0] + best[1], best[2], best[3]))
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
