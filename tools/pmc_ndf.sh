@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage (GPU box): tools/pmc_ndf.sh "<counters>"  : PMC counters of the ndf_lazy_kernel dispatches of the first chunks of S5 x 1.0
+cd /tmp && export TMPDIR=/tmp
+rm -rf /root/repo/gpurun_out/pmcn
+CATCHHIP_FRONT_END_WORKERS=1 CATCHHIP_PREFETCH_DEPTH=0 rocprofv3 --pmc $1 --kernel-trace --output-format csv -d /root/repo/gpurun_out/pmcn -- python /root/repo/tools/s5_profile.py 0.25 once > /dev/null 2>&1
+cd /root/repo
+python - <<'PY'
+import csv, glob, collections
+f = glob.glob("gpurun_out/pmcn/*/*counter_collection.csv")[0]
+per = collections.defaultdict(dict)
+for r in csv.DictReader(open(f)):
+    if "ndf_lazy_kernel" in r["Kernel_Name"]:
+        per[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+        per[int(r["Dispatch_Id"])]["grid"] = float(r.get("Grid_Size", 0) or 0)
+for k, (d, c) in enumerate(sorted(per.items())):
+    if k < 40 and (k < 8 or k % 4 == 0):
+        print(k, "  ".join("%s=%.4g" % kv for kv in sorted(c.items())))
+PY
