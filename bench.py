@@ -261,9 +261,19 @@ class Stepper:
         mid = [g for g in self.big if sizes[g.index] < self.UNION_BELOW]
         members = sorted([g.index for g in mid] + small)
         self.union = None
+        self.union_pool = None
         if not self.ndf and self.UNION_BELOW > 0 and len(members) >= 2:
-            self.union = ResidentUnion(self.ctxs[0], members, groups)
             self.big_alone = [g for g in self.big if sizes[g.index] >= self.UNION_BELOW]
+            # the union instance on a stream (and host thread) of its own beside the large groups, which run one
+            # after the other: each chain has a dozen host read-backs (sizes of work lists, rounds), and the other
+            # chain's kernels fill them (CATCHHIP_BENCH_UNION_BESIDE=0: after them, on the same stream)
+            beside = bool(self.big_alone) and os.environ.get("CATCHHIP_BENCH_UNION_BESIDE", "1") != "0"
+            self.union_ctx = engine.Context(device) if beside else self.ctxs[0]
+            self.union = ResidentUnion(self.union_ctx, members, groups)
+            if beside:
+                self.union_ctx.sync()
+                # (the large groups on two or three streams of their own as well: 88.6 -> 86.3 / 86.0 ms, not kept)
+                self.union_pool = concurrent.futures.ThreadPoolExecutor(1)
         for c in self.ctxs:
             c.sync()
         self.pool = (concurrent.futures.ThreadPoolExecutor(self.width)
@@ -279,11 +289,18 @@ class Stepper:
             out.append((g.index, ids))
         return out
 
-    def step(self, stats=None):
-        """One pass over every group of this rank -> {group index: pick ids}."""
+    def step(self, stats=None, beside=True):
+        """One pass over every group of this rank -> {group index: pick ids}.
+        beside=False: the union instance after the large groups instead of beside them (per-kernel times that
+        no other stream's kernels stretch)."""
         if self.union is not None:
-            out = dict(self._run_lane(self.big_alone, stats))
-            per_group, nrows = self.union.run()
+            if self.union_pool is not None and beside:
+                fut = self.union_pool.submit(self.union.run)
+                out = dict(self._run_lane(self.big_alone, stats))
+                per_group, nrows = fut.result()
+            else:
+                out = dict(self._run_lane(self.big_alone, stats))
+                per_group, nrows = self.union.run()
             out.update(per_group)
             if stats is not None:
                 self._collect(self.union, range(sum(len(ids) for ids in per_group.values())), nrows, stats)
@@ -337,12 +354,17 @@ class Stepper:
     def sync(self):
         for c in self.ctxs:
             c.sync()
+        if getattr(self, "union_pool", None) is not None:
+            self.union_ctx.sync()
 
     def close(self):
         for g in self.resident:
             g.close()
         if self.union is not None:
             self.union.close()
+        if getattr(self, "union_pool", None) is not None:
+            self.union_pool.shutdown()
+            self.union_pool = None
         if self.pool is not None:
             self.pool.shutdown()
 
@@ -802,11 +824,11 @@ def main():
     units = sum(g.n_sets * g.G for g in stepper.resident) + sum(g.n_sets * g.G_local for g in sharded)
     n_cands = sum(g.n_sets for g in stepper.resident) + (sum(g.n_sets for g in sharded) if rank == 0 else 0)
 
-    def run_step(stats=None):
+    def run_step(stats=None, beside=True):
         out = {}
         for g in sharded:                 # all ranks together, in the same order
             out[g.index] = g.step(stats)
-        out.update(stepper.step(stats))
+        out.update(stepper.step(stats, beside))
         return out
 
     def barrier():
@@ -834,6 +856,18 @@ def main():
     # one extra, untimed step with the E_dirty statistics on (SURVEY 8(d) K2's byte formula wants them), and one
     # whose solutions are replayed by the independent check kernels
     dirty_stats, prop = None, None
+    alone_stats, alone_ms = None, None
+    if world == 1 and not args.preflight and stepper.union_pool is not None:
+        # the timed steps run two chains side by side (the large groups | the union instance): their per-kernel
+        # event times include what the other stream's kernels took.  Two more untimed steps one chain after the
+        # other give every kernel's time on an otherwise idle device -- reported beside the timed figures
+        run_step(None, beside=False)
+        alone_stats = []
+        stepper.sync()
+        ta = time.perf_counter()
+        run_step(alone_stats, beside=False)
+        stepper.sync()
+        alone_ms = (time.perf_counter() - ta) * 1e3
     if world == 1 and not args.preflight:
         os.environ["CATCHHIP_FLAT_COUNT_DIRTY"] = "1"
         try:
@@ -982,6 +1016,25 @@ def main():
                     device_ms_per_step=d["ms"],
                     note="frac = min(algorithmic bytes of the kernel's model, PMC traffic) / HIP-event time / peak; "
                          "the K2 round as a whole against SURVEY 8(d)'s formula: roofline_k2")
+        alone = None
+        if alone_stats:
+            ta_ = {}
+            for st in alone_stats:
+                for k, v in st.items():
+                    ta_[k] = ta_.get(k, 0) + v
+            a_ms = {"join_verify": ta_.get("verify_ms", 0.0) + ta_.get("vcount_ms", 0.0), "solver_claim": ta_.get("claim_ms", 0.0),
+                    "rows_build": ta_.get("rows_ms", 0.0)}[dom]
+            a_avg = a_ms / max(d["launches"], 1)
+            roof["one_chain_at_a_time"] = dict(
+                avg_launch_ms=a_avg, device_ms_per_step=a_ms, achieved=gbs(priced, a_avg), frac=gbs(priced, a_avg) / HBM_PEAK_GBS,
+                note="the same kernel in an untimed step that runs the union instance AFTER the large groups instead of beside "
+                     "them: its launches with the device to themselves (the timed steps overlap two chains: a launch's "
+                     "event time then includes the other stream's kernels, and the step is shorter)")
+            alone = {"ms_per_step": alone_ms,
+                     "kernel_ms_per_step": {"k1_scan": ta_.get("scan_ms", 0.0), "k1_join_verify_count": ta_.get("vcount_ms", 0.0),
+                                            "k1_join_verify_write": ta_.get("verify_ms", 0.0), "rows_build": ta_.get("rows_ms", 0.0),
+                                            "k2_greedy": ta_.get("greedy_ms", 0.0), "k2_greedy_rounds_only": ta_.get("rounds_ms", 0.0),
+                                            "k2_claim_launches": ta_.get("claim_ms", 0.0)}}
         out = {
             "metric": "candidate-probe x target-bp / s through SetCoverFilter "
                       "(K1 scan + K2 greedy)",
@@ -1020,6 +1073,7 @@ def main():
                                    "k2_greedy_rounds_only": ms["rounds_ms"], "k2_claim_launches": ms["claim_ms"],
                                    "note": "HIP-event device time summed over the groups of rank 0; "
                                            "groups in flight overlap, so the sum can exceed ms_per_step"},
+            "one_chain_at_a_time": alone,
             "roofline": roof,
             "roofline_k1_verify": dict(bound="hbm", achieved=gbs(verify_bytes, ms["verify_ms"] + ms["vcount_ms"]),
                                        peak=HBM_PEAK_GBS, unit="GB/s",
@@ -1076,6 +1130,13 @@ def main():
             "property_checks": prop,
             "rccl": engine.Context.comm_info() if world > 1 else None,
         }
+
+        if alone is not None:
+            akm = alone["kernel_ms_per_step"]
+            out["roofline_k2"]["frac_one_chain_at_a_time"] = gbs(k2_bytes, akm["k2_greedy_rounds_only"]) / HBM_PEAK_GBS
+            out["roofline_rows"]["frac_one_chain_at_a_time"] = gbs(rows_bytes, akm["rows_build"]) / HBM_PEAK_GBS
+            out["roofline_k1_verify"]["frac_one_chain_at_a_time"] = gbs(
+                verify_bytes, akm["k1_join_verify_count"] + akm["k1_join_verify_write"]) / HBM_PEAK_GBS
         if preflight is not None:
             out["preflight"] = preflight
         if Stepper.ndf:
