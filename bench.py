@@ -1313,7 +1313,7 @@ def main():
                     "work_per_step", "dataset_generation_s", "probes_sha256", "m2_setcoverfilter_wall_s")
             also = {}
             for name, extra in (("S3", ["--workload", "S3", "--steps", "3", "--warmup", "1"]),
-                                ("S5", ["--workload", "S5", "--scale", "%g" % args.also_s5_scale, "--steps", "1", "--warmup", "0"])):
+                                ("S5", ["--workload", "S5", "--scale", "%g" % args.also_s5_scale, "--steps", "1", "--warmup", "1"])):   # (a cold first step is 3-4 s longer: first-use allocations of 100+ GB)
                 ta = time.perf_counter()
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra +

@@ -63,13 +63,13 @@ setup = [k for k in kern if k.startswith(("gr_tile_", "set_ptr", "gr_bitmap"))]
 solver = [k for k in kern if k.startswith(("gf_count_claim", "gf_check_apply", "gr_count", "gr_claim", "gr_check", "gr_apply"))]
 ndfk = [k for k in kern if k.startswith(("ndf_", "mh_"))]
 rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
-               "'python bench.py --workload %s --steps 2 --warmup 1 --no-cpu-baseline --no-property-checks' (3 steps + the "
-               "untimed step with the E_dirty statistics = 4 steps in the run); KB per launch averaged over "
+               "'python bench.py --workload %s --steps 2 --warmup 1 --no-cpu-baseline --no-property-checks' (3 steps, the two "
+               "untimed steps that run one chain at a time and the untimed step with the E_dirty statistics = 6 steps in the run); KB per launch averaged over "
                "the launches of the run (all groups, all rounds); a unit = total KB of its kernels / launches of its "
                "leading kernel(s) (a solver round = one count launch with its claim / apply launches); on "
                "gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md), bench.py doubles it; "
                "other widths and WRITE_SIZE are uncalibrated" % wl,
-       "workload": wl, "steps_in_run": 4,
+       "workload": wl, "steps_in_run": 6,
        "disjoint_units": ["k1_table_hitpos_sort", "join_verify", "rows_build", "solver_setup", "solver_round", "ndf"],
        "units": {"solver_round": unit(solver, [k for k in solver if k.startswith(("gf_count_claim", "gr_count"))]),
                  "gr_claim": unit([k for k in solver if k.startswith("gr_claim")], [k for k in solver if k.startswith("gr_claim")]),
