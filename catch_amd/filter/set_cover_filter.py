@@ -811,11 +811,11 @@ class SetCoverFilter(BaseFilter):
         import time as _time
         stage_s = dict(pack_s=0.0, candidates_s=0.0, near_duplicates_s=0.0, anchors_s=0.0, solve_s=0.0)
 
-        # The front end runs on `workers` threads, each with its own stream (CATCHHIP_FRONT_END_WORKERS; the
+        # The front end runs on `workers` threads, each with its own stream (two; test hook CATCHHIP_FRONT_END_WORKERS; the
         # MinHash filter is ~45 dependent rounds of mostly small launches per chunk, 5.3 of the 6.8 s of
         # S5 x 1.0's filters: two of them side by side overlap).  The filter's draws from `random` are made for
         # every chunk first, in chunk order -- the stream of draws one chunk after the other would make.
-        workers = max(1, int(os.environ.get("CATCHHIP_FRONT_END_WORKERS", "2")))
+        workers = max(1, int(_lib.test_env("CATCHHIP_FRONT_END_WORKERS", "2")))
         piped = depth > 0 and len(chunks) > 1
         drawn_ndf = {}
         if piped and near_duplicate_filter is not None and hasattr(near_duplicate_filter, "_draw_for_groups"):

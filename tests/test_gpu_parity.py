@@ -2313,3 +2313,45 @@ def test_rows_stats_match_fetched_rows(ctx):
         assert union.tolist() == want_union.tolist()
         assert per_set.tolist() == want_sets.tolist() and per_set.sum() > 10
     p.close(); t.close()
+
+
+@pytest.mark.gpu
+def test_neighbour_graph_edge_cases(ctx):
+    """catchhip_sigs_graph on one sequence, on unrelated sequences (no edges), on identical ones (a clique) and
+    with a sequence count that is not a multiple of any tile; the clustering on top of each."""
+    from catch_amd.utils import cluster, lsh
+    rng = np.random.RandomState(11)
+
+    def rand(n):
+        return "".join("ACGT"[x] for x in rng.randint(0, 4, size=n))
+    base = rand(3000)
+    cases = {"one": [rand(2000)],
+             "unrelated": [rand(2000) for _ in range(70)],
+             "clique": [base] * 67,
+             "mixed": [base[:2500] + rand(40) for _ in range(33)] + [rand(1500) for _ in range(100)]}
+    for name, seqs in cases.items():
+        random.seed(9)
+        sigs = lsh.MinHashFamily(12, N=100).signatures(seqs)
+        try:
+            ptr, gidx, gcom = sigs.graph(9)
+            n = len(seqs)
+            assert ptr.shape == (n + 1,) and ptr[0] == 0 and ptr[-1] == gidx.size == gcom.size
+            for j in range(n):
+                row = sigs.common_row(j).astype(np.int64)
+                want = np.nonzero(row >= 9)[0]
+                want = want[want != j]
+                assert np.array_equal(gidx[ptr[j]:ptr[j + 1]], want), (name, j)
+                assert np.array_equal(gcom[ptr[j]:ptr[j + 1]], row[want]), (name, j)
+            if name in ("one", "unrelated"):
+                assert gidx.size == 0
+            if name == "clique":
+                assert gidx.size == n * (n - 1) and set(gcom.tolist()) == {100}
+        finally:
+            sigs.close()
+        random.seed(9)
+        got = cluster.cluster_with_minhash_signatures(dict(enumerate(seqs)), threshold=0.15, cluster_method="simple")
+        assert sorted(x for c in got for x in c) == list(range(len(seqs)))
+        if name == "clique":
+            assert len(got) == 1
+        if name == "unrelated":
+            assert len(got) == len(seqs)
