@@ -622,21 +622,41 @@ class Shard:
     (catchhip_shard): the frontier solver's state over this rank's cover
     rows.  Driven round by round by catch_amd.parallel.sharded_solve."""
 
-    def __init__(self, rows, num_sets, ranks=None):
+    def __init__(self, rows, num_sets, ranks=None, universe_p=None):
+        """universe_p: the fraction to cover of every universe of THIS shard
+        (its own genomes, in order), or None = all of each.  With some below 1
+        the rounds have a third step (verdict + a second exchange of the lost
+        marks; catchhip_shard_create_p)."""
         self.ctx = rows.ctx
         self.rows = rows                     # keeps the rows alive
         self.num_sets = int(num_sets)
         rk = None if ranks is None else np.ascontiguousarray(ranks, np.int64)
+        up = None
+        if universe_p is not None:
+            # (one entry per universe of the shard's rows: the library reads exactly that many)
+            up = np.ascontiguousarray(universe_p, dtype=np.float64)
+            if up.size == 0:
+                up = None
+        self.partial = bool(up is not None and (up < 1.0).any())
+        # whether ANY shard of the instance is partial decides the shape of a round (parallel.sharded_solve): the
+        # caller that knows the whole instance's fractions sets it on every shard
+        self.partial_instance = self.partial
         self._h = ctypes.c_void_p()
-        check(self.ctx._L.catchhip_shard_create(
+        check(self.ctx._L.catchhip_shard_create_p(
             self.ctx._h, rows._h, self.num_sets,
-            None if rk is None else _ptr(rk, c_i64p), ctypes.byref(self._h)))
+            None if rk is None else _ptr(rk, c_i64p),
+            None if up is None else up.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.byref(self._h)))
 
     def count(self):
         check(self.ctx._L.catchhip_shard_count(self._h))
 
     def claim_check(self):
         check(self.ctx._L.catchhip_shard_claim_check(self._h))
+
+    def verdict(self):
+        """Partial coverage: the local universe tests of this round's candidates
+        (failures join the lost marks, which are exchanged once more)."""
+        check(self.ctx._L.catchhip_shard_verdict(self._h))
 
     def apply(self):
         """-> 1 finished, -1 ranks exhausted, 0 another round."""

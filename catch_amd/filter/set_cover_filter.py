@@ -362,9 +362,10 @@ class SetCoverFilter(BaseFilter):
                                      only=set(range(n)))
         costs = [sum(g.size() for g in target_genomes_grouped[i]) if len(input_strs[i]) else 0
                  for i in range(n)]
-        # (full coverage only: the sharded rounds have no universe test yet; ranks -- identify / avoided genomes -- are
-        # fine since round 4: every rank computes the sharded group's ranks itself, they only gate which sets may claim)
-        eligible = self.coverage == 1.0
+        # (ranks -- identify / avoided genomes -- and partial coverage are sharded too since round 4: every rank computes
+        # the group's ranks itself, they only gate which sets may claim; need[u] and the acceptance thresholds of a
+        # universe live on the rank that owns it, the candidates' verdicts travel with the lost marks)
+        eligible = True
         # (a group with fewer genomes than ranks is not sharded: some rank would hold an empty shard)
         sharded, whole = parallel.plan_with_sharding(
             costs, W.size,
@@ -409,11 +410,16 @@ class SetCoverFilter(BaseFilter):
                     ranks = (self._make_ranks_strs(strs, target_genomes_grouped, ctx)
                              if (self.identify or self.avoided_genomes) else None)
                     try:
-                        shard = engine.Shard(rows, len(strs), ranks)
+                        up_all = self._make_universe_p(genomes)
+                        part = any(p_ < 1.0 for p_ in up_all)     # (the same on every rank)
+                        shard = engine.Shard(rows, len(strs), ranks,
+                                             up_all[b[W.rank]:b[W.rank + 1]] if part else None)
+                        shard.partial_instance = part
                         qualifies = True
                     except ValueError as exc:
-                        # the one expected refusal: rows too long for the sharded kernels -> whole group
-                        if "longer than 257" not in str(exc):
+                        # the expected refusals: rows too long for the sharded kernels, partial coverage with too few
+                        # sets for the row-parallel ones -> whole group
+                        if "longer than 257" not in str(exc) and "row-parallel kernels only" not in str(exc):
                             raise
                 except Exception as exc:          # noqa: BLE001 -- reported collectively
                     err = "%s: %s" % (type(exc).__name__, exc)

@@ -82,6 +82,12 @@ def sharded_solve(shards, exchange):
         for sh in shards:
             sh.claim_check()
         exchange(1)
+        # partial coverage (every rank alike: some universe of the INSTANCE may stay partly uncovered): the
+        # candidates that lost nowhere take the universe test on every rank, failures travel as lost marks
+        if any(getattr(sh, "partial_instance", getattr(sh, "partial", False)) for sh in shards):
+            for sh in shards:
+                sh.verdict()
+            exchange(1)
         done = [sh.apply() for sh in shards]
         if any(d != done[0] for d in done):
             raise RuntimeError("sharded solve: shards disagree on termination")

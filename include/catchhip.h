@@ -294,9 +294,19 @@ int catchhip_comm_info(char *buf, int64_t len);
  *     catchhip_shard_apply        accepted sets applied; synchronises; *done =
  *                                 1 finished, -1 ranks exhausted, 0 next round
  * and catchhip_shard_picks returns the picks in the sequential pick order --
- * the same list on every rank, identical to the unsharded solver's.  Every
- * universe must be fully covered (p == 1) and rows at most 257 bases; other
- * instances are solved whole on one rank (catch_amd/parallel.py).
+ * the same list on every rank, identical to the unsharded solver's.  Rows of
+ * at most 257 bases; other instances are solved whole on one rank
+ * (catch_amd/parallel.py).
+ * Partial coverage (catchhip_shard_create_p with universe_p, one fraction per
+ * LOCAL universe, some below 1; set_cover.py:362-373, 393-433): need[u] and the
+ * acceptance thresholds of a universe live on the rank that owns it; a claimant
+ * that lost nowhere must also pass the universe test on EVERY rank, so a round
+ * has a third step between the lost exchange and the apply:
+ *     catchhip_shard_verdict      local universe tests of the candidates left; a
+ *                                 failure is one more lost mark (enqueued)
+ *     all-reduce MAX of the lost buffer once more (which = 1)
+ * (a no-op for shards created without universe_p).  Sharded by the row-parallel
+ * kernels only (65,536 to 2^25 sets; CATCHHIP_EINVAL otherwise: solve it whole).
  * catchhip_shard_buffers exposes the two exchange buffers (device pointers:
  * uint32[gain_count], uint8[lost_count]) for callers with their own
  * transport.  Ask again before EVERY exchange: large shards pack their
@@ -309,6 +319,10 @@ typedef struct catchhip_shard catchhip_shard;
 int catchhip_shard_create(catchhip_ctx *ctx, const catchhip_rows *rows,
                           int64_t num_sets, const int64_t *ranks,
                           catchhip_shard **out);
+int catchhip_shard_create_p(catchhip_ctx *ctx, const catchhip_rows *rows,
+                            int64_t num_sets, const int64_t *ranks,
+                            const double *universe_p, catchhip_shard **out);
+int catchhip_shard_verdict(catchhip_shard *shard);
 int catchhip_shard_destroy(catchhip_shard *shard);
 int catchhip_shard_count(catchhip_shard *shard);
 int catchhip_shard_claim_check(catchhip_shard *shard);

@@ -48,6 +48,18 @@ def main():
     got = [sorted(p.seq_str for p in g) for g in out]
     want = [sorted(c[i] for i in ids) for c, ids in zip(cands, exp)]
     ok = ok and got == want and f.last_timings.get("sharded_groups") == [1]
+    # -c 0.9 (round 4): the sharded group's universes keep their needs and acceptance thresholds on the rank that
+    # owns them; with the row-parallel kernels forced (an instance this small would take the set-parallel ones,
+    # which refuse partial coverage: then the group is solved whole -- both ways the oracle's selection)
+    exp = orc.set_cover_filter(cands, groups, 2, 100, coverage=0.9, cover_extension=50)
+    want = [sorted(c[i] for i in ids) for c, ids in zip(cands, exp)]
+    for forced in ("1", "0"):
+        os.environ["CATCHHIP_SHARD_FLAT"] = forced
+        f = SetCoverFilter(mismatches=2, lcf_thres=100, coverage=0.9, cover_extension=50)
+        out = f.filter([[probe.Probe.from_str(s) for s in c] for c in cands], gen, input_is_grouped=True)
+        got = [sorted(p.seq_str for p in g) for g in out]
+        ok = ok and got == want and f.last_timings.get("sharded_groups") == [1]
+    os.environ.pop("CATCHHIP_SHARD_FLAT", None)
     res = W.allgather(ok)
     if W.rank == 0:
         print("MULTIRANK_PLUGIN_OK" if all(res) else "MULTIRANK_PLUGIN_MISMATCH %s" % res)

@@ -719,7 +719,7 @@ def test_greedy_rccl_solver_single_rank_matches(oracle):
     c2.close()
 
 
-def _sharded_picks(engine, ctx, probes, genomes, bounds, n_sets, ranks, exchange_of):
+def _sharded_picks(engine, ctx, probes, genomes, bounds, n_sets, ranks, exchange_of, universe_p=None):
     """Universe-sharded solve: one targets / rows / shard triple per genome
     range, driven by the product's round loop."""
     from catch_amd import parallel
@@ -730,7 +730,9 @@ def _sharded_picks(engine, ctx, probes, genomes, bounds, n_sets, ranks, exchange
             held.append(t)
             rows = engine.Rows.scan(ctx, probes, t, 2, 100, 0, 50)
             held.append(rows)
-            shards.append(engine.Shard(rows, n_sets, ranks))
+            up = None if universe_p is None else universe_p[bounds[v]:bounds[v + 1]]
+            shards.append(engine.Shard(rows, n_sets, ranks, up))
+            shards[-1].partial_instance = universe_p is not None and any(p < 1.0 for p in universe_p)
         return parallel.sharded_solve(shards, exchange_of(shards))
     finally:
         for h in shards + held[::-1]:
@@ -775,6 +777,28 @@ def test_universe_sharded_solver_equals_unsharded(ctx, oracle, monkeypatch, with
     got = _sharded_picks(engine, ctx, p, genomes, [0, 0, 10, 23, 23], len(cand), ranks,
                          lambda sh: (lambda w: engine.shards_allreduce_local(sh, w)))
     assert got == want
+    # partial coverage (round 4; row-parallel kernels only): need[u] and the acceptance thresholds of a universe on
+    # the rank that owns it, the candidates' verdicts exchanged with the lost marks -- the unsharded picks, in order;
+    # uniform and mixed fractions (a shard whose own universes all want full cover still takes part in the third step)
+    if flat == "1":
+        for up in ([0.9] * len(genomes), [1.0] * 12 + [0.6] * (len(genomes) - 12), [0.35, 1.0] * (len(genomes) // 2) + [0.8]):
+            t = engine.Targets(ctx, genomes)
+            rows = engine.Rows.scan(ctx, p, t, 2, 100, 0, 50)
+            want_p = rows.greedy(len(cand), ranks, up)
+            sid, un, st, en = rows.fetch()
+            exp_p = oracle.lazy_greedy(sid, un, st, en, len(cand), [len(g[0]) for g in genomes], up, ranks)
+            rows.close(); t.close()
+            assert want_p == exp_p and 0 < len(want_p) < len(want)
+            for bounds in (parallel.split_universes(lens, 2), parallel.split_universes(lens, 3), [0, 0, 10, 23, 23]):
+                got = _sharded_picks(engine, ctx, p, genomes, bounds, len(cand), ranks,
+                                     lambda sh: (lambda w: engine.shards_allreduce_local(sh, w)), up)
+                assert got == want_p, (up[:3], bounds)
+    else:
+        t = engine.Targets(ctx, genomes)
+        rows = engine.Rows.scan(ctx, p, t, 2, 100, 0, 50)
+        with pytest.raises(ValueError, match="row-parallel kernels only"):
+            engine.Shard(rows, len(cand), ranks, [0.9] * len(genomes))
+        rows.close(); t.close()
     p.close()
 
 
