@@ -317,6 +317,19 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
     }
 }
 
+// what the lazy resolution keeps resident: keys, values, cursors (16 B) and the two entry lists (8 B) per (table,
+// probe) entry.  It is taken only when that fits what the device has free right now (plus this library's idle
+// cache, which an allocation returns to the driver first): otherwise the table-by-table edge-list variant, which
+// needs a few buffers of n entries (a failed allocation used to fail the filter instead)
+static bool ndf_lazy_fits(size_t tn) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return true;     // (no information: try, as before)
+    int64_t st[4] = {0, 0, 0, 0};
+    (void)catchhip_pool_stats(st);
+    const size_t idle = st[2] > 0 ? (size_t)st[2] : 0;
+    return (double)tn * 24.0 + (double)(64u << 20) <= 0.9 * ((double)fr + (double)idle);
+}
+
 // the rounds of the lazy resolution and the read-back (both families): launch(list or nullptr, nlist, next,
 // next_count) queues one pass over the listed entries
 template <class Launch>
@@ -458,7 +471,7 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
     PhaseTimer tm(ctx, PHASE_NDF);
     ctx->ndf_counters[0] = n; ctx->ndf_counters[1] = ntables; ctx->ndf_counters[2] = ctx->ndf_counters[3] = 0;
     const unsigned nb = (unsigned)div_up(nn, 256);
-    if ((i64)ntables * n <= ((i64)1 << 31) && !chip_test_env("CATCHHIP_NDF_ALL_PAIRS")) {
+    if ((i64)ntables * n <= ((i64)1 << 31) && !chip_test_env("CATCHHIP_NDF_ALL_PAIRS") && ndf_lazy_fits((size_t)ntables * nn)) {
         // lazy resolution (ndf_lazy_kernel): all tables' sorted runs stay resident, one cursor per (table, slot) --
         // 24 bytes per entry, at most 2^31 entries (48 GB); beyond that the edge-list variant below, table by table
         DevBuf<u64> skeys, pairs;
@@ -841,7 +854,8 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
                        id_hi.p, id_lo.p, nuniq.p);
     tm.launch(1);
     ctx->ndf_counters[0] = n; ctx->ndf_counters[1] = ntables; ctx->ndf_counters[2] = ctx->ndf_counters[3] = 0;
-    if (tchunk >= ntables && (i64)ntables * n <= ((i64)1 << 31) && !chip_test_env("CATCHHIP_MH_ALL_PAIRS")) {
+    if (tchunk >= ntables && (i64)ntables * n <= ((i64)1 << 31) && !chip_test_env("CATCHHIP_MH_ALL_PAIRS") &&
+        ndf_lazy_fits((size_t)ntables * nn)) {
         // lazy resolution (ndf_lazy_kernel): all tables' sorted runs stay resident, one cursor per (table, slot) --
         // 24 bytes per entry, at most 2^31 entries (48 GB); beyond that the edge-list variant below, table by table
         DevBuf<u64> skeys, pairs;
