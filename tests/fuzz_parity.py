@@ -125,21 +125,35 @@ def one_case(seed, ctx):
         a = rows.fetch()
         ok_len = a[0].size == 0 or int((a[3] - a[2]).max()) <= 257
         whole = rows.greedy(len(cands[0]))
+        # ... and under partial coverage (row-parallel shards only: odd seeds), fractions per universe
+        up = None
+        if seed % 2 and ok_len:
+            up = [rnd.choice([1.0, 0.9, 0.5, 0.25]) for _ in groups[0]]
+            if all(x >= 1.0 for x in up):
+                up[0] = 0.8
+            whole_p = rows.greedy(len(cands[0]), None, up)
         rows.close(); t.close()
         if ok_len:
             lens = [sum(len(x) for x in gen) for gen in groups[0]]
             for world in (2, 3):
                 b = parallel.split_universes(lens, world)
-                held, shards = [], []
-                for v in range(world):
-                    tv = engine.Targets(ctx, groups[0][b[v]:b[v + 1]])
-                    rv = engine.Rows.scan(ctx, p, tv, m, thres, island, ext)
-                    held += [tv, rv]
-                    shards.append(engine.Shard(rv, len(cands[0])))
-                got_s = parallel.sharded_solve(shards, lambda w: engine.shards_allreduce_local(shards, w))
-                for h in shards + held[::-1]:
-                    h.close()
-                assert got_s == whole, (desc, "sharded", world)
+                for fractions, expect in ((None, whole), (up, whole_p if up else None)):
+                    if fractions is None and expect is None:
+                        continue
+                    if fractions is None and expect is not whole:
+                        continue
+                    held, shards = [], []
+                    for v in range(world):
+                        tv = engine.Targets(ctx, groups[0][b[v]:b[v + 1]])
+                        rv = engine.Rows.scan(ctx, p, tv, m, thres, island, ext)
+                        held += [tv, rv]
+                        shards.append(engine.Shard(rv, len(cands[0]), None,
+                                                   None if fractions is None else fractions[b[v]:b[v + 1]]))
+                        shards[-1].partial_instance = fractions is not None
+                    got_s = parallel.sharded_solve(shards, lambda w: engine.shards_allreduce_local(shards, w))
+                    for h in shards + held[::-1]:
+                        h.close()
+                    assert got_s == expect, (desc, "sharded", world, fractions)
         p.close()
     # near-duplicate filters on the first group's candidates (equal lengths)
     strs = [s for s in cands[0] if len(s) == L][:1500]
