@@ -176,8 +176,13 @@ ndf_node_round_kernel(u32 *__restrict__ status, u32 *__restrict__ flags, u32 n, 
 #define NDF_CUR_NEAR 0x80000000u
 #define NDF_CUR_NONE 0xffffffffu
 #define NDF_OWN_STEPS 8
+#define NDF_WAVE_NEAR_MAX 24
 
 struct HammingFamily {       // ndf_near on the padded rows; the earlier tables' sampled positions lie k entries apart
+    static constexpr bool WAVE_NEAR = false;     // (a comparison is a few XORs and popcounts: nothing to share)
+    static constexpr int wave_near_max = 0;
+    struct Scratch { u32 unused; };
+    __device__ __forceinline__ bool near_wave(u32, u32, Scratch &, u32) const { return false; }
     const u64 *padded;
     int W, d, k;
     const i32 *pos_all;
@@ -239,31 +244,64 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
         }
     }
     const u32 *vals = vals_all + (size_t)t * n;
-    // the mate at y (y < x): a verdict, or on to the next
-    auto examine = [&]() {
-        const u32 j = vals[y];                       // j < i: stable sort keeps indices ascending in a run
-        const u32 sj = st[j];
-        if (sj != 2) {
-            bool is_near = near_known;
-            if (!is_near && fam.same_bucket(t, i, j) && !fam.owned_earlier(t, i, j)) {
-                ++compared;
-                is_near = fam.near(t, i, j);
-                found += is_near ? 1u : 0u;
+    __shared__ typename Family::Scratch s_scratch[4];
+    typename Family::Scratch &scratch = s_scratch[threadIdx.x >> 6];
+    // The comparisons the lanes of this wavefront want right now (lane: its probe pi against mate pj).  A comparison of
+    // two k-mer sets is a merge walk of ~100 dependent steps, ~2,500 instructions -- and the whole wavefront executes
+    // them while typically a handful of its lanes compare (PMC, round 4: 9,500 VALU instructions per wavefront;
+    // the rounds are ALU-bound).  So with fewer than NDF_WAVE_NEAR_MAX lanes wanting one the wavefront runs them one
+    // after the other TOGETHER (Family::near_wave: ~200 instructions each); with more, every lane runs its own.
+    auto compare = [&](bool want, u32 tt, u32 pi, u32 pj) -> bool {
+        bool is_near = false;
+        unsigned long long wb = __ballot(want);
+        if (!wb) return false;
+        if (!Family::WAVE_NEAR || __popcll(wb) >= fam.wave_near_max) {
+            if (want) is_near = fam.near(tt, pi, pj);
+        } else {
+            while (wb) {
+                const int b = __ffsll((long long)wb) - 1;
+                wb &= wb - 1ull;
+                const bool r = fam.near_wave((u32)__shfl((int)pi, b, WAVE), (u32)__shfl((int)pj, b, WAVE), scratch, lane);
+                if ((int)lane == b) is_near = r;
             }
-            if (is_near) { verdict = sj == 1 ? 2u : 3u; return; }   // a kept higher-priority near-duplicate / an undecided one
         }
-        ++y;
-        near_known = false;
+        return is_near;
     };
-    for (int step = 0; walking && !verdict && step < NDF_OWN_STEPS; ++step) {
-        if (y >= x) verdict = 1; else examine();
+    // the mate at y (y < x) of the lanes in `act`: a verdict, or on to the next
+    auto examine = [&](bool act) {
+        u32 j = 0, sj = 2;
+        bool is_near = false, want = false;
+        if (act) {
+            j = vals[y];                             // j < i: stable sort keeps indices ascending in a run
+            sj = st[j];
+            if (sj != 2) {
+                is_near = near_known;
+                want = !is_near && fam.same_bucket(t, i, j) && !fam.owned_earlier(t, i, j);
+            }
+        }
+        const bool r = compare(want, t, i, j);
+        if (want) { ++compared; is_near = r; found += r ? 1u : 0u; }
+        if (act) {
+            if (is_near) verdict = sj == 1 ? 2u : 3u;   // a kept higher-priority near-duplicate / an undecided one
+            else { ++y; near_known = false; }
+        }
+    };
+    for (int step = 0; step < NDF_OWN_STEPS; ++step) {
+        bool act = walking && !verdict;
+        if (act && y >= x) { verdict = 1; act = false; }
+        if (!__ballot(act)) break;
+        examine(act);
     }
     for (;;) {                                       // the walks that are not over yet, one at a time, by the whole wavefront
         const unsigned long long todo = __ballot(walking && !verdict);
         if (!todo) break;
         const int leader = __ffsll((long long)todo) - 1;
+        if (__shfl((int)(y >= x), leader, WAVE)) {    // (the solo steps ended right at the end of its run)
+            if ((int)lane == leader) verdict = 1;
+            continue;
+        }
         if (__shfl((int)near_known, leader, WAVE)) {  // (its blocker first: one look)
-            if ((int)lane == leader) examine();
+            examine((int)lane == leader);
             continue;
         }
         const u32 ly = __shfl(y, leader, WAVE), lx = __shfl(x, leader, WAVE), lt = __shfl(t, leader, WAVE),
@@ -272,17 +310,15 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
         u32 ny = ly, hit_state = 0, ncmp = 0, nfound = 0;
         for (;;) {                                   // 64 mates per step, each lane compares one
             const u32 yy = ny + lane;
-            bool is_near = false;
-            u32 sj = 2;
+            bool want = false;
+            u32 sj = 2, j = 0;
             if (yy < lx) {
-                const u32 j = lvals[yy];
+                j = lvals[yy];
                 sj = st[j];
-                if (sj != 2 && fam.same_bucket(lt, li, j) && !fam.owned_earlier(lt, li, j)) {
-                    ++ncmp;
-                    is_near = fam.near(lt, li, j);
-                    nfound += is_near ? 1u : 0u;
-                }
+                want = sj != 2 && fam.same_bucket(lt, li, j) && !fam.owned_earlier(lt, li, j);
             }
+            const bool is_near = compare(want, lt, li, j);
+            if (want) { ++ncmp; nfound += is_near ? 1u : 0u; }
             const unsigned long long m = __ballot(is_near);
             if (m) {
                 const int first = __ffsll((long long)m) - 1;
@@ -760,6 +796,45 @@ struct MinHashFamily {       // same signature in table t (the key only groups),
     double thres;
     u32 n;
     const u32 *grp;
+    const u32 *need_tab;     // by |A| + |B|: the smallest intersection for which 1 - m / (|A| + |B| - m) <= thres
+    int wave_near_max;       // lanes wanting a comparison from which every lane runs its own (NDF_WAVE_NEAR_MAX)
+    static constexpr bool WAVE_NEAR = true;
+    struct Scratch { u64 h[MH_MAXK], l[MH_MAXK]; };
+    // i near j, by the whole wavefront (i, j wave-uniform): B's k-mers staged in LDS, every lane looks its share of
+    // A's up by binary search, the matches are summed -- |A and B| >= need is what mh_near's walk decides (its early
+    // exits only shorten the walk), `need` from a table of the reference's own two IEEE operations made on the host
+    __device__ __forceinline__ bool near_wave(u32 i, u32 j, Scratch &S, u32 lane) const {
+        const u32 na = nuniq[i], nb = nuniq[j];
+        const u32 most = min(na, nb);
+        const u32 need = min(need_tab[na + nb], most + 1u);
+        if (need > most) return false;
+        if (need == 0) return true;
+        const u64 *bh = id_hi + koff[j], *bl = id_lo + koff[j];
+        for (u32 q = lane; q < nb; q += 64) { S.h[q] = bh[q]; S.l[q] = bl[q]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const u64 *ah = id_hi + koff[i], *al = id_lo + koff[i];
+        u32 cnt = 0;
+        for (u32 q0 = 0; q0 < na; q0 += 64) {
+            const u32 q = q0 + lane;
+            const bool have = q < na;
+            const u64 h = have ? ah[q] : 0ull, l = have ? al[q] : 0ull;
+            u32 lo = 0, hi = nb;                        // first element of B that is not below (h, l)
+            while (__ballot(lo < hi)) {
+                if (lo < hi) {
+                    const u32 mid = (lo + hi) >> 1;
+                    const u64 mh_ = S.h[mid], ml_ = S.l[mid];
+                    if (mh_ < h || (mh_ == h && ml_ < l)) lo = mid + 1; else hi = mid;
+                }
+            }
+            cnt += (have && lo < nb && S.h[lo] == h && S.l[lo] == l) ? 1u : 0u;
+        }
+        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, WAVE);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                // (S is rewritten by the next comparison)
+        return cnt >= need;
+    }
     __device__ __forceinline__ bool same_sig(u32 t, u32 i, u32 j) const {
         const u32 *si = sig_all + ((size_t)t * n + i) * k, *sj = sig_all + ((size_t)t * n + j) * k;
         bool eq = true;
@@ -767,9 +842,22 @@ struct MinHashFamily {       // same signature in table t (the key only groups),
         return eq;
     }
     __device__ __forceinline__ bool same_bucket(u32 t, u32 i, u32 j) const { return (!grp || grp[i] == grp[j]) && same_sig(t, i, j); }
+    // (eight earlier tables per round trip: the first values of both signatures are requested together, a table whose
+    // first values agree is then compared in full -- one table at a time was a chain of up to 24 dependent loads per
+    // mate, and since the comparisons are shared by the wavefront the walks wait for loads, not for the ALU)
     __device__ __forceinline__ bool owned_earlier(u32 t, u32 i, u32 j) const {
-        for (u32 tp = 0; tp < t; ++tp)
-            if (same_sig(tp, i, j)) return true;
+        for (u32 t0 = 0; t0 < t; t0 += 8) {
+            u32 a[8], b[8];
+#pragma unroll
+            for (u32 q = 0; q < 8; ++q) {
+                const u32 tp = min(t0 + q, t - 1);
+                a[q] = sig_all[((size_t)tp * n + i) * k];
+                b[q] = sig_all[((size_t)tp * n + j) * k];
+            }
+#pragma unroll
+            for (u32 q = 0; q < 8; ++q)
+                if (t0 + q < t && a[q] == b[q] && same_sig(t0 + q, i, j)) return true;
+        }
         return false;
     }
     __device__ __forceinline__ bool near(u32, u32 i, u32 j) const {
@@ -891,8 +979,29 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
             tm.launch(1 + 24 + 2);
         }
         lap("signatures + sorts", t_lap);
+        // the intersection the threshold needs, by |A| + |B| (MinHashFamily::near_wave): the reference's expression,
+        // evaluated here with the same two IEEE operations the device's walk uses
+        DevBuf<u32> need_tab;
+        TRY(need_tab.alloc(2 * MH_MAXK + 2));
+        {
+            std::vector<u32> h_need(2 * MH_MAXK + 2);
+            for (u32 S = 0; S < h_need.size(); ++S) {
+                u32 m_ = 0;
+                for (; m_ <= S / 2; ++m_) {
+                    volatile double sim = (double)m_ / (double)(S - m_);
+                    volatile double dist = 1.0 - sim;
+                    if (dist <= dist_thres) break;
+                }
+                h_need[S] = m_;
+            }
+            TRY(chip_pinned_reserve(ctx, sizeof(u32) * h_need.size()));
+            memcpy(ctx->h_big, h_need.data(), sizeof(u32) * h_need.size());
+            HIP_TRY(hipMemcpyAsync(need_tab.p, ctx->h_big, sizeof(u32) * h_need.size(), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));           // (h_big is reused by the read-backs below)
+        }
         MinHashFamily fam{(const u32 *)d_koff.p, (const u32 *)nuniq.p, (const u64 *)id_hi.p, (const u64 *)id_lo.p, (const u32 *)sig.p,
-                          (int)k, dist_thres, nn, grp};
+                          (int)k, dist_thres, nn, grp, (const u32 *)need_tab.p,
+                          chip_test_env("CATCHHIP_NDF_WAVE_NEAR_MAX") ? atoi(chip_test_env("CATCHHIP_NDF_WAVE_NEAR_MAX")) : NDF_WAVE_NEAR_MAX};
         const int rc = ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
                                        [&](const u32 *list, u32 nlist, u32 *next, u32 *next_count) {
             hipLaunchKernelGGL(ndf_lazy_kernel<MinHashFamily>, dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s, fam, nn,
