@@ -207,26 +207,50 @@ struct HammingFamily {       // ndf_near on the padded rows; the earlier tables'
     }
 };
 
-template <class Family>
+// WAKE (round 4, the default): driven by wake-ups instead of polling.  The polling form lists ALL unexhausted entries
+// of every undecided probe every round -- a probe that waits for an undecided mate has its 25 cursors looked at
+// ~45 times (S5 x 1.0: 1.35e9 entry visits per chunk for 6.9e7 comparisons).  Here a probe that finds an undecided
+// near mate j PARKS: wait_on[i] = j (flags is that array), none of its entries is listed again; after every pass one
+// thread per probe looks at its blocker (ndf_wake_kernel): kept -> the probe is dropped; dropped -> the probe wakes
+// up and is listed for the next pass, whose threads are (table, listed probe) pairs in TABLE-major order (the entry
+// is found through inv[table][probe] = slot; table-major, because the blocks of a launch start roughly in order: a
+// probe that parks because of an early table is mostly not walked by the later ones -- entry by entry, a woken
+// probe's 25 cursors sat in one wavefront and all walked: 1.7 x the comparisons); undecided -> it keeps waiting.
+// A probe is kept by the entry that exhausts its last table (left[i] counts them down) -- inside the pass, so
+// chains resolve as far as the timing allows.  Every decision still rests on decided, hence final, states; waits
+// point from a probe to a higher-priority one, so there are no cycles and the highest-priority undecided probe
+// never waits: the same fixed point.  (Built once before the comparisons were shared by the wavefront: a fifth of
+// the entry visits and the same time, because the rounds were ALU-bound then.)
+template <class Family, bool WAKE>
 __global__ void __launch_bounds__(256)
 ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *__restrict__ vals_all,
                 u32 *__restrict__ cursor_all, u32 *status, u32 *flags, unsigned long long *__restrict__ pairs,
-                const u32 *__restrict__ list, u32 nlist, u32 *__restrict__ next, u32 *__restrict__ next_count) {
+                const u32 *__restrict__ list, u32 nlist, u32 *__restrict__ next, u32 *__restrict__ next_count,
+                u32 *__restrict__ left, const u32 *__restrict__ inv, u32 ntables, u32 nslot) {
+    // nslot = slots per table: n at first, fewer once the dropped probes' slots have been compacted away (WAKE)
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const volatile u32 *st = status;
     bool again = false, walking = false, near_known = false;
     u32 e = 0, t = 0, x = 0, i = 0, y = 0, compared = 0, found = 0;
     u32 verdict = 0;                                 // 1 run exhausted, 2 dropped, 3 waits at y
-    if (g < nlist) {
-        e = list ? list[g] : g;
-        t = e / n;
-        x = e - t * n;
-        const u64 *keys = keys_all + (size_t)t * n;
-        i = vals_all[(size_t)t * n + x];
+    if (g < ((WAKE && list) ? nlist * ntables : nlist)) {
+        if (WAKE && list) {
+            t = g / nlist;
+            i = list[g - t * nlist];
+            x = inv[(size_t)t * n + i];
+            e = t * nslot + x;
+        } else {
+            e = list ? list[g] : g;
+            t = e / nslot;
+            x = e - t * nslot;
+            i = vals_all[(size_t)t * nslot + x];
+        }
+        const u64 *keys = keys_all + (size_t)t * nslot;
         const u32 cur = cursor_all[e];
         if (st[i] == 0 && cur != x) {
             again = true;
-            if (((const volatile u32 *)flags)[i] == 0) {   // (else: waiting already in this round)
+            // (polling: flags[i] != 0 = waiting already in this round; wake-ups: flags[i] = the blocker, parked)
+            if (((const volatile u32 *)flags)[i] == (WAKE ? NDF_CUR_NONE : 0u)) {
                 walking = true;
                 if (cur == NDF_CUR_NONE) {           // first visit: the first slot of the run
                     const u64 key = keys[x];
@@ -243,7 +267,7 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
             }
         }
     }
-    const u32 *vals = vals_all + (size_t)t * n;
+    const u32 *vals = vals_all + (size_t)t * nslot;
     __shared__ typename Family::Scratch s_scratch[4];
     typename Family::Scratch &scratch = s_scratch[threadIdx.x >> 6];
     // The comparisons the lanes of this wavefront want right now (lane: its probe pi against mate pj).  A comparison of
@@ -306,7 +330,7 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
         }
         const u32 ly = __shfl(y, leader, WAVE), lx = __shfl(x, leader, WAVE), lt = __shfl(t, leader, WAVE),
                   li = __shfl(i, leader, WAVE);
-        const u32 *lvals = vals_all + (size_t)lt * n;
+        const u32 *lvals = vals_all + (size_t)lt * nslot;
         u32 ny = ly, hit_state = 0, ncmp = 0, nfound = 0;
         for (;;) {                                   // 64 mates per step, each lane compares one
             const u32 yy = ny + lane;
@@ -338,13 +362,17 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
     }
     if (walking) {
         if (verdict == 2) { status[i] = 2; again = false; }
-        else if (verdict == 3) flags[i] = 2;         // wait for the undecided mate at y
-        else again = false;                          // this table has nothing more to say about i
+        else if (verdict == 3) {                     // wait for the undecided mate at y
+            if (WAKE) atomicCAS(&flags[i], NDF_CUR_NONE, vals[y]);      // (one blocker per probe: the first entry to find one)
+            else flags[i] = 2;
+        } else again = false;                        // this table has nothing more to say about i
         cursor_all[e] = verdict == 1 ? x : (y | NDF_CUR_NEAR);
+        // the entry that exhausts a probe's last table: nobody kept is near -- kept
+        if (WAKE && verdict == 1 && atomicSub(&left[i], 1u) == 1u) atomicCAS(&status[i], 0u, 1u);
     }
     if (compared) atomicAdd(&pairs[(g >> 6) & (ES_SHARDS - 1)], (unsigned long long)compared);
     if (found) atomicAdd(&pairs[ES_SHARDS + ((g >> 6) & (ES_SHARDS - 1))], (unsigned long long)found);
-    const unsigned long long bal = __ballot(again);
+    const unsigned long long bal = WAKE ? 0ull : __ballot(again);
     if (bal) {
         u32 base = 0;
         if (lane == 0) base = atomicAdd(next_count, (u32)__popcll(bal));
@@ -353,8 +381,86 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
     }
 }
 
-// what the lazy resolution keeps resident: keys, values, cursors (16 B) and the two entry lists (8 B) per (table,
-// probe) entry.  It is taken only when that fits what the device has free right now (plus this library's idle
+__global__ void __launch_bounds__(256)
+ndf_fill_u32_kernel(u32 *__restrict__ p, u32 n, u32 v) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// inv[table][probe] = the probe's slot in that table's sorted order
+__global__ void __launch_bounds__(256)
+ndf_inv_kernel(const u32 *__restrict__ vals_all, u32 n, u32 nslot, size_t tn, u32 *__restrict__ inv) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= tn) return;
+    const size_t t = e / nslot;
+    inv[t * n + vals_all[e]] = (u32)(e - t * nslot);
+}
+// Compaction of the tables (WAKE): the slots of dropped probes go.  Every table holds every probe once, so all
+// tables keep the same number of slots, and a probe deep in a run of thousands of near-identical strains -- all
+// dropped after the second pass except a few -- no longer walks past them (64 per step, two dependent loads each: a
+// pass that listed 1,469 probes took 4 ms because one of them crossed ~10^5 dropped mates; every pass had such a
+// probe).  flag[e] = the slot's probe is not dropped; pos = exclusive scan of flag over ALL tables' slots (= table *
+// new slots per table + rank inside the table).  Cursors are renumbered: past the dropped mates a cursor pointed at
+// or before; one that reaches its own slot that way has exhausted its table (counted here, as the pass would).
+__global__ void __launch_bounds__(256)
+ndf_cflag_kernel(const u32 *__restrict__ vals_all, const u32 *__restrict__ status, size_t tn, u32 *__restrict__ flag) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < tn) flag[e] = status[vals_all[e]] != 2u ? 1u : 0u;
+    else if (e == tn) flag[e] = 0u;
+}
+__global__ void __launch_bounds__(256)
+ndf_compact_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ cursor,
+                   const u32 *__restrict__ flag, const u32 *__restrict__ pos, u32 nslot, u32 nslot_new, size_t tn,
+                   u64 *__restrict__ keys2, u32 *__restrict__ vals2, u32 *__restrict__ cursor2, u32 *status, u32 *__restrict__ left) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= tn || !flag[e]) return;
+    const u32 t = (u32)(e / nslot), x = (u32)(e - (size_t)t * nslot);
+    const u32 e2 = pos[e], x2 = e2 - t * nslot_new;
+    const u32 i = vals[e];
+    keys2[e2] = keys[e];
+    vals2[e2] = i;
+    u32 cur = cursor[e];
+    if (cur == x) cur = x2;                                  // exhausted before (and counted)
+    else if (cur != NDF_CUR_NONE) {
+        const u32 y = cur & ~NDF_CUR_NEAR;
+        const size_t ey = (size_t)t * nslot + y;
+        const u32 y2 = pos[ey] - t * nslot_new;              // the first surviving mate at or after y
+        if (y2 >= x2) {
+            cur = x2;                                        // only dropped mates were left: this table is done with i
+            if (atomicSub(&left[i], 1u) == 1u) atomicCAS(&status[i], 0u, 1u);
+        } else cur = y2 | (((cur & NDF_CUR_NEAR) && flag[ey]) ? NDF_CUR_NEAR : 0u);
+    }
+    cursor2[e2] = cur;
+}
+
+// after a pass: every undecided probe looks at its blocker; counters[0] = undecided probes, [1] = probes listed
+__global__ void __launch_bounds__(256)
+ndf_wake_kernel(u32 *status, u32 *__restrict__ wait_on, u32 n, u32 *__restrict__ next, u32 *__restrict__ counters) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    bool undecided = false, woken = false;
+    if (i < n && status[i] == 0) {
+        const u32 j = wait_on[i];
+        // (a probe that is neither decided nor parked after a pass cannot exist: every listed entry walks to a
+        // verdict; counted all the same, so that a broken invariant shows as an error instead of a wrong answer)
+        undecided = true;
+        if (j != NDF_CUR_NONE) {
+            const u32 sj = status[j];
+            if (sj == 1) { status[i] = 2; undecided = false; }
+            else if (sj == 2) { wait_on[i] = NDF_CUR_NONE; woken = true; }
+        }
+    }
+    const unsigned long long wb = __ballot(woken);
+    if (wb) {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&counters[1], (u32)__popcll(wb));
+        base = __shfl(base, 0, WAVE);
+        if (woken) next[base + (u32)__popcll(wb & ((1ull << lane) - 1ull))] = i;
+    }
+    const unsigned long long b = __ballot(undecided);
+    if (b && lane == 0) atomicAdd(&counters[0], (u32)__popcll(b));
+}
+
+// what the lazy resolution keeps resident: keys, values, cursors (16 B), the slot of every probe in every table (4 B),
+// and, while the tables are compacted, a second copy and the scan's flags (24 B) per (table, probe) entry.  It is taken only when that fits what the device has free right now (plus this library's idle
 // cache, which an allocation returns to the driver first): otherwise the table-by-table edge-list variant, which
 // needs a few buffers of n entries (a failed allocation used to fail the filter instead)
 static bool ndf_lazy_fits(size_t tn) {
@@ -363,27 +469,73 @@ static bool ndf_lazy_fits(size_t tn) {
     int64_t st[4] = {0, 0, 0, 0};
     (void)catchhip_pool_stats(st);
     const size_t idle = st[2] > 0 ? (size_t)st[2] : 0;
-    return (double)tn * 24.0 + (double)(64u << 20) <= 0.9 * ((double)fr + (double)idle);
+    return (double)tn * 52.0 + (double)(64u << 20) <= 0.9 * ((double)fr + (double)idle);
 }
 
 // the rounds of the lazy resolution and the read-back (both families): launch(list or nullptr, nlist, next,
 // next_count) queues one pass over the listed entries
+// launch(wake, list or nullptr, nlist, next, next_count, left, inv): one pass (polling: over the listed entries;
+// wake-ups: over the tables of the listed probes)
 template <class Launch>
 static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &count, DevBuf<u32> &status, DevBuf<u32> &flags,
-                           DevBuf<u64> &pairs, PhaseTimer &tm, u8 *keep, Launch launch) {
+                           DevBuf<u64> &pairs, PhaseTimer &tm, u8 *keep, Launch launch, DevBuf<u64> &skeys, DevBuf<u32> &svals_buf,
+                           DevBuf<u32> &cursor, u32 ntables) {
+    const u32 *svals = svals_buf.p;
     hipStream_t s = ctx->stream;
     const unsigned nb = (unsigned)div_up(nn, 256);
-    u32 *undecided = count.p + ES_SHARDS * ES_STRIDE;     // [0] undecided probes, [1] entries listed for the next round
-    DevBuf<u32> lists[2];
-    TRY(lists[0].alloc(tn));
-    TRY(lists[1].alloc(tn));
-    u32 left = nn, nlist = (u32)tn;
+    u32 *undecided = count.p + ES_SHARDS * ES_STRIDE;     // [0] undecided probes, [1] entries / probes listed for the next round
+    const bool wake = !chip_test_env("CATCHHIP_NDF_POLL_ROUNDS");
+    DevBuf<u32> lists[2], inv, left_tables;
+    TRY(lists[0].alloc(wake ? (size_t)nn : tn));
+    TRY(lists[1].alloc(wake ? (size_t)nn : tn));
+    if (wake) {
+        TRY(inv.alloc(tn));
+        TRY(left_tables.alloc(nn));
+        hipLaunchKernelGGL(ndf_inv_kernel, dim3((unsigned)div_up((i64)tn, 256)), dim3(256), 0, s, svals, nn, nn, tn, inv.p);
+        HIP_TRY(hipMemsetAsync(flags.p, 0xff, sizeof(u32) * nn, s));       // (flags = wait_on: nobody is parked)
+        hipLaunchKernelGGL(ndf_fill_u32_kernel, dim3(nb), dim3(256), 0, s, left_tables.p, nn, ntables);
+        tm.launch(2);
+    }
+    u32 left = nn, nlist = (u32)tn, nslot = nn;
     const bool trace = getenv("CATCHHIP_TIMING") && atoi(getenv("CATCHHIP_TIMING")) > 1;
+    const bool compacting = wake && !chip_test_env("CATCHHIP_NDF_NO_COMPACTION");
+    DevBuf<u64> skeys2;
+    DevBuf<u32> svals2, cursor2, cflag, cpos, ctmp;
     auto t_round = std::chrono::steady_clock::now();
     for (u32 round = 0; left && round <= nn + 1; ++round) {
+        // the tables without the dropped probes' slots: before the passes 2, 4, 8, 16, ... if a quarter or more would go
+        if (compacting && round >= 2 && (round & (round - 1)) == 0 && nslot > 4096) {
+            const size_t tcur = (size_t)ntables * nslot;
+            TRY(cflag.reserve(tcur + 1));
+            TRY(cpos.reserve(tcur + 1));
+            hipLaunchKernelGGL(ndf_cflag_kernel, dim3((unsigned)div_up((i64)tcur + 1, 256)), dim3(256), 0, s, (const u32 *)svals_buf.p,
+                               (const u32 *)status.p, tcur, cflag.p);
+            TRY(chip_exclusive_scan_u32(ctx, cflag.p, cpos.p, (i64)tcur + 1, ctmp));
+            HIP_TRY(hipMemcpyAsync(ctx->h_pin, cpos.p + tcur, sizeof(u32), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            const u32 total = *(volatile u32 *)ctx->h_pin;
+            if (total % ntables != 0) { chip_set_error("ndf: tables disagree on the surviving probes"); return CATCHHIP_EINVAL; }
+            const u32 nslot2 = total / ntables;
+            if ((u64)nslot2 * 4 <= (u64)nslot * 3) {
+                TRY(skeys2.reserve(tcur));
+                TRY(svals2.reserve(tcur));
+                TRY(cursor2.reserve(tcur));
+                hipLaunchKernelGGL(ndf_compact_kernel, dim3((unsigned)div_up((i64)tcur, 256)), dim3(256), 0, s, (const u64 *)skeys.p,
+                                   (const u32 *)svals_buf.p, (const u32 *)cursor.p, (const u32 *)cflag.p, (const u32 *)cpos.p, nslot, nslot2,
+                                   tcur, skeys2.p, svals2.p, cursor2.p, status.p, left_tables.p);
+                skeys.swap(skeys2); svals_buf.swap(svals2); cursor.swap(cursor2);
+                nslot = nslot2;
+                if (nslot)
+                    hipLaunchKernelGGL(ndf_inv_kernel, dim3((unsigned)div_up((i64)ntables * nslot, 256)), dim3(256), 0, s,
+                                       (const u32 *)svals_buf.p, nn, nslot, (size_t)ntables * nslot, inv.p);
+                tm.launch(4);
+            }
+        }
         HIP_TRY(hipMemsetAsync(undecided, 0, 2 * sizeof(u32), s));
-        if (nlist) launch(round ? (const u32 *)lists[round & 1].p : (const u32 *)nullptr, nlist, lists[(round & 1) ^ 1].p, undecided + 1);
-        hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, undecided);
+        if (nlist) launch(wake, round ? (const u32 *)lists[round & 1].p : (const u32 *)nullptr, nlist, lists[(round & 1) ^ 1].p, undecided + 1,
+                          left_tables.p, (const u32 *)inv.p, nslot);
+        if (wake) hipLaunchKernelGGL(ndf_wake_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, lists[(round & 1) ^ 1].p, undecided);
+        else hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, undecided);
         tm.launch(2);
         HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -401,6 +553,7 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
         nlist = ((volatile u32 *)ctx->h_pin)[1];
     }
     HIP_TRY(hipGetLastError());
+    if (left) { chip_set_error("ndf: %u probes undecided after %u rounds", left, nn + 2); return CATCHHIP_EINVAL; }
     tm.stop();
     std::vector<u32> h_status(nn);
     std::vector<u64> h_pairs(2 * ES_SHARDS);
@@ -529,11 +682,16 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
         }
         HammingFamily fam{(const u64 *)padded.p, W, (int)dist_thres, (int)k, (const i32 *)d_pos.p, d_grp, pstride, ntables >= 4 ? 1 : 0};
         return ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
-                               [&](const u32 *list, u32 nlist, u32 *next, u32 *next_count) {
-            hipLaunchKernelGGL(ndf_lazy_kernel<HammingFamily>, dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s, fam, nn,
-                               (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                               (unsigned long long *)pairs.p, list, nlist, next, next_count);
-        });
+                               [&](bool wake, const u32 *list, u32 nlist, u32 *next, u32 *next_count, u32 *left_tables, const u32 *inv, u32 nslot) {
+            if (wake)
+                hipLaunchKernelGGL((ndf_lazy_kernel<HammingFamily, true>), dim3((unsigned)div_up(list ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
+                                   fam, nn, (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot);
+            else
+                hipLaunchKernelGGL((ndf_lazy_kernel<HammingFamily, false>), dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s, fam, nn,
+                                   (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot);
+        }, skeys, svals, cursor, (u32)ntables);
     }
     u32 cap = (u32)std::max<i64>((i64)1 << 14, std::min<i64>(n * 16, (i64)1 << 28) / ES_SHARDS);   // per shard
     u32 ne = 0;
@@ -1003,11 +1161,16 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
                           (int)k, dist_thres, nn, grp, (const u32 *)need_tab.p,
                           chip_test_env("CATCHHIP_NDF_WAVE_NEAR_MAX") ? atoi(chip_test_env("CATCHHIP_NDF_WAVE_NEAR_MAX")) : NDF_WAVE_NEAR_MAX};
         const int rc = ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
-                                       [&](const u32 *list, u32 nlist, u32 *next, u32 *next_count) {
-            hipLaunchKernelGGL(ndf_lazy_kernel<MinHashFamily>, dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s, fam, nn,
-                               (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                               (unsigned long long *)pairs.p, list, nlist, next, next_count);
-        });
+                                       [&](bool wake, const u32 *list, u32 nlist, u32 *next, u32 *next_count, u32 *left_tables, const u32 *inv, u32 nslot) {
+            if (wake)
+                hipLaunchKernelGGL((ndf_lazy_kernel<MinHashFamily, true>), dim3((unsigned)div_up(list ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
+                                   fam, nn, (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot);
+            else
+                hipLaunchKernelGGL((ndf_lazy_kernel<MinHashFamily, false>), dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s, fam, nn,
+                                   (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot);
+        }, skeys, svals, cursor, (u32)ntables);
         lap("rounds", t_lap);
         return rc;
     }

@@ -1768,8 +1768,11 @@ def test_minhash_filter_lazy_resolution_equals_all_pairs(ctx, monkeypatch):
     cands = list(dict.fromkeys(candidate_probes.candidate_strings_from_sequences(seqs, 100, 50)))
     assert len(cands) > 20000
     out = {}
-    for mode in ("lazy", "all pairs"):
+    for mode in ("lazy", "polling rounds", "all pairs"):
+        if mode == "polling rounds":       # round 3's form of the lazy resolution (every unexhausted cursor listed every round)
+            monkeypatch.setenv("CATCHHIP_NDF_POLL_ROUNDS", "1")
         if mode == "all pairs":
+            monkeypatch.delenv("CATCHHIP_NDF_POLL_ROUNDS")
             monkeypatch.setenv("CATCHHIP_MH_ALL_PAIRS", "1")
         random.seed(41)
         ndf = NearDuplicateFilterWithMinHash(0.6)
@@ -1780,14 +1783,18 @@ def test_minhash_filter_lazy_resolution_equals_all_pairs(ctx, monkeypatch):
         many = ndf._filter_strs_many([cands[:third], cands[third:2 * third], cands[2 * third:]])
         out[mode] = (kept, many, ctx.ndf_counters()["pairs_compared"])
     assert out["lazy"][0] == out["all pairs"][0] and out["lazy"][1] == out["all pairs"][1]
+    assert out["lazy"][0] == out["polling rounds"][0] and out["lazy"][1] == out["polling rounds"][1]
     assert 0 < len(out["lazy"][0]) < len(cands)
     assert out["lazy"][2] < out["all pairs"][2]      # and with far fewer comparisons
     # the Hamming family likewise (CATCHHIP_NDF_ALL_PAIRS=1), several tables
     from catch_amd.filter.near_duplicate_filter import NearDuplicateFilterWithHammingDistance
     monkeypatch.delenv("CATCHHIP_MH_ALL_PAIRS")
     ham = {}
-    for mode in ("lazy", "all pairs"):
+    for mode in ("lazy", "polling rounds", "all pairs"):
+        if mode == "polling rounds":
+            monkeypatch.setenv("CATCHHIP_NDF_POLL_ROUNDS", "1")
         if mode == "all pairs":
+            monkeypatch.delenv("CATCHHIP_NDF_POLL_ROUNDS")
             monkeypatch.setenv("CATCHHIP_NDF_ALL_PAIRS", "1")
         res = []
         for thres in (2, 6):
@@ -1796,6 +1803,7 @@ def test_minhash_filter_lazy_resolution_equals_all_pairs(ctx, monkeypatch):
             res.append(ctx.ndf_counters()["pairs_compared"])
         ham[mode] = res
     assert ham["lazy"][0] == ham["all pairs"][0] and ham["lazy"][2] == ham["all pairs"][2]
+    assert ham["lazy"][0] == ham["polling rounds"][0] and ham["lazy"][2] == ham["polling rounds"][2]
     assert 0 < len(ham["lazy"][2]) < len(ham["lazy"][0]) <= len(cands)
     assert ham["lazy"][1] < ham["all pairs"][1] and ham["lazy"][3] < ham["all pairs"][3]
 
