@@ -760,6 +760,17 @@ extern "C" int catchhip_ndf_hamming(catchhip_ctx *ctx, const u8 *bytes, i64 n, i
 // ------------------------------------------------------------------------
 #define MH_P 2147483647ull
 #define MH_MAXK 256   // k-mers per probe one wavefront sorts
+// A 2,048-bit fingerprint of a probe's k-mer set (round 4): every distinct k-mer sets one bit; excess = distinct
+// k-mers minus bits set.  |A and B| <= popcount(bits A & bits B) + min(excess A, excess B): a pair whose bound is
+// below the intersection the threshold needs is not near -- 32 words instead of a merge walk of ~100 dependent steps.
+// (With 512 bits the bound sat ~15 above the intersection and rejected next to nothing: mates of one bucket share
+// 30-50 of their ~90 k-mers and the threshold needs 52.)
+#define MH_FPW 32
+__device__ __forceinline__ u32 mh_fp_bit(u64 h, u64 l) {
+    u64 x = (l ^ (h * 0x9e3779b97f4a7c15ull)) * 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    return (u32)(x * 0xc4ceb9fe1a85ec53ull >> 53);      // 11 bits
+}
 
 // CPython <= 3.10 str hash of `len` ASCII characters, zero key (see above; internal.h)
 __device__ __forceinline__ long long mh_pyhash(const u8 *__restrict__ src, int len) { return chip_pyhash_seed0(src, len); }
@@ -767,8 +778,9 @@ __device__ __forceinline__ long long mh_pyhash(const u8 *__restrict__ src, int l
 __global__ void __launch_bounds__(64)
 mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, const u32 *__restrict__ koff, u32 n,
                int ks, u32 *__restrict__ xs, u64 *__restrict__ id_hi, u64 *__restrict__ id_lo,
-               u32 *__restrict__ nuniq) {
+               u32 *__restrict__ nuniq, unsigned long long *__restrict__ fp, u32 *__restrict__ fp_excess) {
     __shared__ u64 s_hi[MH_MAXK], s_lo[MH_MAXK];
+    __shared__ unsigned long long s_fp[MH_FPW];
     const u32 lane = threadIdx.x;
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
         const u8 *p = bytes + probe_off[i];
@@ -810,6 +822,7 @@ mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, 
             const u32 j = lane + q * 64;
             if (j < nk) { s_hi[rk[q]] = mh[q]; s_lo[rk[q]] = ml[q]; }
         }
+        if (lane < MH_FPW) s_fp[lane] = 0ull;
         __syncthreads();
         u32 out = 0;
         for (u32 c0 = 0; c0 < nk; c0 += 64) {
@@ -819,10 +832,16 @@ mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, 
             if (first) {
                 const u32 o = out + (u32)__popcll(bal & ((1ull << lane) - 1ull));
                 id_hi[k0 + o] = s_hi[j]; id_lo[k0 + o] = s_lo[j];
+                const u32 bit = mh_fp_bit(s_hi[j], s_lo[j]);
+                atomicOr(&s_fp[bit >> 6], 1ull << (bit & 63u));
             }
             out += (u32)__popcll(bal);
         }
-        if (lane == 0) nuniq[i] = out;
+        __syncthreads();
+        if (lane < MH_FPW) fp[(size_t)i * MH_FPW + lane] = s_fp[lane];
+        u32 set = lane < MH_FPW ? (u32)__popcll(s_fp[lane]) : 0u;
+        for (int d = 32; d > 0; d >>= 1) set += __shfl_xor(set, d, WAVE);
+        if (lane == 0) { nuniq[i] = out; fp_excess[i] = out - set; }
     }
 }
 
@@ -882,17 +901,18 @@ mh_table_kernel(const u64 *__restrict__ keys_all, u32 n, u64 *__restrict__ keys,
 // 84 ms per table, 98 % of the filter.)
 __device__ __forceinline__ bool mh_near(const u64 *__restrict__ ah, const u64 *__restrict__ al, u32 na,
                                         const u64 *__restrict__ bh, const u64 *__restrict__ bl, u32 nb,
-                                        double thres) {
+                                        const u32 *__restrict__ need_tab, const unsigned long long *__restrict__ fa,
+                                        const unsigned long long *__restrict__ fb, u32 exa, u32 exb) {
+    // need_tab[|A| + |B|] = the smallest intersection m with 1 - m / (|A| + |B| - m) <= thres (the reference's two IEEE
+    // operations, evaluated on the host; what a binary search over m with a double division per step found here)
     const u32 most = min(na, nb);
-    u32 lo = 0, hi = most + 1;
-    while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        const double sim = __ddiv_rn((double)mid, (double)(na + nb - mid));
-        if (__dsub_rn(1.0, sim) <= thres) hi = mid; else lo = mid + 1;
-    }
-    const u32 need = lo;
+    const u32 need = min(need_tab[na + nb], most + 1u);
     if (need > most) return false;
     if (need == 0) return true;
+    u32 bound = min(exa, exb);
+#pragma unroll 8
+    for (int w = 0; w < MH_FPW; ++w) bound += (u32)__popcll(fa[w] & fb[w]);
+    if (bound < need) return false;
     u32 x = 0, y = 0, inter = 0;
     while (x < na && y < nb) {
         const u64 h1 = ah[x], l1 = al[x], h2 = bh[y], l2 = bl[y];
@@ -909,7 +929,8 @@ __device__ __forceinline__ bool mh_near(const u64 *__restrict__ ah, const u64 *_
 
 __global__ void __launch_bounds__(256)
 mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, const u64 *__restrict__ id_hi,
-               const u64 *__restrict__ id_lo, const u32 *__restrict__ sig, int k, double thres, u32 n,
+               const u64 *__restrict__ id_lo, const u32 *__restrict__ sig, int k, const u32 *__restrict__ need_tab,
+               const unsigned long long *__restrict__ fp, const u32 *__restrict__ fp_excess, u32 n,
                const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ grp,
                u32 *__restrict__ e_i, u32 *__restrict__ e_j, u32 *__restrict__ count, u32 cap,
                const u32 *__restrict__ sig_earlier, int n_earlier) {
@@ -937,7 +958,7 @@ mh_edge_kernel(const u32 *__restrict__ koff, const u32 *__restrict__ nuniq, cons
         if (seen) continue;
         ++npairs;
         if (mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j],
-                            thres)) {
+                    need_tab, fp + (size_t)i * MH_FPW, fp + (size_t)j * MH_FPW, fp_excess[i], fp_excess[j])) {
             const u32 shard = (x >> 6) & (ES_SHARDS - 1);
             const u32 slot = atomicAdd(&count[shard * ES_STRIDE], 1u);
             if (slot < cap) { e_i[(size_t)shard * cap + slot] = i; e_j[(size_t)shard * cap + slot] = j; }
@@ -951,10 +972,11 @@ struct MinHashFamily {       // same signature in table t (the key only groups),
     const u64 *id_hi, *id_lo;
     const u32 *sig_all;      // [table][probe][k]
     int k;
-    double thres;
     u32 n;
     const u32 *grp;
     const u32 *need_tab;     // by |A| + |B|: the smallest intersection for which 1 - m / (|A| + |B| - m) <= thres
+    const unsigned long long *fp;     // MH_FPW words per probe
+    const u32 *fp_excess;
     int wave_near_max;       // lanes wanting a comparison from which every lane runs its own (NDF_WAVE_NEAR_MAX)
     static constexpr bool WAVE_NEAR = true;
     struct Scratch { u64 h[MH_MAXK], l[MH_MAXK]; };
@@ -967,6 +989,11 @@ struct MinHashFamily {       // same signature in table t (the key only groups),
         const u32 need = min(need_tab[na + nb], most + 1u);
         if (need > most) return false;
         if (need == 0) return true;
+        {   // the fingerprint bound, a word per lane
+            u32 b = lane < MH_FPW ? (u32)__popcll(fp[(size_t)i * MH_FPW + lane] & fp[(size_t)j * MH_FPW + lane]) : 0u;
+            for (int d = 32; d > 0; d >>= 1) b += __shfl_xor(b, d, WAVE);
+            if (b + min(fp_excess[i], fp_excess[j]) < need) return false;
+        }
         const u64 *bh = id_hi + koff[j], *bl = id_lo + koff[j];
         for (u32 q = lane; q < nb; q += 64) { S.h[q] = bh[q]; S.l[q] = bl[q]; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1019,7 +1046,8 @@ struct MinHashFamily {       // same signature in table t (the key only groups),
         return false;
     }
     __device__ __forceinline__ bool near(u32, u32 i, u32 j) const {
-        return mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j], thres);
+        return mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j],
+                       need_tab, fp + (size_t)i * MH_FPW, fp + (size_t)j * MH_FPW, fp_excess[i], fp_excess[j]);
     }
 };
 
@@ -1071,6 +1099,29 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
     TRY(xs.alloc(nkm));
     TRY(id_hi.alloc(nkm));
     TRY(id_lo.alloc(nkm));
+    DevBuf<u64> fp;
+    DevBuf<u32> fp_excess, need_tab;
+    TRY(fp.alloc((size_t)nn * MH_FPW));
+    TRY(fp_excess.alloc(nn));
+    TRY(need_tab.alloc(2 * MH_MAXK + 2));
+    {
+        // the intersection the threshold needs, by |A| + |B| (mh_near, MinHashFamily::near_wave): the reference's
+        // expression, evaluated here with the same two IEEE operations
+        std::vector<u32> h_need(2 * MH_MAXK + 2);
+        for (u32 S = 0; S < h_need.size(); ++S) {
+            u32 m_ = 0;
+            for (; m_ <= S / 2; ++m_) {
+                volatile double sim = (double)m_ / (double)(S - m_);
+                volatile double dist = 1.0 - sim;
+                if (dist <= dist_thres) break;
+            }
+            h_need[S] = m_;
+        }
+        TRY(chip_pinned_reserve(ctx, sizeof(u32) * h_need.size()));
+        memcpy(ctx->h_big, h_need.data(), sizeof(u32) * h_need.size());
+        HIP_TRY(hipMemcpyAsync(need_tab.p, ctx->h_big, sizeof(u32) * h_need.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));           // (h_big is reused below)
+    }
     TRY(nuniq.alloc(nn));
     // signatures / keys of a chunk of tables at a time (<= 16 GB of signatures: all tables of any input
     // that fits a probes object, so that a pair is compared in the first table it meets in only)
@@ -1097,7 +1148,7 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
     const unsigned nb = (unsigned)div_up(nn, 256);
     hipLaunchKernelGGL(mh_kmer_kernel, dim3((unsigned)std::min<i64>(n, (i64)1 << 20)), dim3(64), 0, s,
                        (const u8 *)d_bytes.p, (const u32 *)d_off.p, (const u32 *)d_koff.p, nn, (int)kmer_size, xs.p,
-                       id_hi.p, id_lo.p, nuniq.p);
+                       id_hi.p, id_lo.p, nuniq.p, (unsigned long long *)fp.p, fp_excess.p);
     tm.launch(1);
     ctx->ndf_counters[0] = n; ctx->ndf_counters[1] = ntables; ctx->ndf_counters[2] = ctx->ndf_counters[3] = 0;
     if (tchunk >= ntables && (i64)ntables * n <= ((i64)1 << 31) && !chip_test_env("CATCHHIP_MH_ALL_PAIRS") &&
@@ -1137,28 +1188,8 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
             tm.launch(1 + 24 + 2);
         }
         lap("signatures + sorts", t_lap);
-        // the intersection the threshold needs, by |A| + |B| (MinHashFamily::near_wave): the reference's expression,
-        // evaluated here with the same two IEEE operations the device's walk uses
-        DevBuf<u32> need_tab;
-        TRY(need_tab.alloc(2 * MH_MAXK + 2));
-        {
-            std::vector<u32> h_need(2 * MH_MAXK + 2);
-            for (u32 S = 0; S < h_need.size(); ++S) {
-                u32 m_ = 0;
-                for (; m_ <= S / 2; ++m_) {
-                    volatile double sim = (double)m_ / (double)(S - m_);
-                    volatile double dist = 1.0 - sim;
-                    if (dist <= dist_thres) break;
-                }
-                h_need[S] = m_;
-            }
-            TRY(chip_pinned_reserve(ctx, sizeof(u32) * h_need.size()));
-            memcpy(ctx->h_big, h_need.data(), sizeof(u32) * h_need.size());
-            HIP_TRY(hipMemcpyAsync(need_tab.p, ctx->h_big, sizeof(u32) * h_need.size(), hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));           // (h_big is reused by the read-backs below)
-        }
         MinHashFamily fam{(const u32 *)d_koff.p, (const u32 *)nuniq.p, (const u64 *)id_hi.p, (const u64 *)id_lo.p, (const u32 *)sig.p,
-                          (int)k, dist_thres, nn, grp, (const u32 *)need_tab.p,
+                          (int)k, nn, grp, (const u32 *)need_tab.p, (const unsigned long long *)fp.p, (const u32 *)fp_excess.p,
                           chip_test_env("CATCHHIP_NDF_WAVE_NEAR_MAX") ? atoi(chip_test_env("CATCHHIP_NDF_WAVE_NEAR_MAX")) : NDF_WAVE_NEAR_MAX};
         const int rc = ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
                                        [&](bool wake, const u32 *list, u32 nlist, u32 *next, u32 *next_count, u32 *left_tables, const u32 *inv, u32 nslot) {
@@ -1193,7 +1224,8 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
             TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nn, 64));
             hipLaunchKernelGGL(mh_edge_kernel, dim3(nb), dim3(256), 0, s, (const u32 *)d_koff.p, (const u32 *)nuniq.p,
                                (const u64 *)id_hi.p, (const u64 *)id_lo.p,
-                               (const u32 *)(sig.p + (size_t)tc * nn * k), (int)k, dist_thres, nn,
+                               (const u32 *)(sig.p + (size_t)tc * nn * k), (int)k, (const u32 *)need_tab.p,
+                               (const unsigned long long *)fp.p, (const u32 *)fp_excess.p, nn,
                                (const u64 *)keys.p, (const u32 *)vals.p, grp, e_i.p, e_j.p, count.p, cap,
                                (const u32 *)sig.p, chip_test_env("CATCHHIP_MH_NO_DEDUPE") ? 0 : tc);
             tm.launch(2 + 24);
