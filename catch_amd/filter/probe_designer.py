@@ -39,14 +39,18 @@ class ProbeDesigner:
         when asked to, short ones skipped -- in input order, which is the order
         the clustering numbers them in."""
         out = []
+        L, skip = self.cluster_fragment_length, self.seq_length_to_skip
         for grp in self.genomes:
             for g in grp:
-                pieces = (g.seqs if self.cluster_fragment_length is None else
-                          g.break_into_fragments(self.cluster_fragment_length,
-                                                 include_full_end=True).seqs)
-                out += [s for s in pieces
-                        if self.seq_length_to_skip is None
-                        or len(s) > self.seq_length_to_skip]
+                for seq in g.seqs:
+                    n = len(seq)
+                    if L is None or 0 < n <= L:
+                        pieces = (seq,)      # (what Genome.break_into_fragments(L, include_full_end=True) makes of it,
+                    else:                    #  without a Genome and an OrderedDict per input genome: 198,838 of them)
+                        pieces = [seq[i:i + L] if i + L <= n else seq[max(0, n - L):] for i in range(0, n, L)]
+                    for s_ in pieces:
+                        if skip is None or len(s_) > skip:
+                            out.append(s_)
         return out
 
     def _resolve_cluster_method(self):
