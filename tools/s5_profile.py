@@ -1,6 +1,7 @@
 """cProfile of one design_large step on S5 x scale (GPU box): where the host time of the clustering
 and of the union filter goes."""
 import cProfile, io, os, pstats, random, sys, time
+os.environ.setdefault("CATCHHIP_TEST_HOOKS", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from catch_amd import genome
