@@ -2387,3 +2387,35 @@ def test_neighbour_graph_edge_cases(ctx):
             assert len(got) == 1
         if name == "unrelated":
             assert len(got) == len(seqs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("first", ["hamming", "minhash"])
+def test_union_chunks_in_pipeline_stages_select_what_chunks_one_by_one_select(ctx, monkeypatch, first):
+    """The clustered design's union instances (several clusters per chunk, several chunks): the three-stage
+    pipeline -- front end with the near-duplicate filter on one, two or three worker streams (its draws from
+    `random` made for all chunks ahead), the anchors' np.random draws on a thread of their own, scan + solve on the
+    caller's -- returns what the chunks one after the other on one stream return (-m 5: random anchors)."""
+    from catch_amd import genome
+    from catch_amd.filter import near_duplicate_filter, set_cover_filter
+    from catch_amd.utils import synthetic
+    rng = np.random.Generator(np.random.PCG64(4321))
+    clusters = [[genome.Genome.from_one_seq(g[0]) for g in synthetic.make_species(rng, [int(ln)], n, 2, 0.04, 0.01)]
+                for ln, n in ((4000, 5), (2500, 3), (2600, 4), (6000, 3), (2400, 2), (3000, 3), (2800, 5), (2200, 6), (5000, 2))]
+
+    def run(depth, workers):
+        monkeypatch.setenv("CATCHHIP_PREFETCH_DEPTH", str(depth))
+        monkeypatch.setenv("CATCHHIP_FRONT_END_WORKERS", str(workers))
+        random.seed(15)
+        np.random.seed(16)
+        ndf = (near_duplicate_filter.NearDuplicateFilterWithHammingDistance(2, 100) if first == "hamming"
+               else near_duplicate_filter.NearDuplicateFilterWithMinHash(0.5))
+        scf = set_cover_filter.SetCoverFilter(mismatches=5, lcf_thres=100, cover_extension=25, kmer_probe_map_k=20)
+        out = scf._filter_genomes_device_union(clusters, 100, 50, None, ndf, max_bases=40_000)
+        return out, scf.last_timings["picks"]
+
+    base, picks = run(0, 1)
+    assert all(len(g) > 0 for g in base) and picks == sum(len(g) for g in base)
+    for depth, workers in ((1, 1), (2, 1), (2, 2), (2, 3)):
+        got, p2 = run(depth, workers)
+        assert got == base and p2 == picks, (depth, workers)
