@@ -56,8 +56,8 @@ int catchhip_ctx_sync(catchhip_ctx *ctx);
  * counterpart (the reference keeps its working set in Python objects); the bench
  * reports it so that a step that allocates is visible. */
 int catchhip_pool_stats(int64_t *out4);
-/* Returns every idle cached block (of every context of the calling process's current device) to the
- * driver, after a device synchronisation.  For the seams of a long-running process whose next
+/* Returns every idle cached block of every context of the process to the driver, after a synchronisation of
+ * the current device (blocks of other devices: hipFree itself waits for the device that owns the block).  For the seams of a long-running process whose next
  * phase allocates differently (the cache is keyed by context and size class). */
 int catchhip_pool_trim(void);
 /* Elapsed GPU milliseconds spent in the kernels of the most recent call of
