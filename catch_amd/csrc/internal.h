@@ -239,6 +239,10 @@ struct catchhip_rows {
     DevBuf<unsigned long long> first_key;
     DevBuf<u32> genome_off;  // ngenomes+1
     std::vector<i64> h_genome_off;
+    // gain0[s] = total length of set s's rows (the bucketed row build sums a bucket's merged rows on the way):
+    // the first round's gains of a full-coverage solve, which then needs no count launch of its own; gain0_n = 0: not there
+    DevBuf<u32> gain0;
+    u32 gain0_n = 0;
 };
 
 // ---- timing helpers -----------------------------------------------------

@@ -1563,6 +1563,16 @@ struct JoinRun {
 };
 #define KJ_GIANT_CAP (1u << 20)
 
+__global__ void __launch_bounds__(256)
+rows_gain0_kernel(const unsigned long long *__restrict__ bsum, u32 nb, const i32 *__restrict__ bucket_set, u32 ng,
+                  u32 *__restrict__ gain0) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const u32 v = (u32)bsum[b];
+    const u32 s = bucket_set ? (u32)bucket_set[b] : b;
+    if (v && s < ng) atomicAdd(&gain0[s], v);
+}
+
 static bool join_path_ok(const catchhip_probes *P, int mm) {
     if (!P->pigeonhole || P->k <= 0 || P->pwords < 1 || P->pwords > 8) return false;
     const int nanch = (int)(P->L / P->k);
@@ -1843,7 +1853,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
     bool use_join = use_seed && !want_first && join_path_ok(P, mismatches);
     if (use_join) {
         // key-grouped join (scan_join.inc): leaves the records grouped by bucket in O.B.S
-        TRY(bucket_prepare(O.B, nb, 1, by_sequence));
+        TRY(bucket_prepare(O.B, nb, 1, true));
         sink.rec = nullptr; sink.rank = nullptr; sink.bcnt = O.B.bcnt.p; sink.wcnt = nullptr;
         ts.restart();
         const int rc = run_join(ctx, P, T, mismatches, O.S, O.J, sink, O.B, nb, ts);
@@ -1856,7 +1866,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
             tr.restart();
             // (buckets = probes: every bucket is its probe's anchor runs side by side, each in position order)
             const bool runs = sink.bucket_of == nullptr && O.J.A.ntab <= BK_RUNS_MAX && !chip_test_env("CATCHHIP_MERGE_NO_RUNS");
-            TRY(bucket_finish_async(ctx, O.B, 0, nullptr, by_sequence, !force_radix, tr, dedupe, true,
+            TRY(bucket_finish_async(ctx, O.B, 0, nullptr, true, !force_radix, tr, dedupe, true,
                                     runs ? (const u32 *)O.J.ecnt.p : (const u32 *)nullptr, O.J.A.nanch, O.J.A.ntab));
             tr.stop();
             HIP_TRY(hipGetLastError());
@@ -1871,7 +1881,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
         if (const char *e = chip_test_env("CATCHHIP_SEED_CAP")) O.S.scap = (u32)std::max(1, atoi(e));   // tests: force the retry
         for (int attempt = 0;; ++attempt) {
             const auto dbg0 = std::chrono::steady_clock::now();
-            TRY(bucket_prepare(O.B, nb, O.S.scap, by_sequence));
+            TRY(bucket_prepare(O.B, nb, O.S.scap, true));
             sink.rec = O.B.rec.p; sink.rank = O.B.rank.p; sink.bcnt = O.B.bcnt.p;
             // (the first-discovery keys pair record d with seed d: not compact then)
             O.B.compact = !want_first && !chip_test_env("CATCHHIP_HITS_SPARSE");
@@ -1884,7 +1894,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
             ts.stop();
             O.nrec = O.S.scap; O.nrec_dev = O.S.ctr.p + 1;
             tr.restart();
-            TRY(bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, by_sequence, !force_radix, tr, dedupe));
+            TRY(bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, true, !force_radix, tr, dedupe));
             tr.stop();
             HIP_TRY(hipGetLastError());
             u32 *h = (u32 *)ctx->h_pin;
@@ -1912,7 +1922,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
                           : run_general(ctx, P, T, mismatches, lcf_thres, island, H, ts);
         ts.stop();
         if (rc) return rc;
-        TRY(bucket_prepare(O.B, nb, std::max(H.n, 1u), by_sequence));
+        TRY(bucket_prepare(O.B, nb, std::max(H.n, 1u), true));
         sink.rec = O.B.rec.p; sink.rank = O.B.rank.p; sink.bcnt = O.B.bcnt.p;
         HIP_TRY(hipMemsetAsync(O.B.bcnt.p, 0, sizeof(u32) * ((size_t)nb + 1), ctx->stream));
         HIP_TRY(hipMemsetAsync(O.B.res.p, 0, sizeof(u32) * 8, ctx->stream));
@@ -1924,7 +1934,7 @@ static int scan_and_group(catchhip_ctx *ctx, const catchhip_probes *P, const cat
                                (u32)(P->L > 0 ? P->L : 0), H.n, (const u32 *)T->seq_off.p, (u32)T->nseq, sink);
             tr.launch();
         }
-        TRY(bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, by_sequence, !force_radix, tr, dedupe));
+        TRY(bucket_finish_async(ctx, O.B, O.nrec, O.nrec_dev, true, !force_radix, tr, dedupe));
         tr.stop();
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(ctx->h_pin, O.B.res.p, 8 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
@@ -2129,6 +2139,17 @@ static int cover_scan_impl(catchhip_ctx *ctx, const catchhip_probes *P, const ca
                                    P->bucket_identity ? (const i32 *)nullptr : (const i32 *)P->bucket_set.p, (const uint4 *)O.B.S.p, (u32)R->n, (const u32 *)nullptr, R->set_id.p, R->univ.p,
                                    R->gs.p, R->ge.p, (const u32 *)nullptr, O.nhits == O.nrows ? 1 : 0);
                 tm.launch();
+                if (merge && O.B.bsum.p && O.B.bsum.n >= (size_t)O.B.nb && P->max_set_id < ((i64)1 << 31)) {
+                    // the sets' total row lengths: what the first round of a full-coverage solve would count
+                    const u32 ng = (u32)std::max<i64>(P->max_set_id + 1, (i64)(P->bucket_identity ? O.B.nb : 0));
+                    if ((rc = R->gain0.alloc(ng))) break;
+                    if (hipMemsetAsync(R->gain0.p, 0, sizeof(u32) * (size_t)ng, ctx->stream) != hipSuccess) { rc = CATCHHIP_EHIP; break; }
+                    hipLaunchKernelGGL(rows_gain0_kernel, dim3((unsigned)div_up((i64)O.B.nb, 256)), dim3(256), 0, ctx->stream,
+                                       (const unsigned long long *)O.B.bsum.p, O.B.nb,
+                                       P->bucket_identity ? (const i32 *)nullptr : (const i32 *)P->bucket_set.p, ng, R->gain0.p);
+                    R->gain0_n = ng;
+                    tm.launch();
+                }
             }
         } else {
             MergedRows M;

@@ -46,7 +46,7 @@ def rand_group(rnd):
 
 
 SOLVER_ENV = ("CATCHHIP_FLAT_MIN_ROWS", "CATCHHIP_FLAT_STRIPED", "CATCHHIP_GF_LONG", "CATCHHIP_SEED_LIST",
-              "CATCHHIP_SHARD_FLAT")
+              "CATCHHIP_SHARD_FLAT", "CATCHHIP_FLAT_COUNT_ROUND0")
 
 
 def one_case(seed, ctx):
@@ -54,12 +54,14 @@ def one_case(seed, ctx):
     # which of the equivalent kernel families run (all must give the oracle's result)
     for name in SOLVER_ENV:
         os.environ.pop(name, None)
-    variant = random.Random(seed * 7919 + 13).choice(["default", "flat", "flat_striped", "long", "seed_list"])
+    variant = random.Random(seed * 7919 + 13).choice(["default", "flat", "flat_striped", "flat_count0", "long", "seed_list"])
     os.environ["CATCHHIP_SHARD_FLAT"] = "1" if seed % 2 else "0"
     if variant.startswith("flat"):
         os.environ["CATCHHIP_FLAT_MIN_ROWS"] = "0"
         if variant == "flat_striped":
             os.environ["CATCHHIP_FLAT_STRIPED"] = "1"
+        if variant == "flat_count0":      # round 0's gains counted by a launch instead of taken from the row build
+            os.environ["CATCHHIP_FLAT_COUNT_ROUND0"] = "1"
     elif variant == "long":
         os.environ["CATCHHIP_GF_LONG"] = "1"
     elif variant == "seed_list":
