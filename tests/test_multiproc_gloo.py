@@ -12,6 +12,7 @@ The result must equal the oracle's sequential greedy, on every rank.
 """
 import os
 import socket
+import time
 import sys
 
 import numpy as np
@@ -272,3 +273,115 @@ def test_plan_helpers_single_process():
     assert sharded == [] and whole == [[0], [1, 2]]
     assert parallel.merge_picks([7, 3, 9], [50, 90, 70]) == [3, 9, 7]
     assert parallel.merge_picks([7, 3, 9], [50, 90, 70], {7: 0, 3: 1, 9: 0}) == [9, 7, 3]
+
+
+def test_tcp_group_rejects_strangers_and_bad_ranks(tmp_path):
+    """nothing is unpickled before authentication, garbage and oversized length fields
+    do not end the rendezvous, ranks outside [1, size) and duplicates are refused, a wrong secret is refused --
+    and the real ranks still get through afterwards and their frames are MAC-checked."""
+    import pickle
+    import socket
+    import struct
+    import threading
+
+    from catch_amd import netstore
+
+    port = _free_port()
+    out = {}
+
+    def root():
+        try:
+            g = netstore.TcpGroup(0, 3, "127.0.0.1", port, secret="s3cret", timeout=60)
+            out["gather"] = g.allgather("r0")
+            out["sum"] = g.allreduce(np.arange(4, dtype=np.int64))
+            g.close()
+        except Exception as exc:                      # pragma: no cover
+            out["root_error"] = repr(exc)
+
+    t = threading.Thread(target=root)
+    t.start()
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __reduce__(self):
+            return (open, (str(marker), "w"))
+
+    def stranger(payload, read_first=True):
+        for _ in range(100):
+            try:
+                c = socket.create_connection(("127.0.0.1", port), timeout=2.0)
+                break
+            except OSError:
+                time.sleep(0.05)
+        c.settimeout(5.0)
+        try:
+            if read_first:
+                c.recv(64)
+            c.sendall(payload)
+            try:
+                c.recv(64)
+            except OSError:
+                pass
+        finally:
+            c.close()
+
+    evil = pickle.dumps(("catchhip-store-1", "", Evil()))
+    stranger(b"GET / HTTP/1.1\r\nHost: x\r\n\r\n")
+    stranger(struct.pack("<Q", len(evil)) + evil)                  # round 4's frame format: must not be unpickled
+    stranger(struct.pack("<Q", 1 << 62) + b"x" * 64)               # a huge length field must not allocate
+    stranger(netstore._MAGIC + struct.pack("<I", 1) + b"n" * 16 + b"m" * 32)    # right shape, wrong MAC
+    # right secret, invalid ranks: rank 0 and a rank beyond the job
+    for bad_rank in (0, 3, 7):
+        with pytest.raises((TimeoutError, ConnectionError, OSError)):
+            g = netstore.TcpGroup.__new__(netstore.TcpGroup)
+            g.rank, g.size, g._peers, g._root, g._listen = bad_rank, 3, {}, None, None
+            g._io_timeout = 5.0
+            import hashlib
+            key = hashlib.sha256(b"catchhip-store-key|" + b"s3cret" + b"|" + struct.pack("<I", 3)).digest()
+            g._connect("127.0.0.1", [port], key, time.time() + 0.5)
+    with pytest.raises(TimeoutError):                              # wrong secret
+        netstore.TcpGroup(1, 3, "127.0.0.1", port, secret="other", timeout=0.5)
+    assert not marker.exists()
+
+    res = {}
+
+    def member(r):
+        g = netstore.TcpGroup(r, 3, "127.0.0.1", port, secret="s3cret", timeout=60)
+        res[r] = (g.allgather("r%d" % r), g.allreduce(np.arange(4, dtype=np.int64) * (r + 1)))
+        if r == 1:                                                  # a duplicate of a connected rank is refused
+            with pytest.raises(TimeoutError):
+                netstore.TcpGroup(1, 3, "127.0.0.1", port, secret="s3cret", timeout=0.5)
+        g.close()
+
+    # rank 1 first, alone, so that its duplicate attempt happens while rank 0 still accepts
+    m1 = threading.Thread(target=member, args=(1,))
+    m1.start()
+    time.sleep(1.5)
+    m2 = threading.Thread(target=member, args=(2,))
+    m2.start()
+    for th in (m1, m2, t):
+        th.join(timeout=60)
+    assert "root_error" not in out, out
+    assert out["gather"] == ["r0", "r1", "r2"]
+    assert out["sum"].tolist() == (np.arange(4) * 6).tolist()
+    assert res[1][0] == res[2][0] == out["gather"] and res[1][1].tolist() == out["sum"].tolist()
+
+
+def test_tcp_group_frames_are_authenticated():
+    """A frame whose MAC does not hold (tampered, replayed or out of order) raises instead of being unpickled."""
+    import socket
+
+    from catch_amd import netstore
+
+    a, b = socket.socketpair()
+    key = b"k" * 32
+    tx, rx = netstore._Channel(a, key, True), netstore._Channel(b, key, False)
+    tx.send({"x": 1})
+    assert rx.recv() == {"x": 1}
+    tx.send("again")
+    tx._tx -= 1                                      # replay the same sequence number
+    assert rx.recv() == "again"
+    tx.send("replayed")
+    with pytest.raises(netstore.StoreAuthError):
+        rx.recv()
+    a.close(); b.close()
