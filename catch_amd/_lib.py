@@ -108,6 +108,7 @@ PROTOTYPES = {
     "catchhip_shard_destroy": (ctypes.c_int, [c_vp]),
     "catchhip_shard_count": (ctypes.c_int, [c_vp]),
     "catchhip_shard_create_p": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_i64p, ctypes.POINTER(ctypes.c_double), c_vpp]),
+    "catchhip_shard_create_pi": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_i64p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, c_vpp]),
     "catchhip_shard_verdict": (ctypes.c_int, [c_vp]),
     "catchhip_shard_claim_check": (ctypes.c_int, [c_vp]),
     "catchhip_shard_apply": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int32)]),

@@ -29,10 +29,15 @@ __device__ __forceinline__ void cc_row_words(u32 gs, u32 ge, u32 *w0, u32 *w1, u
 // universe bitmap (every row) + flag of the rows of picked sets
 __global__ void __launch_bounds__(256)
 cc_mark_kernel(const i32 *__restrict__ set_id, const u32 *__restrict__ gs, const u32 *__restrict__ ge, u32 nrows,
-               const u32 *__restrict__ prank, unsigned long long *__restrict__ U, u32 *__restrict__ flag) {
+               const u32 *__restrict__ prank, u32 nsets, unsigned long long *__restrict__ U, u32 *__restrict__ flag,
+               u32 *__restrict__ bad) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrows) return;
-    flag[r] = prank[set_id[r]] != CC_NONE ? 1u : 0u;
+    const i32 sid = set_id[r];
+    // (prank has nsets + 1 entries: a caller whose num_sets is smaller than the rows' largest set id gets
+    // bad_pick_ids, not a read out of bounds -- ADVICE round 4)
+    if (sid < 0 || (u32)sid >= nsets) { atomicAdd(&bad[2], 1u); flag[r] = 0u; }
+    else flag[r] = prank[sid] != CC_NONE ? 1u : 0u;
     if (ge[r] <= gs[r]) return;
     u32 w0, w1; unsigned long long m0, m1;
     cc_row_words(gs[r], ge[r], &w0, &w1, &m0, &m1);
@@ -57,9 +62,12 @@ cc_keys_kernel(const i32 *__restrict__ set_id, const i32 *__restrict__ univ, u32
 __global__ void __launch_bounds__(64)
 cc_replay_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u32 n, const u32 *__restrict__ gs,
                  const u32 *__restrict__ ge, u32 nuniv, unsigned long long *__restrict__ C, u32 *__restrict__ gained,
-                 unsigned long long *__restrict__ cov) {
+                 unsigned long long *__restrict__ cov, const unsigned long long *__restrict__ need) {
     const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nuniv) return;
+    // the greedy's gain of a set in universe u is min(left[u], fresh positions) (set_cover.py:531-550): once the
+    // universe has met its requirement a pick gains nothing there, whatever it still covers
+    const unsigned long long need_u = need[u];
     u32 lo = 0, hi = n;                         // first key of universe u
     while (lo < hi) { const u32 mid = (lo + hi) >> 1; if ((u32)(keys[mid] >> 32) < u) lo = mid + 1; else hi = mid; }
     unsigned long long total = 0;
@@ -77,16 +85,16 @@ cc_replay_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u32
             const unsigned long long add = m & ~C[w];
             if (add) { fresh += (u32)__popcll(add); atomicOr(&C[w], add); }
         }
-        if (fresh) { gained[(u32)keys[i]] = 1u; total += fresh; }
+        if (fresh) { if (total < need_u) gained[(u32)keys[i]] = 1u; total += fresh; }
     }
     cov[u] = total;
 }
 
-// |U_u| against what was covered; int(n - p n) with IEEE doubles, no fused multiply-add (set_cover.py:362-373)
+// |U_u| and the requirement of a universe; int(n - p n) with IEEE doubles, no fused multiply-add (set_cover.py:362-373)
 __global__ void __launch_bounds__(64)
-cc_universe_kernel(const unsigned long long *__restrict__ U, const u32 *__restrict__ genome_off, u32 nuniv,
-                   const double *__restrict__ p, const unsigned long long *__restrict__ cov, u32 *__restrict__ bad,
-                   unsigned long long *__restrict__ sums) {
+cc_need_kernel(const unsigned long long *__restrict__ U, const u32 *__restrict__ genome_off, u32 nuniv,
+               const double *__restrict__ p, unsigned long long *__restrict__ usize_out,
+               unsigned long long *__restrict__ need_out) {
     const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nuniv) return;
     const u32 g0 = genome_off[u], g1 = genome_off[u + 1];
@@ -104,9 +112,17 @@ cc_universe_kernel(const unsigned long long *__restrict__ U, const u32 *__restri
     long long can = (long long)__dsub_rn(n, __dmul_rn(pu, n));
     if (can < 0) can = 0;
     if (can > (long long)usize) can = (long long)usize;
-    const unsigned long long need = usize - (unsigned long long)can;
-    if (cov[u] < need) atomicAdd(&bad[1], 1u);
-    atomicAdd(&sums[0], usize);
+    usize_out[u] = usize;
+    need_out[u] = usize - (unsigned long long)can;
+}
+
+__global__ void __launch_bounds__(64)
+cc_universe_kernel(const unsigned long long *__restrict__ usize, const unsigned long long *__restrict__ need, u32 nuniv,
+                   const unsigned long long *__restrict__ cov, u32 *__restrict__ bad, unsigned long long *__restrict__ sums) {
+    const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nuniv) return;
+    if (cov[u] < need[u]) atomicAdd(&bad[1], 1u);
+    atomicAdd(&sums[0], usize[u]);
     atomicAdd(&sums[1], cov[u]);
 }
 
@@ -130,7 +146,7 @@ extern "C" int catchhip_rows_cover_check(catchhip_ctx *ctx, const catchhip_rows 
     for (int i = 0; i < 5; ++i) out5[i] = 0;
     DevBuf<u32> prank, flag, pos, tmp, gained, bad, vals, vals_alt;
     DevBuf<u64> keys, keys_alt;
-    DevBuf<unsigned long long> U, C, cov, sums;
+    DevBuf<unsigned long long> U, C, cov, sums, usize, need;
     DevBuf<i64> d_picks;
     DevBuf<double> d_p;
     TRY(prank.alloc((size_t)nsets + 1));
@@ -142,6 +158,8 @@ extern "C" int catchhip_rows_cover_check(catchhip_ctx *ctx, const catchhip_rows 
     TRY(C.alloc(nwords));
     TRY(cov.alloc((size_t)nuniv + 1));
     TRY(sums.alloc(2));
+    TRY(usize.alloc((size_t)nuniv + 1));
+    TRY(need.alloc((size_t)nuniv + 1));
     TRY(d_picks.alloc((size_t)np + 1));
     HIP_TRY(hipMemsetAsync(prank.p, 0xff, sizeof(u32) * ((size_t)nsets + 1), s));
     HIP_TRY(hipMemsetAsync(gained.p, 0, sizeof(u32) * ((size_t)np + 1), s));
@@ -160,7 +178,7 @@ extern "C" int catchhip_rows_cover_check(catchhip_ctx *ctx, const catchhip_rows 
     u32 nkeys = 0;
     if (nrows) {
         hipLaunchKernelGGL(cc_mark_kernel, dim3((unsigned)div_up(nrows, 256)), dim3(256), 0, s, (const i32 *)R->set_id.p,
-                           (const u32 *)R->gs.p, (const u32 *)R->ge.p, nrows, (const u32 *)prank.p, U.p, flag.p);
+                           (const u32 *)R->gs.p, (const u32 *)R->ge.p, nrows, (const u32 *)prank.p, nsets, U.p, flag.p, bad.p);
         HIP_TRY(hipMemsetAsync(flag.p + nrows, 0, sizeof(u32), s));
         TRY(chip_exclusive_scan_u32(ctx, flag.p, pos.p, (i64)nrows + 1, tmp));
         HIP_TRY(hipMemcpyAsync(ctx->h_pin, pos.p + nrows, sizeof(u32), hipMemcpyDeviceToHost, s));
@@ -176,12 +194,15 @@ extern "C" int catchhip_rows_cover_check(catchhip_ctx *ctx, const catchhip_rows 
         TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, (i64)nkeys, 32 + ceil_log2_u64((u64)nuniv + 1)));
     }
     if (nuniv) {
-        hipLaunchKernelGGL(cc_replay_kernel, dim3((unsigned)div_up(nuniv, 64)), dim3(64), 0, s, (const u64 *)keys.p,
-                           (const u32 *)vals.p, nkeys, (const u32 *)R->gs.p, (const u32 *)R->ge.p, nuniv, C.p, gained.p, cov.p);
-        hipLaunchKernelGGL(cc_universe_kernel, dim3((unsigned)div_up(nuniv, 64)), dim3(64), 0, s,
+        hipLaunchKernelGGL(cc_need_kernel, dim3((unsigned)div_up(nuniv, 64)), dim3(64), 0, s,
                            (const unsigned long long *)U.p, (const u32 *)R->genome_off.p, nuniv,
-                           universe_p ? (const double *)d_p.p : (const double *)nullptr, (const unsigned long long *)cov.p,
-                           bad.p, sums.p);
+                           universe_p ? (const double *)d_p.p : (const double *)nullptr, usize.p, need.p);
+        hipLaunchKernelGGL(cc_replay_kernel, dim3((unsigned)div_up(nuniv, 64)), dim3(64), 0, s, (const u64 *)keys.p,
+                           (const u32 *)vals.p, nkeys, (const u32 *)R->gs.p, (const u32 *)R->ge.p, nuniv, C.p, gained.p, cov.p,
+                           (const unsigned long long *)need.p);
+        hipLaunchKernelGGL(cc_universe_kernel, dim3((unsigned)div_up(nuniv, 64)), dim3(64), 0, s,
+                           (const unsigned long long *)usize.p, (const unsigned long long *)need.p, nuniv,
+                           (const unsigned long long *)cov.p, bad.p, sums.p);
     }
     if (np) hipLaunchKernelGGL(cc_picks_kernel, dim3((unsigned)div_up(np, 256)), dim3(256), 0, s, (const u32 *)gained.p, np, bad.p);
     HIP_TRY(hipGetLastError());

@@ -622,11 +622,14 @@ class Shard:
     (catchhip_shard): the frontier solver's state over this rank's cover
     rows.  Driven round by round by catch_amd.parallel.sharded_solve."""
 
-    def __init__(self, rows, num_sets, ranks=None, universe_p=None):
+    def __init__(self, rows, num_sets, ranks=None, universe_p=None, instance_partial=None):
         """universe_p: the fraction to cover of every universe of THIS shard
         (its own genomes, in order), or None = all of each.  With some below 1
         the rounds have a third step (verdict + a second exchange of the lost
-        marks; catchhip_shard_create_p)."""
+        marks; catchhip_shard_create_pi).  instance_partial: whether any
+        universe of the WHOLE instance, on whatever rank, is partial -- the
+        same value on every rank, so that all of them build the same kind of
+        shard (None: decided from this shard's universe_p alone)."""
         self.ctx = rows.ctx
         self.rows = rows                     # keeps the rows alive
         self.num_sets = int(num_sets)
@@ -638,14 +641,17 @@ class Shard:
             if up.size == 0:
                 up = None
         self.partial = bool(up is not None and (up < 1.0).any())
-        # whether ANY shard of the instance is partial decides the shape of a round (parallel.sharded_solve): the
-        # caller that knows the whole instance's fractions sets it on every shard
+        if instance_partial is not None:
+            self.partial = bool(instance_partial)
+        # whether ANY shard of the instance is partial decides the shape of a round (parallel.sharded_solve) and the
+        # kernels of every shard
         self.partial_instance = self.partial
         self._h = ctypes.c_void_p()
-        check(self.ctx._L.catchhip_shard_create_p(
+        check(self.ctx._L.catchhip_shard_create_pi(
             self.ctx._h, rows._h, self.num_sets,
             None if rk is None else _ptr(rk, c_i64p),
-            None if up is None else up.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.byref(self._h)))
+            None if up is None else up.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+            -1 if instance_partial is None else int(bool(instance_partial)), ctypes.byref(self._h)))
 
     def count(self):
         check(self.ctx._L.catchhip_shard_count(self._h))

@@ -412,9 +412,12 @@ class SetCoverFilter(BaseFilter):
                     try:
                         up_all = self._make_universe_p(genomes)
                         part = any(p_ < 1.0 for p_ in up_all)     # (the same on every rank)
+                        # partial-ness is a property of the INSTANCE: a rank whose own genomes all have p == 1
+                        # (coverage in bases, genomes shorter than it) still builds a partial shard -- the same
+                        # kernels, round shape and refusals on every rank
                         shard = engine.Shard(rows, len(strs), ranks,
-                                             up_all[b[W.rank]:b[W.rank + 1]] if part else None)
-                        shard.partial_instance = part
+                                             up_all[b[W.rank]:b[W.rank + 1]] if part else None,
+                                             instance_partial=part)
                         qualifies = True
                     except ValueError as exc:
                         # the expected refusals: rows too long for the sharded kernels, partial coverage with too few

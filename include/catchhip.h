@@ -322,6 +322,16 @@ int catchhip_shard_create(catchhip_ctx *ctx, const catchhip_rows *rows,
 int catchhip_shard_create_p(catchhip_ctx *ctx, const catchhip_rows *rows,
                             int64_t num_sets, const int64_t *ranks,
                             const double *universe_p, catchhip_shard **out);
+/* instance_partial: 1 / 0 = whether any universe of the WHOLE instance (on any
+ * rank) has a fraction below 1 -- the caller passes the same value on every
+ * rank so that all of them run the same kernels and refuse the same instances
+ * even when a rank's own universes all have fraction 1 (coverage given in
+ * bases: catch/filter/set_cover_filter.py:761-792); -1 = decide from this
+ * shard's universe_p (what catchhip_shard_create_p does). */
+int catchhip_shard_create_pi(catchhip_ctx *ctx, const catchhip_rows *rows,
+                             int64_t num_sets, const int64_t *ranks,
+                             const double *universe_p, int instance_partial,
+                             catchhip_shard **out);
 int catchhip_shard_verdict(catchhip_shard *shard);
 int catchhip_shard_destroy(catchhip_shard *shard);
 int catchhip_shard_count(catchhip_shard *shard);

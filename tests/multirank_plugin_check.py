@@ -59,6 +59,20 @@ def main():
         out = f.filter([[probe.Probe.from_str(s) for s in c] for c in cands], gen, input_is_grouped=True)
         got = [sorted(p.seq_str for p in g) for g in out]
         ok = ok and got == want and f.last_timings.get("sharded_groups") == [1]
+    # coverage given in BASES: the sharded group's first nine genomes are shorter than the
+    # coverage asked for (p == 1.0), the last five longer (p < 1): with two ranks the first rank's own universes are
+    # all full-coverage ones -- it must still build a partial shard and run the partial rounds (the instance is)
+    groups_b = [g for g in groups]
+    groups_b[1] = [[g[0][:4000]] for g in groups[1][:9]] + [list(g) for g in groups[1][9:]]
+    cands_b = [candidates(g, 100, 50) for g in groups_b]
+    gen_b = [[genome.Genome.from_one_seq(g[0]) for g in grp] for grp in groups_b]
+    exp = orc.set_cover_filter(cands_b, groups_b, 2, 100, coverage=4500, cover_extension=50)
+    want = [sorted(c[i] for i in ids) for c, ids in zip(cands_b, exp)]
+    os.environ["CATCHHIP_SHARD_FLAT"] = "1"
+    f = SetCoverFilter(mismatches=2, lcf_thres=100, coverage=4500, cover_extension=50)
+    out = f.filter([[probe.Probe.from_str(s) for s in c] for c in cands_b], gen_b, input_is_grouped=True)
+    got = [sorted(p.seq_str for p in g) for g in out]
+    ok = ok and got == want and f.last_timings.get("sharded_groups") == [1]
     os.environ.pop("CATCHHIP_SHARD_FLAT", None)
     res = W.allgather(ok)
     if W.rank == 0:

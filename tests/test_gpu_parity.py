@@ -731,8 +731,11 @@ def _sharded_picks(engine, ctx, probes, genomes, bounds, n_sets, ranks, exchange
             rows = engine.Rows.scan(ctx, probes, t, 2, 100, 0, 50)
             held.append(rows)
             up = None if universe_p is None else universe_p[bounds[v]:bounds[v + 1]]
-            shards.append(engine.Shard(rows, n_sets, ranks, up))
-            shards[-1].partial_instance = universe_p is not None and any(p < 1.0 for p in universe_p)
+            # partial-ness is the INSTANCE's: a shard whose own universes all want full cover is
+            # still built as a partial shard -- the same kernels and round shape on every rank
+            part = universe_p is not None and any(p < 1.0 for p in universe_p)
+            shards.append(engine.Shard(rows, n_sets, ranks, up if part else None, instance_partial=part))
+            assert shards[-1].partial_instance == part
         return parallel.sharded_solve(shards, exchange_of(shards))
     finally:
         for h in shards + held[::-1]:
