@@ -177,12 +177,16 @@ ndf_node_round_kernel(u32 *__restrict__ status, u32 *__restrict__ flags, u32 n, 
 #define NDF_CUR_NONE 0xffffffffu
 #define NDF_OWN_STEPS 8
 #define NDF_WAVE_NEAR_MAX 24
+#define NDF_DRAIN_BLOCKS 1280u     // the drain launch: 256 CUs x 5 workgroups of 4 wavefronts (32 KB of LDS each)
 
 struct HammingFamily {       // ndf_near on the padded rows; the earlier tables' sampled positions lie k entries apart
     static constexpr bool WAVE_NEAR = false;     // (a comparison is a few XORs and popcounts: nothing to share)
     static constexpr int wave_near_max = 0;
+    static constexpr bool WAVE64 = false;
     struct Scratch { u32 unused; };
     __device__ __forceinline__ bool near_wave(u32, u32, Scratch &, u32) const { return false; }
+    __device__ __forceinline__ bool wave64_stage(u32, Scratch &, u32) const { return false; }
+    __device__ __forceinline__ int wave64_first_near(u32, unsigned long long, u32, Scratch &, u32, u32 &) const { return -1; }
     const u64 *padded;
     int W, d, k;
     const i32 *pos_all;
@@ -221,30 +225,82 @@ struct HammingFamily {       // ndf_near on the padded rows; the earlier tables'
 // point from a probe to a higher-priority one, so there are no cycles and the highest-priority undecided probe
 // never waits: the same fixed point.  (Built once before the comparisons were shared by the wavefront: a fifth of
 // the entry visits and the same time, because the rounds were ALU-bound then.)
-template <class Family, bool WAKE>
+// Deferred walks (round 5).  A wavefront of 64 entries used to finish its long walks one after the other: with a few
+// hundred probes listed, 64 walks of tens of microseconds each sat in ONE wavefront while the device idled (a pass over
+// 666 probes: 3 ms), and in the large passes the slowest wavefront set the time.  Now a pass has two launches: the
+// first gives every entry its NDF_OWN_STEPS own steps and files the walks that are not over in a queue (dq; the cursor
+// is saved); the second (drain) is a fixed grid of wavefronts that take the queued walks one by one through a ticket
+// share -- one walk per wavefront at a time, 64 mates per step.  Any order of the walks gives the same fixed point
+// (decisions rest on final states only).  The queue has ES_SHARDS shards (a counter on ONE address takes ~10 ns per
+// atomic: 100 k walks filed or handed out through one counter were 1-2 ms of every pass); the wavefronts of the first
+// launch file round-robin, shard s is drained by the wavefronts with (id & 63) == s, strided.
+struct NdfQueue {
+    u32 *dq; u32 *dq_count; u32 segcap;      // shard s: dq[s * segcap ..), its length dq_count[s * ES_STRIDE]
+    // Live tables (round 5, <= 64 tables): bit t of live[i] = table t has not run out for probe i.  A woken probe is
+    // listed once per LIVE table (ndf_wake_kernel: list[t * n ..) holds table t's probes, toff[t] = entries before
+    // table t) -- the pass used to start 25 threads per woken probe of which four in five found an exhausted cursor
+    // after three dependent scattered loads (0.25 ns each: 110 of the 250 ms of a chunk's rounds).
+    unsigned long long *live;
+    u32 toff[65];
+};
+
+template <class Family, bool WAKE, bool DRAIN = false>
 __global__ void __launch_bounds__(256)
 ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *__restrict__ vals_all,
                 u32 *__restrict__ cursor_all, u32 *status, u32 *flags, unsigned long long *__restrict__ pairs,
                 const u32 *__restrict__ list, u32 nlist, u32 *__restrict__ next, u32 *__restrict__ next_count,
-                u32 *__restrict__ left, const u32 *__restrict__ inv, u32 ntables, u32 nslot) {
+                u32 *__restrict__ left, const u32 *__restrict__ inv, u32 ntables, u32 nslot, bool wave64, NdfQueue Q) {
     // nslot = slots per table: n at first, fewer once the dropped probes' slots have been compacted away (WAKE)
-    const u32 g = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const volatile u32 *st = status;
-    bool again = false, walking = false, near_known = false;
+    __shared__ typename Family::Scratch s_scratch[4];
+    typename Family::Scratch &scratch = s_scratch[threadIdx.x >> 6];
+    constexpr bool drain = WAKE && DRAIN;
+    for (u32 iter = 0;; ++iter) {
+    bool again = false, walking = false, near_known = false, valid = false, deferred = false;
     u32 e = 0, t = 0, x = 0, i = 0, y = 0, compared = 0, found = 0;
     u32 verdict = 0;                                 // 1 run exhausted, 2 dropped, 3 waits at y
-    if (g < ((WAKE && list) ? nlist * ntables : nlist)) {
-        if (WAKE && list) {
-            t = g / nlist;
-            i = list[g - t * nlist];
-            x = inv[(size_t)t * n + i];
-            e = t * nslot + x;
-        } else {
-            e = list ? list[g] : g;
+    if (drain) {
+        const u32 shard = wave_id & (ES_SHARDS - 1u);
+        const u32 w = (wave_id >> 6) + iter * ((gridDim.x * blockDim.x) >> 12);     // (grid wavefronts / ES_SHARDS per stride)
+        if (w >= Q.dq_count[shard * ES_STRIDE]) break;
+        if (lane == 0) {
+            valid = true;
+            e = Q.dq[(size_t)shard * Q.segcap + w];
             t = e / nslot;
             x = e - t * nslot;
-            i = vals_all[(size_t)t * nslot + x];
+            i = vals_all[e];
         }
+    } else {
+        if (iter) break;
+        const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+        if (g < ((WAKE && list && !Q.live) ? nlist * ntables : nlist)) {
+            valid = true;
+            if (WAKE && list && Q.live) {            // per-table lists of the live entries
+                u32 lo = 0, hi = ntables;            // the last table with toff[t] <= g
+                while (hi - lo > 1u) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (Q.toff[mid] <= g) lo = mid; else hi = mid;
+                }
+                t = lo;
+                i = list[(size_t)t * n + (g - Q.toff[t])];
+                x = inv[(size_t)t * n + i];
+                e = t * nslot + x;
+            } else if (WAKE && list) {
+                t = g / nlist;
+                i = list[g - t * nlist];
+                x = inv[(size_t)t * n + i];
+                e = t * nslot + x;
+            } else {
+                e = list ? list[g] : g;
+                t = e / nslot;
+                x = e - t * nslot;
+                i = vals_all[(size_t)t * nslot + x];
+            }
+        }
+    }
+    if (valid) {
         const u64 *keys = keys_all + (size_t)t * nslot;
         const u32 cur = cursor_all[e];
         if (st[i] == 0 && cur != x) {
@@ -268,8 +324,6 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
         }
     }
     const u32 *vals = vals_all + (size_t)t * nslot;
-    __shared__ typename Family::Scratch s_scratch[4];
-    typename Family::Scratch &scratch = s_scratch[threadIdx.x >> 6];
     // The comparisons the lanes of this wavefront want right now (lane: its probe pi against mate pj).  A comparison of
     // two k-mer sets is a merge walk of ~100 dependent steps, ~2,500 instructions -- and the whole wavefront executes
     // them while typically a handful of its lanes compare (PMC, round 4: 9,500 VALU instructions per wavefront;
@@ -310,14 +364,30 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
             else { ++y; near_known = false; }
         }
     };
-    for (int step = 0; step < NDF_OWN_STEPS; ++step) {
-        bool act = walking && !verdict;
-        if (act && y >= x) { verdict = 1; act = false; }
-        if (!__ballot(act)) break;
-        examine(act);
+    if (!drain)
+        for (int step = 0; step < NDF_OWN_STEPS; ++step) {
+            bool act = walking && !verdict;
+            if (act && y >= x) { verdict = 1; act = false; }
+            if (!__ballot(act)) break;
+            examine(act);
+        }
+    if (WAKE && Q.dq && !drain) {                    // the walks that are not over: into the queue
+        if (walking && !verdict && y >= x) verdict = 1;
+        deferred = walking && !verdict;
+        const unsigned long long db = __ballot(deferred);
+        if (db) {
+            const u32 shard = wave_id & (ES_SHARDS - 1u);
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&Q.dq_count[shard * ES_STRIDE], (u32)__popcll(db));
+            base = __shfl(base, 0, WAVE);
+            if (deferred) {
+                Q.dq[(size_t)shard * Q.segcap + base + (u32)__popcll(db & ((1ull << lane) - 1ull))] = e;
+                cursor_all[e] = y | (near_known ? NDF_CUR_NEAR : 0u);
+            }
+        }
     }
     for (;;) {                                       // the walks that are not over yet, one at a time, by the whole wavefront
-        const unsigned long long todo = __ballot(walking && !verdict);
+        const unsigned long long todo = __ballot(walking && !verdict && !deferred);
         if (!todo) break;
         const int leader = __ffsll((long long)todo) - 1;
         if (__shfl((int)(y >= x), leader, WAVE)) {    // (the solo steps ended right at the end of its run)
@@ -328,11 +398,14 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
             examine((int)lane == leader);
             continue;
         }
-        const u32 ly = __shfl(y, leader, WAVE), lx = __shfl(x, leader, WAVE), lt = __shfl(t, leader, WAVE),
-                  li = __shfl(i, leader, WAVE);
+        const u32 ly = __shfl(y, leader, WAVE), lx = __shfl(x, leader, WAVE),
+                  lt = (u32)__builtin_amdgcn_readfirstlane(__shfl((int)t, leader, WAVE)),
+                  li = (u32)__builtin_amdgcn_readfirstlane(__shfl((int)i, leader, WAVE));
         const u32 *lvals = vals_all + (size_t)lt * nslot;
         u32 ny = ly, hit_state = 0, ncmp = 0, nfound = 0;
-        for (;;) {                                   // 64 mates per step, each lane compares one
+        // (MinHash: the walking probe's k-mers staged in LDS once, every comparison then by the whole wavefront)
+        const bool staged = Family::WAVE64 && wave64 && fam.wave64_stage(li, scratch, lane);
+        for (;;) {                                   // 64 mates per step, each lane looks at one
             const u32 yy = ny + lane;
             bool want = false;
             u32 sj = 2, j = 0;
@@ -341,11 +414,17 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
                 sj = st[j];
                 want = sj != 2 && fam.same_bucket(lt, li, j) && !fam.owned_earlier(lt, li, j);
             }
-            const bool is_near = compare(want, lt, li, j);
-            if (want) { ++ncmp; nfound += is_near ? 1u : 0u; }
-            const unsigned long long m = __ballot(is_near);
-            if (m) {
-                const int first = __ffsll((long long)m) - 1;
+            int first = -1;
+            if (staged) {
+                first = fam.wave64_first_near(li, __ballot(want), j, scratch, lane, ncmp);
+                nfound += (first >= 0 && lane == 0) ? 1u : 0u;
+            } else {
+                const bool is_near = compare(want, lt, li, j);
+                if (want) { ++ncmp; nfound += is_near ? 1u : 0u; }
+                const unsigned long long m = __ballot(is_near);
+                if (m) first = __ffsll((long long)m) - 1;
+            }
+            if (first >= 0) {
                 ny += (u32)first;
                 hit_state = __shfl(sj, first, WAVE);
                 break;
@@ -360,7 +439,7 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
             verdict = y >= x ? 1u : (hit_state == 1 ? 2u : 3u);
         }
     }
-    if (walking) {
+    if (walking && !deferred) {
         if (verdict == 2) { status[i] = 2; again = false; }
         else if (verdict == 3) {                     // wait for the undecided mate at y
             if (WAKE) atomicCAS(&flags[i], NDF_CUR_NONE, vals[y]);      // (one blocker per probe: the first entry to find one)
@@ -368,16 +447,25 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
         } else again = false;                        // this table has nothing more to say about i
         cursor_all[e] = verdict == 1 ? x : (y | NDF_CUR_NEAR);
         // the entry that exhausts a probe's last table: nobody kept is near -- kept
-        if (WAKE && verdict == 1 && atomicSub(&left[i], 1u) == 1u) atomicCAS(&status[i], 0u, 1u);
+        if (WAKE && verdict == 1) {
+            if (Q.live) atomicAnd(&Q.live[i], ~(1ull << t));
+            if (atomicSub(&left[i], 1u) == 1u) atomicCAS(&status[i], 0u, 1u);
+        }
     }
-    if (compared) atomicAdd(&pairs[(g >> 6) & (ES_SHARDS - 1)], (unsigned long long)compared);
-    if (found) atomicAdd(&pairs[ES_SHARDS + ((g >> 6) & (ES_SHARDS - 1))], (unsigned long long)found);
+    if (__ballot(compared != 0u)) {                  // (one atomic per wavefront and counter)
+        for (int o = 32; o > 0; o >>= 1) { compared += __shfl_xor(compared, o, WAVE); found += __shfl_xor(found, o, WAVE); }
+        if (lane == 0) {
+            atomicAdd(&pairs[wave_id & (ES_SHARDS - 1)], (unsigned long long)compared);
+            if (found) atomicAdd(&pairs[ES_SHARDS + (wave_id & (ES_SHARDS - 1))], (unsigned long long)found);
+        }
+    }
     const unsigned long long bal = WAKE ? 0ull : __ballot(again);
     if (bal) {
         u32 base = 0;
         if (lane == 0) base = atomicAdd(next_count, (u32)__popcll(bal));
         base = __shfl(base, 0, WAVE);
         if (again) next[base + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = e;
+    }
     }
 }
 
@@ -410,7 +498,8 @@ ndf_cflag_kernel(const u32 *__restrict__ vals_all, const u32 *__restrict__ statu
 __global__ void __launch_bounds__(256)
 ndf_compact_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ cursor,
                    const u32 *__restrict__ flag, const u32 *__restrict__ pos, u32 nslot, u32 nslot_new, size_t tn,
-                   u64 *__restrict__ keys2, u32 *__restrict__ vals2, u32 *__restrict__ cursor2, u32 *status, u32 *__restrict__ left) {
+                   u64 *__restrict__ keys2, u32 *__restrict__ vals2, u32 *__restrict__ cursor2, u32 *status, u32 *__restrict__ left,
+                   unsigned long long *__restrict__ live) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= tn || !flag[e]) return;
     const u32 t = (u32)(e / nslot), x = (u32)(e - (size_t)t * nslot);
@@ -426,21 +515,26 @@ ndf_compact_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, c
         const u32 y2 = pos[ey] - t * nslot_new;              // the first surviving mate at or after y
         if (y2 >= x2) {
             cur = x2;                                        // only dropped mates were left: this table is done with i
+            if (live) atomicAnd(&live[i], ~(1ull << t));
             if (atomicSub(&left[i], 1u) == 1u) atomicCAS(&status[i], 0u, 1u);
         } else cur = y2 | (((cur & NDF_CUR_NEAR) && flag[ey]) ? NDF_CUR_NEAR : 0u);
     }
     cursor2[e2] = cur;
 }
 
-// after a pass: every undecided probe looks at its blocker; counters[0] = undecided probes, [1] = probes listed
-__global__ void __launch_bounds__(256)
-ndf_wake_kernel(u32 *status, u32 *__restrict__ wait_on, u32 n, u32 *__restrict__ next, u32 *__restrict__ counters) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+// after a pass: every undecided probe looks at its blocker; counters[1] = probes listed for the next pass, counters[0] =
+// undecided probes (counted when the rounds are traced, otherwise just a flag that somebody is).  One atomic per
+// WORKGROUP of 1,024 for the list (round 5: one per wavefront plus one for the count were 140 k atomics on ONE address
+// each, 1.4 ms of every pass)
+__global__ void __launch_bounds__(1024)
+ndf_wake_kernel(u32 *status, u32 *__restrict__ wait_on, u32 n, u32 *__restrict__ next, u32 *__restrict__ counters, int count_undecided) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ u32 s_cnt[16], s_und[16], s_base;
     bool undecided = false, woken = false;
     if (i < n && status[i] == 0) {
         const u32 j = wait_on[i];
         // (a probe that is neither decided nor parked after a pass cannot exist: every listed entry walks to a
-        // verdict; counted all the same, so that a broken invariant shows as an error instead of a wrong answer)
+        // verdict; the read-back checks that nothing is left undecided)
         undecided = true;
         if (j != NDF_CUR_NONE) {
             const u32 sj = status[j];
@@ -448,15 +542,70 @@ ndf_wake_kernel(u32 *status, u32 *__restrict__ wait_on, u32 n, u32 *__restrict__
             else if (sj == 2) { wait_on[i] = NDF_CUR_NONE; woken = true; }
         }
     }
-    const unsigned long long wb = __ballot(woken);
-    if (wb) {
-        u32 base = 0;
-        if (lane == 0) base = atomicAdd(&counters[1], (u32)__popcll(wb));
-        base = __shfl(base, 0, WAVE);
-        if (woken) next[base + (u32)__popcll(wb & ((1ull << lane) - 1ull))] = i;
+    const unsigned long long wb = __ballot(woken), ub = __ballot(undecided);
+    if (lane == 0) { s_cnt[wv] = (u32)__popcll(wb); s_und[wv] = (u32)__popcll(ub); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 tot = 0, und = 0;
+        for (u32 w = 0; w < (blockDim.x >> 6); ++w) { const u32 c = s_cnt[w]; s_cnt[w] = tot; tot += c; und += s_und[w]; }
+        s_base = tot ? atomicAdd(&counters[1], tot) : 0u;
+        if (und) { if (count_undecided) atomicAdd(&counters[0], und); else if (((volatile u32 *)counters)[0] == 0u) counters[0] = 1u; }    // (a flag is enough for the loop)
     }
-    const unsigned long long b = __ballot(undecided);
-    if (b && lane == 0) atomicAdd(&counters[0], (u32)__popcll(b));
+    __syncthreads();
+    if (woken) next[s_base + s_cnt[wv] + (u32)__popcll(wb & ((1ull << lane) - 1ull))] = i;
+}
+
+// the same with live tables: a woken probe goes into the list of every table that has not run out for it
+// (tlist[t * n ..), tcount[t * ES_STRIDE] entries; one atomic per workgroup and table)
+__global__ void __launch_bounds__(1024)
+ndf_wake_live_kernel(u32 *status, u32 *__restrict__ wait_on, u32 n, const unsigned long long *__restrict__ live, u32 ntables,
+                     u32 *__restrict__ tlist, u32 *__restrict__ tcount, u32 *__restrict__ counters, int count_undecided) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ u32 s_tc[64][16], s_tbase[64], s_und[16];
+    bool undecided = false, woken = false;
+    if (i < n && status[i] == 0) {
+        const u32 j = wait_on[i];
+        undecided = true;
+        if (j != NDF_CUR_NONE) {
+            const u32 sj = status[j];
+            if (sj == 1) { status[i] = 2; undecided = false; }
+            else if (sj == 2) { wait_on[i] = NDF_CUR_NONE; woken = true; }
+        }
+    }
+    const unsigned long long ub = __ballot(undecided);
+    if (lane == 0) s_und[wv] = (u32)__popcll(ub);
+    const unsigned long long mask = woken ? live[i] : 0ull;
+    const int any = __syncthreads_or(woken ? 1 : 0);
+    if (threadIdx.x == 0) {
+        u32 und = 0;
+        for (u32 w = 0; w < 16; ++w) und += s_und[w];
+        if (und) { if (count_undecided) atomicAdd(&counters[0], und); else if (((volatile u32 *)counters)[0] == 0u) counters[0] = 1u; }
+    }
+    if (!any) return;
+    for (u32 t = 0; t < ntables; ++t) {
+        const unsigned long long b = __ballot((mask >> t) & 1ull);
+        if (lane == 0) s_tc[t][wv] = (u32)__popcll(b);
+    }
+    __syncthreads();
+    if (threadIdx.x < ntables) {
+        const u32 t = threadIdx.x;
+        u32 tot = 0;
+        for (u32 w = 0; w < 16; ++w) { const u32 c = s_tc[t][w]; s_tc[t][w] = tot; tot += c; }
+        s_tbase[t] = tot ? atomicAdd(&tcount[t * ES_STRIDE], tot) : 0u;
+    }
+    __syncthreads();
+    for (u32 t = 0; t < ntables; ++t) {
+        const bool mine = (mask >> t) & 1ull;
+        const unsigned long long b = __ballot(mine);
+        if (mine) tlist[(size_t)t * n + s_tbase[t] + s_tc[t][wv] + (u32)__popcll(b & ((1ull << lane) - 1ull))] = i;
+    }
+}
+// counters[0..1] and the tables' counts, side by side for one read-back
+__global__ void __launch_bounds__(64)
+ndf_gather_kernel(const u32 *__restrict__ counters, const u32 *__restrict__ tcount, u32 ntables, u32 *__restrict__ out) {
+    const u32 t = threadIdx.x;
+    if (t < 2) out[t] = counters[t];
+    if (t < ntables) out[2 + t] = tcount[t * ES_STRIDE];
 }
 
 // what the lazy resolution keeps resident: keys, values, cursors (16 B), the slot of every probe in every table (4 B),
@@ -469,7 +618,7 @@ static bool ndf_lazy_fits(size_t tn) {
     int64_t st[4] = {0, 0, 0, 0};
     (void)catchhip_pool_stats(st);
     const size_t idle = st[2] > 0 ? (size_t)st[2] : 0;
-    return (double)tn * 52.0 + (double)(64u << 20) <= 0.9 * ((double)fr + (double)idle);
+    return (double)tn * 60.0 + (double)(64u << 20) <= 0.9 * ((double)fr + (double)idle);
 }
 
 // the rounds of the lazy resolution and the read-back (both families): launch(list or nullptr, nlist, next,
@@ -485,9 +634,21 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
     const unsigned nb = (unsigned)div_up(nn, 256);
     u32 *undecided = count.p + ES_SHARDS * ES_STRIDE;     // [0] undecided probes, [1] entries / probes listed for the next round
     const bool wake = !chip_test_env("CATCHHIP_NDF_POLL_ROUNDS");
-    DevBuf<u32> lists[2], inv, left_tables;
+    DevBuf<u32> lists[2], inv, left_tables, dq;
     TRY(lists[0].alloc(wake ? (size_t)nn : tn));
     TRY(lists[1].alloc(wake ? (size_t)nn : tn));
+    const bool queued = wake && !chip_test_env("CATCHHIP_NDF_NO_QUEUE");    // (test hook: the walks finished inside their wavefronts)
+    const bool live_lists = wake && ntables <= 64 && !chip_test_env("CATCHHIP_NDF_NO_LIVE_LISTS");
+    DevBuf<u64> live;
+    DevBuf<u32> tlist, tcount, rb;
+    if (live_lists) {
+        TRY(live.alloc(nn)); TRY(tlist.alloc(tn)); TRY(tcount.alloc(64 * ES_STRIDE)); TRY(rb.alloc(2 + 64));
+        HIP_TRY(hipMemsetAsync(live.p, 0xff, sizeof(u64) * nn, s));        // (bits beyond the tables never matter: only listed tables are looked at)
+    }
+    NdfQueue Q{};
+    const u32 dq_segcap = (u32)(tn / ES_SHARDS) + 64u * 2u;      // (wavefronts file round-robin: a shard gets at most its share + one wavefront's)
+    DevBuf<u32> dq_count;
+    if (queued) { TRY(dq.alloc((size_t)dq_segcap * ES_SHARDS)); TRY(dq_count.alloc(ES_SHARDS * ES_STRIDE)); }
     if (wake) {
         TRY(inv.alloc(tn));
         TRY(left_tables.alloc(nn));
@@ -522,7 +683,7 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
                 TRY(cursor2.reserve(tcur));
                 hipLaunchKernelGGL(ndf_compact_kernel, dim3((unsigned)div_up((i64)tcur, 256)), dim3(256), 0, s, (const u64 *)skeys.p,
                                    (const u32 *)svals_buf.p, (const u32 *)cursor.p, (const u32 *)cflag.p, (const u32 *)cpos.p, nslot, nslot2,
-                                   tcur, skeys2.p, svals2.p, cursor2.p, status.p, left_tables.p);
+                                   tcur, skeys2.p, svals2.p, cursor2.p, status.p, left_tables.p, (unsigned long long *)live.p);
                 skeys.swap(skeys2); svals_buf.swap(svals2); cursor.swap(cursor2);
                 nslot = nslot2;
                 if (nslot)
@@ -532,13 +693,35 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
             }
         }
         HIP_TRY(hipMemsetAsync(undecided, 0, 2 * sizeof(u32), s));
-        if (nlist) launch(wake, round ? (const u32 *)lists[round & 1].p : (const u32 *)nullptr, nlist, lists[(round & 1) ^ 1].p, undecided + 1,
-                          left_tables.p, (const u32 *)inv.p, nslot);
-        if (wake) hipLaunchKernelGGL(ndf_wake_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, lists[(round & 1) ^ 1].p, undecided);
+        if (queued) HIP_TRY(hipMemsetAsync(dq_count.p, 0, sizeof(u32) * ES_SHARDS * ES_STRIDE, s));
+        Q.dq = queued ? dq.p : (u32 *)nullptr; Q.dq_count = dq_count.p; Q.segcap = dq_segcap;
+        Q.live = live_lists ? (unsigned long long *)live.p : (unsigned long long *)nullptr;
+        if (nlist) {
+            const u32 *cur_list = !round ? (const u32 *)nullptr : live_lists ? (const u32 *)tlist.p : (const u32 *)lists[round & 1].p;
+            launch(wake, cur_list, nlist, lists[(round & 1) ^ 1].p, undecided + 1, left_tables.p, (const u32 *)inv.p, nslot, Q, false);
+            if (queued) {
+                launch(wake, cur_list, nlist, lists[(round & 1) ^ 1].p, undecided + 1, left_tables.p, (const u32 *)inv.p, nslot, Q, true);
+                tm.launch(1);
+            }
+        }
+        if (live_lists) {       // (the pass has read its lists: the same buffer takes the next ones)
+            HIP_TRY(hipMemsetAsync(tcount.p, 0, sizeof(u32) * 64 * ES_STRIDE, s));
+            hipLaunchKernelGGL(ndf_wake_live_kernel, dim3((unsigned)div_up(nn, 1024)), dim3(1024), 0, s, status.p, flags.p, nn,
+                               (const unsigned long long *)live.p, ntables, tlist.p, tcount.p, undecided, trace ? 1 : 0);
+            hipLaunchKernelGGL(ndf_gather_kernel, dim3(1), dim3(64), 0, s, (const u32 *)undecided, (const u32 *)tcount.p, ntables, rb.p);
+            tm.launch(1);
+        } else if (wake) hipLaunchKernelGGL(ndf_wake_kernel, dim3((unsigned)div_up(nn, 1024)), dim3(1024), 0, s, status.p, flags.p, nn, lists[(round & 1) ^ 1].p, undecided, trace ? 1 : 0);
         else hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, undecided);
         tm.launch(2);
-        HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
+        if (live_lists) HIP_TRY(hipMemcpyAsync(ctx->h_pin, rb.p, (2 + ntables) * sizeof(u32), hipMemcpyDeviceToHost, s));
+        else HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (live_lists) {       // entries of the next pass: the tables' lists one after the other
+            u32 tot = 0;
+            for (u32 t = 0; t < ntables; ++t) { Q.toff[t] = tot; tot += ((volatile u32 *)ctx->h_pin)[2 + t]; }
+            for (u32 t = ntables; t <= 64; ++t) Q.toff[t] = tot;
+            ((volatile u32 *)ctx->h_pin)[1] = tot;
+        }
         if (trace) {
             const auto t1 = std::chrono::steady_clock::now();
             u64 hp[2 * ES_SHARDS], cmp = 0;
@@ -549,7 +732,7 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
                     std::chrono::duration<double, std::milli>(t1 - t_round).count(), (unsigned long long)cmp);
             t_round = std::chrono::steady_clock::now();
         }
-        left = ((volatile u32 *)ctx->h_pin)[0];
+        left = ((volatile u32 *)ctx->h_pin)[0];       // (wake-ups: a flag unless the rounds are traced)
         nlist = ((volatile u32 *)ctx->h_pin)[1];
     }
     HIP_TRY(hipGetLastError());
@@ -682,15 +865,19 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
         }
         HammingFamily fam{(const u64 *)padded.p, W, (int)dist_thres, (int)k, (const i32 *)d_pos.p, d_grp, pstride, ntables >= 4 ? 1 : 0};
         return ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
-                               [&](bool wake, const u32 *list, u32 nlist, u32 *next, u32 *next_count, u32 *left_tables, const u32 *inv, u32 nslot) {
-            if (wake)
-                hipLaunchKernelGGL((ndf_lazy_kernel<HammingFamily, true>), dim3((unsigned)div_up(list ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
+                               [&](bool wake, const u32 *list, u32 nlist, u32 *next, u32 *next_count, u32 *left_tables, const u32 *inv, u32 nslot, NdfQueue Q, bool drain) {
+            if (wake && drain)
+                hipLaunchKernelGGL((ndf_lazy_kernel<HammingFamily, true, true>), dim3(drain ? NDF_DRAIN_BLOCKS : (unsigned)div_up((list && !Q.live) ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
                                    fam, nn, (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot);
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, false, Q);
+                        else if (wake)
+                hipLaunchKernelGGL((ndf_lazy_kernel<HammingFamily, true>), dim3(drain ? NDF_DRAIN_BLOCKS : (unsigned)div_up((list && !Q.live) ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
+                                   fam, nn, (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, false, Q);
             else
                 hipLaunchKernelGGL((ndf_lazy_kernel<HammingFamily, false>), dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s, fam, nn,
                                    (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot);
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, false, Q);
         }, skeys, svals, cursor, (u32)ntables);
     }
     u32 cap = (u32)std::max<i64>((i64)1 << 14, std::min<i64>(n * 16, (i64)1 << 28) / ES_SHARDS);   // per shard
@@ -766,11 +953,16 @@ extern "C" int catchhip_ndf_hamming(catchhip_ctx *ctx, const u8 *bytes, i64 n, i
 // (With 512 bits the bound sat ~15 above the intersection and rejected next to nothing: mates of one bucket share
 // 30-50 of their ~90 k-mers and the threshold needs 52.)
 #define MH_FPW 32
+#define MH_TAB_BITS 10
+#define MH_TAB (1u << MH_TAB_BITS)   // slots of the staged probe's k-mer table (<= MH_MAXK = 256 codes)
 __device__ __forceinline__ u32 mh_fp_bit(u64 h, u64 l) {
     u64 x = (l ^ (h * 0x9e3779b97f4a7c15ull)) * 0xff51afd7ed558ccdull;
     x ^= x >> 33;
     return (u32)(x * 0xc4ceb9fe1a85ec53ull >> 53);      // 11 bits
 }
+
+#define MH_KC_NONE 0xffffffffu
+__device__ __forceinline__ u32 mh_base2(u8 ch) { return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u; }
 
 // CPython <= 3.10 str hash of `len` ASCII characters, zero key (see above; internal.h)
 __device__ __forceinline__ long long mh_pyhash(const u8 *__restrict__ src, int len) { return chip_pyhash_seed0(src, len); }
@@ -778,13 +970,20 @@ __device__ __forceinline__ long long mh_pyhash(const u8 *__restrict__ src, int l
 __global__ void __launch_bounds__(64)
 mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, const u32 *__restrict__ koff, u32 n,
                int ks, u32 *__restrict__ xs, u64 *__restrict__ id_hi, u64 *__restrict__ id_lo,
-               u32 *__restrict__ nuniq, unsigned long long *__restrict__ fp, u32 *__restrict__ fp_excess) {
+               u32 *__restrict__ nuniq, unsigned long long *__restrict__ fp, u32 *__restrict__ fp_excess,
+               u32 *__restrict__ kc, u32 kstride) {
     __shared__ u64 s_hi[MH_MAXK], s_lo[MH_MAXK];
     __shared__ unsigned long long s_fp[MH_FPW];
     const u32 lane = threadIdx.x;
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
         const u8 *p = bytes + probe_off[i];
         const u32 k0 = koff[i], nk = koff[i + 1] - k0;
+        // packed form (kc, round 5): a probe of A/C/G/T only has its distinct k-mers as 2-bit codes as well (<= 15
+        // characters, so that 0xffffffff is free to mean "nothing"); any other character: the row starts with MH_KC_NONE
+        bool bad = ks > 15;
+        if (kc)
+            for (u32 j = lane; j < nk + (u32)ks - 1u; j += 64) bad = bad || mh_base2(p[j]) > 3u;
+        const bool packable = kc && !__ballot(bad);
         __syncthreads();
         for (u32 j = lane; j < nk; j += 64) {
             const long long h = mh_pyhash(p + j, ks);
@@ -834,9 +1033,24 @@ mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, 
                 id_hi[k0 + o] = s_hi[j]; id_lo[k0 + o] = s_lo[j];
                 const u32 bit = mh_fp_bit(s_hi[j], s_lo[j]);
                 atomicOr(&s_fp[bit >> 6], 1ull << (bit & 63u));
+                if (kc) {
+                    u32 code = MH_KC_NONE;
+                    if (packable) {
+                        code = 0;
+                        for (int c = 0; c < ks; ++c) {       // the bytes as stored above: big endian, the last <= 8 in lo
+                            const int inlo = ks < 8 ? ks : 8;
+                            const u64 ch = c < ks - 8 ? (s_hi[j] >> (8 * (ks - 8 - 1 - c))) & 0xffull
+                                                      : (s_lo[j] >> (8 * (inlo - 1 - (c - (ks > 8 ? ks - 8 : 0))))) & 0xffull;
+                            code = (code << 2) | mh_base2((u8)ch);
+                        }
+                    }
+                    kc[(size_t)i * kstride + o] = code;
+                }
             }
             out += (u32)__popcll(bal);
         }
+        if (kc)
+            for (u32 q = out + lane; q < kstride; q += 64) kc[(size_t)i * kstride + q] = MH_KC_NONE;
         __syncthreads();
         if (lane < MH_FPW) fp[(size_t)i * MH_FPW + lane] = s_fp[lane];
         u32 set = lane < MH_FPW ? (u32)__popcll(s_fp[lane]) : 0u;
@@ -854,7 +1068,7 @@ mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, 
 __global__ void __launch_bounds__(256)
 mh_keys_all_kernel(const u32 *__restrict__ xs, const u32 *__restrict__ koff, u32 n, const u64 *__restrict__ ab,
                    int k, int ntables, int t0, int nt, const u32 *__restrict__ grp, u32 *__restrict__ sig_all,
-                   u64 *__restrict__ keys_all) {
+                   u64 *__restrict__ keys_all, u32 *__restrict__ sig0T = nullptr, u32 tstride = 0) {
     const u32 lane = threadIdx.x & 63;
     const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= n) return;
@@ -876,6 +1090,8 @@ mh_keys_all_kernel(const u32 *__restrict__ xs, const u32 *__restrict__ koff, u32
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) best = min(best, (u32)__shfl_xor((int)best, d, WAVE));
             if (lane == 0) sig_all[((size_t)(t - t0) * n + i) * k + f] = best;
+            // (the first value of every table's signature once more, a row per probe: what owned_earlier looks at)
+            if (lane == 0 && f == 0 && sig0T) sig0T[(size_t)i * tstride + t] = best;
             h = (h ^ (u64)best) * 0x100000001b3ull;
         }
         if (lane == 0) keys_all[(size_t)(t - t0) * n + i] = h;
@@ -978,8 +1194,93 @@ struct MinHashFamily {       // same signature in table t (the key only groups),
     const unsigned long long *fp;     // MH_FPW words per probe
     const u32 *fp_excess;
     int wave_near_max;       // lanes wanting a comparison from which every lane runs its own (NDF_WAVE_NEAR_MAX)
+    const u32 *kc;           // [probe][kstride] 2-bit codes of the distinct k-mers, MH_KC_NONE-padded (row[0] == NONE: not packable)
+    u32 kstride;
+    const u32 *sig0T;        // [probe][tstride]: the first value of every table's signature
+    u32 tstride;
     static constexpr bool WAVE_NEAR = true;
-    struct Scratch { u64 h[MH_MAXK], l[MH_MAXK]; };
+    static constexpr bool WAVE64 = true;
+    struct Scratch { u64 h[MH_MAXK], l[MH_MAXK]; u32 tab[MH_TAB]; };
+    // The shared walk (round 5).  A wavefront that walks ONE probe's run compares that probe with thousands of mates:
+    // its k-mer codes go into an open-addressing table in LDS once (wave64_stage), and a comparison is then every lane
+    // looking ITS k-mers of the mate up there -- the mate's row read coalesced, no dependent global loads, ~40
+    // instructions per comparison for the wavefront, four mates in flight -- instead of a merge walk per lane
+    // (~100 dependent steps with their global loads, a full step of 64 mates ~50 us).
+    __device__ __forceinline__ u32 tab_slot(u32 c) const { return (c * 0x9E3779B1u) >> (32 - MH_TAB_BITS); }
+    __device__ __forceinline__ bool wave64_stage(u32 i, Scratch &S, u32 lane) const {      // i wave-uniform
+        if (!kc || kc[(size_t)i * kstride] == MH_KC_NONE) return false;
+        for (u32 q = lane; q < MH_TAB; q += 64) S.tab[q] = MH_KC_NONE;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const u32 na = nuniq[i];
+        for (u32 q = lane; q < na; q += 64) {
+            const u32 c = kc[(size_t)i * kstride + q];
+            u32 sl = tab_slot(c);
+            while (atomicCAS(&S.tab[sl], MH_KC_NONE, c) != MH_KC_NONE) sl = (sl + 1u) & (MH_TAB - 1u);   // (codes are distinct)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return true;
+    }
+    __device__ __forceinline__ u32 tab_has(const Scratch &S, u32 c) const {
+        if (c == MH_KC_NONE) return 0u;
+        u32 sl = tab_slot(c);
+        for (;;) {
+            const u32 v = S.tab[sl];
+            if (v == c) return 1u;
+            if (v == MH_KC_NONE) return 0u;
+            sl = (sl + 1u) & (MH_TAB - 1u);
+        }
+    }
+    // the first mate near i among the lanes in `want` (lane b holds mate j), in lane order; -1: none.  The staged probe
+    // is i; ncmp counts the comparisons made (the walk ends at the first near mate, so the ones after it are not made
+    // -- up to three of its batch are).
+    __device__ __forceinline__ int wave64_first_near(u32 i, unsigned long long want, u32 j, Scratch &S, u32 lane, u32 &ncmp) const {
+        const u32 na = __builtin_amdgcn_readfirstlane(nuniq[i]);
+        while (want) {
+            int b[4];
+            u32 jb[4], nbv[4], need[4], cnt[4];
+            bool slow[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                b[m] = want ? __ffsll((long long)want) - 1 : -1;
+                if (want) want &= want - 1ull;
+                jb[m] = (u32)__builtin_amdgcn_readfirstlane(__shfl((int)j, b[m] < 0 ? 0 : b[m], WAVE));
+                nbv[m] = 0; need[m] = 1; cnt[m] = 0; slow[m] = false;
+                if (b[m] >= 0) {
+                    nbv[m] = __builtin_amdgcn_readfirstlane(nuniq[jb[m]]);
+                    need[m] = min(need_tab[na + nbv[m]], min(na, nbv[m]) + 1u);
+                    slow[m] = kc[(size_t)jb[m] * kstride] == MH_KC_NONE;     // (a mate with other characters: the merge walk, by one lane)
+                }
+            }
+            ncmp += (lane == 0) ? (u32)((b[0] >= 0) + (b[1] >= 0) + (b[2] >= 0) + (b[3] >= 0)) : 0u;
+            const u32 nbmax = max(max(nbv[0], nbv[1]), max(nbv[2], nbv[3]));
+            for (u32 q0 = 0; q0 < nbmax; q0 += 64) {
+                u32 c[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    c[m] = (b[m] >= 0 && !slow[m] && q0 + lane < nbv[m]) ? kc[(size_t)jb[m] * kstride + q0 + lane] : MH_KC_NONE;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) cnt[m] += (u32)__popcll(__ballot(tab_has(S, c[m]) != 0u));
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (b[m] < 0) break;
+                bool r;
+                if (slow[m]) {
+                    bool mine = false;
+                    if ((int)lane == b[m]) mine = near(0, i, jb[m]);
+                    r = __ballot(mine) != 0ull;
+                } else {
+                    r = need[m] <= min(na, nbv[m]) && cnt[m] >= need[m];
+                }
+                if (r) return b[m];
+            }
+        }
+        return -1;
+    }
     // i near j, by the whole wavefront (i, j wave-uniform): B's k-mers staged in LDS, every lane looks its share of
     // A's up by binary search, the matches are summed -- |A and B| >= need is what mh_near's walk decides (its early
     // exits only shorten the walk), `need` from a table of the reference's own two IEEE operations made on the host
@@ -1036,8 +1337,8 @@ struct MinHashFamily {       // same signature in table t (the key only groups),
 #pragma unroll
             for (u32 q = 0; q < 8; ++q) {
                 const u32 tp = min(t0 + q, t - 1);
-                a[q] = sig_all[((size_t)tp * n + i) * k];
-                b[q] = sig_all[((size_t)tp * n + j) * k];
+                a[q] = sig0T ? sig0T[(size_t)i * tstride + tp] : sig_all[((size_t)tp * n + i) * k];   // (a row per probe: one line
+                b[q] = sig0T ? sig0T[(size_t)j * tstride + tp] : sig_all[((size_t)tp * n + j) * k];   //  instead of eight)
             }
 #pragma unroll
             for (u32 q = 0; q < 8; ++q)
@@ -1146,13 +1447,23 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
 
     PhaseTimer tm(ctx, PHASE_NDF);
     const unsigned nb = (unsigned)div_up(nn, 256);
+    const bool lazy = tchunk >= ntables && (i64)ntables * n <= ((i64)1 << 31) && !chip_test_env("CATCHHIP_MH_ALL_PAIRS") &&
+                      ndf_lazy_fits((size_t)ntables * nn);
+    // the shared walks' packed k-mer codes and the transposed first signature values (lazy resolution only;
+    // CATCHHIP_MH_NO_WAVE64, a test hook, keeps round 4's walks for the equality tests)
+    const bool wave64 = lazy && !chip_test_env("CATCHHIP_MH_NO_WAVE64");
+    DevBuf<u32> kc, sig0T;
+    u32 max_nk = 1;
+    for (i64 i = 0; i < n; ++i) max_nk = std::max(max_nk, h_koff[i + 1] - h_koff[i]);
+    const u32 kstride = (max_nk + 31u) & ~31u, tstride = ((u32)ntables + 3u) & ~3u;
+    if (wave64) TRY(kc.alloc((size_t)nn * kstride));
+    if (lazy) TRY(sig0T.alloc((size_t)nn * tstride));
     hipLaunchKernelGGL(mh_kmer_kernel, dim3((unsigned)std::min<i64>(n, (i64)1 << 20)), dim3(64), 0, s,
                        (const u8 *)d_bytes.p, (const u32 *)d_off.p, (const u32 *)d_koff.p, nn, (int)kmer_size, xs.p,
-                       id_hi.p, id_lo.p, nuniq.p, (unsigned long long *)fp.p, fp_excess.p);
+                       id_hi.p, id_lo.p, nuniq.p, (unsigned long long *)fp.p, fp_excess.p, wave64 ? kc.p : (u32 *)nullptr, kstride);
     tm.launch(1);
     ctx->ndf_counters[0] = n; ctx->ndf_counters[1] = ntables; ctx->ndf_counters[2] = ctx->ndf_counters[3] = 0;
-    if (tchunk >= ntables && (i64)ntables * n <= ((i64)1 << 31) && !chip_test_env("CATCHHIP_MH_ALL_PAIRS") &&
-        ndf_lazy_fits((size_t)ntables * nn)) {
+    if (lazy) {
         // lazy resolution (ndf_lazy_kernel): all tables' sorted runs stay resident, one cursor per (table, slot) --
         // 24 bytes per entry, at most 2^31 entries (48 GB); beyond that the edge-list variant below, table by table
         DevBuf<u64> skeys, pairs;
@@ -1177,7 +1488,7 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
         HIP_TRY(hipMemsetAsync(pairs.p, 0, sizeof(u64) * 2 * ES_SHARDS, s));
         hipLaunchKernelGGL(mh_keys_all_kernel, dim3((unsigned)div_up((i64)nn * 64, 256)), dim3(256), 0, s,
                            (const u32 *)xs.p, (const u32 *)d_koff.p, nn, (const u64 *)d_ab.p, (int)k, (int)ntables, 0,
-                           (int)ntables, grp, sig.p, keys_all.p);
+                           (int)ntables, grp, sig.p, keys_all.p, sig0T.p, tstride);
         tm.launch(1);
         for (int t = 0; t < ntables; ++t) {
             hipLaunchKernelGGL(mh_table_kernel, dim3(nb), dim3(256), 0, s, (const u64 *)(keys_all.p + (size_t)t * nn), nn,
@@ -1190,17 +1501,22 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
         lap("signatures + sorts", t_lap);
         MinHashFamily fam{(const u32 *)d_koff.p, (const u32 *)nuniq.p, (const u64 *)id_hi.p, (const u64 *)id_lo.p, (const u32 *)sig.p,
                           (int)k, nn, grp, (const u32 *)need_tab.p, (const unsigned long long *)fp.p, (const u32 *)fp_excess.p,
-                          chip_test_env("CATCHHIP_NDF_WAVE_NEAR_MAX") ? atoi(chip_test_env("CATCHHIP_NDF_WAVE_NEAR_MAX")) : NDF_WAVE_NEAR_MAX};
+                          chip_test_env("CATCHHIP_NDF_WAVE_NEAR_MAX") ? atoi(chip_test_env("CATCHHIP_NDF_WAVE_NEAR_MAX")) : NDF_WAVE_NEAR_MAX,
+                          (const u32 *)kc.p, kstride, (const u32 *)sig0T.p, tstride};
         const int rc = ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
-                                       [&](bool wake, const u32 *list, u32 nlist, u32 *next, u32 *next_count, u32 *left_tables, const u32 *inv, u32 nslot) {
-            if (wake)
-                hipLaunchKernelGGL((ndf_lazy_kernel<MinHashFamily, true>), dim3((unsigned)div_up(list ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
+                                       [&](bool wake, const u32 *list, u32 nlist, u32 *next, u32 *next_count, u32 *left_tables, const u32 *inv, u32 nslot, NdfQueue Q, bool drain) {
+            if (wake && drain)
+                hipLaunchKernelGGL((ndf_lazy_kernel<MinHashFamily, true, true>), dim3(drain ? NDF_DRAIN_BLOCKS : (unsigned)div_up((list && !Q.live) ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
                                    fam, nn, (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot);
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, wave64, Q);
+                        else if (wake)
+                hipLaunchKernelGGL((ndf_lazy_kernel<MinHashFamily, true>), dim3(drain ? NDF_DRAIN_BLOCKS : (unsigned)div_up((list && !Q.live) ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
+                                   fam, nn, (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, wave64, Q);
             else
                 hipLaunchKernelGGL((ndf_lazy_kernel<MinHashFamily, false>), dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s, fam, nn,
                                    (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot);
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, wave64, Q);
         }, skeys, svals, cursor, (u32)ntables);
         lap("rounds", t_lap);
         return rc;

@@ -1,0 +1,25 @@
+export CATCHHIP_TEST_HOOKS=1 CATCHHIP_FRONT_END_WORKERS=1 CATCHHIP_PREFETCH_DEPTH=0
+R=$PWD
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/s5kt -- python $R/tools/s5_profile.py 1.0 once > $R/gpurun_out/s5kt.out 2>&1
+cd $R
+f=$(ls gpurun_out/s5kt/*/*kernel_stats.csv | head -1)
+cp $f gpurun_out/s5_kernel_stats_q.csv
+head -30 $f | cut -c1-150
+# per-dispatch: lazy kernels of the first chunk
+python - <<'PY'
+import csv, glob
+f = glob.glob("gpurun_out/s5kt/*/*kernel_trace.csv")[0]
+rows = [r for r in csv.DictReader(open(f))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+n = 0
+out = []
+for r in rows:
+    nm = r["Kernel_Name"]
+    if "ndf_lazy" in nm or "ndf_wake" in nm:
+        tag = "drain" if "Lb1ELb1E" in nm or "true, true" in nm else ("wake" if "wake" in nm else "pass")
+        out.append((tag, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size") or r.get("Grid_Size_X")))
+for o in out[:150]:
+    print(o)
+PY
+rm -rf gpurun_out/s5kt

@@ -34,6 +34,7 @@ def step():
 
 if len(sys.argv) < 3 or sys.argv[2] != "once":
     step()
+print("MARK monotonic_ns %d boottime_ns %d" % (time.clock_gettime_ns(time.CLOCK_MONOTONIC), time.clock_gettime_ns(time.CLOCK_BOOTTIME)), flush=True)
 pr = cProfile.Profile()
 pr.enable()
 step()
