@@ -677,16 +677,14 @@ static int cand_set_order(catchhip_ctx *ctx, const catchhip_candidates *C, DevBu
     return 0;
 }
 
-// keep[] (host) -> the candidate list becomes the kept ones, in the reference's order (see cand_set_order)
+// flag[0..n) (device, 0 / 1; n + 1 words allocated) -> the candidate list becomes the kept ones, in the reference's
+// order (see cand_set_order)
 static int cand_apply_keep(catchhip_ctx *ctx, catchhip_candidates *C, DevBuf<u32> &opos, DevBuf<u32> &ogrp,
-                           const std::vector<u8> &keep, i64 *nkept) {
+                           DevBuf<u32> &flag, i64 *nkept) {
     hipStream_t s = ctx->stream;
     const u32 n = (u32)C->nuniq;
-    std::vector<u32> h((size_t)n + 1, 0);
-    for (u32 i = 0; i < n; ++i) h[i] = keep[i] ? 1u : 0u;
-    DevBuf<u32> flag, at, tmp, out;
-    TRY(flag.alloc((size_t)n + 1));
-    HIP_TRY(hipMemcpyAsync(flag.p, h.data(), sizeof(u32) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
+    DevBuf<u32> at, tmp, out;
+    HIP_TRY(hipMemsetAsync(flag.p + n, 0, sizeof(u32), s));
     TRY(cand_scan(ctx, flag, at, (i64)n + 1, tmp));
     u32 nk = 0;
     TRY(cand_read_u32(ctx, at.p + n, &nk));
@@ -720,10 +718,11 @@ static int cand_ndf_hamming(catchhip_ctx *ctx, catchhip_candidates *C, const i32
     DevBuf<u32> opos, ogrp;
     DevBuf<u8> rows;
     TRY(cand_priority_rows(ctx, C, opos, rows, ogrp));
-    std::vector<u8> keep((size_t)C->nuniq, 0);
-    TRY(chip_ndf_hamming_device(ctx, rows.p, C->nuniq, C->L, positions, ntables, k, dist_thres, keep.data(),
-                                C->grouped ? (const u32 *)ogrp.p : (const u32 *)nullptr, C->grouped ? ngroups : 1));
-    return cand_apply_keep(ctx, C, opos, ogrp, keep, nkept);
+    DevBuf<u32> flag;      // the verdicts stay on the device (round 5)
+    TRY(flag.alloc((size_t)C->nuniq + 1));
+    TRY(chip_ndf_hamming_device(ctx, rows.p, C->nuniq, C->L, positions, ntables, k, dist_thres, nullptr,
+                                C->grouped ? (const u32 *)ogrp.p : (const u32 *)nullptr, C->grouped ? ngroups : 1, flag.p));
+    return cand_apply_keep(ctx, C, opos, ogrp, flag, nkept);
 }
 
 extern "C" int catchhip_candidates_ndf_hamming(catchhip_ctx *ctx, catchhip_candidates *C, const i32 *positions,
@@ -756,24 +755,13 @@ static int cand_ndf_minhash(catchhip_ctx *ctx, catchhip_candidates *C, i32 kmer_
     DevBuf<u32> opos, ogrp;
     DevBuf<u8> rows;
     TRY(cand_priority_rows(ctx, C, opos, rows, ogrp));
-    std::vector<i64> off((size_t)C->nuniq + 1);
-    for (i64 i = 0; i <= C->nuniq; ++i) off[(size_t)i] = i * C->L;
-    std::vector<i64> goff;
-    if (C->grouped) {   // groups are runs of the priority order
-        std::vector<u32> hg((size_t)C->nuniq);
-        HIP_TRY(hipMemcpyAsync(hg.data(), ogrp.p, sizeof(u32) * (size_t)C->nuniq, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        goff.assign((size_t)ngroups + 1, 0);
-        for (i64 i = 0; i < C->nuniq; ++i) {
-            ARG_CHECK((i64)hg[(size_t)i] < ngroups);
-            goff[(size_t)hg[(size_t)i] + 1]++;
-        }
-        for (i64 g = 0; g < ngroups; ++g) goff[(size_t)g + 1] += goff[(size_t)g];
-    }
-    std::vector<u8> keep((size_t)C->nuniq, 0);
-    TRY(chip_ndf_minhash_device(ctx, rows.p, off.data(), C->nuniq, C->grouped ? goff.data() : nullptr,
-                                C->grouped ? ngroups : 1, kmer_size, ab, ntables, k, dist_thres, keep.data()));
-    return cand_apply_keep(ctx, C, opos, ogrp, keep, nkept);
+    // equal-length rows, their groups (runs of the priority order) and the verdicts all stay on the device (round 5)
+    if (C->grouped) ARG_CHECK(ngroups >= C->ngroups);
+    DevBuf<u32> flag;
+    TRY(flag.alloc((size_t)C->nuniq + 1));
+    TRY(chip_ndf_minhash_rows(ctx, rows.p, C->nuniq, C->L, C->grouped ? (const u32 *)ogrp.p : (const u32 *)nullptr,
+                              C->grouped ? ngroups : 1, kmer_size, ab, ntables, k, dist_thres, flag.p));
+    return cand_apply_keep(ctx, C, opos, ogrp, flag, nkept);
 }
 
 extern "C" int catchhip_candidates_ndf_minhash(catchhip_ctx *ctx, catchhip_candidates *C, i32 kmer_size,

@@ -210,9 +210,11 @@ int chip_probes_pack_planes(catchhip_probes *p);
 
 // near-duplicate filters on probes already on the device (ndf.hip): n rows of L
 // characters / rows at probe_off[] (>= 16 bytes of slack after the last one);
-// keep[] is a host array
+// keep[] is a host array; d_keep_flags (instead, or nullptr) takes the verdicts as 0/1 words on the device
 int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, const i32 *positions, i32 ntables,
-                            i32 k, i32 dist_thres, u8 *keep, const u32 *d_grp, i64 ngroups);
+                            i32 k, i32 dist_thres, u8 *keep, const u32 *d_grp, i64 ngroups, u32 *d_keep_flags = nullptr);
+int chip_ndf_minhash_rows(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i64 L, const u32 *d_grp, i64 ngroups, i32 kmer_size,
+                          const i64 *ab, i32 ntables, i32 k, double dist_thres, u32 *d_keep_flags);
 int chip_ndf_minhash_device(catchhip_ctx *ctx, const u8 *d_rows, const i64 *probe_off, i64 n, const i64 *group_off,
                             i64 ngroups, i32 kmer_size, const i64 *ab, i32 ntables, i32 k, double dist_thres,
                             u8 *keep);

@@ -234,22 +234,15 @@ struct HammingFamily {       // ndf_near on the padded rows; the earlier tables'
 // (decisions rest on final states only).  The queue has ES_SHARDS shards (a counter on ONE address takes ~10 ns per
 // atomic: 100 k walks filed or handed out through one counter were 1-2 ms of every pass); the wavefronts of the first
 // launch file round-robin, shard s is drained by the wavefronts with (id & 63) == s, strided.
-struct NdfQueue {
-    u32 *dq; u32 *dq_count; u32 segcap;      // shard s: dq[s * segcap ..), its length dq_count[s * ES_STRIDE]
-    // Live tables (round 5, <= 64 tables): bit t of live[i] = table t has not run out for probe i.  A woken probe is
-    // listed once per LIVE table (ndf_wake_kernel: list[t * n ..) holds table t's probes, toff[t] = entries before
-    // table t) -- the pass used to start 25 threads per woken probe of which four in five found an exhausted cursor
-    // after three dependent scattered loads (0.25 ns each: 110 of the 250 ms of a chunk's rounds).
-    unsigned long long *live;
-    u32 toff[65];
-};
+struct NdfQueue { u32 *dq; u32 *dq_count; u32 segcap; };     // shard s: dq[s * segcap ..), its length dq_count[s * ES_STRIDE]
 
 template <class Family, bool WAKE, bool DRAIN = false>
 __global__ void __launch_bounds__(256)
 ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *__restrict__ vals_all,
                 u32 *__restrict__ cursor_all, u32 *status, u32 *flags, unsigned long long *__restrict__ pairs,
                 const u32 *__restrict__ list, u32 nlist, u32 *__restrict__ next, u32 *__restrict__ next_count,
-                u32 *__restrict__ left, const u32 *__restrict__ inv, u32 ntables, u32 nslot, bool wave64, NdfQueue Q) {
+                u32 *__restrict__ left, const u32 *__restrict__ inv, u32 ntables, u32 nslot, u32 TS, bool wave64, NdfQueue Q) {
+    // cursor_all, inv: probe-major, [probe][TS] (round 5: a probe's tables side by side)
     // nslot = slots per table: n at first, fewer once the dropped probes' slots have been compacted away (WAKE)
     const u32 lane = threadIdx.x & 63;
     const u32 wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -275,22 +268,12 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
     } else {
         if (iter) break;
         const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-        if (g < ((WAKE && list && !Q.live) ? nlist * ntables : nlist)) {
+        if (g < ((WAKE && list) ? nlist * ntables : nlist)) {
             valid = true;
-            if (WAKE && list && Q.live) {            // per-table lists of the live entries
-                u32 lo = 0, hi = ntables;            // the last table with toff[t] <= g
-                while (hi - lo > 1u) {
-                    const u32 mid = (lo + hi) >> 1;
-                    if (Q.toff[mid] <= g) lo = mid; else hi = mid;
-                }
-                t = lo;
-                i = list[(size_t)t * n + (g - Q.toff[t])];
-                x = inv[(size_t)t * n + i];
-                e = t * nslot + x;
-            } else if (WAKE && list) {
+            if (WAKE && list) {
                 t = g / nlist;
                 i = list[g - t * nlist];
-                x = inv[(size_t)t * n + i];
+                x = inv[(size_t)i * TS + t];
                 e = t * nslot + x;
             } else {
                 e = list ? list[g] : g;
@@ -302,7 +285,7 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
     }
     if (valid) {
         const u64 *keys = keys_all + (size_t)t * nslot;
-        const u32 cur = cursor_all[e];
+        const u32 cur = cursor_all[(size_t)i * TS + t];
         if (st[i] == 0 && cur != x) {
             again = true;
             // (polling: flags[i] != 0 = waiting already in this round; wake-ups: flags[i] = the blocker, parked)
@@ -382,7 +365,7 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
             base = __shfl(base, 0, WAVE);
             if (deferred) {
                 Q.dq[(size_t)shard * Q.segcap + base + (u32)__popcll(db & ((1ull << lane) - 1ull))] = e;
-                cursor_all[e] = y | (near_known ? NDF_CUR_NEAR : 0u);
+                cursor_all[(size_t)i * TS + t] = y | (near_known ? NDF_CUR_NEAR : 0u);
             }
         }
     }
@@ -445,12 +428,9 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
             if (WAKE) atomicCAS(&flags[i], NDF_CUR_NONE, vals[y]);      // (one blocker per probe: the first entry to find one)
             else flags[i] = 2;
         } else again = false;                        // this table has nothing more to say about i
-        cursor_all[e] = verdict == 1 ? x : (y | NDF_CUR_NEAR);
+        cursor_all[(size_t)i * TS + t] = verdict == 1 ? x : (y | NDF_CUR_NEAR);
         // the entry that exhausts a probe's last table: nobody kept is near -- kept
-        if (WAKE && verdict == 1) {
-            if (Q.live) atomicAnd(&Q.live[i], ~(1ull << t));
-            if (atomicSub(&left[i], 1u) == 1u) atomicCAS(&status[i], 0u, 1u);
-        }
+        if (WAKE && verdict == 1 && atomicSub(&left[i], 1u) == 1u) atomicCAS(&status[i], 0u, 1u);
     }
     if (__ballot(compared != 0u)) {                  // (one atomic per wavefront and counter)
         for (int o = 32; o > 0; o >>= 1) { compared += __shfl_xor(compared, o, WAVE); found += __shfl_xor(found, o, WAVE); }
@@ -469,6 +449,140 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
     }
 }
 
+// One wavefront per listed probe, a lane per table (round 5; <= 64 tables).  The entry-per-thread pass above spends its
+// time waiting: a woken probe's ~24 unexhausted cursors are 24 threads in different wavefronts, each with its own
+// scattered loads of the slot, the cursor and the probe's state, and the comparisons the lanes of a wavefront want are
+// run one after the other, each a chain of dependent loads (PMC: 13 % VALU, 40 % TA, ~80 us per wavefront).  Here the
+// probe's cursors and slots are one row each (probe-major arrays, a cache line per probe), its k-mer codes are staged in
+// LDS ONCE for all its tables' comparisons (Family::wave64_stage; four mates in flight, no dependent loads), and the
+// tables are looked at in table order: the first table with a near mate that is not dropped decides (kept: the probe is
+// dropped; undecided: it parks), the later tables are not compared -- what the table-major order of the entry pass
+// achieved by timing.  A table whose walk is not over after NDF_PROBE_STEPS mates goes to the queue of deferred walks
+// (64 mates per step there).
+#define NDF_PROBE_STEPS 6
+template <class Family>
+__global__ void __launch_bounds__(256)
+ndf_probe_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *__restrict__ vals_all,
+                 u32 *__restrict__ cursor_all, u32 *status, u32 *flags, unsigned long long *__restrict__ pairs,
+                 const u32 *__restrict__ list, u32 nlist, u32 *__restrict__ left, const u32 *__restrict__ inv,
+                 u32 ntables, u32 nslot, u32 TS, bool wave64, NdfQueue Q) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const volatile u32 *st = status;
+    __shared__ typename Family::Scratch s_scratch[4];
+    typename Family::Scratch &scratch = s_scratch[threadIdx.x >> 6];
+    if (wave_id >= nlist) return;
+    const u32 i = (u32)__builtin_amdgcn_readfirstlane((int)(list ? list[wave_id] : wave_id));
+    if (st[i] != 0u || ((const volatile u32 *)flags)[i] != NDF_CUR_NONE) return;      // (decided or parked meanwhile)
+    const u32 t = lane;
+    const bool active = t < ntables;
+    const u32 x = active ? inv[(size_t)i * TS + t] : 0u;
+    const u32 cur = active ? cursor_all[(size_t)i * TS + t] : x;
+    const u64 *keys = keys_all + (size_t)(active ? t : 0u) * nslot;
+    const u32 *vals = vals_all + (size_t)(active ? t : 0u) * nslot;
+    bool walking = active && cur != x, near_known = false;
+    u32 y = 0, exhausted = 0;           // exhausted: this lane's table ran out in this pass
+    if (walking) {
+        if (cur == NDF_CUR_NONE) {                   // first visit: the first slot of the run
+            if (x == 0u || keys[x - 1u] != keys[x]) y = x;       // (alone in its bucket, or the run's head: one look)
+            else {
+                const u64 key = keys[x];
+                u32 lo = 0, hi = x - 1u;
+                while (lo < hi) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (keys[mid] < key) lo = mid + 1; else hi = mid;
+                }
+                y = lo;
+            }
+        } else {
+            near_known = (cur & NDF_CUR_NEAR) != 0;
+            y = cur & ~NDF_CUR_NEAR;
+        }
+    }
+    if (!__ballot(walking)) return;
+    const bool staged = Family::WAVE64 && wave64 && fam.wave64_stage(i, scratch, lane);
+    u32 compared = 0, found = 0;
+    u32 outcome = 0, blocker = 0;       // wave-uniform: 0 nothing yet, 2 dropped, 3 parks on `blocker`
+    for (int step = 0; step < NDF_PROBE_STEPS; ++step) {
+        bool act = walking && !exhausted;
+        if (act && y >= x) { exhausted = 1; act = false; }
+        if (!__ballot(act)) break;
+        u32 j = 0, sj = 2;
+        bool is_near = false, want = false;
+        if (act) {
+            j = vals[y];                             // j < i: stable sort keeps indices ascending in a run
+            sj = st[j];
+            if (sj != 2) {
+                is_near = near_known;
+                want = !is_near && fam.same_bucket(t, i, j) && !fam.owned_earlier(t, i, j);
+            }
+        }
+        // the tables in order: nothing beyond the first table with a known blocker needs a comparison
+        const unsigned long long kb = __ballot(is_near);
+        const unsigned long long below = kb ? ((1ull << (__ffsll((long long)kb) - 1)) - 1ull) : ~0ull;
+        unsigned long long wb = __ballot(want) & below;
+        int hit = -1;
+        if (wb) {
+            if (staged) {
+                u32 ncmp = 0;
+                hit = fam.wave64_first_near(i, wb, j, scratch, lane, ncmp);
+                compared += ncmp;
+                found += (hit >= 0 && lane == 0) ? 1u : 0u;
+            } else {
+                const bool mine = (wb >> lane) & 1ull;
+                const bool r = mine ? fam.near(t, i, j) : false;
+                if (mine) { ++compared; found += r ? 1u : 0u; }
+                const unsigned long long m = __ballot(r);
+                if (m) hit = __ffsll((long long)m) - 1;
+            }
+        }
+        const int known = kb ? __ffsll((long long)kb) - 1 : 64;
+        const int decisive = hit >= 0 ? hit : known;          // (hit < known by construction)
+        if (decisive < 64) {
+            // the lanes before it looked at a mate that is not near (or dropped): on; the decisive lane remembers its mate
+            if (act && (int)lane < decisive) { ++y; near_known = false; }
+            if ((int)lane == decisive) near_known = true;
+            const u32 dsj = __shfl(sj, decisive, WAVE);
+            blocker = __shfl(j, decisive, WAVE);
+            outcome = dsj == 1u ? 2u : 3u;
+            break;
+        }
+        if (act) { ++y; near_known = false; }
+    }
+    if (walking && !exhausted && y >= x) exhausted = 1;      // (also when the probe parks: a cursor at its own slot MEANS ran out, and is counted)
+    if (outcome == 2u) {
+        if (lane == 0) status[i] = 2;
+    } else {
+        // cursors back; the tables that ran out are counted; the probe parks, or its unfinished walks are queued
+        const unsigned long long eb = __ballot(exhausted != 0u);
+        if (walking) cursor_all[(size_t)i * TS + t] = exhausted ? x : (y | (near_known ? NDF_CUR_NEAR : 0u));
+        if (outcome == 3u) {
+            if (lane == 0) flags[i] = blocker;       // (this wavefront is the only one that walks probe i in this launch)
+        } else if (Q.dq) {
+            const bool deferred = walking && !exhausted;
+            const unsigned long long db = __ballot(deferred);
+            if (db) {
+                const u32 shard = wave_id & (ES_SHARDS - 1u);
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(&Q.dq_count[shard * ES_STRIDE], (u32)__popcll(db));
+                base = __shfl(base, 0, WAVE);
+                if (deferred) Q.dq[(size_t)shard * Q.segcap + base + (u32)__popcll(db & ((1ull << lane) - 1ull))] = t * nslot + x;
+            }
+        }
+        if (eb && lane == 0) {
+            const u32 c = (u32)__popcll(eb);
+            if (atomicSub(&left[i], c) == c) atomicCAS(&status[i], 0u, 1u);      // the last tables: nobody kept is near -- kept
+        }
+    }
+    if (__ballot(compared != 0u)) {
+        for (int o = 32; o > 0; o >>= 1) { compared += __shfl_xor(compared, o, WAVE); found += __shfl_xor(found, o, WAVE); }
+        if (lane == 0) {
+            atomicAdd(&pairs[wave_id & (ES_SHARDS - 1)], (unsigned long long)compared);
+            if (found) atomicAdd(&pairs[ES_SHARDS + (wave_id & (ES_SHARDS - 1))], (unsigned long long)found);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 ndf_fill_u32_kernel(u32 *__restrict__ p, u32 n, u32 v) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -476,11 +590,11 @@ ndf_fill_u32_kernel(u32 *__restrict__ p, u32 n, u32 v) {
 }
 // inv[table][probe] = the probe's slot in that table's sorted order
 __global__ void __launch_bounds__(256)
-ndf_inv_kernel(const u32 *__restrict__ vals_all, u32 n, u32 nslot, size_t tn, u32 *__restrict__ inv) {
+ndf_inv_kernel(const u32 *__restrict__ vals_all, u32 TS, u32 nslot, size_t tn, u32 *__restrict__ inv) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= tn) return;
     const size_t t = e / nslot;
-    inv[t * n + vals_all[e]] = (u32)(e - t * nslot);
+    inv[(size_t)vals_all[e] * TS + t] = (u32)(e - t * nslot);
 }
 // Compaction of the tables (WAKE): the slots of dropped probes go.  Every table holds every probe once, so all
 // tables keep the same number of slots, and a probe deep in a run of thousands of near-identical strains -- all
@@ -496,10 +610,9 @@ ndf_cflag_kernel(const u32 *__restrict__ vals_all, const u32 *__restrict__ statu
     else if (e == tn) flag[e] = 0u;
 }
 __global__ void __launch_bounds__(256)
-ndf_compact_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ cursor,
+ndf_compact_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u32 *__restrict__ cursor, u32 TS,
                    const u32 *__restrict__ flag, const u32 *__restrict__ pos, u32 nslot, u32 nslot_new, size_t tn,
-                   u64 *__restrict__ keys2, u32 *__restrict__ vals2, u32 *__restrict__ cursor2, u32 *status, u32 *__restrict__ left,
-                   unsigned long long *__restrict__ live) {
+                   u64 *__restrict__ keys2, u32 *__restrict__ vals2, u32 *status, u32 *__restrict__ left) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= tn || !flag[e]) return;
     const u32 t = (u32)(e / nslot), x = (u32)(e - (size_t)t * nslot);
@@ -507,7 +620,7 @@ ndf_compact_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, c
     const u32 i = vals[e];
     keys2[e2] = keys[e];
     vals2[e2] = i;
-    u32 cur = cursor[e];
+    u32 cur = cursor[(size_t)i * TS + t];                    // (probe-major: renumbered in place)
     if (cur == x) cur = x2;                                  // exhausted before (and counted)
     else if (cur != NDF_CUR_NONE) {
         const u32 y = cur & ~NDF_CUR_NEAR;
@@ -515,11 +628,10 @@ ndf_compact_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, c
         const u32 y2 = pos[ey] - t * nslot_new;              // the first surviving mate at or after y
         if (y2 >= x2) {
             cur = x2;                                        // only dropped mates were left: this table is done with i
-            if (live) atomicAnd(&live[i], ~(1ull << t));
             if (atomicSub(&left[i], 1u) == 1u) atomicCAS(&status[i], 0u, 1u);
         } else cur = y2 | (((cur & NDF_CUR_NEAR) && flag[ey]) ? NDF_CUR_NEAR : 0u);
     }
-    cursor2[e2] = cur;
+    cursor[(size_t)i * TS + t] = cur;
 }
 
 // after a pass: every undecided probe looks at its blocker; counters[1] = probes listed for the next pass, counters[0] =
@@ -555,57 +667,37 @@ ndf_wake_kernel(u32 *status, u32 *__restrict__ wait_on, u32 n, u32 *__restrict__
     if (woken) next[s_base + s_cnt[wv] + (u32)__popcll(wb & ((1ull << lane) - 1ull))] = i;
 }
 
-// the same with live tables: a woken probe goes into the list of every table that has not run out for it
-// (tlist[t * n ..), tcount[t * ES_STRIDE] entries; one atomic per workgroup and table)
-__global__ void __launch_bounds__(1024)
-ndf_wake_live_kernel(u32 *status, u32 *__restrict__ wait_on, u32 n, const unsigned long long *__restrict__ live, u32 ntables,
-                     u32 *__restrict__ tlist, u32 *__restrict__ tcount, u32 *__restrict__ counters, int count_undecided) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ u32 s_tc[64][16], s_tbase[64], s_und[16];
-    bool undecided = false, woken = false;
-    if (i < n && status[i] == 0) {
-        const u32 j = wait_on[i];
-        undecided = true;
-        if (j != NDF_CUR_NONE) {
-            const u32 sj = status[j];
-            if (sj == 1) { status[i] = 2; undecided = false; }
-            else if (sj == 2) { wait_on[i] = NDF_CUR_NONE; woken = true; }
-        }
-    }
-    const unsigned long long ub = __ballot(undecided);
-    if (lane == 0) s_und[wv] = (u32)__popcll(ub);
-    const unsigned long long mask = woken ? live[i] : 0ull;
-    const int any = __syncthreads_or(woken ? 1 : 0);
-    if (threadIdx.x == 0) {
-        u32 und = 0;
-        for (u32 w = 0; w < 16; ++w) und += s_und[w];
-        if (und) { if (count_undecided) atomicAdd(&counters[0], und); else if (((volatile u32 *)counters)[0] == 0u) counters[0] = 1u; }
-    }
-    if (!any) return;
-    for (u32 t = 0; t < ntables; ++t) {
-        const unsigned long long b = __ballot((mask >> t) & 1ull);
-        if (lane == 0) s_tc[t][wv] = (u32)__popcll(b);
-    }
-    __syncthreads();
-    if (threadIdx.x < ntables) {
-        const u32 t = threadIdx.x;
-        u32 tot = 0;
-        for (u32 w = 0; w < 16; ++w) { const u32 c = s_tc[t][w]; s_tc[t][w] = tot; tot += c; }
-        s_tbase[t] = tot ? atomicAdd(&tcount[t * ES_STRIDE], tot) : 0u;
-    }
-    __syncthreads();
-    for (u32 t = 0; t < ntables; ++t) {
-        const bool mine = (mask >> t) & 1ull;
-        const unsigned long long b = __ballot(mine);
-        if (mine) tlist[(size_t)t * n + s_tbase[t] + s_tc[t][wv] + (u32)__popcll(b & ((1ull << lane) - 1ull))] = i;
-    }
+// Where the verdicts go (round 5): a host array of bytes (the C-ABI entry points), or 0/1 flags on the device for
+// callers that go on there (the candidates object: no 20-MB read-back and re-upload per call).
+struct NdfKeep { u8 *host; u32 *d_flags; };
+__global__ void __launch_bounds__(256)
+ndf_flags_kernel(const u32 *__restrict__ status, u32 n, u32 *__restrict__ flags, u32 *__restrict__ unresolved) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 st = status[i];
+    flags[i] = st == 1u ? 1u : 0u;
+    if (st == 0u) atomicAdd(unresolved, 1u);
 }
-// counters[0..1] and the tables' counts, side by side for one read-back
-__global__ void __launch_bounds__(64)
-ndf_gather_kernel(const u32 *__restrict__ counters, const u32 *__restrict__ tcount, u32 ntables, u32 *__restrict__ out) {
-    const u32 t = threadIdx.x;
-    if (t < 2) out[t] = counters[t];
-    if (t < ntables) out[2 + t] = tcount[t * ES_STRIDE];
+static int ndf_keep_out(catchhip_ctx *ctx, u32 nn, const u32 *d_status, NdfKeep keep) {
+    hipStream_t s = ctx->stream;
+    if (keep.d_flags) {
+        DevBuf<u32> bad;
+        TRY(bad.alloc(1));
+        HIP_TRY(hipMemsetAsync(bad.p, 0, sizeof(u32), s));
+        hipLaunchKernelGGL(ndf_flags_kernel, dim3((unsigned)div_up(nn, 256)), dim3(256), 0, s, d_status, nn, keep.d_flags, bad.p);
+        HIP_TRY(hipMemcpyAsync(ctx->h_pin, bad.p, sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (*(volatile u32 *)ctx->h_pin) { chip_set_error("ndf: unresolved probe"); return CATCHHIP_EINVAL; }
+        return 0;
+    }
+    std::vector<u32> h_status(nn);
+    HIP_TRY(hipMemcpyAsync(h_status.data(), d_status, sizeof(u32) * nn, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (u32 i = 0; i < nn; ++i) {
+        if (h_status[i] == 0) { chip_set_error("ndf: unresolved probe"); return CATCHHIP_EINVAL; }
+        keep.host[i] = h_status[i] == 1 ? 1 : 0;
+    }
+    return 0;
 }
 
 // what the lazy resolution keeps resident: keys, values, cursors (16 B), the slot of every probe in every table (4 B),
@@ -618,50 +710,60 @@ static bool ndf_lazy_fits(size_t tn) {
     int64_t st[4] = {0, 0, 0, 0};
     (void)catchhip_pool_stats(st);
     const size_t idle = st[2] > 0 ? (size_t)st[2] : 0;
-    return (double)tn * 60.0 + (double)(64u << 20) <= 0.9 * ((double)fr + (double)idle);
+    return (double)tn * 64.0 + (double)(64u << 20) <= 0.9 * ((double)fr + (double)idle);
 }
 
 // the rounds of the lazy resolution and the read-back (both families): launch(list or nullptr, nlist, next,
 // next_count) queues one pass over the listed entries
 // launch(wake, list or nullptr, nlist, next, next_count, left, inv): one pass (polling: over the listed entries;
 // wake-ups: over the tables of the listed probes)
+// probe-major stride of the cursor / slot arrays: a power of two up to 16 tables, then whole cache lines
+static u32 ndf_table_stride(u32 ntables) {
+    if (ntables > 16) return (ntables + 31u) & ~31u;
+    u32 ts = 1;
+    while (ts < ntables) ts <<= 1;
+    return ts;
+}
+
+// launch(wake, list, nlist, next, next_count, left, inv, nslot, Q, mode): mode 0 = one pass of ndf_lazy_kernel (polling:
+// over the listed entries; wake-ups: over the tables of the listed probes), 1 = its drain launch over the queue of
+// deferred walks, 2 = ndf_probe_kernel over the listed probes (nullptr: all of them)
 template <class Launch>
 static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &count, DevBuf<u32> &status, DevBuf<u32> &flags,
-                           DevBuf<u64> &pairs, PhaseTimer &tm, u8 *keep, Launch launch, DevBuf<u64> &skeys, DevBuf<u32> &svals_buf,
+                           DevBuf<u64> &pairs, PhaseTimer &tm, NdfKeep keep, Launch launch, DevBuf<u64> &skeys, DevBuf<u32> &svals_buf,
                            DevBuf<u32> &cursor, u32 ntables) {
     const u32 *svals = svals_buf.p;
     hipStream_t s = ctx->stream;
     const unsigned nb = (unsigned)div_up(nn, 256);
     u32 *undecided = count.p + ES_SHARDS * ES_STRIDE;     // [0] undecided probes, [1] entries / probes listed for the next round
     const bool wake = !chip_test_env("CATCHHIP_NDF_POLL_ROUNDS");
+    const u32 TS = ndf_table_stride(ntables);
     DevBuf<u32> lists[2], inv, left_tables, dq;
     TRY(lists[0].alloc(wake ? (size_t)nn : tn));
     TRY(lists[1].alloc(wake ? (size_t)nn : tn));
-    const bool queued = wake && !chip_test_env("CATCHHIP_NDF_NO_QUEUE");    // (test hook: the walks finished inside their wavefronts)
-    const bool live_lists = wake && ntables <= 64 && !chip_test_env("CATCHHIP_NDF_NO_LIVE_LISTS");
-    DevBuf<u64> live;
-    DevBuf<u32> tlist, tcount, rb;
-    if (live_lists) {
-        TRY(live.alloc(nn)); TRY(tlist.alloc(tn)); TRY(tcount.alloc(64 * ES_STRIDE)); TRY(rb.alloc(2 + 64));
-        HIP_TRY(hipMemsetAsync(live.p, 0xff, sizeof(u64) * nn, s));        // (bits beyond the tables never matter: only listed tables are looked at)
-    }
+    // test hooks: the walks finished inside their wavefronts / the entry-per-thread pass in every round
+    const bool queued = wake && !chip_test_env("CATCHHIP_NDF_NO_QUEUE");
+    const bool probe_pass = queued && ntables <= 64 && !chip_test_env("CATCHHIP_NDF_NO_PROBE_PASS");
+    const bool probe_round0 = probe_pass && chip_test_env("CATCHHIP_NDF_PROBE_ROUND0") != nullptr;
     NdfQueue Q{};
     const u32 dq_segcap = (u32)(tn / ES_SHARDS) + 64u * 2u;      // (wavefronts file round-robin: a shard gets at most its share + one wavefront's)
     DevBuf<u32> dq_count;
     if (queued) { TRY(dq.alloc((size_t)dq_segcap * ES_SHARDS)); TRY(dq_count.alloc(ES_SHARDS * ES_STRIDE)); }
     if (wake) {
-        TRY(inv.alloc(tn));
+        TRY(inv.alloc((size_t)nn * TS));
         TRY(left_tables.alloc(nn));
-        hipLaunchKernelGGL(ndf_inv_kernel, dim3((unsigned)div_up((i64)tn, 256)), dim3(256), 0, s, svals, nn, nn, tn, inv.p);
+        hipLaunchKernelGGL(ndf_inv_kernel, dim3((unsigned)div_up((i64)tn, 256)), dim3(256), 0, s, svals, TS, nn, tn, inv.p);
         HIP_TRY(hipMemsetAsync(flags.p, 0xff, sizeof(u32) * nn, s));       // (flags = wait_on: nobody is parked)
         hipLaunchKernelGGL(ndf_fill_u32_kernel, dim3(nb), dim3(256), 0, s, left_tables.p, nn, ntables);
         tm.launch(2);
+    } else {
+        TRY(inv.alloc(1));
     }
-    u32 left = nn, nlist = (u32)tn, nslot = nn;
+    u32 left = nn, nlist = probe_round0 ? nn : (u32)tn, nslot = nn;
     const bool trace = getenv("CATCHHIP_TIMING") && atoi(getenv("CATCHHIP_TIMING")) > 1;
     const bool compacting = wake && !chip_test_env("CATCHHIP_NDF_NO_COMPACTION");
     DevBuf<u64> skeys2;
-    DevBuf<u32> svals2, cursor2, cflag, cpos, ctmp;
+    DevBuf<u32> svals2, cflag, cpos, ctmp;
     auto t_round = std::chrono::steady_clock::now();
     for (u32 round = 0; left && round <= nn + 1; ++round) {
         // the tables without the dropped probes' slots: before the passes 2, 4, 8, 16, ... if a quarter or more would go
@@ -680,48 +782,34 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
             if ((u64)nslot2 * 4 <= (u64)nslot * 3) {
                 TRY(skeys2.reserve(tcur));
                 TRY(svals2.reserve(tcur));
-                TRY(cursor2.reserve(tcur));
                 hipLaunchKernelGGL(ndf_compact_kernel, dim3((unsigned)div_up((i64)tcur, 256)), dim3(256), 0, s, (const u64 *)skeys.p,
-                                   (const u32 *)svals_buf.p, (const u32 *)cursor.p, (const u32 *)cflag.p, (const u32 *)cpos.p, nslot, nslot2,
-                                   tcur, skeys2.p, svals2.p, cursor2.p, status.p, left_tables.p, (unsigned long long *)live.p);
-                skeys.swap(skeys2); svals_buf.swap(svals2); cursor.swap(cursor2);
+                                   (const u32 *)svals_buf.p, cursor.p, TS, (const u32 *)cflag.p, (const u32 *)cpos.p, nslot, nslot2,
+                                   tcur, skeys2.p, svals2.p, status.p, left_tables.p);
+                skeys.swap(skeys2); svals_buf.swap(svals2);
                 nslot = nslot2;
                 if (nslot)
                     hipLaunchKernelGGL(ndf_inv_kernel, dim3((unsigned)div_up((i64)ntables * nslot, 256)), dim3(256), 0, s,
-                                       (const u32 *)svals_buf.p, nn, nslot, (size_t)ntables * nslot, inv.p);
+                                       (const u32 *)svals_buf.p, TS, nslot, (size_t)ntables * nslot, inv.p);
                 tm.launch(4);
             }
         }
         HIP_TRY(hipMemsetAsync(undecided, 0, 2 * sizeof(u32), s));
         if (queued) HIP_TRY(hipMemsetAsync(dq_count.p, 0, sizeof(u32) * ES_SHARDS * ES_STRIDE, s));
         Q.dq = queued ? dq.p : (u32 *)nullptr; Q.dq_count = dq_count.p; Q.segcap = dq_segcap;
-        Q.live = live_lists ? (unsigned long long *)live.p : (unsigned long long *)nullptr;
         if (nlist) {
-            const u32 *cur_list = !round ? (const u32 *)nullptr : live_lists ? (const u32 *)tlist.p : (const u32 *)lists[round & 1].p;
-            launch(wake, cur_list, nlist, lists[(round & 1) ^ 1].p, undecided + 1, left_tables.p, (const u32 *)inv.p, nslot, Q, false);
+            const u32 *cur_list = round ? (const u32 *)lists[round & 1].p : (const u32 *)nullptr;
+            const int mode = (probe_pass && (round || probe_round0)) ? 2 : 0;
+            launch(wake, cur_list, nlist, lists[(round & 1) ^ 1].p, undecided + 1, left_tables.p, (const u32 *)inv.p, nslot, Q, mode);
             if (queued) {
-                launch(wake, cur_list, nlist, lists[(round & 1) ^ 1].p, undecided + 1, left_tables.p, (const u32 *)inv.p, nslot, Q, true);
+                launch(wake, cur_list, nlist, lists[(round & 1) ^ 1].p, undecided + 1, left_tables.p, (const u32 *)inv.p, nslot, Q, 1);
                 tm.launch(1);
             }
         }
-        if (live_lists) {       // (the pass has read its lists: the same buffer takes the next ones)
-            HIP_TRY(hipMemsetAsync(tcount.p, 0, sizeof(u32) * 64 * ES_STRIDE, s));
-            hipLaunchKernelGGL(ndf_wake_live_kernel, dim3((unsigned)div_up(nn, 1024)), dim3(1024), 0, s, status.p, flags.p, nn,
-                               (const unsigned long long *)live.p, ntables, tlist.p, tcount.p, undecided, trace ? 1 : 0);
-            hipLaunchKernelGGL(ndf_gather_kernel, dim3(1), dim3(64), 0, s, (const u32 *)undecided, (const u32 *)tcount.p, ntables, rb.p);
-            tm.launch(1);
-        } else if (wake) hipLaunchKernelGGL(ndf_wake_kernel, dim3((unsigned)div_up(nn, 1024)), dim3(1024), 0, s, status.p, flags.p, nn, lists[(round & 1) ^ 1].p, undecided, trace ? 1 : 0);
+        if (wake) hipLaunchKernelGGL(ndf_wake_kernel, dim3((unsigned)div_up(nn, 1024)), dim3(1024), 0, s, status.p, flags.p, nn, lists[(round & 1) ^ 1].p, undecided, trace ? 1 : 0);
         else hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, undecided);
         tm.launch(2);
-        if (live_lists) HIP_TRY(hipMemcpyAsync(ctx->h_pin, rb.p, (2 + ntables) * sizeof(u32), hipMemcpyDeviceToHost, s));
-        else HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (live_lists) {       // entries of the next pass: the tables' lists one after the other
-            u32 tot = 0;
-            for (u32 t = 0; t < ntables; ++t) { Q.toff[t] = tot; tot += ((volatile u32 *)ctx->h_pin)[2 + t]; }
-            for (u32 t = ntables; t <= 64; ++t) Q.toff[t] = tot;
-            ((volatile u32 *)ctx->h_pin)[1] = tot;
-        }
         if (trace) {
             const auto t1 = std::chrono::steady_clock::now();
             u64 hp[2 * ES_SHARDS], cmp = 0;
@@ -732,25 +820,22 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
                     std::chrono::duration<double, std::milli>(t1 - t_round).count(), (unsigned long long)cmp);
             t_round = std::chrono::steady_clock::now();
         }
+        const bool idle = wake && !nlist;             // (no pass in this round)
         left = ((volatile u32 *)ctx->h_pin)[0];       // (wake-ups: a flag unless the rounds are traced)
         nlist = ((volatile u32 *)ctx->h_pin)[1];
+        // two rounds in a row without a woken probe: whoever is undecided now neither waits nor walks (a broken invariant)
+        if (idle && left && !nlist) { chip_set_error("ndf: undecided probes that nobody will wake"); return CATCHHIP_EINVAL; }
     }
     HIP_TRY(hipGetLastError());
     if (left) { chip_set_error("ndf: %u probes undecided after %u rounds", left, nn + 2); return CATCHHIP_EINVAL; }
     tm.stop();
-    std::vector<u32> h_status(nn);
     std::vector<u64> h_pairs(2 * ES_SHARDS);
-    HIP_TRY(hipMemcpyAsync(h_status.data(), status.p, sizeof(u32) * nn, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(h_pairs.data(), pairs.p, sizeof(u64) * 2 * ES_SHARDS, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     tm.finish();
     // pairs compared / of them near (the all-pairs variant reports the length of its edge list there)
     for (int sh = 0; sh < ES_SHARDS; ++sh) { ctx->ndf_counters[2] += (i64)h_pairs[sh]; ctx->ndf_counters[3] += (i64)h_pairs[ES_SHARDS + sh]; }
-    for (u32 i = 0; i < nn; ++i) {
-        if (h_status[i] == 0) { chip_set_error("ndf: unresolved probe"); return CATCHHIP_EINVAL; }
-        keep[i] = h_status[i] == 1 ? 1 : 0;
-    }
-    return 0;
+    return ndf_keep_out(ctx, nn, status.p, keep);
 }
 
 // greedy resolution rounds over the edge list + read-back (shared by the two
@@ -776,7 +861,7 @@ static int ndf_fullest_shard(catchhip_ctx *ctx, const u32 *count, u32 *out) {
 
 // segused: edges in the fullest shard (the round kernel only looks at that many slots per shard)
 static int ndf_resolve(catchhip_ctx *ctx, u32 nn, u32 segused, u32 segcap, DevBuf<u32> &e_i, DevBuf<u32> &e_j,
-                       DevBuf<u32> &count, DevBuf<u32> &status, DevBuf<u32> &flags, PhaseTimer &tm, u8 *keep) {
+                       DevBuf<u32> &count, DevBuf<u32> &status, DevBuf<u32> &flags, PhaseTimer &tm, NdfKeep keep) {
     hipStream_t s = ctx->stream;
     const unsigned nb = (unsigned)div_up(nn, 256);
     u32 *undecided = count.p + ES_SHARDS * ES_STRIDE;
@@ -793,25 +878,20 @@ static int ndf_resolve(catchhip_ctx *ctx, u32 nn, u32 segused, u32 segcap, DevBu
         if (*(volatile u32 *)ctx->h_pin == 0) break;
     }
     tm.stop();
-    std::vector<u32> h_status(nn);
-    HIP_TRY(hipMemcpyAsync(h_status.data(), status.p, sizeof(u32) * nn, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     tm.finish();
-    for (u32 i = 0; i < nn; ++i) {
-        if (h_status[i] == 0) { chip_set_error("ndf: unresolved probe"); return CATCHHIP_EINVAL; }
-        keep[i] = h_status[i] == 1 ? 1 : 0;
-    }
-    return 0;
+    return ndf_keep_out(ctx, nn, status.p, keep);
 }
 
 // the filter on probes whose characters are already on the device (n rows of L)
 // d_grp / ngroups: optional group of every row (device array); positions is then
 // [ngroups][ntables][k], every group with its own sampled positions
 int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, const i32 *positions, i32 ntables,
-                            i32 k, i32 dist_thres, u8 *keep, const u32 *d_grp, i64 ngroups) {
+                            i32 k, i32 dist_thres, u8 *keep_host, const u32 *d_grp, i64 ngroups, u32 *d_keep_flags) {
     ARG_CHECK(ctx && n >= 0 && L > 0 && ntables >= 1 && k >= 1 && positions);
     if (n == 0) return 0;
-    ARG_CHECK(d_rows && keep);
+    ARG_CHECK(d_rows && (keep_host || d_keep_flags));
+    const NdfKeep keep{keep_host, d_keep_flags};
     ARG_CHECK(n < ((i64)1 << 31) && n * (i64)L < ((i64)1 << 40));
     if (!d_grp) ngroups = 1;
     ARG_CHECK(ngroups >= 1);
@@ -851,9 +931,10 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
         const size_t tn = (size_t)ntables * nn;
         TRY(skeys.alloc(tn));
         TRY(svals.alloc(tn));
-        TRY(cursor.alloc(tn));
+        const u32 TS = ndf_table_stride((u32)ntables);
+        TRY(cursor.alloc((size_t)nn * TS));
         TRY(pairs.alloc(2 * ES_SHARDS));
-        HIP_TRY(hipMemsetAsync(cursor.p, 0xff, sizeof(u32) * tn, s));
+        HIP_TRY(hipMemsetAsync(cursor.p, 0xff, sizeof(u32) * (size_t)nn * TS, s));
         HIP_TRY(hipMemsetAsync(pairs.p, 0, sizeof(u64) * 2 * ES_SHARDS, s));
         for (int t = 0; t < ntables; ++t) {
             hipLaunchKernelGGL(ndf_key_kernel, dim3(nb), dim3(256), 0, s, d_bytes.p, nn, (int)L,
@@ -865,19 +946,23 @@ int chip_ndf_hamming_device(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i32 L, c
         }
         HammingFamily fam{(const u64 *)padded.p, W, (int)dist_thres, (int)k, (const i32 *)d_pos.p, d_grp, pstride, ntables >= 4 ? 1 : 0};
         return ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
-                               [&](bool wake, const u32 *list, u32 nlist, u32 *next, u32 *next_count, u32 *left_tables, const u32 *inv, u32 nslot, NdfQueue Q, bool drain) {
-            if (wake && drain)
-                hipLaunchKernelGGL((ndf_lazy_kernel<HammingFamily, true, true>), dim3(drain ? NDF_DRAIN_BLOCKS : (unsigned)div_up((list && !Q.live) ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
+                               [&](bool wake, const u32 *list, u32 nlist, u32 *next, u32 *next_count, u32 *left_tables, const u32 *inv, u32 nslot, NdfQueue Q, int mode) {
+            if (wake && mode == 2)
+                hipLaunchKernelGGL((ndf_probe_kernel<HammingFamily>), dim3((unsigned)div_up((i64)nlist * 64, 256)), dim3(256), 0, s,
                                    fam, nn, (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, false, Q);
+                                   (unsigned long long *)pairs.p, list, nlist, left_tables, inv, (u32)ntables, nslot, TS, false, Q);
+            else if (wake && mode == 1)
+                hipLaunchKernelGGL((ndf_lazy_kernel<HammingFamily, true, true>), dim3(mode == 1 ? NDF_DRAIN_BLOCKS : (unsigned)div_up(list ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
+                                   fam, nn, (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, TS, false, Q);
                         else if (wake)
-                hipLaunchKernelGGL((ndf_lazy_kernel<HammingFamily, true>), dim3(drain ? NDF_DRAIN_BLOCKS : (unsigned)div_up((list && !Q.live) ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
+                hipLaunchKernelGGL((ndf_lazy_kernel<HammingFamily, true>), dim3(mode == 1 ? NDF_DRAIN_BLOCKS : (unsigned)div_up(list ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
                                    fam, nn, (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, false, Q);
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, TS, false, Q);
             else
                 hipLaunchKernelGGL((ndf_lazy_kernel<HammingFamily, false>), dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s, fam, nn,
                                    (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, false, Q);
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, TS, false, Q);
         }, skeys, svals, cursor, (u32)ntables);
     }
     u32 cap = (u32)std::max<i64>((i64)1 << 14, std::min<i64>(n * 16, (i64)1 << 28) / ES_SHARDS);   // per shard
@@ -917,7 +1002,7 @@ extern "C" int catchhip_ndf_hamming(catchhip_ctx *ctx, const u8 *bytes, i64 n, i
     DevBuf<u8> d_bytes;
     TRY(d_bytes.alloc((size_t)n * L));
     HIP_TRY(hipMemcpyAsync(d_bytes.p, bytes, (size_t)n * L, hipMemcpyHostToDevice, ctx->stream));
-    return chip_ndf_hamming_device(ctx, d_bytes.p, n, L, positions, ntables, k, dist_thres, keep, nullptr, 1);
+    return chip_ndf_hamming_device(ctx, d_bytes.p, n, L, positions, ntables, k, dist_thres, keep, nullptr, 1, nullptr);
 }
 
 // ------------------------------------------------------------------------
@@ -1352,14 +1437,27 @@ struct MinHashFamily {       // same signature in table t (the key only groups),
     }
 };
 
+// off[i] = i * a for i <= n (the offsets of equal-length rows)
+__global__ void __launch_bounds__(256)
+ndf_iota_mul_kernel(u32 *__restrict__ out, u32 n_plus_1, u32 a) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_plus_1) out[i] = i * a;
+}
+
 // bytes_on_device: `bytes` already lives on the device (>= probe_off[n] + 16 bytes allocated)
+// Equal-length rows on the device (round 5: the candidates object's calls; the host arrays of 5 M offsets, k-mer
+// offsets and groups, their loops and their pageable uploads were ~100 ms per call beside ~130 ms of kernels):
+// probe_off == nullptr and equal_len = the row length; the group of every row as a device array (d_grp_dev, or none);
+// the verdicts as flags on the device (keep.d_flags).
 static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off, i64 n, const i64 *group_off,
                             i64 ngroups, i32 kmer_size, const i64 *ab, i32 ntables, i32 k, double dist_thres,
-                            u8 *keep, bool bytes_on_device = false) {
+                            NdfKeep keep, bool bytes_on_device = false, i64 equal_len = 0, const u32 *d_grp_dev = nullptr) {
     ARG_CHECK(ctx && n >= 0 && kmer_size >= 1 && kmer_size <= 16 && ntables >= 1 && k >= 1 && k <= 16 && ab);
     PoolScope pool_scope(ctx);
     if (n == 0) return 0;
-    ARG_CHECK(bytes && probe_off && keep && probe_off[0] == 0);
+    ARG_CHECK(bytes && (keep.host || keep.d_flags));
+    ARG_CHECK(probe_off ? probe_off[0] == 0 : (bytes_on_device && equal_len > 0));
+    ARG_CHECK(!(group_off && d_grp_dev));
     std::vector<u32> h_grp;
     if (group_off) {
         ARG_CHECK(ngroups >= 1 && group_off[0] == 0 && group_off[ngroups] == n);
@@ -1368,26 +1466,44 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
             ARG_CHECK(group_off[g + 1] >= group_off[g]);
             for (i64 i = group_off[g]; i < group_off[g + 1]; ++i) h_grp[(size_t)i] = (u32)g;
         }
+    } else if (d_grp_dev) {
+        ARG_CHECK(ngroups >= 1);
     } else {
         ngroups = 1;
     }
-    ARG_CHECK(n < ((i64)1 << 31) && probe_off[n] < ((i64)1 << 32));
-    std::vector<u32> h_off((size_t)n + 1), h_koff((size_t)n + 1, 0);
-    for (i64 i = 0; i <= n; ++i) h_off[i] = (u32)probe_off[i];
-    for (i64 i = 0; i < n; ++i) {
-        const i64 len = probe_off[i + 1] - probe_off[i];
-        // lsh.py:113 asserts kmer_size <= len(s)
-        if (len < kmer_size) { chip_set_error("ndf minhash: probe %lld shorter than the k-mer size", (long long)i); return CATCHHIP_EINVAL; }
-        const i64 nk = len - kmer_size + 1;
+    const i64 total_bytes = probe_off ? probe_off[n] : n * equal_len;
+    ARG_CHECK(n < ((i64)1 << 31) && total_bytes < ((i64)1 << 32));
+    std::vector<u32> h_off, h_koff;
+    u32 max_nk = 1;
+    size_t nkm = 0;
+    if (probe_off) {
+        h_off.resize((size_t)n + 1);
+        h_koff.assign((size_t)n + 1, 0);
+        for (i64 i = 0; i <= n; ++i) h_off[i] = (u32)probe_off[i];
+        for (i64 i = 0; i < n; ++i) {
+            const i64 len = probe_off[i + 1] - probe_off[i];
+            // lsh.py:113 asserts kmer_size <= len(s)
+            if (len < kmer_size) { chip_set_error("ndf minhash: probe %lld shorter than the k-mer size", (long long)i); return CATCHHIP_EINVAL; }
+            const i64 nk = len - kmer_size + 1;
+            if (nk > MH_MAXK) { chip_set_error("ndf minhash: more than %d k-mers per probe not supported", MH_MAXK); return CATCHHIP_EINVAL; }
+            h_koff[i + 1] = h_koff[i] + (u32)nk;
+            max_nk = std::max(max_nk, (u32)nk);
+        }
+        nkm = h_koff[n];
+    } else {
+        if (equal_len < kmer_size) { chip_set_error("ndf minhash: probes shorter than the k-mer size"); return CATCHHIP_EINVAL; }
+        const i64 nk = equal_len - kmer_size + 1;
         if (nk > MH_MAXK) { chip_set_error("ndf minhash: more than %d k-mers per probe not supported", MH_MAXK); return CATCHHIP_EINVAL; }
-        h_koff[i + 1] = h_koff[i] + (u32)nk;
+        ARG_CHECK(n * nk < ((i64)1 << 32));
+        max_nk = (u32)nk;
+        nkm = (size_t)(n * nk);
     }
     for (i64 t = 0; t < ngroups * (i64)ntables * k; ++t)
         ARG_CHECK(ab[2 * t] >= 1 && ab[2 * t] <= (i64)MH_P && ab[2 * t + 1] >= 0 && ab[2 * t + 1] <= (i64)MH_P);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const u32 nn = (u32)n;
-    const size_t total = (size_t)probe_off[n], nkm = h_koff[n];
+    const size_t total = (size_t)total_bytes;
     DevBuf<u8> d_bytes_own;
     DevBuf<u64> d_ab, keys, keys_alt, id_hi, id_lo;
     DevBuf<u32> d_off, d_koff, xs, nuniq, sig, vals, vals_alt, e_i, e_j, count, status, flags, d_grp;
@@ -1438,9 +1554,14 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
     if (!bytes_on_device) HIP_TRY(hipMemcpyAsync(d_bytes_own.p, bytes, total, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_ab.p, ab, sizeof(i64) * (size_t)ngroups * ntables * k * 2, hipMemcpyHostToDevice, s));
     if (group_off) HIP_TRY(hipMemcpyAsync(d_grp.p, h_grp.data(), sizeof(u32) * (size_t)n, hipMemcpyHostToDevice, s));
-    const u32 *grp = group_off ? (const u32 *)d_grp.p : (const u32 *)nullptr;
-    HIP_TRY(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_koff.p, h_koff.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, s));
+    const u32 *grp = group_off ? (const u32 *)d_grp.p : d_grp_dev;
+    if (probe_off) {
+        HIP_TRY(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_koff.p, h_koff.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, s));
+    } else {
+        hipLaunchKernelGGL(ndf_iota_mul_kernel, dim3((unsigned)div_up(n + 1, 256)), dim3(256), 0, s, d_off.p, (u32)n + 1u, (u32)equal_len);
+        hipLaunchKernelGGL(ndf_iota_mul_kernel, dim3((unsigned)div_up(n + 1, 256)), dim3(256), 0, s, d_koff.p, (u32)n + 1u, max_nk);
+    }
     HIP_TRY(hipMemsetAsync(count.p, 0, ES_WORDS * sizeof(u32), s));
     HIP_TRY(hipMemsetAsync(status.p, 0, sizeof(u32) * nn, s));
     HIP_TRY(hipMemsetAsync(flags.p, 0, sizeof(u32) * nn, s));
@@ -1453,8 +1574,6 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
     // CATCHHIP_MH_NO_WAVE64, a test hook, keeps round 4's walks for the equality tests)
     const bool wave64 = lazy && !chip_test_env("CATCHHIP_MH_NO_WAVE64");
     DevBuf<u32> kc, sig0T;
-    u32 max_nk = 1;
-    for (i64 i = 0; i < n; ++i) max_nk = std::max(max_nk, h_koff[i + 1] - h_koff[i]);
     const u32 kstride = (max_nk + 31u) & ~31u, tstride = ((u32)ntables + 3u) & ~3u;
     if (wave64) TRY(kc.alloc((size_t)nn * kstride));
     if (lazy) TRY(sig0T.alloc((size_t)nn * tstride));
@@ -1482,9 +1601,10 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
         lap("k-mers", t_lap);
         TRY(skeys.alloc(tn));
         TRY(svals.alloc(tn));
-        TRY(cursor.alloc(tn));
+        const u32 TS = ndf_table_stride((u32)ntables);
+        TRY(cursor.alloc((size_t)nn * TS));
         TRY(pairs.alloc(2 * ES_SHARDS));
-        HIP_TRY(hipMemsetAsync(cursor.p, 0xff, sizeof(u32) * tn, s));
+        HIP_TRY(hipMemsetAsync(cursor.p, 0xff, sizeof(u32) * (size_t)nn * TS, s));
         HIP_TRY(hipMemsetAsync(pairs.p, 0, sizeof(u64) * 2 * ES_SHARDS, s));
         hipLaunchKernelGGL(mh_keys_all_kernel, dim3((unsigned)div_up((i64)nn * 64, 256)), dim3(256), 0, s,
                            (const u32 *)xs.p, (const u32 *)d_koff.p, nn, (const u64 *)d_ab.p, (int)k, (int)ntables, 0,
@@ -1504,19 +1624,23 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
                           chip_test_env("CATCHHIP_NDF_WAVE_NEAR_MAX") ? atoi(chip_test_env("CATCHHIP_NDF_WAVE_NEAR_MAX")) : NDF_WAVE_NEAR_MAX,
                           (const u32 *)kc.p, kstride, (const u32 *)sig0T.p, tstride};
         const int rc = ndf_lazy_rounds(ctx, nn, tn, count, status, flags, pairs, tm, keep,
-                                       [&](bool wake, const u32 *list, u32 nlist, u32 *next, u32 *next_count, u32 *left_tables, const u32 *inv, u32 nslot, NdfQueue Q, bool drain) {
-            if (wake && drain)
-                hipLaunchKernelGGL((ndf_lazy_kernel<MinHashFamily, true, true>), dim3(drain ? NDF_DRAIN_BLOCKS : (unsigned)div_up((list && !Q.live) ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
+                                       [&](bool wake, const u32 *list, u32 nlist, u32 *next, u32 *next_count, u32 *left_tables, const u32 *inv, u32 nslot, NdfQueue Q, int mode) {
+            if (wake && mode == 2)
+                hipLaunchKernelGGL((ndf_probe_kernel<MinHashFamily>), dim3((unsigned)div_up((i64)nlist * 64, 256)), dim3(256), 0, s,
                                    fam, nn, (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, wave64, Q);
+                                   (unsigned long long *)pairs.p, list, nlist, left_tables, inv, (u32)ntables, nslot, TS, wave64, Q);
+            else if (wake && mode == 1)
+                hipLaunchKernelGGL((ndf_lazy_kernel<MinHashFamily, true, true>), dim3(mode == 1 ? NDF_DRAIN_BLOCKS : (unsigned)div_up(list ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
+                                   fam, nn, (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, TS, wave64, Q);
                         else if (wake)
-                hipLaunchKernelGGL((ndf_lazy_kernel<MinHashFamily, true>), dim3(drain ? NDF_DRAIN_BLOCKS : (unsigned)div_up((list && !Q.live) ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
+                hipLaunchKernelGGL((ndf_lazy_kernel<MinHashFamily, true>), dim3(mode == 1 ? NDF_DRAIN_BLOCKS : (unsigned)div_up(list ? (i64)nlist * ntables : (i64)nlist, 256)), dim3(256), 0, s,
                                    fam, nn, (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, wave64, Q);
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, TS, wave64, Q);
             else
                 hipLaunchKernelGGL((ndf_lazy_kernel<MinHashFamily, false>), dim3((unsigned)div_up((i64)nlist, 256)), dim3(256), 0, s, fam, nn,
                                    (const u64 *)skeys.p, (const u32 *)svals.p, cursor.p, status.p, flags.p,
-                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, wave64, Q);
+                                   (unsigned long long *)pairs.p, list, nlist, next, next_count, left_tables, inv, (u32)ntables, nslot, TS, wave64, Q);
         }, skeys, svals, cursor, (u32)ntables);
         lap("rounds", t_lap);
         return rc;
@@ -1557,21 +1681,31 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
 
 extern "C" int catchhip_ndf_minhash(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off, i64 n, i32 kmer_size,
                                     const i64 *ab, i32 ntables, i32 k, double dist_thres, u8 *keep) {
-    return ndf_minhash_impl(ctx, bytes, probe_off, n, nullptr, 1, kmer_size, ab, ntables, k, dist_thres, keep);
+    ARG_CHECK(keep || n == 0);
+    return ndf_minhash_impl(ctx, bytes, probe_off, n, nullptr, 1, kmer_size, ab, ntables, k, dist_thres, NdfKeep{keep, nullptr});
 }
 
 extern "C" int catchhip_ndf_minhash_many(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe_off, i64 n,
                                          const i64 *group_off, i64 ngroups, i32 kmer_size, const i64 *ab,
                                          i32 ntables, i32 k, double dist_thres, u8 *keep) {
     ARG_CHECK(group_off && ngroups >= 1);
+    ARG_CHECK(keep || n == 0);
     return ndf_minhash_impl(ctx, bytes, probe_off, n, group_off, ngroups, kmer_size, ab, ntables, k, dist_thres,
-                            keep);
+                            NdfKeep{keep, nullptr});
 }
 
 // the MinHash filter on probes whose characters are already on the device
 int chip_ndf_minhash_device(catchhip_ctx *ctx, const u8 *d_rows, const i64 *probe_off, i64 n, const i64 *group_off,
                             i64 ngroups, i32 kmer_size, const i64 *ab, i32 ntables, i32 k, double dist_thres,
                             u8 *keep) {
-    return ndf_minhash_impl(ctx, d_rows, probe_off, n, group_off, ngroups, kmer_size, ab, ntables, k, dist_thres, keep,
-                            true);
+    ARG_CHECK(keep || n == 0);
+    return ndf_minhash_impl(ctx, d_rows, probe_off, n, group_off, ngroups, kmer_size, ab, ntables, k, dist_thres,
+                            NdfKeep{keep, nullptr}, true);
+}
+// the same on n rows of L characters, groups (if any) and verdicts on the device: d_keep_flags[i] = 1 kept, 0 dropped
+int chip_ndf_minhash_rows(catchhip_ctx *ctx, const u8 *d_rows, i64 n, i64 L, const u32 *d_grp, i64 ngroups, i32 kmer_size,
+                          const i64 *ab, i32 ntables, i32 k, double dist_thres, u32 *d_keep_flags) {
+    ARG_CHECK(d_keep_flags || n == 0);
+    return ndf_minhash_impl(ctx, d_rows, nullptr, n, nullptr, d_grp ? ngroups : 1, kmer_size, ab, ntables, k, dist_thres,
+                            NdfKeep{nullptr, d_keep_flags}, true, L, d_grp);
 }

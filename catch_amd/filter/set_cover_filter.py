@@ -819,6 +819,8 @@ class SetCoverFilter(BaseFilter):
 
         import time as _time
         stage_s = dict(pack_s=0.0, candidates_s=0.0, near_duplicates_s=0.0, anchors_s=0.0, solve_s=0.0)
+        events = []      # (stage, chunk number, start, end) in seconds since the call began: the pipeline's timeline
+        t_call = _time.perf_counter()
 
         # The front end runs on `workers` threads, each with its own stream (two; test hook CATCHHIP_FRONT_END_WORKERS; the
         # MinHash filter is ~45 dependent rounds of mostly small launches per chunk, 5.3 of the 6.8 s of
@@ -860,6 +862,7 @@ class SetCoverFilter(BaseFilter):
                 stage_s["pack_s"] += t1 - t0
                 stage_s["candidates_s"] += t2 - t1
                 stage_s["near_duplicates_s"] += t3 - t2
+                events.append(("front", chunk_no[id(chunk)], t0 - t_call, t3 - t_call))
             except BaseException:
                 for h in (cands, targets):
                     if h is not None:
@@ -876,6 +879,7 @@ class SetCoverFilter(BaseFilter):
             got = probe.anchor_entries_equal_length(n, probe_length, self.mismatches, self.lcf_thres,
                                                     min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
             stage_s["anchors_s"] += _time.perf_counter() - t0
+            events.append(("anchors", len(events), t0 - t_call, _time.perf_counter() - t_call))
             return got
 
         # Three stages since round 4 (depth >= 2): front end of chunk i + 2 | anchors of chunk i + 1 | scan and solve
@@ -919,6 +923,7 @@ class SetCoverFilter(BaseFilter):
                         self.island_of_exact_match, self.cover_extension, cands.n,
                         None, universe_p, self.scan_mode, as_array=True)
                     stage_s["solve_s"] += _time.perf_counter() - t0
+                    events.append(("solve", chunk_no[id(chunk)], t0 - t_call, _time.perf_counter() - t_call))
                     # candidate-probe x target-bp of the chunk: every cluster's own candidates x its bases
                     per_group = np.bincount(cands.groups(), minlength=len(chunk)) if cands.n else np.zeros(len(chunk), np.int64)
                     gbases = np.array([sum(g.size() for g in target_genomes_grouped[gi]) for gi in chunk], dtype=np.float64)
@@ -937,11 +942,13 @@ class SetCoverFilter(BaseFilter):
                         if h is not None:
                             h.close()
                 _accumulate(timings, ctx, nrows, int(ids.size))
+                events.append(("out", chunk_no[id(chunk)], events[-1][3] if events else 0.0, _time.perf_counter() - t_call))
         finally:
             for p in (pre2, pre):
                 if p is not None:
                     p.close()
         timings.update(stage_s)
+        timings["pipe_events"] = events
         self.last_timings = timings
         return out
 

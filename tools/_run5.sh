@@ -1,3 +1,2 @@
-export CATCHHIP_TEST_HOOKS=1
-python tools/s5_time.py 1.0 "CATCHHIP_FRONT_END_WORKERS=3" "CATCHHIP_FRONT_END_WORKERS=4" "CATCHHIP_FRONT_END_WORKERS=6" 2>&1 | tail -3
-nproc
+export CATCHHIP_TEST_HOOKS=1 S5_TIME_EVENTS=1
+python tools/s5_time.py 1.0 "" 2>&1 | tail -62
