@@ -171,6 +171,8 @@ PROTOTYPES = {
     "catchhip_candidates_groups": (ctypes.c_int, [c_vp, c_vp, c_i32p]),
     "catchhip_probes_from_candidates": (ctypes.c_int, [
         c_vp, c_vp, c_i32p, c_i32p, ctypes.c_int64, ctypes.c_int32, c_vpp]),
+    "catchhip_probes_from_candidates_draws": (ctypes.c_int, [
+        c_vp, c_vp, c_u8p, ctypes.c_int32, ctypes.c_int32, c_vpp]),
     "catchhip_adapter_votes": (ctypes.c_int, [
         c_vp, c_vp, ctypes.c_int64, c_i64p, c_i64p, c_i64p]),
     "catchhip_rows_stats": (ctypes.c_int, [

@@ -797,8 +797,44 @@ extern "C" int catchhip_candidates_groups(catchhip_ctx *ctx, const catchhip_cand
     return 0;
 }
 
-extern "C" int catchhip_probes_from_candidates(catchhip_ctx *ctx, const catchhip_candidates *C, const i32 *ent_probe,
-                                               const i32 *ent_pos, i64 nent, i32 k, catchhip_probes **out) {
+// Random anchors from their DRAWS (round 5): draws[probe][m] = the m positions np.random drew for the probe
+// (catch/probe.py:356-405: 20 per probe, repeats allowed).  The table is the sorted distinct positions of every probe --
+// a 256-bit set per probe on the device instead of a NumPy row sort, boolean masks and 8-byte entries on the host
+// (3.5 x the time of the draws themselves, and 570 MB of pageable uploads per 2 M probes).
+__global__ void __launch_bounds__(256)
+cand_draws_count_kernel(const u8 *__restrict__ draws, u32 n, u32 m, u32 *__restrict__ cnt) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    u32 c = 0;
+    if (i < n) {
+        u64 b[4] = {0, 0, 0, 0};
+        for (u32 q = 0; q < m; ++q) { const u32 v = draws[(size_t)i * m + q]; b[v >> 6] |= 1ull << (v & 63u); }
+        c = (u32)(__popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]));
+    }
+    cnt[i] = c;       // (entry n: the sentinel of the prefix sum)
+}
+__global__ void __launch_bounds__(256)
+cand_draws_fill_kernel(const u8 *__restrict__ draws, u32 n, u32 m, const u32 *__restrict__ ptr, i32 *__restrict__ ent_probe,
+                       i32 *__restrict__ ent_pos, u32 *__restrict__ sent_probe, u32 *__restrict__ sent_pos) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 b[4] = {0, 0, 0, 0};
+    for (u32 q = 0; q < m; ++q) { const u32 v = draws[(size_t)i * m + q]; b[v >> 6] |= 1ull << (v & 63u); }
+    u32 o = ptr[i];
+    for (u32 w = 0; w < 4; ++w) {
+        u64 x = b[w];
+        while (x) {
+            const u32 v = w * 64u + (u32)(__ffsll((long long)x) - 1);
+            x &= x - 1ull;
+            ent_probe[o] = (i32)i; ent_pos[o] = (i32)v;
+            sent_probe[o] = i; sent_pos[o] = v;
+            ++o;
+        }
+    }
+}
+
+static int probes_from_candidates_impl(catchhip_ctx *ctx, const catchhip_candidates *C, const i32 *ent_probe,
+                                       const i32 *ent_pos, i64 nent, i32 k, catchhip_probes **out, const u8 *draws, i32 m) {
     ARG_CHECK(ctx && C && C->ctx == ctx && out && k > 0 && k <= C->L);
     ARG_CHECK((ent_probe == nullptr) == (ent_pos == nullptr));
     PoolScope pool_scope(ctx);
@@ -806,8 +842,25 @@ extern "C" int catchhip_probes_from_candidates(catchhip_ctx *ctx, const catchhip
     HIP_TRY(hipSetDevice(ctx->device));
     const i64 n = C->nuniq, L = C->L;
     ARG_CHECK(n * L < ((i64)1 << 31));
-    const bool pigeon = ent_probe == nullptr;
-    if (pigeon) {
+    const bool pigeon = ent_probe == nullptr && draws == nullptr;
+    DevBuf<u8> d_draws;
+    DevBuf<u32> d_cnt, d_ptr, d_tmp;
+    if (draws) {
+        // the anchors' count first (the probes object is sized by it): distinct draws per probe, prefix sum
+        ARG_CHECK(m >= 1 && L - k + 1 <= 256 && n * (i64)m < ((i64)1 << 32));
+        for (i64 e = 0; e < n * m; ++e) ARG_CHECK((i64)draws[e] + k <= L);
+        TRY(d_draws.alloc((size_t)(n * m) + 1));
+        TRY(d_cnt.alloc((size_t)n + 1));
+        TRY(chip_pinned_reserve(ctx, (size_t)(n * m) + 1));
+        memcpy(ctx->h_big, draws, (size_t)(n * m));
+        HIP_TRY(hipMemcpyAsync(d_draws.p, ctx->h_big, (size_t)(n * m), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(cand_draws_count_kernel, dim3((unsigned)div_up(n + 1, 256)), dim3(256), 0, ctx->stream,
+                           (const u8 *)d_draws.p, (u32)n, (u32)m, d_cnt.p);
+        TRY(cand_scan(ctx, d_cnt, d_ptr, n + 1, d_tmp));
+        u32 total_ent = 0;
+        TRY(cand_read_u32(ctx, d_ptr.p + n, &total_ent));
+        nent = total_ent;
+    } else if (pigeon) {
         ARG_CHECK(L % k == 0);
         nent = n * (L / k);
     } else {
@@ -847,7 +900,17 @@ extern "C" int catchhip_probes_from_candidates(catchhip_ctx *ctx, const catchhip
                            s, (const u8 *)C->T->bytes.p, (const u32 *)C->upos.p, (u32)n, (u32)L, p->bytes.p,
                            p->probe_off.p, p->set_id.p, p->bucket_of.p, p->bucket_set.p);
         p->bucket_identity = true;
-        if (pigeon) {
+        if (draws) {
+            p->pigeonhole = false;
+            if (n) {
+                hipLaunchKernelGGL(cand_draws_fill_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, s, (const u8 *)d_draws.p,
+                                   (u32)n, (u32)m, (const u32 *)d_ptr.p, p->ent_probe.p, p->ent_pos.p, p->sent_probe.p, p->sent_pos.p);
+            }
+            if (hipMemcpyAsync(p->ent_ptr.p, d_ptr.p, sizeof(u32) * ((size_t)n + 1), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                rc = CATCHHIP_EHIP;
+                break;
+            }
+        } else if (pigeon) {
             const u32 nanch = (u32)(L / k);
             p->pigeonhole = n > 0;
             hipLaunchKernelGGL(cand_pigeon_kernel, dim3((unsigned)div_up(std::max<i64>(nent, n + 1), 256)), dim3(256), 0,
@@ -897,4 +960,16 @@ extern "C" int catchhip_probes_from_candidates(catchhip_ctx *ctx, const catchhip
     if (rc) { delete p; return rc; }
     *out = p;
     return 0;
+}
+
+extern "C" int catchhip_probes_from_candidates(catchhip_ctx *ctx, const catchhip_candidates *C, const i32 *ent_probe,
+                                               const i32 *ent_pos, i64 nent, i32 k, catchhip_probes **out) {
+    return probes_from_candidates_impl(ctx, C, ent_probe, ent_pos, nent, k, out, nullptr, 0);
+}
+
+extern "C" int catchhip_probes_from_candidates_draws(catchhip_ctx *ctx, const catchhip_candidates *C, const u8 *draws,
+                                                     i32 draws_per_probe, i32 k, catchhip_probes **out) {
+    ARG_CHECK(draws || (C && C->nuniq == 0));
+    if (!draws) return probes_from_candidates_impl(ctx, C, nullptr, nullptr, 0, k, out, (const u8 *)"", 1);
+    return probes_from_candidates_impl(ctx, C, nullptr, nullptr, 0, k, out, draws, draws_per_probe);
 }

@@ -468,6 +468,21 @@ class Candidates:
                 int(k), ctypes.byref(p._h)))
         return p
 
+    def probes_from_draws(self, k, draws):
+        """Probes object of the unique candidates with random anchors given as
+        the positions np.random drew (uint8 [n][draws per probe]): the sorted
+        distinct positions of every probe, built on the device."""
+        p = Probes.__new__(Probes)
+        p.ctx, p.n = self.ctx, self.n
+        p._h = ctypes.c_void_p()
+        d = np.ascontiguousarray(draws, dtype=np.uint8)
+        if self.n == 0:
+            d = np.zeros((1, 1), np.uint8)
+        assert d.ndim == 2 and (self.n == 0 or d.shape[0] == self.n)
+        check(self.ctx._L.catchhip_probes_from_candidates_draws(
+            self.ctx._h, self._h, _ptr(d, c_u8p), int(d.shape[1]), int(k), ctypes.byref(p._h)))
+        return p
+
     def close(self):
         if self._h:
             self.ctx._L.catchhip_candidates_destroy(self._h)

@@ -563,10 +563,8 @@ class SetCoverFilter(BaseFilter):
                         near_duplicate_filter._apply_to_grouped_candidates(cands, len(items[gi]))
                     else:
                         near_duplicate_filter._apply_to_candidates(cands)
-                k, ep, eo = probe.anchor_entries_equal_length(
-                    cands.n, probe_length, self.mismatches, self.lcf_thres,
-                    min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
-                probes = cands.probes(k, ep, eo)
+                probes = _probes_of_candidates(cands, _anchors_for_candidates(
+                    cands.n, probe_length, self.mismatches, self.lcf_thres, self.kmer_probe_map_k))
                 made.append(probes)
             except BaseException:
                 for h in reversed(made):
@@ -876,8 +874,7 @@ class SetCoverFilter(BaseFilter):
 
         def anchors(n):
             t0 = _time.perf_counter()
-            got = probe.anchor_entries_equal_length(n, probe_length, self.mismatches, self.lcf_thres,
-                                                    min_k=self.kmer_probe_map_k, k=self.kmer_probe_map_k)
+            got = _anchors_for_candidates(n, probe_length, self.mismatches, self.lcf_thres, self.kmer_probe_map_k)
             stage_s["anchors_s"] += _time.perf_counter() - t0
             events.append(("anchors", len(events), t0 - t_call, _time.perf_counter() - t_call))
             return got
@@ -915,9 +912,9 @@ class SetCoverFilter(BaseFilter):
                                   for p in self._make_universe_p(target_genomes_grouped[gi])]
                     timings["candidates"] += ncand
                     timings["unique_candidates"] += nuniq
-                    k, ep, eo = drawn if drawn is not None else anchors(cands.n)
+                    anch = drawn if drawn is not None else anchors(cands.n)
                     t0 = _time.perf_counter()
-                    probes = cands.probes(k, ep, eo)
+                    probes = _probes_of_candidates(cands, anch)
                     ids, nrows = engine.setcover_filter(
                         ctx, probes, targets, self.mismatches, self.lcf_thres,
                         self.island_of_exact_match, self.cover_extension, cands.n,
@@ -1087,3 +1084,27 @@ def _contexts(n):
             _extra_ctxs[key] = engine.Context(dev)
         out.append(_extra_ctxs[key])
     return out
+
+
+def _anchors_for_candidates(n, probe_length, mismatches, lcf_thres, map_k):
+    """(k, "table" | "draws" | "entries", payload) for the device front end's n
+    equal-length candidates: the pigeonhole table (payload None), random anchors
+    as their np.random draws (the device sorts and de-duplicates them), or -- for
+    probes longer than 256 + k -- as host-made entries.  The same np.random draws
+    in all three forms."""
+    if probe_length - map_k + 1 <= 256:
+        k, draws = probe.anchor_draws_equal_length(n, probe_length, mismatches, lcf_thres,
+                                                   min_k=map_k, k=map_k)
+        return (k, "table", None) if draws is None else (k, "draws", draws)
+    k, ep, eo = probe.anchor_entries_equal_length(n, probe_length, mismatches, lcf_thres,
+                                                  min_k=map_k, k=map_k)
+    return (k, "table", None) if ep is None else (k, "entries", (ep, eo))
+
+
+def _probes_of_candidates(cands, anchors):
+    k, kind, payload = anchors
+    if kind == "draws":
+        return cands.probes_from_draws(k, payload)
+    if kind == "entries":
+        return cands.probes(k, payload[0], payload[1])
+    return cands.probes(k)

@@ -242,3 +242,26 @@ def anchor_entries_equal_length(nprobes, probe_length, mismatches, lcf_thres,
     pos = np.random.randint(0, L - k + 1, size=(nprobes, num_kmers_per_probe))
     ent_probe, ent_pos = _entries_from_draws(np.arange(nprobes, dtype=np.int64), pos)
     return k, ent_probe, ent_pos
+
+
+def anchor_draws_equal_length(nprobes, probe_length, mismatches, lcf_thres,
+                              min_k=20, k=20, num_kmers_per_probe=20):
+    """anchor_entries_equal_length with the random anchors left as their draws:
+    returns (k, draws) with draws = None for the pigeonhole table, else the
+    uint8 array [nprobes][num_kmers_per_probe] of the positions np.random drew
+    (the same call, hence the same stream of draws); the device sorts and
+    de-duplicates them (engine.Candidates.probes_from_draws).  Only for
+    probe_length - k + 1 <= 256 (else use anchor_entries_equal_length)."""
+    L = probe_length
+    use_random = (mismatches is None or lcf_thres is None or lcf_thres < L)
+    if not use_random:
+        kk = pigeonhole_kmer_length(L, mismatches)
+        if kk >= min_k:
+            return kk, None
+    if k > L:
+        raise ValueError("k is larger than the length of a probe")
+    assert L - k + 1 <= 256
+    if nprobes == 0:
+        return k, np.zeros((0, num_kmers_per_probe), np.uint8)
+    pos = np.random.randint(0, L - k + 1, size=(nprobes, num_kmers_per_probe))
+    return k, pos.astype(np.uint8)

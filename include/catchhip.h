@@ -605,6 +605,15 @@ int catchhip_candidates_groups(catchhip_ctx *ctx, const catchhip_candidates *can
 int catchhip_probes_from_candidates(catchhip_ctx *ctx, const catchhip_candidates *cands,
                                     const int32_t *ent_probe, const int32_t *ent_pos,
                                     int64_t nent, int32_t k, catchhip_probes **out);
+/* The same with RANDOM anchors given as their draws (catch/probe.py:356-405:
+ * construct_kmer_probe_map_to_find_probe_covers draws num_kmers_per_probe = 20
+ * positions per probe with np.random, repeats allowed; the map keeps a probe
+ * once per distinct k-mer position): draws[probe][draws_per_probe], one byte
+ * each (probe_length - k + 1 <= 256), in the order np.random.randint made them.
+ * The table is every probe's sorted distinct positions, built on the device. */
+int catchhip_probes_from_candidates_draws(catchhip_ctx *ctx, const catchhip_candidates *cands,
+                                          const uint8_t *draws, int32_t draws_per_probe,
+                                          int32_t k, catchhip_probes **out);
 
 /* Statistics of a row table without fetching it (coverage analysis of large
  * designs, catch/coverage_analysis.py:282-335): per universe total_len = sum of

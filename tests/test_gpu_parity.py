@@ -2245,6 +2245,21 @@ def test_probes_from_device_candidates_scan_like_string_probes(ctx, m, thres):
     ids0, _ = engine.setcover_filter(ctx, p_str, t, m, thres, 0, 30, len(strs))
     ids1, _ = engine.setcover_filter(ctx, p_dev, t, m, thres, 0, 30, len(strs))
     assert list(ids0) == list(ids1)
+    if m != 2:
+        # random anchors handed over as their np.random draws (the device sorts and de-duplicates them): the same
+        # draws, the same table
+        np.random.seed(2)
+        k2, draws = probe.anchor_draws_equal_length(c.n, 100, m, thres)
+        assert k2 == k and draws.dtype == np.uint8 and draws.shape == (c.n, 20)
+        p_drw = c.probes_from_draws(k2, draws)
+        rows = engine.Rows.scan(ctx, p_drw, t, m, thres, 0, 30)
+        assert rows_as_tuples(*rows.fetch()) == outs[0]
+        rows.close()
+        ids2, _ = engine.setcover_filter(ctx, p_drw, t, m, thres, 0, 30, len(strs))
+        assert list(ids2) == list(ids0)
+        p_drw.close()
+        with pytest.raises(ValueError):           # a position beyond the last k-mer of the probe
+            c.probes_from_draws(k2, np.full((c.n, 20), 100 - k2 + 1, np.uint8))
     p_str.close(); p_dev.close(); c.close(); t.close()
 
 
