@@ -576,6 +576,54 @@ def cpu_baseline_s3(ctx, scale=0.03):
                                                  len(kept), cores)), gpu_s, same
 
 
+def cpu_baseline_s5(n_genomes=40):
+    """configs[4]'s filters on the CPU: the oracle's chain (candidate windows -> MinHash near-duplicate filter 0.6 ->
+    set cover with -m 5 -e 50 and 20 random anchors per probe) on the first `n_genomes` genomes of the S5 generator as
+    ONE cluster -- bounded to tens of seconds: the oracle's MinHash filter is the reference's Python loop with the hash
+    in C, ~1 ms per candidate.  The clustering pre-step is not in the sample (the oracle's needs minutes for a few
+    thousand fragments).  The GPU runs the same chain on the same input (same `random` / `np.random` seeds) and must
+    select the same probes."""
+    import random
+    from catch_amd import genome
+    from catch_amd.filter import candidate_probes, near_duplicate_filter, set_cover_filter
+    from oracle import oracle as orc
+    orc.build()
+    genomes = synthetic.dataset("S5", scale=0.002)[0][:n_genomes]
+    seqs = [s for g in genomes for s in g]
+    nbases = sum(len(s) for s in seqs)
+    cores = orc.set_threads(orc.hw_threads())
+    t0 = time.perf_counter()
+    cands = candidate_probes.candidate_strings_from_sequences(seqs, PROBE_LEN, STRIDE)
+    random.seed(21)
+    np.random.seed(22)
+    params = orc.minhash_draw_params(orc.minhash_num_tables(0.6), 3)
+    kept = orc.ndf_minhash(cands, 0.6, params)
+    t1 = time.perf_counter()
+    exp = orc.set_cover_filter([kept], [genomes], 5, PROBE_LEN, coverage=1.0, cover_extension=EXT, lazy=True)[0]
+    el = time.perf_counter() - t0
+    orc.set_threads(1)
+    want = sorted(kept[j] for j in exp)
+    gobjs = [[genome.Genome.from_one_seq(g[0]) for g in genomes]]
+    gpu_s, got = None, None
+    for _ in range(2):          # (the second pass: pools and lazily built tables warm)
+        random.seed(21)
+        np.random.seed(22)
+        ndf = near_duplicate_filter.NearDuplicateFilterWithMinHash(0.6)
+        scf = set_cover_filter.SetCoverFilter(mismatches=5, lcf_thres=PROBE_LEN, coverage=1.0, cover_extension=EXT,
+                                              kmer_probe_map_k=20)
+        t2 = time.perf_counter()
+        got = scf._filter_genomes_device_union(gobjs, PROBE_LEN, STRIDE, None, ndf)
+        gpu_s = time.perf_counter() - t2
+    same = sorted(got[0]) == want
+    units = float(len(kept)) * nbases
+    return dict(value=units / el, unit="probe*bp/s", cores=cores, kind="port", seconds=el, passes=1,
+                ndf_seconds=t1 - t0, set_cover_seconds=el - (t1 - t0),
+                sample="the first %d genomes of the S5 generator (%d bp) as one cluster: %d windows -> %d after the MinHash "
+                       "filter -> %d probes; the oracle's MinHash filter (the reference's Python loop, hash in C, 1 core), "
+                       "scans on %d OpenMP threads, lazy greedy on 1; clustering not in the sample"
+                       % (len(genomes), nbases, len(cands), len(kept), len(exp), cores)), gpu_s, same
+
+
 def m2_passes(groups, steps, warm, depth):
     """SURVEY 8(d) M2 through the plugin: every pass starts from the host's
     sequence strings (nothing resident) and ends with the selected ids on the
@@ -622,6 +670,42 @@ def seed_verify_bytes(seeds, dropped, hits, L=PROBE_LEN):
     entry 4 B, per hit a 16-B record."""
     live = seeds - dropped
     return live * (12 + 0.375 * (L + 32) + 0.375 * L + 4) + 4.0 * dropped + 16.0 * hits
+
+
+def s5_roofline(dom, dms, dbytes, dl, args):
+    """The roofline object of the configs[4] leg for its dominant unit.  HBM: SURVEY 8(d)'s algorithmic bytes over the
+    unit's device time (HIP events on the streams it runs on).  The counters of the committed rocprofv3 passes of this
+    command (profiles/r05_pmc_S5.json, tools/collect_profiles.sh) give the traffic (2 x FETCH_SIZE + WRITE_SIZE per
+    filter call) and, because the near-duplicate filter is neither HBM- nor MFMA-bound, the VALU issue fraction
+    SQ_INSTS_VALU x 4 cycles / (256 CUs x 4 SIMDs x busy cycles) beside it."""
+    def gbs(b, t_ms):
+        return b / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+    roof = dict(bound="hbm", kernel=dom, achieved=gbs(dbytes, dms), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=gbs(dbytes, dms) / HBM_PEAK_GBS, traffic=None,
+                algorithmic_bytes_per_launch=dbytes / max(dl, 1), avg_launch_ms=dms / max(dl, 1),
+                launches_per_step=dl, device_ms_per_step=dms)
+    try:
+        with open(os.path.join(REPO, "profiles", "r05_pmc_%s.json" % args.workload)) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return roof
+    if rec.get("workload") != args.workload or rec.get("scale", 1.0) != args.scale:
+        return roof
+    unit = rec["units"].get("ndf" if dom.startswith("MinHash") else
+                            "join_verify" if "verify" in dom else "rows_build" if "row build" in dom else "solver_round")
+    if unit:
+        per_step = 1.0 / max(rec.get("steps_in_run", 1), 1)
+        tb = (2.0 * unit["FETCH_SIZE_KB"] + unit["WRITE_SIZE_KB"]) * 1024.0 * per_step
+        roof["traffic"] = tb / max(dl, 1)
+        roof["traffic_bytes_per_step"] = tb
+        roof["traffic_source"] = "profiles/r05_pmc_%s.json: (2 x FETCH_SIZE + WRITE_SIZE) of the unit's kernels / steps of the run / launches" % args.workload
+        if unit.get("SQ_INSTS_VALU"):
+            roof["valu"] = dict(insts_per_step=unit["SQ_INSTS_VALU"] * per_step,
+                                issue_frac=unit.get("valu_issue_frac"),
+                                note="SQ_INSTS_VALU x 4 cycles (a 64-wide wavefront on a 16-lane SIMD) / (1,024 SIMDs x "
+                                     "the kernels' busy cycles, GRBM_GUI_ACTIVE / 8 XCDs): the filter's passes are chains of "
+                                     "dependent scattered loads -- latency-bound, neither the HBM nor the VALU roof")
+    return roof
 
 
 def bench_design_large(args):
@@ -710,7 +794,14 @@ def bench_design_large(args):
     def gbs(b, t_ms):
         return b / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
     lookup_ms = per.get("scan_ms", 0.0) - per.get("verify_ms", 0.0)
-    cands_ms = {"seed_verify4_kernel (K1 verify)": (per.get("verify_ms", 0.0), vb, per.get("verify_launches", 0)),
+    # SURVEY 8(d) K3 for the MinHash family: N probes x (L characters + T tables x (8 + 4) B x 4 radix passes, read and
+    # written) + per compared pair the two k-mer code rows (4 B per distinct k-mer)
+    N3, T3, C3 = per.get("ndf_probes", 0), per.get("ndf_tables", 0), per.get("ndf_pairs", 0)
+    k3_bytes = N3 * (PROBE_LEN + T3 * 12.0 * 4 * 2) + C3 * 2.0 * 4 * (PROBE_LEN - 10 + 1)
+    n_ndf_calls = max(1, int(round(per.get("union_chunks", 1))))
+    cands_ms = {"MinHash near-duplicate filter (K3: mh_kmer + mh_keys_all + 25 radix sorts + ndf_lazy / ndf_probe passes)":
+                (per.get("ndf_ms", 0.0), k3_bytes, n_ndf_calls),
+                "seed_verify4_kernel (K1 verify)": (per.get("verify_ms", 0.0), vb, per.get("verify_launches", 0)),
                 "bucketed row build": (per.get("rows_ms", 0.0), 44.0 * hits + 40.0 * rows, per.get("rows_launches", 0)),
                 "frontier solver rounds (K2)": (per.get("rounds_ms", 0.0),
                                                 12.0 * per.get("rows_recounted", 0) + 8.0 * per.get("bitmap_words_read", 0),
@@ -733,20 +824,25 @@ def bench_design_large(args):
                             "merge": per["merge_s"]},
         "kernel_ms_per_step": {"k1_scan": per.get("scan_ms", 0.0), "k1_seed_verify": per.get("verify_ms", 0.0),
                                "k1_table_lookup": lookup_ms, "rows_build": per.get("rows_ms", 0.0),
-                               "k2_greedy": per.get("greedy_ms", 0.0), "k2_greedy_rounds_only": per.get("rounds_ms", 0.0)},
-        "roofline": dict(bound="hbm", kernel=dom, achieved=gbs(dbytes, dms), peak=HBM_PEAK_GBS, unit="GB/s",
-                         frac=gbs(dbytes, dms) / HBM_PEAK_GBS, traffic=None,
-                         algorithmic_bytes_per_launch=dbytes / max(dl, 1), avg_launch_ms=dms / max(dl, 1),
-                         launches_per_step=dl, device_ms_per_step=dms),
+                               "k2_greedy": per.get("greedy_ms", 0.0), "k2_greedy_rounds_only": per.get("rounds_ms", 0.0),
+                               "k3_minhash_filter (two worker streams side by side: sums their stream times)": per.get("ndf_ms", 0.0)},
+        "roofline": s5_roofline(dom, dms, dbytes, dl, args),
         "work_per_step": {"candidates": per.get("candidates"), "unique_candidates": per.get("unique_candidates"),
                           "table_matches": seeds, "hits": hits, "rows": rows, "picks": per.get("picks"),
-                          "rounds": per.get("greedy_iters"), "probes": len(set(probes))},
+                          "rounds": per.get("greedy_iters"), "probes": len(set(probes)),
+                          "ndf_probes": N3, "ndf_tables": T3, "ndf_pairs_compared": C3, "ndf_kept": per.get("ndf_kept")},
         "probes_sha256": dg,
         "parity_vs_golden_digests": (None if gold is None else dg == gold["probes_sha256"]),
         "dataset_generation_s": gen_s,
         "step_seconds": [st["wall_s"] for st in steps],
         "device_memory": engine.pool_stats(),
     }
+    if not args.no_cpu_baseline and args.scale == 1.0:
+        base, gpu_s, same = cpu_baseline_s5()
+        out["cpu_baseline"] = base
+        out["parity_vs_oracle_on_cpu_sample"] = same
+        out["gpu_ms_on_cpu_sample"] = gpu_s * 1e3
+        out["speedup_vs_cpu_oracle_on_sample"] = base["seconds"] / gpu_s
     if not args.no_solver_check:
         # property check where no oracle digest exists: the two kernel families of the frontier solver
         # (set-parallel fused / row-parallel flat) must select the same probes
@@ -1311,14 +1407,17 @@ def main():
             engine.pool_trim()
             keep = ("ms_per_step", "value", "unit", "steps", "warmup", "kernel_ms_per_step", "roofline", "roofline_k3",
                     "wall_s_per_step", "parity_vs_golden_digests", "property_checks", "solver_families_agree",
-                    "work_per_step", "dataset_generation_s", "probes_sha256", "m2_setcoverfilter_wall_s")
+                    "work_per_step", "dataset_generation_s", "probes_sha256", "m2_setcoverfilter_wall_s", "cpu_baseline",
+                    "parity_vs_oracle_on_cpu_sample", "gpu_ms_on_cpu_sample", "speedup_vs_cpu_oracle_on_sample")
             also = {}
-            for name, extra in (("S3", ["--workload", "S3", "--steps", "3", "--warmup", "1"]),
-                                ("S5", ["--workload", "S5", "--scale", "%g" % args.also_s5_scale, "--steps", "1", "--warmup", "1"])):   # (a cold first step is 3-4 s longer: first-use allocations of 100+ GB)
+            for name, extra in (("S3", ["--workload", "S3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]),
+                                # (a cold first step is 3-4 s longer: first-use allocations of 100+ GB; the S5 leg times its
+                                # own CPU sample -- the oracle's MinHash filter + set cover on 40 genomes, ~20 s)
+                                ("S5", ["--workload", "S5", "--scale", "%g" % args.also_s5_scale, "--steps", "1", "--warmup", "1"])):
                 ta = time.perf_counter()
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra +
-                                       ["--no-cpu-baseline", "--no-m2", "--no-partial", "--no-overlap-figure", "--no-also"],
+                                       ["--no-m2", "--no-partial", "--no-overlap-figure", "--no-also"],
                                        capture_output=True, text=True, timeout=1200)
                     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
                     sub = json.loads(line)

@@ -1058,6 +1058,7 @@ mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, 
                u32 *__restrict__ nuniq, unsigned long long *__restrict__ fp, u32 *__restrict__ fp_excess,
                u32 *__restrict__ kc, u32 kstride) {
     __shared__ u64 s_hi[MH_MAXK], s_lo[MH_MAXK];
+    __shared__ u32 s_code[MH_MAXK];
     __shared__ unsigned long long s_fp[MH_FPW];
     const u32 lane = threadIdx.x;
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
@@ -1066,45 +1067,61 @@ mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, 
         // packed form (kc, round 5): a probe of A/C/G/T only has its distinct k-mers as 2-bit codes as well (<= 15
         // characters, so that 0xffffffff is free to mean "nothing"); any other character: the row starts with MH_KC_NONE
         bool bad = ks > 15;
-        if (kc)
-            for (u32 j = lane; j < nk + (u32)ks - 1u; j += 64) bad = bad || mh_base2(p[j]) > 3u;
-        const bool packable = kc && !__ballot(bad);
+        for (u32 j = lane; j < nk + (u32)ks - 1u; j += 64) bad = bad || mh_base2(p[j]) > 3u;
+        const bool packable = !__ballot(bad);
         __syncthreads();
         for (u32 j = lane; j < nk; j += 64) {
             const long long h = mh_pyhash(p + j, ks);
             xs[k0 + j] = (u32)((u64)(h < 0 ? -h : h) % MH_P);
             u64 lo = 0, hi = 0;   // the k-mer's bytes, big endian: order = string order
+            u32 code = 0;         // (A < C < G < T in the codes as in the bytes: the same order)
             for (int c = 0; c < ks; ++c) {
                 const u64 ch = p[j + c];
                 if (c < ks - 8) hi = (hi << 8) | ch; else lo = (lo << 8) | ch;
+                code = (code << 2) | (mh_base2((u8)ch) & 3u);
             }
             if (ks <= 8) hi = 0;
-            s_hi[j] = hi; s_lo[j] = lo;
+            s_hi[j] = hi; s_lo[j] = lo; s_code[j] = code;
         }
         __syncthreads();
-        // rank sort; equal k-mers get consecutive ranks, the first of each group is kept
+        // rank sort; equal k-mers get consecutive ranks, the first of each group is kept.  By the 32-bit codes when the
+        // probe has them (round 5: the 128-bit comparisons of all four register slots were 3,300 of the kernel's ~4,500
+        // instructions per probe), and only over the slots the probe fills
         u64 mh[MH_MAXK / 64], ml[MH_MAXK / 64];
-        u32 rk[MH_MAXK / 64];
+        u32 mc[MH_MAXK / 64], rk[MH_MAXK / 64];
 #pragma unroll
         for (int q = 0; q < MH_MAXK / 64; ++q) {
             const u32 j = lane + q * 64;
             rk[q] = 0;
-            mh[q] = j < nk ? s_hi[j] : 0; ml[q] = j < nk ? s_lo[j] : 0;
+            mh[q] = j < nk ? s_hi[j] : 0; ml[q] = j < nk ? s_lo[j] : 0; mc[q] = j < nk ? s_code[j] : 0;
         }
-        for (u32 y = 0; y < nk; ++y) {
-            const u64 h = s_hi[y], l = s_lo[y];
+        if (packable) {
+            for (u32 y = 0; y < nk; ++y) {
+                const u32 c = s_code[y];
 #pragma unroll
-            for (int q = 0; q < MH_MAXK / 64; ++q) {
-                const u32 j = lane + q * 64;
-                const bool less = h < mh[q] || (h == mh[q] && (l < ml[q] || (l == ml[q] && y < j)));
-                rk[q] += less ? 1u : 0u;
+                for (int q = 0; q < MH_MAXK / 64; ++q) {
+                    if ((u32)q * 64u >= nk) break;
+                    const u32 j = lane + q * 64;
+                    rk[q] += (c < mc[q] || (c == mc[q] && y < j)) ? 1u : 0u;
+                }
+            }
+        } else {
+            for (u32 y = 0; y < nk; ++y) {
+                const u64 h = s_hi[y], l = s_lo[y];
+#pragma unroll
+                for (int q = 0; q < MH_MAXK / 64; ++q) {
+                    if ((u32)q * 64u >= nk) break;
+                    const u32 j = lane + q * 64;
+                    const bool less = h < mh[q] || (h == mh[q] && (l < ml[q] || (l == ml[q] && y < j)));
+                    rk[q] += less ? 1u : 0u;
+                }
             }
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < MH_MAXK / 64; ++q) {
             const u32 j = lane + q * 64;
-            if (j < nk) { s_hi[rk[q]] = mh[q]; s_lo[rk[q]] = ml[q]; }
+            if (j < nk) { s_hi[rk[q]] = mh[q]; s_lo[rk[q]] = ml[q]; s_code[rk[q]] = mc[q]; }
         }
         if (lane < MH_FPW) s_fp[lane] = 0ull;
         __syncthreads();
@@ -1118,19 +1135,7 @@ mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, 
                 id_hi[k0 + o] = s_hi[j]; id_lo[k0 + o] = s_lo[j];
                 const u32 bit = mh_fp_bit(s_hi[j], s_lo[j]);
                 atomicOr(&s_fp[bit >> 6], 1ull << (bit & 63u));
-                if (kc) {
-                    u32 code = MH_KC_NONE;
-                    if (packable) {
-                        code = 0;
-                        for (int c = 0; c < ks; ++c) {       // the bytes as stored above: big endian, the last <= 8 in lo
-                            const int inlo = ks < 8 ? ks : 8;
-                            const u64 ch = c < ks - 8 ? (s_hi[j] >> (8 * (ks - 8 - 1 - c))) & 0xffull
-                                                      : (s_lo[j] >> (8 * (inlo - 1 - (c - (ks > 8 ? ks - 8 : 0))))) & 0xffull;
-                            code = (code << 2) | mh_base2((u8)ch);
-                        }
-                    }
-                    kc[(size_t)i * kstride + o] = code;
-                }
+                if (kc) kc[(size_t)i * kstride + o] = packable ? s_code[j] : MH_KC_NONE;
             }
             out += (u32)__popcll(bal);
         }
@@ -1144,43 +1149,57 @@ mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, 
     }
 }
 
-// Signatures and grouping keys of tables [t0, t0 + nt) for every probe: one
-// wavefront per probe, the probe's k-mer hashes in registers (<= 4 per lane,
-// read once, coalesced), one wave-min per hash function.  (One thread per probe
-// walking its own row of xs re-read every row once per function and table with
-// 64 different cache lines per load instruction: 17 ms per table for 3.9 M
-// probes, 85 % of the filter's device time.)
+// Signatures and grouping keys of tables [t0, t0 + nt) for every probe.  Round 5: one THREAD per (probe, table) that
+// walks the probe's k-mer hashes (the lanes of a wavefront cover two or three probes: the loads are broadcasts) and
+// keeps the k minima in registers -- no wave reductions (the wavefront-per-probe form spent 450 LDS-routed shuffles per
+// probe on its 75 wave-mins) and a 32 x 32 -> 64-bit multiply with the Mersenne fold 2^32 = 2 (mod p) instead of the
+// 64 x 64-bit product the compiler made of `a * x + b` on u64 operands: 552 -> ~200 ms per S5 step.
+// (The first version, one thread per probe and table walking its own row of xs with a load per function, fetched 64
+// different cache lines per load instruction: 17 ms per table for 3.9 M probes; here a thread loads each hash once.)
+__device__ __forceinline__ u32 mh_axb_mod(u32 a, u32 x, u32 b) {     // (a x + b) mod (2^31 - 1), a, x < p, b <= p
+    const u64 prod = (u64)a * (u64)x;                               // < 2^62
+    const u64 v = (prod & 0xffffffffull) + 2ull * (prod >> 32) + (u64)b;   // 2^32 = 2 (mod p); v < 2^33
+    u32 t = (u32)(v & MH_P) + (u32)(v >> 31);                       // < 2^31 + 4
+    return min(t, t - (u32)MH_P);                                   // (t - p wraps when t < p)
+}
+#define MH_KF 4      // hash functions per pass over the k-mers (k = 3 in the reference)
 __global__ void __launch_bounds__(256)
 mh_keys_all_kernel(const u32 *__restrict__ xs, const u32 *__restrict__ koff, u32 n, const u64 *__restrict__ ab,
                    int k, int ntables, int t0, int nt, const u32 *__restrict__ grp, u32 *__restrict__ sig_all,
                    u64 *__restrict__ keys_all, u32 *__restrict__ sig0T = nullptr, u32 tstride = 0) {
-    const u32 lane = threadIdx.x & 63;
-    const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (i >= n) return;
+    const u64 g64 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g64 >= (u64)n * (u32)nt) return;
+    const u32 i = (u32)(g64 / (u32)nt), tt = (u32)(g64 - (u64)i * (u32)nt);
+    const int t = t0 + (int)tt;
     const u32 k0 = koff[i], nk = koff[i + 1] - k0;   // <= MH_MAXK = 256
-    u64 x[4];
+    const u32 gidx = grp ? grp[i] : 0u;
+    const u64 *abt = ab + ((size_t)gidx * ntables + t) * k * 2;
+    u64 h = 0xcbf29ce484222325ull;
+    if (grp) h = (h ^ (u64)gidx) * 0x100000001b3ull;   // the group is part of the key
+    for (int f0 = 0; f0 < k; f0 += MH_KF) {
+        u32 a[MH_KF], b[MH_KF], best[MH_KF];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) x[q] = (lane + 64u * q < nk) ? (u64)xs[k0 + lane + 64u * q] : ~0ull;
-    const u32 g = grp ? grp[i] : 0u;
-    const u64 *abg = ab + (size_t)g * ntables * k * 2;
-    for (int t = t0; t < t0 + nt; ++t) {
-        u64 h = 0xcbf29ce484222325ull;
-        if (grp) h = (h ^ (u64)g) * 0x100000001b3ull;   // the group is part of the key
-        for (int f = 0; f < k; ++f) {
-            const u64 a = abg[((size_t)t * k + f) * 2] % MH_P, b = abg[((size_t)t * k + f) * 2 + 1];
-            u32 best = 0xffffffffu;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (x[q] != ~0ull) best = min(best, mod_mersenne31(a * x[q] + b));   // a, x < p: the sum is < 2^63
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) best = min(best, (u32)__shfl_xor((int)best, d, WAVE));
-            if (lane == 0) sig_all[((size_t)(t - t0) * n + i) * k + f] = best;
-            // (the first value of every table's signature once more, a row per probe: what owned_earlier looks at)
-            if (lane == 0 && f == 0 && sig0T) sig0T[(size_t)i * tstride + t] = best;
-            h = (h ^ (u64)best) * 0x100000001b3ull;
+        for (int q = 0; q < MH_KF; ++q) {
+            const int f = min(f0 + q, k - 1);
+            a[q] = (u32)(abt[f * 2] % MH_P); b[q] = (u32)abt[f * 2 + 1];
+            best[q] = 0xffffffffu;
         }
-        if (lane == 0) keys_all[(size_t)(t - t0) * n + i] = h;
+        for (u32 y = 0; y < nk; ++y) {
+            const u32 x = xs[k0 + y];
+#pragma unroll
+            for (int q = 0; q < MH_KF; ++q) best[q] = min(best[q], mh_axb_mod(a[q], x, b[q]));
+        }
+#pragma unroll
+        for (int q = 0; q < MH_KF; ++q) {
+            const int f = f0 + q;
+            if (f >= k) break;
+            sig_all[((size_t)tt * n + i) * k + f] = best[q];
+            // (the first value of every table's signature once more, a row per probe: what owned_earlier looks at)
+            if (f == 0 && sig0T) sig0T[(size_t)i * tstride + t] = best[q];
+            h = (h ^ (u64)best[q]) * 0x100000001b3ull;
+        }
     }
+    keys_all[(size_t)tt * n + i] = h;
 }
 
 __global__ void __launch_bounds__(256)
@@ -1606,7 +1625,7 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
         TRY(pairs.alloc(2 * ES_SHARDS));
         HIP_TRY(hipMemsetAsync(cursor.p, 0xff, sizeof(u32) * (size_t)nn * TS, s));
         HIP_TRY(hipMemsetAsync(pairs.p, 0, sizeof(u64) * 2 * ES_SHARDS, s));
-        hipLaunchKernelGGL(mh_keys_all_kernel, dim3((unsigned)div_up((i64)nn * 64, 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL(mh_keys_all_kernel, dim3((unsigned)div_up((i64)nn * ntables, 256)), dim3(256), 0, s,
                            (const u32 *)xs.p, (const u32 *)d_koff.p, nn, (const u64 *)d_ab.p, (int)k, (int)ntables, 0,
                            (int)ntables, grp, sig.p, keys_all.p, sig0T.p, tstride);
         tm.launch(1);
@@ -1654,7 +1673,7 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
         for (int t = 0; t < ntables; ++t) {
             const int tc = t % tchunk;
             if (tc == 0) {
-                hipLaunchKernelGGL(mh_keys_all_kernel, dim3((unsigned)div_up((i64)nn * 64, 256)), dim3(256), 0, s,
+                hipLaunchKernelGGL(mh_keys_all_kernel, dim3((unsigned)div_up((i64)nn * std::min(tchunk, ntables - t), 256)), dim3(256), 0, s,
                                    (const u32 *)xs.p, (const u32 *)d_koff.p, nn, (const u64 *)d_ab.p, (int)k,
                                    (int)ntables, t, std::min(tchunk, ntables - t), grp, sig.p, keys_all.p);
                 tm.launch(1);

@@ -816,7 +816,8 @@ class SetCoverFilter(BaseFilter):
         depth = int(os.environ.get("CATCHHIP_PREFETCH_DEPTH", "2"))
 
         import time as _time
-        stage_s = dict(pack_s=0.0, candidates_s=0.0, near_duplicates_s=0.0, anchors_s=0.0, solve_s=0.0)
+        stage_s = dict(pack_s=0.0, candidates_s=0.0, near_duplicates_s=0.0, anchors_s=0.0, solve_s=0.0,
+                       ndf_ms=0.0, ndf_probes=0, ndf_pairs=0, ndf_kept=0)
         events = []      # (stage, chunk number, start, end) in seconds since the call began: the pipeline's timeline
         t_call = _time.perf_counter()
 
@@ -850,6 +851,13 @@ class SetCoverFilter(BaseFilter):
                         near_duplicate_filter._apply_to_grouped_candidates(cands, len(chunk), drawn_ndf[chunk_no[id(chunk)]])
                     else:
                         near_duplicate_filter._apply_to_grouped_candidates(cands, len(chunk))
+                    # device time of the filter (HIP events around its launches on this worker's stream) and its work
+                    stage_s["ndf_ms"] += bctx.kernel_ms(engine.PHASE_NDF)[0]
+                    cnt = bctx.ndf_counters()
+                    stage_s["ndf_probes"] += cnt["probes"]
+                    stage_s["ndf_pairs"] += cnt["pairs_compared"]
+                    stage_s["ndf_tables"] = cnt["tables"]
+                    stage_s["ndf_kept"] += cands.n
                 bctx.sync()
                 if bctx is not ctx:
                     # handed over here, while this stream is idle: a rebind later would wait for the NEXT chunk's
@@ -945,6 +953,7 @@ class SetCoverFilter(BaseFilter):
                 if p is not None:
                     p.close()
         timings.update(stage_s)
+        timings["union_chunks"] = len(chunks)
         timings["pipe_events"] = events
         self.last_timings = timings
         return out

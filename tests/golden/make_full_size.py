@@ -28,7 +28,7 @@ from catch_amd.filter import candidate_probes  # noqa: E402
 from catch_amd.utils import synthetic  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
-OUT = os.path.join(HERE, "full_size_picks.json")
+OUT = os.environ.get("FULL_SIZE_OUT", os.path.join(HERE, "full_size_picks.json"))   # (FULL_SIZE_OUT: several jobs side by side)
 L, STRIDE, MISMATCHES, EXT = 100, 50, 2, 50
 
 

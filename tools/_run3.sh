@@ -5,7 +5,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/s5kt -- py
 cd $R
 f=$(ls gpurun_out/s5kt/*/*kernel_stats.csv | head -1)
 cp $f gpurun_out/s5_kernel_stats_q.csv
-head -12 $f | cut -c1-150
+python tools/kstats.py $f 14
 # per-dispatch: lazy kernels of the first chunk
 python - <<'PY'
 import csv, glob

@@ -1,2 +1,4 @@
 export CATCHHIP_TEST_HOOKS=1
-python -m pytest tests -m gpu -q 2>&1 | tail -8
+python -m pytest tests -m gpu -x -q -k "minhash or ndf or config5 or chains or candidates or cluster or design" 2>&1 | tail -3
+bash tools/_run3.sh 2>&1 | grep " ms " | head -12
+python tools/s5_time.py 1.0 "" 2>&1 | tail -1
