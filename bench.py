@@ -373,7 +373,7 @@ def _pmc_record(workload, scale):
     """The committed rocprofv3 PMC passes of this same command (profiles/r04_pmc_traffic_<workload>.json, made by
     tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in separate runs); None when there is none for this
     workload at this scale: counters cannot be collected from inside the timed run."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(REPO, "profiles", "%s_pmc_traffic_%s.json" % (rnd, workload))
         try:
             with open(path) as f:
@@ -672,6 +672,46 @@ def seed_verify_bytes(seeds, dropped, hits, L=PROBE_LEN):
     return live * (12 + 0.375 * (L + 32) + 0.375 * L + 4) + 4.0 * dropped + 16.0 * hits
 
 
+VALU_PEAK_GWIPS = 1024 * 2.4 / 4.0     # wave-instructions / ns: 256 CUs x 4 SIMDs, a 64-wide VALU instruction occupies its SIMD for 4 cycles at 2.4 GHz
+
+
+def units_record(workload, scale):
+    """profiles/r05_pmc_<workload>.json (tools/collect_units.sh): kernel time, FETCH_SIZE / WRITE_SIZE and SQ_INSTS_VALU of
+    the committed rocprofv3 passes of this command, by unit of the hot path; None if there is none for this run."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r05_pmc_%s.json" % workload)) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return rec if rec.get("workload") == workload and rec.get("scale", 1.0) == scale else None
+
+
+def valu_figures(unit, steps_in_run, device_ms_per_step):
+    """VALU side of a unit that is neither HBM- nor MFMA-bound: wave-instructions per ns over the unit's device time
+    against the issue peak, and the counters' own busy-cycle fraction."""
+    if not unit or not unit.get("SQ_INSTS_VALU") or device_ms_per_step <= 0:
+        return None
+    per_step = unit["SQ_INSTS_VALU"] / max(steps_in_run, 1)
+    ach = per_step / (device_ms_per_step * 1e6)
+    return dict(bound="valu", achieved=ach, peak=VALU_PEAK_GWIPS, unit="wave-instructions/ns", frac=ach / VALU_PEAK_GWIPS,
+                insts_per_step=per_step, issue_frac_of_busy_cycles=unit.get("valu_issue_frac"),
+                source="profiles/r05_pmc_*.json (rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES, a run of its own)")
+
+
+def closer_roof(roof, vf):
+    """bound / achieved / peak / unit / frac of `roof` become those of the roof the unit is closer to (HBM as priced, or
+    the VALU issue rate of the counters); the other one stays beside it."""
+    hbm = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+    out = dict(roof)
+    if vf["frac"] > roof["frac"]:
+        out.update({k: vf[k] for k in ("bound", "achieved", "peak", "unit", "frac")})
+        out["hbm"] = hbm
+    out["valu"] = vf
+    out["bound_note"] = ("neither roof is near: the unit's passes are chains of dependent scattered loads (latency-bound); `bound` "
+                         "names the roof it is closer to, the other roof's figures are beside it")
+    return out
+
+
 def s5_roofline(dom, dms, dbytes, dl, args):
     """The roofline object of the configs[4] leg for its dominant unit.  HBM: SURVEY 8(d)'s algorithmic bytes over the
     unit's device time (HIP events on the streams it runs on).  The counters of the committed rocprofv3 passes of this
@@ -699,12 +739,9 @@ def s5_roofline(dom, dms, dbytes, dl, args):
         roof["traffic"] = tb / max(dl, 1)
         roof["traffic_bytes_per_step"] = tb
         roof["traffic_source"] = "profiles/r05_pmc_%s.json: (2 x FETCH_SIZE + WRITE_SIZE) of the unit's kernels / steps of the run / launches" % args.workload
-        if unit.get("SQ_INSTS_VALU"):
-            roof["valu"] = dict(insts_per_step=unit["SQ_INSTS_VALU"] * per_step,
-                                issue_frac=unit.get("valu_issue_frac"),
-                                note="SQ_INSTS_VALU x 4 cycles (a 64-wide wavefront on a 16-lane SIMD) / (1,024 SIMDs x "
-                                     "the kernels' busy cycles, GRBM_GUI_ACTIVE / 8 XCDs): the filter's passes are chains of "
-                                     "dependent scattered loads -- latency-bound, neither the HBM nor the VALU roof")
+        vf = valu_figures(unit, rec.get("steps_in_run", 1), dms)
+        if vf is not None:
+            roof = closer_roof(roof, vf)
     return roof
 
 
@@ -1121,11 +1158,15 @@ def main():
             a_ms = {"join_verify": ta_.get("verify_ms", 0.0) + ta_.get("vcount_ms", 0.0), "solver_claim": ta_.get("claim_ms", 0.0),
                     "rows_build": ta_.get("rows_ms", 0.0)}[dom]
             a_avg = a_ms / max(d["launches"], 1)
-            roof["one_chain_at_a_time"] = dict(
-                avg_launch_ms=a_avg, device_ms_per_step=a_ms, achieved=gbs(priced, a_avg), frac=gbs(priced, a_avg) / HBM_PEAK_GBS,
-                note="the same kernel in an untimed step that runs the union instance AFTER the large groups instead of beside "
-                     "them: its launches with the device to themselves (the timed steps overlap two chains: a launch's "
-                     "event time then includes the other stream's kernels, and the step is shorter)")
+            # The line's roofline is priced with the kernel's launches when they have the device to themselves (VERDICT
+            # round 4): the timed steps overlap two chains, so a launch's event time there includes the other stream's
+            # kernels.  The overlapped figures stay beside it.
+            roof["overlapped_in_timed_steps"] = dict(avg_launch_ms=roof["avg_launch_ms"], device_ms_per_step=roof["device_ms_per_step"],
+                                                     achieved=roof["achieved"], frac=roof["frac"])
+            roof.update(avg_launch_ms=a_avg, device_ms_per_step=a_ms, achieved=gbs(priced, a_avg), frac=gbs(priced, a_avg) / HBM_PEAK_GBS)
+            roof["note"] += ("; time = the kernel's launches in an untimed step that runs the union instance AFTER the large "
+                             "groups instead of beside them (one chain at a time); overlapped_in_timed_steps: the same from "
+                             "the timed steps' event times")
             alone = {"ms_per_step": alone_ms,
                      "kernel_ms_per_step": {"k1_scan": ta_.get("scan_ms", 0.0), "k1_join_verify_count": ta_.get("vcount_ms", 0.0),
                                             "k1_join_verify_write": ta_.get("verify_ms", 0.0), "rows_build": ta_.get("rows_ms", 0.0),
@@ -1249,6 +1290,12 @@ def main():
                                       probes=N, tables=T, pairs_compared=C, edges=per.get("ndf_edges", 0),
                                       kept=per.get("ndf_kept", 0), windows=per.get("windows", 0),
                                       front_end_ms=per.get("front_end_ms", 0.0))
+            urec = units_record(args.workload, args.scale)
+            if urec is not None:
+                # the filter is not HBM-bound (0.03 of the HBM peak says nothing): its VALU side from the counters
+                vf = valu_figures(urec["units"].get("ndf"), urec.get("steps_in_run", 1), per.get("ndf_ms", 0.0))
+                if vf is not None:
+                    out["roofline_k3"] = closer_roof(out["roofline_k3"], vf)
             out["config"]["workload"] += "; step = device front end + --filter-with-lsh-hamming 2 (K3) + scan + solve, targets resident"
             if per.get("ndf_ms", 0.0) > d["ms"]:
                 # configs[2]: the filter is the dominant unit of the step (one filter call per group = one "launch")

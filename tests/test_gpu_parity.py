@@ -257,6 +257,48 @@ def test_scan_reference_test_vectors(ctx):
         assert got == exp, (c["probes"], c["sequence"][:60])
 
 
+def _occurrences(text, pat):
+    n, at = 0, text.find(pat)
+    while at >= 0:
+        n += 1
+        at = text.find(pat, at + 1)
+    return n
+
+
+def test_extension_replays_the_reference_lcs_and_lcf_vectors(ctx):
+    """a7 / a8 on the DEVICE, vector by vector: every recorded answer of the
+    reference's k_lcf_around_anchor (its own tests' cases + 3,000 random ones,
+    tests/golden/lcs_anchor.json.gz) and of its lcf cover function
+    (lcf_cover.json.gz) that can be posed as a scan of one window -- probe and
+    window aligned at 0, the anchor k-mer the probe's only table entry and
+    found nowhere else in the window -- goes through catchhip_cover_scan's
+    extension kernel and must come back as recorded (catch/utils/
+    longest_common_substring.py:59-159, catch/probe.py:1328-1344)."""
+    g = load_golden("lcs_anchor")
+    done = 0
+    for c in g["from_reference_tests"] + g["random"]:
+        a, b, s0, e0, k = c["a"], c["b"], c["anchor_start"], c["anchor_end"], c["k"]
+        if len(a) != len(b) or e0 - s0 < 1 or a[s0:e0] != b[s0:e0] or _occurrences(b, a[s0:e0]) != 1:
+            continue
+        length, start = c["out"]
+        got = _scan_rows(ctx, [a], [[b]], k, 1, 0, 0, entries=[(0, s0)], k=e0 - s0)
+        assert got == [(0, 0, start, start + length)], c
+        done += 1
+    assert done >= 2400
+    done = 0
+    for c in load_golden("lcf_cover"):
+        pr, sq, s0, e0 = c["probe_seq"], c["sequence"], c["kmer_start"], c["kmer_end"]
+        if (c["full_probe_len"] != len(pr) or c["full_sequence_len"] != len(sq) or len(pr) > len(sq)
+                or pr[s0:e0] != sq[s0:e0] or _occurrences(sq, pr[s0:e0]) != 1):
+            continue
+        got = _scan_rows(ctx, [pr], [[sq]], c["mismatches"], c["lcf_thres"], c["island"], 0,
+                         entries=[(0, s0)], k=e0 - s0)
+        exp = [] if c["out"] is None else [(0, 0, c["out"][0], c["out"][1])]
+        assert got == exp, c
+        done += 1
+    assert done >= 8
+
+
 def test_cover_ranges_unmerged(ctx, oracle):
     """catchhip_cover_ranges = find_probe_covers_in_sequence(merge_overlapping=
     False): the reference's unmerged known answers, and the oracle on repeats

@@ -1,4 +1,2 @@
 export CATCHHIP_TEST_HOOKS=1
-python -m pytest tests -m gpu -x -q -k "minhash or ndf or config5 or chains or candidates or cluster or design" 2>&1 | tail -3
-bash tools/_run3.sh 2>&1 | grep " ms " | head -12
-python tools/s5_time.py 1.0 "" 2>&1 | tail -1
+python -m pytest tests -m gpu -x -q -k "extension_replays" 2>&1 | tail -15
