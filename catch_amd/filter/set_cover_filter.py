@@ -486,6 +486,8 @@ class SetCoverFilter(BaseFilter):
         timings = dict(scan_ms=0.0, rows_ms=0.0, greedy_ms=0.0, picks=0,
                        rows=0, scan_launches=0, greedy_launches=0,
                        candidates=0, unique_candidates=0)
+        import time as _time
+        events, t_call = [], _time.perf_counter()      # (stage, item, start, end): the pipeline's timeline
         todo = [i for i, g in enumerate(target_genomes_grouped) if len(g) > 0]
         width = max(1, int(os.environ.get("CATCHHIP_GROUPS_IN_FLIGHT", "4")))
         sizes = {i: sum(g.size() for g in target_genomes_grouped[i]) for i in todo}
@@ -548,9 +550,11 @@ class SetCoverFilter(BaseFilter):
             uctx = ctx or engine.upload_context()
             target_genomes = genomes_of(gi)
             made = []
+            t_b0 = _time.perf_counter()
             try:
                 targets = engine.Targets(uctx, [g.seqs for g in target_genomes])
                 made.append(targets)
+                events.append(("pack", gi, t_b0 - t_call, _time.perf_counter() - t_call))
                 if len(items[gi]) > 1:
                     targets.set_groups(np.repeat(np.arange(len(items[gi])),
                                                  [len(target_genomes_grouped[member]) for member in items[gi]]))
@@ -566,6 +570,7 @@ class SetCoverFilter(BaseFilter):
                 probes = _probes_of_candidates(cands, _anchors_for_candidates(
                     cands.n, probe_length, self.mismatches, self.lcf_thres, self.kmer_probe_map_k))
                 made.append(probes)
+                events.append(("build", gi, t_b0 - t_call, _time.perf_counter() - t_call))
             except BaseException:
                 for h in reversed(made):
                     h.close()
@@ -645,18 +650,23 @@ class SetCoverFilter(BaseFilter):
                 import threading
                 nl = max(1, min(lane_count, len(order)))
                 ctxs = _contexts(nl)
-                lists = [[order[j] for j in lane] for lane in _lpt([sizes[gi] for gi in order], nl)]
+                # What an item costs a lane: its bases plus a fixed share (round 5: a 25-Mbase group takes 7-9 ms, the
+                # 265-Mbase one 62 -- ~12 Mbases' worth of launches and read-backs per instance; with plain sizes the
+                # lane that got the eight medium groups of S4 ran 40 ms longer than the lane with the large one)
+                fixed = float(os.environ.get("CATCHHIP_LANE_FIXED_MBASES", "12")) * 1e6
+                cost = {gi: sizes[gi] + fixed for gi in order}
+                lists = [[order[j] for j in lane] for lane in _lpt([cost[gi] for gi in order], nl)]
                 lane_of = {gi: li for li, lst in enumerate(lists) for gi in lst}
                 if keep_input_order:
                     production = list(order)
                 else:
-                    # the order in which the lanes will ask for their groups if time goes as size
+                    # the order in which the lanes will ask for their groups if time goes as cost
                     production, at, clock = [], [0] * nl, [0.0] * nl
                     while len(production) < len(order):
                         li = min((l for l in range(nl) if at[l] < len(lists[l])), key=lambda l: (clock[l], l))
                         gi = lists[li][at[li]]
                         production.append(gi)
-                        clock[li] += sizes[gi]
+                        clock[li] += cost[gi]
                         at[li] += 1
                 if keep_input_order:
                     # (the lanes then take their groups in production order too)
@@ -666,15 +676,29 @@ class SetCoverFilter(BaseFilter):
                 slots = threading.Semaphore(max(2, depth) * nl)
                 res_lock = threading.Lock()
 
-                def producer():
-                    for gi in production:
+                # Builders: one (CATCHHIP_BUILDERS, a test hook, starts more when no random numbers are drawn while
+                # building; each takes the next item of the production order when it is free).  Measured in round 5 on S4
+                # from host strings: two builders, or lanes balanced by cost instead of size, leave the pass at 0.128-0.133 s
+                # -- the three lanes' kernels share one device, and the pass is within ~10 % of the device work it holds
+                # (96 ms of scans and solves one chain at a time + ~20 ms of front-end kernels + 0.5 GB of uploads).
+                nbuilders = 1 if keep_input_order else max(1, int(_lib.test_env("CATCHHIP_BUILDERS", "1")))
+                next_item = [0]
+                take_lock = threading.Lock()
+
+                def producer(worker=0):
+                    while True:
                         slots.acquire()
-                        if errors:
+                        with take_lock:
+                            at_ = next_item[0]
+                            next_item[0] += 1
+                        if at_ >= len(production) or errors:
+                            slots.release()
                             return
+                        gi = production[at_]
                         try:
                             # built on the upload context of the DEVICE whose lane will consume it: with CATCHHIP_DEVICES
                             # the lanes sit on several GPUs, and an object cannot change hands across devices
-                            res = build(gi, engine.upload_context(ctxs[lane_of[gi]].device))
+                            res = build(gi, engine.upload_context(ctxs[lane_of[gi]].device, index=worker))
                         except BaseException as exc:
                             with cv:
                                 errors.append(exc)
@@ -695,6 +719,7 @@ class SetCoverFilter(BaseFilter):
                             targets, cands, probes, ncand, nuniq = built.pop(gi)
                         slots.release()
                         try:
+                            t_s0 = _time.perf_counter()
                             for h in (targets, cands, probes):
                                 h.rebind(ctx)
                             if cands.n == 0:
@@ -704,7 +729,10 @@ class SetCoverFilter(BaseFilter):
                                 ctx, probes, targets, self.mismatches, self.lcf_thres,
                                 self.island_of_exact_match, self.cover_extension, cands.n, None,
                                 universe_p_of(gi), self.scan_mode)
+                            t_s1 = _time.perf_counter()
                             finish(ctx, gi, targets, cands, probes, ncand, nuniq, ids, nrows, res_lock)
+                            events.append(("solve lane %d" % li, gi, t_s0 - t_call, t_s1 - t_call))
+                            events.append(("finish lane %d" % li, gi, t_s1 - t_call, _time.perf_counter() - t_call))
                         except BaseException as exc:
                             with cv:
                                 errors.append(exc)
@@ -720,18 +748,19 @@ class SetCoverFilter(BaseFilter):
                         if errors:
                             return
 
-                prod = threading.Thread(target=producer, name="catchhip-prefetch")
+                prods = [threading.Thread(target=producer, args=(w,), name="catchhip-prefetch") for w in range(nbuilders)]
                 threads = [threading.Thread(target=lane, args=(li,), name="catchhip-lane") for li in range(1, nl)]
-                prod.start()
+                for t in prods:
+                    t.start()
                 for t in threads:
                     t.start()
                 lane(0)
                 for t in threads:
                     t.join()
-                if errors:
-                    for _ in range(len(production) + 1):
-                        slots.release()              # let the producer run into the error flag and stop
-                prod.join()
+                for _ in range(len(production) + nbuilders + 1):
+                    slots.release()                  # let the builders run off the end of the list (or into the error flag)
+                for t in prods:
+                    t.join()
                 for res in built.values():           # built, never consumed (after an error)
                     discard(res)
                 if errors:
@@ -769,6 +798,7 @@ class SetCoverFilter(BaseFilter):
         finally:
             if pre is not None:
                 pre.close()
+        timings["pipe_events"] = events
         self.last_timings = timings
         return out
 
