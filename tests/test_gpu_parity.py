@@ -1073,18 +1073,22 @@ def test_full_size_config3_matches_oracle_digests(ctx):
     assert _digest_in_order(ids) == g["picks_in_order_sha256"]
 
 
-def test_full_size_config5_design_large_matches_oracle_digest(ctx, tmp_path, capsys):
-    """BASELINE configs[4] at a real scale (S5 x 0.01: 2,132 genomes, 48 Mbp,
+@pytest.mark.parametrize("scale", [0.01, 0.02, 0.05])
+def test_full_size_config5_design_large_matches_oracle_digest(ctx, tmp_path, capsys, scale):
+    """BASELINE configs[4] at real scales (S5 x 0.01: 2,132 genomes, 48 Mbp,
     2,598 fragments -> 1,130 clusters, 826 k candidates after the MinHash
-    near-duplicate filter): `design_large` defaults end to end (-m 5 random
-    anchors, -e 50, cluster 0.15 from 50-kb fragments, MinHash filter 0.6, set
-    cover per cluster) writes exactly the probes the oracle's chain of the same
-    steps selects (tests/golden/make_full_size.py S5:0.01, 12 minutes of CPU)."""
+    near-duplicate filter; round 5: x 0.02 = 3,939 genomes, 84 Mbp -> 1,392
+    clusters, 348 k probes; x 0.05 = 10,172 genomes, 195 Mbp, 11,757 fragments ->
+    1,663 clusters, 1.69 M candidates after the filter, 415,548 probes):
+    `design_large` defaults end to end (-m 5 random anchors, -e 50, cluster 0.15
+    from 50-kb fragments, MinHash filter 0.6, set cover per cluster) writes
+    exactly the probes the oracle's chain of the same steps selects
+    (tests/golden/make_full_size.py S5:<scale>: 12, 31 and 87 minutes of CPU)."""
     import hashlib
     from catch_amd import design
     from catch_amd.utils import synthetic, seq_io
-    g = _full_size("S5:0.01")["design"]
-    genomes = synthetic.dataset("S5", scale=0.01)[0]
+    g = _full_size("S5:%g" % scale)["design"]
+    genomes = synthetic.dataset("S5", scale=scale)[0]
     assert len(genomes) == g["genomes"]
     fn = tmp_path / "s5.fasta"
     with open(fn, "w") as f:
