@@ -1052,6 +1052,16 @@ __device__ __forceinline__ u32 mh_base2(u8 ch) { return ch == 'A' ? 0u : ch == '
 // CPython <= 3.10 str hash of `len` ASCII characters, zero key (see above; internal.h)
 __device__ __forceinline__ long long mh_pyhash(const u8 *__restrict__ src, int len) { return chip_pyhash_seed0(src, len); }
 
+// does any probe hold a character outside A/C/G/T?  (then the 16-byte k-mer ids are kept for every probe; otherwise the
+// 2-bit codes are all there is: 16 B x 91 k-mers x 5 M probes of writes and as much memory less per call)
+__global__ void __launch_bounds__(256)
+mh_other_chars_kernel(const u8 *__restrict__ bytes, u64 total, u32 *__restrict__ flag) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    bool other = false;
+    for (u64 at = (u64)blockIdx.x * blockDim.x + threadIdx.x; at < total; at += stride) other = other || mh_base2(bytes[at]) > 3u;
+    if (__ballot(other) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 __global__ void __launch_bounds__(64)
 mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, const u32 *__restrict__ koff, u32 n,
                int ks, u32 *__restrict__ xs, u64 *__restrict__ id_hi, u64 *__restrict__ id_lo,
@@ -1132,7 +1142,7 @@ mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, 
             const unsigned long long bal = __ballot(first);
             if (first) {
                 const u32 o = out + (u32)__popcll(bal & ((1ull << lane) - 1ull));
-                id_hi[k0 + o] = s_hi[j]; id_lo[k0 + o] = s_lo[j];
+                if (id_hi) { id_hi[k0 + o] = s_hi[j]; id_lo[k0 + o] = s_lo[j]; }
                 const u32 bit = mh_fp_bit(s_hi[j], s_lo[j]);
                 atomicOr(&s_fp[bit >> 6], 1ull << (bit & 63u));
                 if (kc) kc[(size_t)i * kstride + o] = packable ? s_code[j] : MH_KC_NONE;
@@ -1238,6 +1248,31 @@ __device__ __forceinline__ bool mh_near(const u64 *__restrict__ ah, const u64 *_
         const u64 h1 = ah[x], l1 = al[x], h2 = bh[y], l2 = bl[y];
         const u32 eq = (h1 == h2) & (l1 == l2);
         const u32 lt = (h1 < h2) | ((h1 == h2) & (l1 < l2));
+        inter += eq;
+        x += eq | lt;
+        y += eq | (lt ^ 1u);
+        if (inter >= need) return true;
+        if (inter + min(na - x, nb - y) < need) return false;
+    }
+    return false;
+}
+
+// the same on the probes' sorted 2-bit codes (round 5: both probes of A/C/G/T only)
+__device__ __forceinline__ bool mh_near_codes(const u32 *__restrict__ a, u32 na, const u32 *__restrict__ b, u32 nb,
+                                              const u32 *__restrict__ need_tab, const unsigned long long *__restrict__ fa,
+                                              const unsigned long long *__restrict__ fb, u32 exa, u32 exb) {
+    const u32 most = min(na, nb);
+    const u32 need = min(need_tab[na + nb], most + 1u);
+    if (need > most) return false;
+    if (need == 0) return true;
+    u32 bound = min(exa, exb);
+#pragma unroll 8
+    for (int w = 0; w < MH_FPW; ++w) bound += (u32)__popcll(fa[w] & fb[w]);
+    if (bound < need) return false;
+    u32 x = 0, y = 0, inter = 0;
+    while (x < na && y < nb) {
+        const u32 c1 = a[x], c2 = b[y];
+        const u32 eq = c1 == c2, lt = c1 < c2;
         inter += eq;
         x += eq | lt;
         y += eq | (lt ^ 1u);
@@ -1399,6 +1434,33 @@ struct MinHashFamily {       // same signature in table t (the key only groups),
             for (int d = 32; d > 0; d >>= 1) b += __shfl_xor(b, d, WAVE);
             if (b + min(fp_excess[i], fp_excess[j]) < need) return false;
         }
+        if (kc && kc[(size_t)i * kstride] != MH_KC_NONE && kc[(size_t)j * kstride] != MH_KC_NONE) {
+            // both probes have their 2-bit codes (round 5): B's sorted codes in LDS, 32-bit binary searches
+            u32 *sb = (u32 *)S.h;
+            const u32 *bc = kc + (size_t)j * kstride, *ac = kc + (size_t)i * kstride;
+            for (u32 q = lane; q < nb; q += 64) sb[q] = bc[q];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            u32 cnt = 0;
+            for (u32 q0 = 0; q0 < na; q0 += 64) {
+                const u32 q = q0 + lane;
+                const bool have = q < na;
+                const u32 c = have ? ac[q] : 0u;
+                u32 lo = 0, hi = nb;                    // first element of B that is not below c
+                while (__ballot(lo < hi)) {
+                    if (lo < hi) {
+                        const u32 mid = (lo + hi) >> 1;
+                        if (sb[mid] < c) lo = mid + 1; else hi = mid;
+                    }
+                }
+                cnt += (have && lo < nb && sb[lo] == c) ? 1u : 0u;
+            }
+            for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, WAVE);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();            // (S is rewritten by the next comparison)
+            return cnt >= need;
+        }
         const u64 *bh = id_hi + koff[j], *bl = id_lo + koff[j];
         for (u32 q = lane; q < nb; q += 64) { S.h[q] = bh[q]; S.l[q] = bl[q]; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1451,6 +1513,9 @@ struct MinHashFamily {       // same signature in table t (the key only groups),
         return false;
     }
     __device__ __forceinline__ bool near(u32, u32 i, u32 j) const {
+        if (kc && kc[(size_t)i * kstride] != MH_KC_NONE && kc[(size_t)j * kstride] != MH_KC_NONE)
+            return mh_near_codes(kc + (size_t)i * kstride, nuniq[i], kc + (size_t)j * kstride, nuniq[j], need_tab,
+                                 fp + (size_t)i * MH_FPW, fp + (size_t)j * MH_FPW, fp_excess[i], fp_excess[j]);
         return mh_near(id_hi + koff[i], id_lo + koff[i], nuniq[i], id_hi + koff[j], id_lo + koff[j], nuniq[j],
                        need_tab, fp + (size_t)i * MH_FPW, fp + (size_t)j * MH_FPW, fp_excess[i], fp_excess[j]);
     }
@@ -1533,8 +1598,6 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
     TRY(d_off.alloc((size_t)n + 1));
     TRY(d_koff.alloc((size_t)n + 1));
     TRY(xs.alloc(nkm));
-    TRY(id_hi.alloc(nkm));
-    TRY(id_lo.alloc(nkm));
     DevBuf<u64> fp;
     DevBuf<u32> fp_excess, need_tab;
     TRY(fp.alloc((size_t)nn * MH_FPW));
@@ -1596,6 +1659,18 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
     const u32 kstride = (max_nk + 31u) & ~31u, tstride = ((u32)ntables + 3u) & ~3u;
     if (wave64) TRY(kc.alloc((size_t)nn * kstride));
     if (lazy) TRY(sig0T.alloc((size_t)nn * tstride));
+    // The 16-byte k-mer ids only where a probe may lack its codes: any character outside A/C/G/T, k-mers of 16, or no
+    // code rows at all (the edge-list variant)
+    bool want_ids = !wave64 || kmer_size > 15;
+    if (!want_ids) {
+        HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(u32), s));
+        hipLaunchKernelGGL(mh_other_chars_kernel, dim3(2048), dim3(256), 0, s, (const u8 *)d_bytes.p, (u64)total, count.p);
+        HIP_TRY(hipMemcpyAsync(ctx->h_pin, count.p, sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        want_ids = *(volatile u32 *)ctx->h_pin != 0u;
+        HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(u32), s));
+    }
+    if (want_ids) { TRY(id_hi.alloc(nkm)); TRY(id_lo.alloc(nkm)); }
     hipLaunchKernelGGL(mh_kmer_kernel, dim3((unsigned)std::min<i64>(n, (i64)1 << 20)), dim3(64), 0, s,
                        (const u8 *)d_bytes.p, (const u32 *)d_off.p, (const u32 *)d_koff.p, nn, (int)kmer_size, xs.p,
                        id_hi.p, id_lo.p, nuniq.p, (unsigned long long *)fp.p, fp_excess.p, wave64 ? kc.p : (u32 *)nullptr, kstride);
