@@ -1,3 +1,6 @@
+#!/bin/bash
+# usage (GPU box): tools/ndf_kernel_trace.sh   -> kernel totals of one S5 x 1.0 design_large step with ONE front-end worker (kernels with the
+# device to themselves) and, per union chunk, the near-duplicate filter's launches: round-0 pass, probe passes, drain, wake-ups
 export CATCHHIP_TEST_HOOKS=1 CATCHHIP_FRONT_END_WORKERS=1 CATCHHIP_PREFETCH_DEPTH=0
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
