@@ -1460,7 +1460,7 @@ def main():
             for name, extra in (("S3", ["--workload", "S3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]),
                                 # (a cold first step is 3-4 s longer: first-use allocations of 100+ GB; the S5 leg times its
                                 # own CPU sample -- the oracle's MinHash filter + set cover on 40 genomes, ~20 s)
-                                ("S5", ["--workload", "S5", "--scale", "%g" % args.also_s5_scale, "--steps", "1", "--warmup", "1"])):
+                                ("S5", ["--workload", "S5", "--scale", "%g" % args.also_s5_scale, "--steps", "2", "--warmup", "1"])):
                 ta = time.perf_counter()
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra +
