@@ -279,7 +279,11 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
                 e = list ? list[g] : g;
                 t = e / nslot;
                 x = e - t * nslot;
-                i = vals_all[(size_t)t * nslot + x];
+                // (round 0 of the wake-up form: the first slot of a run has nobody before it -- ndf_init_kernel wrote its
+                // cursor as run out and left it out of the probe's count, so it costs two coalesced key loads here
+                // instead of five scattered accesses)
+                if (WAKE && !list && (x == 0u || keys_all[e - 1] != keys_all[e])) valid = false;
+                else i = vals_all[(size_t)t * nslot + x];
             }
         }
     }
@@ -596,6 +600,25 @@ ndf_inv_kernel(const u32 *__restrict__ vals_all, u32 TS, u32 nslot, size_t tn, u
     const size_t t = e / nslot;
     inv[(size_t)vals_all[e] * TS + t] = (u32)(e - t * nslot);
 }
+// inv, and round 5's head start: an entry that is the first of its run (or alone in its bucket: most entries) has
+// nobody to look at -- its cursor is written as run out here (cursor == its own slot), the others count towards the probe's
+// tables still to run out (left), and a probe without any is kept by ndf_keep_unshared_kernel
+__global__ void __launch_bounds__(256)
+ndf_init_kernel(const u32 *__restrict__ vals_all, const u64 *__restrict__ keys_all, u32 TS, u32 nslot, size_t tn,
+                u32 *__restrict__ inv, u32 *__restrict__ cursor, u32 *__restrict__ left) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= tn) return;
+    const size_t t = e / nslot;
+    const u32 x = (u32)(e - t * nslot), i = vals_all[e];
+    inv[(size_t)i * TS + t] = x;
+    if (x == 0u || keys_all[e - 1] != keys_all[e]) cursor[(size_t)i * TS + t] = x;
+    else atomicAdd(&left[i], 1u);
+}
+__global__ void __launch_bounds__(256)
+ndf_keep_unshared_kernel(u32 *__restrict__ status, const u32 *__restrict__ left, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && left[i] == 0u) status[i] = 1u;
+}
 // Compaction of the tables (WAKE): the slots of dropped probes go.  Every table holds every probe once, so all
 // tables keep the same number of slots, and a probe deep in a run of thousands of near-identical strains -- all
 // dropped after the second pass except a few -- no longer walks past them (64 per step, two dependent loads each: a
@@ -752,9 +775,11 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
     if (wake) {
         TRY(inv.alloc((size_t)nn * TS));
         TRY(left_tables.alloc(nn));
-        hipLaunchKernelGGL(ndf_inv_kernel, dim3((unsigned)div_up((i64)tn, 256)), dim3(256), 0, s, svals, TS, nn, tn, inv.p);
+        HIP_TRY(hipMemsetAsync(left_tables.p, 0, sizeof(u32) * nn, s));
+        hipLaunchKernelGGL(ndf_init_kernel, dim3((unsigned)div_up((i64)tn, 256)), dim3(256), 0, s, svals, (const u64 *)skeys.p, TS, nn, tn,
+                           inv.p, cursor.p, left_tables.p);
+        hipLaunchKernelGGL(ndf_keep_unshared_kernel, dim3(nb), dim3(256), 0, s, status.p, (const u32 *)left_tables.p, nn);
         HIP_TRY(hipMemsetAsync(flags.p, 0xff, sizeof(u32) * nn, s));       // (flags = wait_on: nobody is parked)
-        hipLaunchKernelGGL(ndf_fill_u32_kernel, dim3(nb), dim3(256), 0, s, left_tables.p, nn, ntables);
         tm.launch(2);
     } else {
         TRY(inv.alloc(1));
