@@ -409,7 +409,8 @@ __global__ __launch_bounds__(64 * NEIGH_WAVES) void sig_graph_kernel(
     extern __shared__ u32 s_mem[];
     u32 *s_b = s_mem, *s_q = s_mem + (size_t)64 * N;       // s_b[i * 64 + lane], s_q[q * N + i]
     __shared__ unsigned long long s_qfp[SG_QT][NEIGH_FPW + 1];
-    __shared__ u32 s_qx[SG_QT];
+    __shared__ u32 s_qx[SG_QT], s_np;
+    __shared__ uint16_t s_pairs[SG_QT * 64];
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 kq = t0 + lane;
     const u32 kc = kq < nseq ? kq : nseq - 1;
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(64 * NEIGH_WAVES) void sig_graph_kernel(
             s_qfp[q][w] = fpT[(size_t)w * nseq + min(q0 + q, nseq - 1)];
         }
         if (threadIdx.x < SG_QT) s_qx[threadIdx.x] = excess[min(q0 + threadIdx.x, nseq - 1)];
+        if (threadIdx.x == 0) s_np = 0;
         __syncthreads();
         u32 need = 0;
         for (u32 q = wave; q < SG_QT; q += NEIGH_WAVES) {
@@ -445,13 +447,29 @@ __global__ __launch_bounds__(64 * NEIGH_WAVES) void sig_graph_kernel(
         }
         for (u32 t = threadIdx.x; t < SG_QT * N; t += 64 * NEIGH_WAVES) s_q[t] = sig[(size_t)min(q0 + t / N, nseq - 1) * N + (t % N)];
         __syncthreads();
+        // Round 5: the survivors are walked LANE-PACKED.  A query's near targets are the same stretch of other strains'
+        // genomes -- one or two of a wavefront's 64 consecutive targets --, so a wavefront that walked "its" query for the
+        // lanes that needed it ran the ~N-step walk for one or two lanes at a time; the (query, target) pairs of the tile
+        // are listed in LDS instead and every lane of the workgroup takes one.
         for (u32 q = wave; q < SG_QT; q += NEIGH_WAVES) {
-            if (!__ballot((need >> q) & 1u)) continue;
+            const bool mine = (need >> q) & 1u;
+            const unsigned long long b = __ballot(mine);
+            if (!b) continue;
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&s_np, (u32)__popcll(b));
+            base = __shfl(base, 0, WAVE);
+            if (mine) s_pairs[base + (u32)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)((q << 8) | lane);
+        }
+        __syncthreads();
+        const u32 np = s_np;
+        for (u32 p0 = wave * 64; p0 < np; p0 += 64 * NEIGH_WAVES) {
+            const u32 p = p0 + lane;
+            const bool have = p < np;
+            const u32 pr = have ? s_pairs[p] : 0u, q = pr >> 8, tl = pr & 63u;
             const u32 *a = s_q + (size_t)q * N;
             u32 c = 0;
-            if ((need >> q) & 1u)
-                c = walk_common(N, [&](u32 i) { return a[i]; }, [&](u32 i) { return s_b[i * 64 + lane]; });
-            const bool hit = c >= min_common && ((need >> q) & 1u);
+            if (have) c = walk_common(N, [&](u32 i) { return a[i]; }, [&](u32 i) { return s_b[i * 64 + tl]; });
+            const bool hit = have && c >= min_common;
             const unsigned long long b = __ballot(hit);
             if (!b) continue;
             const u32 nh = (u32)__popcll(b);
@@ -460,9 +478,10 @@ __global__ __launch_bounds__(64 * NEIGH_WAVES) void sig_graph_kernel(
             base = __shfl(base, 0, WAVE);
             if (hit) {
                 const unsigned long long pos = base + 2ull * (u32)__popcll(b & ((1ull << lane) - 1ull));
+                const u32 kt = t0 + tl;
                 if (pos + 1 < cap) {
-                    out_key[pos] = ((unsigned long long)(q0 + q) << 32) | kq; out_val[pos] = c;
-                    out_key[pos + 1] = ((unsigned long long)kq << 32) | (q0 + q); out_val[pos + 1] = c;
+                    out_key[pos] = ((unsigned long long)(q0 + q) << 32) | kt; out_val[pos] = c;
+                    out_key[pos + 1] = ((unsigned long long)kt << 32) | (q0 + q); out_val[pos + 1] = c;
                 }
             }
         }
