@@ -234,7 +234,21 @@ struct HammingFamily {       // ndf_near on the padded rows; the earlier tables'
 // (decisions rest on final states only).  The queue has ES_SHARDS shards (a counter on ONE address takes ~10 ns per
 // atomic: 100 k walks filed or handed out through one counter were 1-2 ms of every pass); the wavefronts of the first
 // launch file round-robin, shard s is drained by the wavefronts with (id & 63) == s, strided.
-struct NdfQueue { u32 *dq; u32 *dq_count; u32 segcap; };     // shard s: dq[s * segcap ..), its length dq_count[s * ES_STRIDE]
+struct NdfQueue {
+    u32 *dq; u32 *dq_count; u32 segcap;      // shard s: dq[s * segcap ..), its length dq_count[s * ES_STRIDE]
+    u32 *st2;                                // the states once more, 2 bits per probe (see ndf_state); null: polling rounds
+};
+// A mate's state is looked up once per mate examined, at random: the 4-byte words of 5 M probes are 18 MB that miss the
+// L2 (PMC, round 5: ndf_cflag_kernel alone fetched 125 GB per S5 step for "is the probe at this slot dropped?").  The same
+// states packed 16 to a word -- 1.1 MB, resident in every XCD's L2 -- are kept beside them: 0 undecided, 1 kept, 2 dropped
+// only ever go 0 -> 1 or 0 -> 2, so a decision is an atomicOr; a reader that sees the old 0 sees what it would have seen a
+// moment earlier.
+__device__ __forceinline__ u32 ndf_state(const volatile u32 *st, const u32 *st2, u32 j) {
+    return st2 ? (((const volatile u32 *)st2)[j >> 4] >> ((j & 15u) * 2u)) & 3u : st[j];
+}
+__device__ __forceinline__ void ndf_mark(u32 *st2, u32 i, u32 v) {
+    if (st2) atomicOr(&st2[i >> 4], v << ((i & 15u) * 2u));
+}
 
 template <class Family, bool WAKE, bool DRAIN = false>
 __global__ void __launch_bounds__(256)
@@ -338,7 +352,7 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
         bool is_near = false, want = false;
         if (act) {
             j = vals[y];                             // j < i: stable sort keeps indices ascending in a run
-            sj = st[j];
+            sj = ndf_state(st, Q.st2, j);
             if (sj != 2) {
                 is_near = near_known;
                 want = !is_near && fam.same_bucket(t, i, j) && !fam.owned_earlier(t, i, j);
@@ -398,7 +412,7 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
             u32 sj = 2, j = 0;
             if (yy < lx) {
                 j = lvals[yy];
-                sj = st[j];
+                sj = ndf_state(st, Q.st2, j);
                 want = sj != 2 && fam.same_bucket(lt, li, j) && !fam.owned_earlier(lt, li, j);
             }
             int first = -1;
@@ -427,14 +441,14 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
         }
     }
     if (walking && !deferred) {
-        if (verdict == 2) { status[i] = 2; again = false; }
+        if (verdict == 2) { status[i] = 2; ndf_mark(Q.st2, i, 2u); again = false; }
         else if (verdict == 3) {                     // wait for the undecided mate at y
             if (WAKE) atomicCAS(&flags[i], NDF_CUR_NONE, vals[y]);      // (one blocker per probe: the first entry to find one)
             else flags[i] = 2;
         } else again = false;                        // this table has nothing more to say about i
         cursor_all[(size_t)i * TS + t] = verdict == 1 ? x : (y | NDF_CUR_NEAR);
         // the entry that exhausts a probe's last table: nobody kept is near -- kept
-        if (WAKE && verdict == 1 && atomicSub(&left[i], 1u) == 1u) atomicCAS(&status[i], 0u, 1u);
+        if (WAKE && verdict == 1 && atomicSub(&left[i], 1u) == 1u && atomicCAS(&status[i], 0u, 1u) == 0u) ndf_mark(Q.st2, i, 1u);
     }
     if (__ballot(compared != 0u)) {                  // (one atomic per wavefront and counter)
         for (int o = 32; o > 0; o >>= 1) { compared += __shfl_xor(compared, o, WAVE); found += __shfl_xor(found, o, WAVE); }
@@ -515,7 +529,7 @@ ndf_probe_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 
         bool is_near = false, want = false;
         if (act) {
             j = vals[y];                             // j < i: stable sort keeps indices ascending in a run
-            sj = st[j];
+            sj = ndf_state(st, Q.st2, j);
             if (sj != 2) {
                 is_near = near_known;
                 want = !is_near && fam.same_bucket(t, i, j) && !fam.owned_earlier(t, i, j);
@@ -555,7 +569,7 @@ ndf_probe_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 
     }
     if (walking && !exhausted && y >= x) exhausted = 1;      // (also when the probe parks: a cursor at its own slot MEANS ran out, and is counted)
     if (outcome == 2u) {
-        if (lane == 0) status[i] = 2;
+        if (lane == 0) { status[i] = 2; ndf_mark(Q.st2, i, 2u); }
     } else {
         // cursors back; the tables that ran out are counted; the probe parks, or its unfinished walks are queued
         const unsigned long long eb = __ballot(exhausted != 0u);
@@ -575,7 +589,7 @@ ndf_probe_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 
         }
         if (eb && lane == 0) {
             const u32 c = (u32)__popcll(eb);
-            if (atomicSub(&left[i], c) == c) atomicCAS(&status[i], 0u, 1u);      // the last tables: nobody kept is near -- kept
+            if (atomicSub(&left[i], c) == c && atomicCAS(&status[i], 0u, 1u) == 0u) ndf_mark(Q.st2, i, 1u);      // the last tables: nobody kept is near -- kept
         }
     }
     if (__ballot(compared != 0u)) {
@@ -615,9 +629,9 @@ ndf_init_kernel(const u32 *__restrict__ vals_all, const u64 *__restrict__ keys_a
     else atomicAdd(&left[i], 1u);
 }
 __global__ void __launch_bounds__(256)
-ndf_keep_unshared_kernel(u32 *__restrict__ status, const u32 *__restrict__ left, u32 n) {
+ndf_keep_unshared_kernel(u32 *__restrict__ status, const u32 *__restrict__ left, u32 n, u32 *__restrict__ st2) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && left[i] == 0u) status[i] = 1u;
+    if (i < n && left[i] == 0u) { status[i] = 1u; ndf_mark(st2, i, 1u); }
 }
 // Compaction of the tables (WAKE): the slots of dropped probes go.  Every table holds every probe once, so all
 // tables keep the same number of slots, and a probe deep in a run of thousands of near-identical strains -- all
@@ -627,15 +641,16 @@ ndf_keep_unshared_kernel(u32 *__restrict__ status, const u32 *__restrict__ left,
 // new slots per table + rank inside the table).  Cursors are renumbered: past the dropped mates a cursor pointed at
 // or before; one that reaches its own slot that way has exhausted its table (counted here, as the pass would).
 __global__ void __launch_bounds__(256)
-ndf_cflag_kernel(const u32 *__restrict__ vals_all, const u32 *__restrict__ status, size_t tn, u32 *__restrict__ flag) {
+ndf_cflag_kernel(const u32 *__restrict__ vals_all, const u32 *__restrict__ status, size_t tn, u32 *__restrict__ flag,
+                 const u32 *__restrict__ st2) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < tn) flag[e] = status[vals_all[e]] != 2u ? 1u : 0u;
+    if (e < tn) flag[e] = ndf_state(status, st2, vals_all[e]) != 2u ? 1u : 0u;
     else if (e == tn) flag[e] = 0u;
 }
 __global__ void __launch_bounds__(256)
 ndf_compact_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u32 *__restrict__ cursor, u32 TS,
                    const u32 *__restrict__ flag, const u32 *__restrict__ pos, u32 nslot, u32 nslot_new, size_t tn,
-                   u64 *__restrict__ keys2, u32 *__restrict__ vals2, u32 *status, u32 *__restrict__ left) {
+                   u64 *__restrict__ keys2, u32 *__restrict__ vals2, u32 *status, u32 *__restrict__ left, u32 *__restrict__ st2) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= tn || !flag[e]) return;
     const u32 t = (u32)(e / nslot), x = (u32)(e - (size_t)t * nslot);
@@ -651,7 +666,7 @@ ndf_compact_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u
         const u32 y2 = pos[ey] - t * nslot_new;              // the first surviving mate at or after y
         if (y2 >= x2) {
             cur = x2;                                        // only dropped mates were left: this table is done with i
-            if (atomicSub(&left[i], 1u) == 1u) atomicCAS(&status[i], 0u, 1u);
+            if (atomicSub(&left[i], 1u) == 1u && atomicCAS(&status[i], 0u, 1u) == 0u) ndf_mark(st2, i, 1u);
         } else cur = y2 | (((cur & NDF_CUR_NEAR) && flag[ey]) ? NDF_CUR_NEAR : 0u);
     }
     cursor[(size_t)i * TS + t] = cur;
@@ -662,7 +677,8 @@ ndf_compact_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u
 // WORKGROUP of 1,024 for the list (round 5: one per wavefront plus one for the count were 140 k atomics on ONE address
 // each, 1.4 ms of every pass)
 __global__ void __launch_bounds__(1024)
-ndf_wake_kernel(u32 *status, u32 *__restrict__ wait_on, u32 n, u32 *__restrict__ next, u32 *__restrict__ counters, int count_undecided) {
+ndf_wake_kernel(u32 *status, u32 *__restrict__ wait_on, u32 n, u32 *__restrict__ next, u32 *__restrict__ counters, int count_undecided,
+                u32 *__restrict__ st2) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ u32 s_cnt[16], s_und[16], s_base;
     bool undecided = false, woken = false;
@@ -672,8 +688,8 @@ ndf_wake_kernel(u32 *status, u32 *__restrict__ wait_on, u32 n, u32 *__restrict__
         // verdict; the read-back checks that nothing is left undecided)
         undecided = true;
         if (j != NDF_CUR_NONE) {
-            const u32 sj = status[j];
-            if (sj == 1) { status[i] = 2; undecided = false; }
+            const u32 sj = ndf_state(status, st2, j);
+            if (sj == 1) { status[i] = 2; ndf_mark(st2, i, 2u); undecided = false; }
             else if (sj == 2) { wait_on[i] = NDF_CUR_NONE; woken = true; }
         }
     }
@@ -769,6 +785,11 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
     const bool probe_pass = queued && ntables <= 64 && !chip_test_env("CATCHHIP_NDF_NO_PROBE_PASS");
     const bool probe_round0 = probe_pass && chip_test_env("CATCHHIP_NDF_PROBE_ROUND0") != nullptr;
     NdfQueue Q{};
+    DevBuf<u32> st2;
+    if (wake && !chip_test_env("CATCHHIP_NDF_NO_PACKED_STATES")) {
+        TRY(st2.alloc(((size_t)nn + 15) / 16 + 1));
+        HIP_TRY(hipMemsetAsync(st2.p, 0, sizeof(u32) * (((size_t)nn + 15) / 16 + 1), s));
+    }
     const u32 dq_segcap = (u32)(tn / ES_SHARDS) + 64u * 2u;      // (wavefronts file round-robin: a shard gets at most its share + one wavefront's)
     DevBuf<u32> dq_count;
     if (queued) { TRY(dq.alloc((size_t)dq_segcap * ES_SHARDS)); TRY(dq_count.alloc(ES_SHARDS * ES_STRIDE)); }
@@ -778,7 +799,7 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
         HIP_TRY(hipMemsetAsync(left_tables.p, 0, sizeof(u32) * nn, s));
         hipLaunchKernelGGL(ndf_init_kernel, dim3((unsigned)div_up((i64)tn, 256)), dim3(256), 0, s, svals, (const u64 *)skeys.p, TS, nn, tn,
                            inv.p, cursor.p, left_tables.p);
-        hipLaunchKernelGGL(ndf_keep_unshared_kernel, dim3(nb), dim3(256), 0, s, status.p, (const u32 *)left_tables.p, nn);
+        hipLaunchKernelGGL(ndf_keep_unshared_kernel, dim3(nb), dim3(256), 0, s, status.p, (const u32 *)left_tables.p, nn, st2.p);
         HIP_TRY(hipMemsetAsync(flags.p, 0xff, sizeof(u32) * nn, s));       // (flags = wait_on: nobody is parked)
         tm.launch(2);
     } else {
@@ -797,7 +818,7 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
             TRY(cflag.reserve(tcur + 1));
             TRY(cpos.reserve(tcur + 1));
             hipLaunchKernelGGL(ndf_cflag_kernel, dim3((unsigned)div_up((i64)tcur + 1, 256)), dim3(256), 0, s, (const u32 *)svals_buf.p,
-                               (const u32 *)status.p, tcur, cflag.p);
+                               (const u32 *)status.p, tcur, cflag.p, (const u32 *)st2.p);
             TRY(chip_exclusive_scan_u32(ctx, cflag.p, cpos.p, (i64)tcur + 1, ctmp));
             HIP_TRY(hipMemcpyAsync(ctx->h_pin, cpos.p + tcur, sizeof(u32), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
@@ -809,7 +830,7 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
                 TRY(svals2.reserve(tcur));
                 hipLaunchKernelGGL(ndf_compact_kernel, dim3((unsigned)div_up((i64)tcur, 256)), dim3(256), 0, s, (const u64 *)skeys.p,
                                    (const u32 *)svals_buf.p, cursor.p, TS, (const u32 *)cflag.p, (const u32 *)cpos.p, nslot, nslot2,
-                                   tcur, skeys2.p, svals2.p, status.p, left_tables.p);
+                                   tcur, skeys2.p, svals2.p, status.p, left_tables.p, st2.p);
                 skeys.swap(skeys2); svals_buf.swap(svals2);
                 nslot = nslot2;
                 if (nslot)
@@ -820,7 +841,7 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
         }
         HIP_TRY(hipMemsetAsync(undecided, 0, 2 * sizeof(u32), s));
         if (queued) HIP_TRY(hipMemsetAsync(dq_count.p, 0, sizeof(u32) * ES_SHARDS * ES_STRIDE, s));
-        Q.dq = queued ? dq.p : (u32 *)nullptr; Q.dq_count = dq_count.p; Q.segcap = dq_segcap;
+        Q.dq = queued ? dq.p : (u32 *)nullptr; Q.dq_count = dq_count.p; Q.segcap = dq_segcap; Q.st2 = st2.p;
         if (nlist) {
             const u32 *cur_list = round ? (const u32 *)lists[round & 1].p : (const u32 *)nullptr;
             const int mode = (probe_pass && (round || probe_round0)) ? 2 : 0;
@@ -830,7 +851,7 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
                 tm.launch(1);
             }
         }
-        if (wake) hipLaunchKernelGGL(ndf_wake_kernel, dim3((unsigned)div_up(nn, 1024)), dim3(1024), 0, s, status.p, flags.p, nn, lists[(round & 1) ^ 1].p, undecided, trace ? 1 : 0);
+        if (wake) hipLaunchKernelGGL(ndf_wake_kernel, dim3((unsigned)div_up(nn, 1024)), dim3(1024), 0, s, status.p, flags.p, nn, lists[(round & 1) ^ 1].p, undecided, trace ? 1 : 0, st2.p);
         else hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, undecided);
         tm.launch(2);
         HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));

@@ -38,12 +38,14 @@ def unit_of(name):
         if n.startswith(pre):
             return u
     return "other"
+per_kernel = collections.defaultdict(lambda: collections.defaultdict(float))     # kernel -> counter -> total over the run
 def pmc(dirname):
     f = sorted(glob.glob(out + "/" + dirname + "/*/*counter_collection.csv"), key=os.path.getmtime)[-1:]
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     if not f: return acc
     for r in csv.DictReader(open(f[0])):
         acc[unit_of(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        per_kernel[r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]][r["Counter_Name"]] += float(r["Counter_Value"])
     return acc
 fe, wr, va = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_valu")
 # device time and launches per unit from the kernel summary of the plain trace run
@@ -69,12 +71,17 @@ rec = {"note": "rocprofv3 passes of 'python bench.py --workload %s --scale %g --
                "--pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES in runs of their own; totals over the run by unit of the hot path "
                "(kernels by name prefix); on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md): "
                "bench.py prices traffic as 2 x FETCH_SIZE + WRITE_SIZE" % (wl, sc, steps - 1, steps),
-       "workload": wl, "scale": sc, "steps_in_run": steps, "units": units}
+       "workload": wl, "scale": sc, "steps_in_run": steps, "units": units,
+       "kernels_by_fetch": [dict(kernel=k, FETCH_SIZE_KB=v.get("FETCH_SIZE", 0.0), WRITE_SIZE_KB=v.get("WRITE_SIZE", 0.0),
+                                 SQ_INSTS_VALU=v.get("SQ_INSTS_VALU", 0.0))
+                            for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0.0))[:24]]}
 json.dump(rec, open(out + "/pmc.json", "w"), indent=1)
 for u, v in sorted(units.items(), key=lambda kv: -kv[1]["kernel_ms_in_run"]):
     print("%-22s %9.1f ms %7d launches  fetch %8.2f GB  write %8.2f GB  valu %s" % (
         u, v["kernel_ms_in_run"], v["launches_in_run"], v["FETCH_SIZE_KB"] / 1e6, v["WRITE_SIZE_KB"] / 1e6,
         ("%.3f" % v["valu_issue_frac"]) if v["valu_issue_frac"] is not None else "-"))
-print(open(out + "/bench_under_rocprof.json").read()[:600])
+for r in rec["kernels_by_fetch"][:14]:
+    print("  %-56s fetch %8.1f GB  write %8.1f GB" % (r["kernel"], r["FETCH_SIZE_KB"] / 1e6, r["WRITE_SIZE_KB"] / 1e6))
+print(open(out + "/bench_under_rocprof.json").read()[:300])
 PY
 rm -rf $out/trace $out/pmc_fetch $out/pmc_write $out/pmc_valu
