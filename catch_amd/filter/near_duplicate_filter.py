@@ -225,7 +225,21 @@ class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
         return _as_the_reference_returns_them([s for s, kp in zip(order, keep) if kp])
 
     def _draw_for_groups(self, ngroups):
-        """See NearDuplicateFilterWithHammingDistance._draw_for_groups."""
+        """See NearDuplicateFilterWithHammingDistance._draw_for_groups.  Many
+        groups (the clusters of a clustered design: 2,848 x 25 tables x 3 x 2 =
+        427 k `random.randint` calls, 0.3 s of interpreter on the critical path
+        of an S5 step) are drawn from a copy of the interpreter's Mersenne
+        Twister in NumPy, word for word what `random` would have consumed, and
+        `random` is left in the state those calls would have left it in."""
+        if ngroups * self.num_tables() * self.k >= 4096:
+            try:
+                pairs = _randint_pairs_like_random(ngroups * self.num_tables() * self.k, self.P)
+            except Exception:      # noqa: BLE001 -- any surprise: the plain calls (the state is untouched until the end)
+                pairs = None
+            if pairs is not None:
+                T, k = self.num_tables(), self.k
+                it = iter(pairs)
+                return [[[next(it) for _ in range(k)] for _ in range(T)] for _ in range(ngroups)]
         return [self._draw_params() for _ in range(ngroups)]
 
     def _apply_to_grouped_candidates(self, cands, ngroups, drawn=None):
@@ -262,3 +276,52 @@ class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
             orders, self.kmer_size, params, self.dist_thres)
         return [_as_the_reference_returns_them([s for s, kp in zip(order, keep) if kp])
                 for order, keep in zip(orders, keeps)]
+
+
+def _randint_pairs_like_random(npairs, P):
+    """npairs times (random.randint(1, P), random.randint(0, P)) for P = 2**31 - 1, exactly as the interpreter
+    draws them, and `random` advanced as those calls would advance it.  randint(1, P) is 1 + getrandbits(31) -- one
+    32-bit output of the generator, shifted (rejected only if it equals P: then this function gives up) --,
+    randint(0, P) is getrandbits(32) repeated until it is below 2**31 (CPython's _randbelow_with_getrandbits).  So
+    the stream parses as [a][words >= 2**31]*[b] ..., a two-state machine: the state before word i is "next is an
+    a" iff the run of words below 2**31 that ends just before i has odd length (even if that run starts the
+    stream).  Returns None when `random` is not the Mersenne Twister this relies on."""
+    import numpy as np
+    st = random.getstate()
+    if P != 2 ** 31 - 1 or st[0] != 3 or len(st[1]) != 625:
+        return None
+    key, pos = np.array(st[1][:-1], dtype=np.uint32), int(st[1][-1])
+    bg = np.random.MT19937()
+
+    def rewind():
+        bg.state = {"bit_generator": "MT19937", "state": {"key": key, "pos": pos}}
+    R = int(npairs * 3.3) + 64
+    while True:
+        rewind()
+        raw = bg.random_raw(R).astype(np.uint32)
+        below = raw < (1 << 31)
+        idx = np.arange(R, dtype=np.int64)
+        last_not = np.maximum.accumulate(np.where(~below, idx, -1))
+        run = np.empty(R + 1, dtype=np.int64)          # words below 2**31 immediately before i
+        run[0] = 0
+        run[1:] = idx - last_not
+        is_a = (run & 1) == 1
+        from_start = (np.arange(R + 1, dtype=np.int64) - run) == 0
+        is_a = np.where(from_start, ~is_a, is_a)
+        is_a[0] = True
+        at = np.nonzero(is_a)[0]
+        if at.size >= npairs + 1:
+            break
+        R *= 2
+    at = at[:npairs + 1]
+    a = raw[at[:-1]] >> 1
+    if (a >= P).any():
+        return None
+    b = raw[at[1:] - 1]
+    rewind()
+    if int(at[-1]):
+        bg.random_raw(int(at[-1]))
+    s2 = bg.state["state"]
+    out = list(zip((a.astype(np.int64) + 1).tolist(), b.astype(np.int64).tolist()))
+    random.setstate((st[0], tuple(int(x) for x in s2["key"]) + (int(s2["pos"]),), st[2]))
+    return out

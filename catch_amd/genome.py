@@ -7,6 +7,8 @@ _DROP_ATCG = str.maketrans("", "", "ATCG")
 
 
 class Genome:
+    __slots__ = ("seqs", "chrs", "_size", "_size_unambig")      # (a clustered design makes one per fragment: 224 k at S5)
+
     def __init__(self, seqs, chrs=None):
         if len(seqs) > 1 and chrs is None:
             raise ValueError(("When there is more than one sequence, chrs "

@@ -553,3 +553,29 @@ def test_prefetch_pool_hands_results_over_in_order_and_discards_what_is_left():
             seen.append(it_)
     pool.close()
     assert seen == [10, 11, 12]
+
+
+def test_minhash_parameter_draws_in_bulk_equal_the_interpreter():
+    """NearDuplicateFilterWithMinHash._draw_for_groups for many groups (a copy of
+    `random`'s Mersenne Twister parsed in NumPy) == one _draw_params call per
+    group, values and the state `random` is left in; few groups take the plain
+    calls."""
+    import random
+    from catch_amd.filter.near_duplicate_filter import (NearDuplicateFilterWithMinHash,
+                                                        _randint_pairs_like_random)
+    f = NearDuplicateFilterWithMinHash(0.6)
+    for seed, groups in ((21, 300), (3, 57), (99, 2)):
+        random.seed(seed)
+        want = [f._draw_params() for _ in range(groups)]
+        after = random.random()
+        random.seed(seed)
+        got = f._draw_for_groups(groups)
+        assert got == want and random.random() == after
+    P = 2 ** 31 - 1
+    for seed in range(5):
+        random.seed(1000 + seed)
+        want = [(random.randint(1, P), random.randint(0, P)) for _ in range(5000)]
+        st = random.getstate()
+        random.seed(1000 + seed)
+        assert _randint_pairs_like_random(5000, P) == want and random.getstate() == st
+    assert _randint_pairs_like_random(10, 2 ** 31 - 2) is None       # (another modulus: not what this parses)
