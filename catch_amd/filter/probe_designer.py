@@ -81,8 +81,8 @@ class ProbeDesigner:
             dict(enumerate(seqs)), threshold=self.cluster_threshold,
             cluster_method=method)
         logger.info("%d clusters; sizes %s", len(clusters), [len(c) for c in clusters])
-        return [[genome.Genome.from_one_seq(seqs[i]) for i in members]
-                for members in clusters]
+        one = genome.Genome.from_one_seq
+        return [[one(seqs[i]) for i in members] for members in clusters]
 
     # -- object pipeline ----------------------------------------------------
     @staticmethod

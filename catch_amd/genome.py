@@ -68,4 +68,10 @@ class Genome:
 
     @staticmethod
     def from_one_seq(seq):
-        return Genome([seq])
+        # (no argument checks to make, and the size is known: a clustered design builds one per fragment)
+        g = object.__new__(Genome)
+        g.seqs = [seq]
+        g.chrs = None
+        g._size = len(seq)
+        g._size_unambig = None
+        return g
