@@ -144,6 +144,7 @@ PROTOTYPES = {
     "catchhip_dfs_seen": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32p), c_i64p]),
     "catchhip_dfs_new_queued": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32p), c_i64p]),
     "catchhip_dfs_set_copy_rank": (ctypes.c_int, [c_vp, c_i64p]),
+    "catchhip_dfs_set_copy_members": (ctypes.c_int, [c_vp, c_i64p, ctypes.c_int64]),
     "catchhip_dfs_push": (ctypes.c_int, [c_vp, c_i64p, c_u8p, ctypes.c_int64]),
     "catchhip_dfs_counts": (ctypes.c_int, [c_vp, c_i64p]),
     "catchhip_cover_scan_first_seen": (ctypes.c_int, [

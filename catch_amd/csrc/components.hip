@@ -159,6 +159,20 @@ extern "C" int catchhip_dfs_set_copy_rank(catchhip_dfs *d, const i64 *rank) {
     return 0;
 }
 
+// the same from the copy's members in its iteration order (rank = position): only the members' ranks are written -- the
+// search only ever asks for vertices that are still in `remaining` -- instead of an n-entry array zeroed, scattered and
+// copied per call (444 calls for the 224 k fragments of S5)
+extern "C" int catchhip_dfs_set_copy_members(catchhip_dfs *d, const i64 *members, i64 count) {
+    ARG_CHECK(d && count >= 0 && (count == 0 || members));
+    if (d->rank.size() != d->n) d->rank.assign(d->n, 0);
+    for (i64 k = 0; k < count; ++k) {
+        ARG_CHECK(members[k] >= 0 && members[k] < (i64)d->n);
+        d->rank[(size_t)members[k]] = k;
+    }
+    d->have_rank = true;
+    return 0;
+}
+
 // what a real difference found for the vertex of status 3: its neighbours in the difference's order, near[i] != 0
 // for the absorbed ones
 extern "C" int catchhip_dfs_push(catchhip_dfs *d, const i64 *ks, const u8 *near, i64 count) {

@@ -301,9 +301,7 @@ def _components_over_graph(n, ptr, gidx, gcom, near_common, row_fn, threshold, e
             elif status.value == 2:
                 cp = remaining.copy()
                 members = np.fromiter(cp, dtype=np.int64, count=len(cp))
-                copy_rank = np.zeros(n, dtype=np.int64)
-                copy_rank[members] = np.arange(members.size)
-                _lib.check(L.catchhip_dfs_set_copy_rank(h, copy_rank.ctypes.data_as(_lib.c_i64p)))
+                _lib.check(L.catchhip_dfs_set_copy_members(h, members.ctypes.data_as(_lib.c_i64p), int(members.size)))
             else:
                 j = int(vertex.value)
                 queued.update(listed(L.catchhip_dfs_new_queued).tolist())

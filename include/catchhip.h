@@ -470,6 +470,8 @@ int catchhip_dfs_run(catchhip_dfs *dfs, int64_t m, int32_t *status, int64_t *ver
 int catchhip_dfs_seen(catchhip_dfs *dfs, const uint32_t **p, int64_t *count);
 int catchhip_dfs_new_queued(catchhip_dfs *dfs, const uint32_t **p, int64_t *count);
 int catchhip_dfs_set_copy_rank(catchhip_dfs *dfs, const int64_t *rank);
+/* the same from the members of remaining.copy() in its iteration order (a member's rank is its position) */
+int catchhip_dfs_set_copy_members(catchhip_dfs *dfs, const int64_t *members, int64_t count);
 int catchhip_dfs_push(catchhip_dfs *dfs, const int64_t *ks, const uint8_t *near, int64_t count);
 int catchhip_dfs_counts(const catchhip_dfs *dfs, int64_t *out3);
 /* cluster.create_condensed_dist_matrix (catch/utils/cluster.py:102-194) for the
