@@ -858,6 +858,12 @@ class SetCoverFilter(BaseFilter):
         workers = max(1, int(_lib.test_env("CATCHHIP_FRONT_END_WORKERS", "2")))
         piped = depth > 0 and len(chunks) > 1
         drawn_ndf = {}
+        if near_duplicate_filter is not None and not hasattr(near_duplicate_filter, "_draw_for_groups"):
+            # (a filter that cannot draw ahead would draw from the global `random` on two threads at
+            # once -- a nondeterministic selection; one builder keeps its draws in chunk order)
+            workers = 1
+        import threading as _threading
+        stage_lock = _threading.Lock()       # (the builders add their stage times and counters side by side)
         if piped and near_duplicate_filter is not None and hasattr(near_duplicate_filter, "_draw_for_groups"):
             for ci, chunk in enumerate(chunks):
                 drawn_ndf[ci] = near_duplicate_filter._draw_for_groups(len(chunk))
@@ -882,12 +888,13 @@ class SetCoverFilter(BaseFilter):
                     else:
                         near_duplicate_filter._apply_to_grouped_candidates(cands, len(chunk))
                     # device time of the filter (HIP events around its launches on this worker's stream) and its work
-                    stage_s["ndf_ms"] += bctx.kernel_ms(engine.PHASE_NDF)[0]
-                    cnt = bctx.ndf_counters()
-                    stage_s["ndf_probes"] += cnt["probes"]
-                    stage_s["ndf_pairs"] += cnt["pairs_compared"]
-                    stage_s["ndf_tables"] = cnt["tables"]
-                    stage_s["ndf_kept"] += cands.n
+                    ndf_ms_, cnt = bctx.kernel_ms(engine.PHASE_NDF)[0], bctx.ndf_counters()
+                    with stage_lock:
+                        stage_s["ndf_ms"] += ndf_ms_
+                        stage_s["ndf_probes"] += cnt["probes"]
+                        stage_s["ndf_pairs"] += cnt["pairs_compared"]
+                        stage_s["ndf_tables"] = cnt["tables"]
+                        stage_s["ndf_kept"] += cands.n
                 bctx.sync()
                 if bctx is not ctx:
                     # handed over here, while this stream is idle: a rebind later would wait for the NEXT chunk's
@@ -895,10 +902,11 @@ class SetCoverFilter(BaseFilter):
                     for h in (targets, cands):
                         h.rebind(ctx)
                 t3 = _time.perf_counter()
-                stage_s["pack_s"] += t1 - t0
-                stage_s["candidates_s"] += t2 - t1
-                stage_s["near_duplicates_s"] += t3 - t2
-                events.append(("front", chunk_no[id(chunk)], t0 - t_call, t3 - t_call))
+                with stage_lock:
+                    stage_s["pack_s"] += t1 - t0
+                    stage_s["candidates_s"] += t2 - t1
+                    stage_s["near_duplicates_s"] += t3 - t2
+                    events.append(("front", chunk_no[id(chunk)], t0 - t_call, t3 - t_call))
             except BaseException:
                 for h in (cands, targets):
                     if h is not None:
