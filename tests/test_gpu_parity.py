@@ -1857,6 +1857,38 @@ def test_minhash_filter_lazy_resolution_equals_all_pairs(ctx, monkeypatch):
     assert ham["lazy"][1] < ham["all pairs"][1] and ham["lazy"][3] < ham["all pairs"][3]
 
 
+@pytest.mark.parametrize("hook", ["CATCHHIP_MH_NO_WAVE64", "CATCHHIP_NDF_NO_QUEUE", "CATCHHIP_NDF_NO_PROBE_PASS",
+                                  "CATCHHIP_NDF_PROBE_ROUND0", "CATCHHIP_NDF_NO_PACKED_STATES"])
+def test_near_duplicate_filter_pass_forms_agree(ctx, monkeypatch, hook):
+    """Round 5's forms of the lazy resolution -- walks with the probe's k-mer codes staged in LDS, deferred walks
+    drained from a queue, one wavefront per woken probe, the first slot of a run settled by the init launch, states
+    packed 2 bits per probe -- keep exactly the probes the round-4 forms keep (each hook switches one of them off,
+    CATCHHIP_NDF_PROBE_ROUND0 sends round 0 through the probe kernel too): both families, with and without groups,
+    on strains of one species next to unrelated sequences, incl. probes with N (no 2-bit codes: 16-byte ids)."""
+    from catch_amd.filter import candidate_probes
+    from catch_amd.utils import synthetic
+    from catch_amd.filter.near_duplicate_filter import (NearDuplicateFilterWithMinHash,
+                                                        NearDuplicateFilterWithHammingDistance)
+    groups = synthetic.dataset("S5m", scale=0.02)[0]
+    seqs = [s for g in groups for s in g]
+    cands = list(dict.fromkeys(candidate_probes.candidate_strings_from_sequences(seqs, 100, 50)))
+    cands += [c[:37] + "N" + c[38:] for c in cands[:300]]          # single N: such windows are candidates in CATCH
+    third = len(cands) // 3
+
+    def run():
+        random.seed(41)
+        a = NearDuplicateFilterWithMinHash(0.6)._filter_strs(cands)
+        random.seed(41)
+        b = NearDuplicateFilterWithMinHash(0.6)._filter_strs_many([cands[:third], cands[third:2 * third], cands[2 * third:]])
+        random.seed(43)
+        c = NearDuplicateFilterWithHammingDistance(6, 100)._filter_strs(cands)
+        return a, b, c
+    want = run()
+    monkeypatch.setenv(hook, "1")
+    got = run()
+    assert got == want and 0 < len(want[0]) < len(cands) and 0 < len(want[2]) < len(cands)
+
+
 def test_cluster_with_minhash_signatures_golden(ctx):
     """cluster.cluster_with_minhash_signatures (signatures + distances on the
     device, search / linkage on the host) == the reference's clusters, same
