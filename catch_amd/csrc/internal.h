@@ -294,6 +294,9 @@ int chip_exclusive_scan_u32(catchhip_ctx *ctx, const u32 *in, u32 *out, i64 n,
 // Result ends in keys/vals (the alt buffers are scratch of the same size).
 int chip_radix_sort_pairs(catchhip_ctx *ctx, DevBuf<u64> &keys, DevBuf<u64> &keys_alt,
                           DevBuf<u32> &vals, DevBuf<u32> &vals_alt, i64 n, int key_bits, int first_bit = 0);
+// nseg segments of n keys each, side by side, every segment sorted on its own (one set of launches for all)
+int chip_radix_sort_pairs_segments(catchhip_ctx *ctx, DevBuf<u64> &keys, DevBuf<u64> &keys_alt, DevBuf<u32> &vals,
+                                   DevBuf<u32> &vals_alt, i64 n, i64 nseg, int key_bits, int first_bit = 0);
 
 // v mod (2^31 - 1) for v < 2^63 without a 64-bit division: 2^31 = 1 (mod p),
 // so the 31-bit digits of v add up (two folds leave at most p + 1)

@@ -1258,6 +1258,15 @@ mh_keys_all_kernel(const u32 *__restrict__ xs, const u32 *__restrict__ koff, u32
     keys_all[(size_t)tt * n + i] = h;
 }
 
+// the same for all tables at once: keys_all[t][i] -> (key, i) at t * n + i
+__global__ void __launch_bounds__(256)
+mh_tables_kernel(const u64 *__restrict__ keys_all, u32 n, u64 tn, u64 *__restrict__ keys, u32 *__restrict__ vals, int key_shift) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= tn) return;
+    keys[e] = keys_all[e] >> key_shift;
+    vals[e] = (u32)(e % n);
+}
+
 __global__ void __launch_bounds__(256)
 mh_table_kernel(const u64 *__restrict__ keys_all, u32 n, u64 *__restrict__ keys, u32 *__restrict__ vals, int key_shift = 0) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1750,13 +1759,23 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
                            (const u32 *)xs.p, (const u32 *)d_koff.p, nn, (const u64 *)d_ab.p, (int)k, (int)ntables, 0,
                            (int)ntables, grp, sig.p, keys_all.p, sig0T.p, tstride);
         tm.launch(1);
-        for (int t = 0; t < ntables; ++t) {
-            hipLaunchKernelGGL(mh_table_kernel, dim3(nb), dim3(256), 0, s, (const u64 *)(keys_all.p + (size_t)t * nn), nn,
-                               keys.p, vals.p, 32);
-            TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nn, 32));
-            HIP_TRY(hipMemcpyAsync(skeys.p + (size_t)t * nn, keys.p, sizeof(u64) * nn, hipMemcpyDeviceToDevice, s));
-            HIP_TRY(hipMemcpyAsync(svals.p + (size_t)t * nn, vals.p, sizeof(u32) * nn, hipMemcpyDeviceToDevice, s));
-            tm.launch(1 + 24 + 2);
+        if (chip_test_env("CATCHHIP_MH_SORT_ONE_BY_ONE")) {      // (test hook: round 4's table-by-table sorts)
+            for (int t = 0; t < ntables; ++t) {
+                hipLaunchKernelGGL(mh_table_kernel, dim3(nb), dim3(256), 0, s, (const u64 *)(keys_all.p + (size_t)t * nn), nn,
+                                   keys.p, vals.p, 32);
+                TRY(chip_radix_sort_pairs(ctx, keys, keys_alt, vals, vals_alt, nn, 32));
+                HIP_TRY(hipMemcpyAsync(skeys.p + (size_t)t * nn, keys.p, sizeof(u64) * nn, hipMemcpyDeviceToDevice, s));
+                HIP_TRY(hipMemcpyAsync(svals.p + (size_t)t * nn, vals.p, sizeof(u32) * nn, hipMemcpyDeviceToDevice, s));
+                tm.launch(1 + 24 + 2);
+            }
+        } else {
+            // all tables' (key, probe) pairs side by side, sorted as segments by one set of launches
+            DevBuf<u64> skeys_alt;
+            DevBuf<u32> svals_alt;
+            hipLaunchKernelGGL(mh_tables_kernel, dim3((unsigned)div_up((i64)tn, 256)), dim3(256), 0, s, (const u64 *)keys_all.p, nn,
+                               (u64)tn, skeys.p, svals.p, 32);
+            TRY(chip_radix_sort_pairs_segments(ctx, skeys, skeys_alt, svals, svals_alt, nn, ntables, 32));
+            tm.launch(1 + 24);
         }
         lap("signatures + sorts", t_lap);
         MinHashFamily fam{(const u32 *)d_koff.p, (const u32 *)nuniq.p, (const u64 *)id_hi.p, (const u64 *)id_lo.p, (const u32 *)sig.p,

@@ -114,6 +114,9 @@ int chip_exclusive_scan_u32(catchhip_ctx *ctx, const u32 *in, u32 *out, i64 n, D
 
 __global__ void __launch_bounds__(RS_THREADS)
 radix_hist(const u64 *__restrict__ keys, i64 n, int shift, u32 *__restrict__ hist, u32 nblocks) {
+    // (blockIdx.y = segment of a segmented sort: segments of n keys side by side, every segment sorted on its own)
+    keys += (size_t)blockIdx.y * n;
+    hist += (size_t)blockIdx.y * 256 * nblocks;
     __shared__ u32 h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -148,9 +151,14 @@ radix_scatter(const u64 *__restrict__ keys_in, const u32 *__restrict__ vals_in,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i64 tile0 = (i64)blockIdx.x * RS_TILE;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    {   // segment blockIdx.y: its keys, and its part of the histogram (scanned over ALL segments: minus the keys before it)
+        const size_t seg = blockIdx.y;
+        keys_in += seg * (size_t)n; vals_in += seg * (size_t)n; keys_out += seg * (size_t)n; vals_out += seg * (size_t)n;
+        hist_scanned += seg * 256 * nblocks;
+    }
 #pragma unroll
     for (int w = 0; w < RS_WAVES; ++w) wave_cnt[w][tid] = 0;
-    gbase[tid] = hist_scanned[(size_t)tid * nblocks + blockIdx.x];
+    gbase[tid] = hist_scanned[(size_t)tid * nblocks + blockIdx.x] - (u32)((size_t)blockIdx.y * (size_t)n);
     __syncthreads();
     u64 key[RS_ROUNDS];
     u32 val[RS_ROUNDS], rnk[RS_ROUNDS];       // rnk: rank among this wavefront's keys of the same digit
@@ -235,5 +243,34 @@ int chip_radix_sort_pairs(catchhip_ctx *ctx, DevBuf<u64> &keys, DevBuf<u64> &key
     }
     HIP_TRY(hipGetLastError());
     // scratch (hist/tmp) returns to the pool; reuse is ordered by the stream
+    return 0;
+}
+
+// The same for `nseg` segments of n keys each, side by side in keys / vals (round 5: the 25 tables of a MinHash filter
+// call in one go -- 350 sorts of ~10 launches per S5 step were 11,000 small launches queued behind other streams' kernels).
+int chip_radix_sort_pairs_segments(catchhip_ctx *ctx, DevBuf<u64> &keys, DevBuf<u64> &keys_alt, DevBuf<u32> &vals,
+                                   DevBuf<u32> &vals_alt, i64 n, i64 nseg, int key_bits, int first_bit) {
+    if (n <= 1 || nseg <= 0) return 0;
+    if (n * nseg >= ((i64)1 << 32) || nseg > 65535) {
+        chip_set_error("radix sort: too many keys in all segments");
+        return CATCHHIP_EINVAL;
+    }
+    TRY(keys_alt.reserve((size_t)(n * nseg)));
+    TRY(vals_alt.reserve((size_t)(n * nseg)));
+    const u32 nblocks = (u32)div_up(n, RS_TILE);
+    DevBuf<u32> hist, tmp;
+    TRY(hist.alloc((size_t)256 * nblocks * (size_t)nseg));
+    int passes = (key_bits + 7) / 8;
+    if (passes < 1) passes = 1;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = first_bit + 8 * p;
+        hipLaunchKernelGGL(radix_hist, dim3(nblocks, (unsigned)nseg), dim3(RS_THREADS), 0, ctx->stream, keys.p, n, shift, hist.p, nblocks);
+        TRY(chip_exclusive_scan_u32(ctx, hist.p, hist.p, (i64)256 * nblocks * nseg, tmp));
+        hipLaunchKernelGGL(radix_scatter, dim3(nblocks, (unsigned)nseg), dim3(RS_THREADS), 0, ctx->stream, keys.p, vals.p,
+                           keys_alt.p, vals_alt.p, n, shift, hist.p, nblocks);
+        keys.swap(keys_alt);
+        vals.swap(vals_alt);
+    }
+    HIP_TRY(hipGetLastError());
     return 0;
 }
