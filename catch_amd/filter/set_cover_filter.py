@@ -824,6 +824,7 @@ class SetCoverFilter(BaseFilter):
                        rows=0, scan_launches=0, greedy_launches=0,
                        candidates=0, unique_candidates=0)
         ctx = engine.default_context()
+        max_bases = int(float(_lib.test_env("CATCHHIP_UNION_MAX_MBASES", str(max_bases / 1e6))) * 1e6)     # (test hook)
         chunks, at = [], 0
         while at < ngroups:
             chunk, bases = [], 0
