@@ -307,15 +307,18 @@ __global__ __launch_bounds__(64) void sig_neigh_lds_kernel(const u32 *__restrict
 // The neighbour lists of several vertices in one launch (the search asks for the vertex it explores and for
 // those it is about to: the far neighbours it has just stacked).  Entry = query << 48 | index << 16 | common.
 // Almost every (query, target) pair is a pair of unrelated sequences, and finding that out by the walk costs
-// ~N dependent reads.  A fingerprint settles it first: every signature value sets one of 4,096 bits (64 words
+// ~N dependent reads.  A fingerprint settles it first: every signature value sets one of 2,048 bits (32 words
 // per sequence, stored [word][sequence]); `excess` = N - the bits set (values that fell on a bit already set,
 // repeated values included).  The walk matches equal values pairwise, so
 //     common <= sum over values of min(multiplicity in A, in B) <= popcount(bits A & bits B) + min(excess A, excess B)
 // and a pair whose bound is below min_common cannot be a neighbour.  Unrelated signatures share two or three
 // bits by chance; only the workgroups that hold a survivor stage their 64 signatures in LDS and walk.
 #define NEIGH_MAXQ 32
-#define NEIGH_FPW 64          // 64-bit words of a fingerprint
-__device__ __forceinline__ u32 neigh_fp_bit(u32 v) { return (v * 2654435761u) >> 20; }   // 12 bits
+// (Round 5: 2,048 bits.  With 4,096 the AND-popcount bound was ~250 of sig_graph_kernel's 419 ms at 182 VGPRs; 2,048 bits pass
+// more related-but-not-near pairs to the walk, which is cheap since the survivors are walked lane-packed: 330 ms.  1,024 bits:
+// 1,119 ms -- then nearly every tile of 32 queries holds a survivor and stages its signatures.)
+#define NEIGH_FPW 32          // 64-bit words of a fingerprint
+__device__ __forceinline__ u32 neigh_fp_bit(u32 v) { return (v * 2654435761u) >> 21; }   // 11 bits
 
 __global__ __launch_bounds__(256) void sig_fp_build_kernel(const u32 *__restrict__ sig, u32 nseq, u32 N,
                                                            unsigned long long *__restrict__ fpT) {
