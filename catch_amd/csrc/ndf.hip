@@ -681,6 +681,9 @@ ndf_wake_kernel(u32 *status, u32 *__restrict__ wait_on, u32 n, u32 *__restrict__
                 u32 *__restrict__ st2) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ u32 s_cnt[16], s_und[16], s_base;
+    __shared__ u32 s_drop;                       // probes this workgroup dropped (counters[2]: progress without a pass)
+    if (threadIdx.x == 0) s_drop = 0;
+    __syncthreads();
     bool undecided = false, woken = false;
     if (i < n && status[i] == 0) {
         const u32 j = wait_on[i];
@@ -689,7 +692,7 @@ ndf_wake_kernel(u32 *status, u32 *__restrict__ wait_on, u32 n, u32 *__restrict__
         undecided = true;
         if (j != NDF_CUR_NONE) {
             const u32 sj = ndf_state(status, st2, j);
-            if (sj == 1) { status[i] = 2; ndf_mark(st2, i, 2u); undecided = false; }
+            if (sj == 1) { status[i] = 2; ndf_mark(st2, i, 2u); undecided = false; s_drop = 1u; }
             else if (sj == 2) { wait_on[i] = NDF_CUR_NONE; woken = true; }
         }
     }
@@ -701,6 +704,7 @@ ndf_wake_kernel(u32 *status, u32 *__restrict__ wait_on, u32 n, u32 *__restrict__
         for (u32 w = 0; w < (blockDim.x >> 6); ++w) { const u32 c = s_cnt[w]; s_cnt[w] = tot; tot += c; und += s_und[w]; }
         s_base = tot ? atomicAdd(&counters[1], tot) : 0u;
         if (und) { if (count_undecided) atomicAdd(&counters[0], und); else if (((volatile u32 *)counters)[0] == 0u) counters[0] = 1u; }    // (a flag is enough for the loop)
+        if (s_drop && ((volatile u32 *)counters)[2] == 0u) counters[2] = 1u;
     }
     __syncthreads();
     if (woken) next[s_base + s_cnt[wv] + (u32)__popcll(wb & ((1ull << lane) - 1ull))] = i;
@@ -839,7 +843,7 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
                 tm.launch(4);
             }
         }
-        HIP_TRY(hipMemsetAsync(undecided, 0, 2 * sizeof(u32), s));
+        HIP_TRY(hipMemsetAsync(undecided, 0, 3 * sizeof(u32), s));       // ([2]: the wake-up launch dropped somebody)
         if (queued) HIP_TRY(hipMemsetAsync(dq_count.p, 0, sizeof(u32) * ES_SHARDS * ES_STRIDE, s));
         Q.dq = queued ? dq.p : (u32 *)nullptr; Q.dq_count = dq_count.p; Q.segcap = dq_segcap; Q.st2 = st2.p;
         if (nlist) {
@@ -854,7 +858,7 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
         if (wake) hipLaunchKernelGGL(ndf_wake_kernel, dim3((unsigned)div_up(nn, 1024)), dim3(1024), 0, s, status.p, flags.p, nn, lists[(round & 1) ^ 1].p, undecided, trace ? 1 : 0, st2.p);
         else hipLaunchKernelGGL(ndf_node_round_kernel, dim3(nb), dim3(256), 0, s, status.p, flags.p, nn, undecided);
         tm.launch(2);
-        HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ctx->h_pin, undecided, 3 * sizeof(u32), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (trace) {
             const auto t1 = std::chrono::steady_clock::now();
@@ -869,8 +873,14 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
         const bool idle = wake && !nlist;             // (no pass in this round)
         left = ((volatile u32 *)ctx->h_pin)[0];       // (wake-ups: a flag unless the rounds are traced)
         nlist = ((volatile u32 *)ctx->h_pin)[1];
-        // two rounds in a row without a woken probe: whoever is undecided now neither waits nor walks (a broken invariant)
-        if (idle && left && !nlist) { chip_set_error("ndf: undecided probes that nobody will wake"); return CATCHHIP_EINVAL; }
+        // A round without a pass in which the wake-up launch neither woke nor dropped anybody: whoever is undecided now
+        // neither waits nor walks (a broken invariant).  (A round that only DROPS is progress: a chain of probes each
+        // parked on the next resolves one link per wake-up launch -- the first form of this check stopped there: fuzz
+        // seed 31188, 4,720 of 5,608 probes of near-identical small groups undecided after round 0.)
+        if (idle && left && !nlist && !((volatile u32 *)ctx->h_pin)[2]) {
+            chip_set_error("ndf: undecided probes that nobody will wake");
+            return CATCHHIP_EINVAL;
+        }
     }
     HIP_TRY(hipGetLastError());
     if (left) { chip_set_error("ndf: %u probes undecided after %u rounds", left, nn + 2); return CATCHHIP_EINVAL; }

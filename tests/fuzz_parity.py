@@ -245,7 +245,11 @@ def main():
     t0 = time.time()
     n = 0
     while time.time() - t0 < budget:
-        one_case(seed0 + n, ctx)
+        try:
+            one_case(seed0 + n, ctx)
+        except BaseException:
+            print("fuzz: FAILED at seed %d (python tests/fuzz_parity.py 1 %d reproduces it)" % (seed0 + n, seed0 + n), flush=True)
+            raise
         n += 1
     print("fuzz: %d cases ok (seeds %d..%d) in %.0f s" % (n, seed0, seed0 + n - 1, time.time() - t0))
 

@@ -1889,6 +1889,14 @@ def test_near_duplicate_filter_pass_forms_agree(ctx, monkeypatch, hook):
     assert got == want and 0 < len(want[0]) < len(cands) and 0 < len(want[2]) < len(cands)
 
 
+def test_fuzz_case_whose_wake_ups_only_drop(ctx):
+    """tests/fuzz_parity.py seed 31188 (round 5): 5,608 candidates of near-identical small groups, 13 MinHash tables --
+    after a compaction keeps probes whose last tables ran out, a round without a pass only DROPS probes (parked on
+    the newly kept ones) and wakes nobody; the loop must go on (its first stuck-check stopped there)."""
+    import fuzz_parity
+    fuzz_parity.one_case(31188, ctx)
+
+
 def test_cluster_with_minhash_signatures_golden(ctx):
     """cluster.cluster_with_minhash_signatures (signatures + distances on the
     device, search / linkage on the host) == the reference's clusters, same
