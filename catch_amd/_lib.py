@@ -147,6 +147,11 @@ PROTOTYPES = {
     "catchhip_dfs_set_copy_members": (ctypes.c_int, [c_vp, c_i64p, ctypes.c_int64]),
     "catchhip_dfs_push": (ctypes.c_int, [c_vp, c_i64p, c_u8p, ctypes.c_int64]),
     "catchhip_dfs_counts": (ctypes.c_int, [c_vp, c_i64p]),
+    "catchhip_dfs_run_all": (ctypes.c_int, [c_vp, c_u32p, c_i64p, c_i64p, c_i64p]),
+    "catchhip_pyintset_create": (ctypes.c_int, [ctypes.c_uint32, c_vpp]),
+    "catchhip_pyintset_destroy": (None, [c_vp]),
+    "catchhip_pyintset_isub": (ctypes.c_int, [c_vp, c_u32p, ctypes.c_int64]),
+    "catchhip_pyintset_list": (ctypes.c_int, [c_vp, ctypes.c_int32, c_u32p, ctypes.c_int64, ctypes.POINTER(c_u32p), c_i64p]),
     "catchhip_cover_scan_first_seen": (ctypes.c_int, [
         c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_int32, c_u32p, c_vpp, c_i64p]),

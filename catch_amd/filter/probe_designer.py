@@ -73,7 +73,10 @@ class ProbeDesigner:
             logger.warning("Clustering ignores the %d input groupings: anything that "
                            "relies on them (e.g. --identify) no longer sees them",
                            len(self.genomes))
+        import time
+        t0 = time.perf_counter()
         seqs = self._sequences_to_cluster()
+        t1 = time.perf_counter()
         method = self._resolve_cluster_method()
         logger.info("MinHash clustering of %d sequences (%s, threshold %f)",
                     len(seqs), method, self.cluster_threshold)
@@ -81,8 +84,12 @@ class ProbeDesigner:
             dict(enumerate(seqs)), threshold=self.cluster_threshold,
             cluster_method=method)
         logger.info("%d clusters; sizes %s", len(clusters), [len(c) for c in clusters])
+        t2 = time.perf_counter()
         one = genome.Genome.from_one_seq
-        return [[one(seqs[i]) for i in members] for members in clusters]
+        out = [[one(seqs[i]) for i in members] for members in clusters]
+        # wall seconds by stage of the clustering pre-step (tools/s5_time.py, bench.py --workload S5)
+        self.cluster_timings = dict(cluster.last_timings, fragments_s=t1 - t0, genomes_s=time.perf_counter() - t2)
+        return out
 
     # -- object pipeline ----------------------------------------------------
     @staticmethod

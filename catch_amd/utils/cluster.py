@@ -265,11 +265,71 @@ def _components(n, row_fn, threshold, early_stop_threshold, neighbors_fn=None, n
     return components
 
 
+last_timings = {}        # wall seconds of the last cluster_with_minhash_signatures call by stage (tools, bench.py)
+_native_sets_ok = None
+_native_stats = {}      # catchhip_dfs_run_all's extra counters, summed (tools/s5_profile.py prints them)
+
+
+def _native_sets_available():
+    """Whether the library's emulation of a CPython set of small ints (catch_amd/csrc/components.hip, PyIntSet)
+    lays its tables out as THIS interpreter does: set(range(n)), `-=`, copy() and both forms of `a - b` are
+    compared with real sets on ~150 cases, once per process (~0.1 s).  Any difference sends the
+    search back to the step-wise path, where every set whose layout matters is a real one."""
+    global _native_sets_ok
+    if _native_sets_ok is None:
+        import ctypes
+        L = _lib.lib()
+        rs = np.random.RandomState(4242)     # (a private generator: the callers' random streams are untouched)
+        p32, cnt = _lib.c_u32p(), ctypes.c_int64(0)
+
+        def listed(h, which, keys=()):
+            k = np.ascontiguousarray(np.fromiter(keys, dtype=np.uint32, count=len(keys)))
+            _lib.check(L.catchhip_pyintset_list(h, which, k.ctypes.data_as(_lib.c_u32p), int(k.size),
+                                                ctypes.byref(p32), ctypes.byref(cnt)))
+            return np.ctypeslib.as_array(p32, shape=(cnt.value,)).tolist() if cnt.value else []
+        ok = True
+        # (60,000: beyond 50,000 entries a rebuilt table is 2 x, not 4 x, the entries)
+        for n, rounds in ((1, 1), (9, 6), (40, 8), (300, 10), (2500, 10), (60000, 2)):
+            if not ok:
+                break
+            h = ctypes.c_void_p()
+            _lib.check(L.catchhip_pyintset_create(n, ctypes.byref(h)))
+            try:
+                remaining = set(range(n))
+                for _ in range(rounds):
+                    m = len(remaining)
+                    if m == 0:
+                        break
+                    members = np.fromiter(remaining, dtype=np.int64, count=m)
+                    ok = ok and listed(h, 0) == members.tolist() and listed(h, 1) == list(remaining.copy())
+                    for frac in (0.02, 0.3, 0.7):
+                        queued = set()
+                        for k in members[rs.permutation(m)[:max(1, min(m, int(m * frac)))]].tolist():
+                            queued.add(k)
+                        ok = ok and listed(h, 2, queued) == list(remaining - queued)
+                    if rs.random_sample() < 0.5:
+                        a = int(members[rs.randint(m)])
+                        w = max(1, m // int(rs.choice((3, 7, 20))))
+                        cc = set(members[(members >= a) & (members < a + w)].tolist())
+                    else:
+                        cc = set(members[rs.permutation(m)[:max(1, m // int(rs.choice((2, 5, 11))))]].tolist())
+                    remaining -= cc
+                    k = np.fromiter(cc, dtype=np.uint32, count=len(cc))
+                    _lib.check(L.catchhip_pyintset_isub(h, k.ctypes.data_as(_lib.c_u32p), int(k.size)))
+            finally:
+                L.catchhip_pyintset_destroy(h)
+        _native_sets_ok = bool(ok)
+    return _native_sets_ok
+
+
 def _components_over_graph(n, ptr, gidx, gcom, near_common, row_fn, threshold, early_stop_threshold):
-    """_components with the neighbour lists of every vertex on the host (CSR) and the explored vertices whose
-    neighbour order is known without a set difference run natively (catch_amd/csrc/components.hip,
-    catchhip_dfs_*): the same search, the same real `remaining` set -- whose layout decides which case an
-    explored vertex is -- and the real differences and copies built here exactly as _components builds them."""
+    """_components with the neighbour lists of every vertex on the host (CSR), run natively
+    (catch_amd/csrc/components.hip).  Round 6: the whole search in one call (catchhip_dfs_run_all) with
+    `remaining` emulated slot for slot, when the emulation agrees with this interpreter's sets
+    (_native_sets_available); otherwise, and under the CATCHHIP_CLUSTER_STEPWISE test hook, step by step
+    (catchhip_dfs_run): the explored vertices whose neighbour order is known without a set difference natively, the
+    same real `remaining` set -- whose layout decides which case an explored vertex is -- and the real differences
+    and copies built here exactly as _components builds them."""
     import ctypes
     L = _lib.lib()
     h = ctypes.c_void_p()
@@ -278,6 +338,25 @@ def _components_over_graph(n, ptr, gidx, gcom, near_common, row_fn, threshold, e
     gcom = np.ascontiguousarray(gcom, dtype=np.uint32)
     _lib.check(L.catchhip_dfs_create(n, ptr.ctypes.data_as(_lib.c_i64p), gidx.ctypes.data_as(_lib.c_u32p),
                                      gcom.ctypes.data_as(_lib.c_u32p), int(near_common), ctypes.byref(h)))
+    if not _lib.test_env("CATCHHIP_CLUSTER_STEPWISE") and _native_sets_available():
+        try:
+            comp = np.empty(n, dtype=np.uint32)
+            cptr = np.empty(n + 1, dtype=np.int64)
+            ncomp = ctypes.c_int64(0)
+            stats = (ctypes.c_int64 * 8)()
+            _lib.check(L.catchhip_dfs_run_all(h, comp.ctypes.data_as(_lib.c_u32p), cptr.ctypes.data_as(_lib.c_i64p),
+                                              ctypes.byref(ncomp), stats))
+        finally:
+            L.catchhip_dfs_destroy(h)
+        for k, v in zip(("ascending", "copy rank", "real difference"), stats):
+            _path_counts[k] += int(v)
+        for k, v in zip(("order not needed", "copies", "differences built", "keys inserted", "home-slot orders"), list(stats)[3:]):
+            _native_stats[k] = _native_stats.get(k, 0) + int(v)
+        _native_stats["searches"] = _native_stats.get("searches", 0) + 1
+        cptr = cptr[:ncomp.value + 1]
+        components = [np.sort(comp[a:b]).tolist() for a, b in zip(cptr[:-1].tolist(), cptr[1:].tolist())]
+        components.sort(key=len, reverse=True)
+        return components
     remaining = set(range(n))
     queued = set()
     components = []
@@ -350,7 +429,10 @@ def _components_of_signatures(sigs, threshold,
             and hasattr(sigs, "graph"):
         # the whole neighbour graph in one device pass (round 4): the search reads its lists from the CSR
         # copy, and the distance rows of the real differences come from it too
+        import time as _time
+        t0 = _time.perf_counter()
         g = sigs.graph(int(within[0]))
+        last_timings["graph_s"] = _time.perf_counter() - t0
         if g is not None:
             ptr, gidx, gcom = g
             lut = 1.0 - np.arange(sigs.N + 1, dtype=np.float64) / N
@@ -401,7 +483,11 @@ def cluster_with_minhash_signatures(seqs, k=12, N=100, threshold=0.1,
     if num_seqs == 0:
         family._draw()
         return []
+    import time as _time
+    t0 = _time.perf_counter()
+    last_timings.clear()
     sigs = family.signatures([seqs[n] for n in names])
+    last_timings["signatures_s"] = _time.perf_counter() - t0
     try:
         if cluster_method == "simple":
             logger.info(("Clustering %d sequences at Jaccard distance "
@@ -418,4 +504,7 @@ def cluster_with_minhash_signatures(seqs, k=12, N=100, threshold=0.1,
                 sigs.condensed(lut), jaccard_dist_threshold)
     finally:
         sigs.close()
+    last_timings["total_s"] = _time.perf_counter() - t0
+    last_timings["search_s"] = (last_timings["total_s"] - last_timings["signatures_s"]
+                                - last_timings.get("graph_s", 0.0))
     return [[names[i] for i in c] for c in clusters]

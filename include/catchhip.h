@@ -474,6 +474,24 @@ int catchhip_dfs_set_copy_rank(catchhip_dfs *dfs, const int64_t *rank);
 int catchhip_dfs_set_copy_members(catchhip_dfs *dfs, const int64_t *members, int64_t count);
 int catchhip_dfs_push(catchhip_dfs *dfs, const int64_t *ks, const uint8_t *near, int64_t count);
 int catchhip_dfs_counts(const catchhip_dfs *dfs, int64_t *out3);
+/* The whole search in one call (round 6; nothing is handed back to the interpreter): `indices_to_consider`
+ * (catch/utils/cluster.py:284, :343) is kept as CPython lays it out -- set(range(n)), `-=` with its dummies and
+ * rebuilds, copy(), and the difference built insert by insert -- so the order of `list(a - b)` (:303-304) is the
+ * interpreter's.  On a fresh handle.  comp[n]: vertices component after component in discovery order;
+ * comp_ptr[n + 1]; stats[8] (may be null): explored vertices by the case of their difference (ascending, a copy of
+ * the set, built insert by insert), how many of them had fewer than two new neighbours (no order to establish),
+ * copies simulated, differences simulated, keys those inserted, orders read off the keys' home slots (the members
+ * span fewer keys than the table has slots). */
+int catchhip_dfs_run_all(catchhip_dfs *dfs, uint32_t *comp, int64_t *comp_ptr, int64_t *ncomp, int64_t *stats);
+/* The emulated set by itself, for checking it against the interpreter (catch_amd/utils/cluster.py does so once per
+ * process): create = set(range(n)); isub: s -= set(keys); list(which = 0: list(s), 1: list(s.copy()),
+ * 2: list(s - set(keys))) -> *p (valid until the next call on the handle), *count. */
+typedef struct catchhip_pyintset catchhip_pyintset;
+int catchhip_pyintset_create(uint32_t n, catchhip_pyintset **out);
+void catchhip_pyintset_destroy(catchhip_pyintset *s);
+int catchhip_pyintset_isub(catchhip_pyintset *s, const uint32_t *keys, int64_t count);
+int catchhip_pyintset_list(catchhip_pyintset *s, int32_t which, const uint32_t *keys, int64_t count,
+                           const uint32_t **p, int64_t *n);
 /* cluster.create_condensed_dist_matrix (catch/utils/cluster.py:102-194) for the
  * signature distance: out[n(n-1)/2] float32 in SciPy's condensed order, entry
  * (i, j) = lut[common(i, j)] with lut[N+1] supplied by the caller (the float32

@@ -458,35 +458,99 @@ def test_components_search_shortcut_equals_the_set_order():
     assert took["ascending"] > 1000 and took["copy rank"] > 200 and took["real difference"] > 1000, took
 
 
-def test_native_components_search_equals_the_interpreter_on_random_graphs():
-    """catchhip_dfs_* (catch_amd/csrc/components.hip: the explored vertices whose neighbour order is known without
-    a set difference, run natively) == _components (the same search in the interpreter) on planted-cluster graphs
-    large enough for all three cases -- ascending differences, differences that are copies of `remaining`, real
-    differences -- with early-stop absorption; components and case counts.  No GPU: host code only."""
-    from catch_amd.utils import cluster
-    assert cluster._fast_order_available()
-    for seed, n, ncl in ((1, 2500, 40), (2, 9000, 300), (3, 700, 3), (4, 1, 1), (5, 4000, 4000)):
-        rng = np.random.RandomState(seed)
+def _planted_graph(seed, n, ncl, p, contiguous):
+    """CSR graph of planted clusters (random labels, or -- as the fragments of a species lie -- contiguous blocks with
+    a few strays), each pair of a cluster joined with probability p, 9-100 common values per edge."""
+    rng = np.random.RandomState(seed)
+    if contiguous:
+        label = np.sort(rng.randint(0, ncl, size=n))
+        stray = rng.random_sample(n) < 0.02
+        label[stray] = rng.randint(0, ncl, size=int(stray.sum()))
+    else:
         label = rng.randint(0, ncl, size=n)
-        rows, cols, com = [], [], []
-        for c in range(ncl):
-            mem = np.nonzero(label == c)[0]
-            if mem.size < 2:
-                continue
-            a, b = np.meshgrid(mem, mem, indexing="ij")
-            keep = (a < b) & (rng.random_sample(a.shape) < 0.5)
-            aa, bb = a[keep], b[keep]
-            cc = rng.randint(9, 101, size=aa.size)
-            rows += [aa, bb]; cols += [bb, aa]; com += [cc, cc]
-        if rows:
-            rows, cols, com = np.concatenate(rows), np.concatenate(cols), np.concatenate(com)
-            o = np.lexsort((cols, rows))
-            rows, cols, com = rows[o], cols[o], com[o]
-        else:
-            rows = cols = com = np.zeros(0, dtype=np.int64)
-        ptr = np.zeros(n + 1, dtype=np.int64)
-        np.cumsum(np.bincount(rows, minlength=n), out=ptr[1:])
-        gidx, gcom = cols.astype(np.uint32), com.astype(np.uint32)
+    rows, cols, com = [], [], []
+    for c in range(ncl):
+        mem = np.nonzero(label == c)[0]
+        if mem.size < 2:
+            continue
+        a, b = np.meshgrid(mem, mem, indexing="ij")
+        keep = (a < b) & (rng.random_sample(a.shape) < p)
+        aa, bb = a[keep], b[keep]
+        cc = rng.randint(9, 101, size=aa.size)
+        rows += [aa, bb]; cols += [bb, aa]; com += [cc, cc]
+    if rows:
+        rows, cols, com = np.concatenate(rows), np.concatenate(cols), np.concatenate(com)
+        o = np.lexsort((cols, rows))
+        rows, cols, com = rows[o], cols[o], com[o]
+    else:
+        rows = cols = com = np.zeros(0, dtype=np.int64)
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=n), out=ptr[1:])
+    return ptr, cols.astype(np.uint32), com.astype(np.uint32)
+
+
+def test_emulated_int_set_equals_the_interpreters():
+    """PyIntSet (catch_amd/csrc/components.hip) == this interpreter's set of small ints, slot for slot:
+    set(range(n)), `-=` (dummies, the rebuild beyond mask / 4 of them), copy(), and `a - b` in both of CPython's
+    forms, by iteration order.  The product runs a shorter version of this once per process."""
+    import ctypes
+    from catch_amd import _lib
+    from catch_amd.utils import cluster
+    assert cluster._native_sets_available()
+    L = _lib.lib()
+    p32, cnt = _lib.c_u32p(), ctypes.c_int64(0)
+
+    def listed(h, which, keys=()):
+        k = np.ascontiguousarray(np.fromiter(keys, dtype=np.uint32, count=len(keys)))
+        _lib.check(L.catchhip_pyintset_list(h, which, k.ctypes.data_as(_lib.c_u32p), int(k.size),
+                                            ctypes.byref(p32), ctypes.byref(cnt)))
+        return np.ctypeslib.as_array(p32, shape=(cnt.value,)).tolist() if cnt.value else []
+    rs = np.random.RandomState(5)
+    cases = 0
+    for n in (1, 5, 9, 40, 300, 2500, 70000, 130000):
+        h = ctypes.c_void_p()
+        _lib.check(L.catchhip_pyintset_create(n, ctypes.byref(h)))
+        remaining = set(range(n))
+        for it in range(25 if n < 100000 else 8):
+            m = len(remaining)
+            if m == 0:
+                break
+            members = np.fromiter(remaining, dtype=np.int64, count=m)
+            assert listed(h, 0) == members.tolist(), (n, it)
+            assert listed(h, 1) == list(remaining.copy()), (n, it)
+            for frac in (0.01, 0.2, 0.3, 0.6, 0.95):
+                queued = set()
+                for k in members[rs.permutation(m)[:max(1, min(m, int(m * frac)))]].tolist():
+                    queued.add(k)
+                assert listed(h, 2, queued) == list(remaining - queued), (n, it, frac)
+                cases += 1
+            if rs.random_sample() < 0.5:      # a contiguous stretch (a species' fragments), or scattered members
+                a = int(members[rs.randint(m)])
+                cc = set(members[(members >= a) & (members < a + max(1, m // int(rs.choice((3, 7, 20)))))].tolist())
+            else:
+                cc = set(members[rs.permutation(m)[:max(1, m // int(rs.choice((2, 5, 11))))]].tolist())
+            remaining -= cc
+            k = np.fromiter(cc, dtype=np.uint32, count=len(cc))
+            _lib.check(L.catchhip_pyintset_isub(h, k.ctypes.data_as(_lib.c_u32p), int(k.size)))
+        L.catchhip_pyintset_destroy(h)
+    assert cases > 500
+
+
+def test_native_components_search_equals_the_interpreter_on_random_graphs(monkeypatch):
+    """catchhip_dfs_run_all (catch_amd/csrc/components.hip: the whole search natively, `remaining` emulated slot for
+    slot) == the step-wise native path (catchhip_dfs_run: real sets in the interpreter wherever a layout matters)
+    == _components (the same search in the interpreter) on planted-cluster graphs large enough for all three
+    cases -- ascending differences, differences that are copies of `remaining`, differences built insert by insert
+    -- with early-stop absorption: components and case counts; two graphs of 60,000 vertices (VERDICT round 5
+    item 2: at least 50 k vertices with all three order cases), clusters scattered over the ids (every order
+    simulated) and lying in blocks (orders read off the home slots).  No GPU: host code only."""
+    from catch_amd.utils import cluster
+    assert cluster._fast_order_available() and cluster._native_sets_available()
+    for seed, n, ncl, p, contiguous in ((1, 2500, 40, 0.5, False), (2, 9000, 300, 0.5, False), (3, 700, 3, 0.5, False),
+                                        (4, 1, 1, 0.5, False), (5, 4000, 4000, 0.5, False), (6, 9000, 120, 0.4, True),
+                                        (11, 60000, 1500, 0.3, False), (12, 60000, 40, 0.02, False),
+                                        (13, 60000, 700, 0.3, True)):
+        ptr, gidx, gcom = _planted_graph(seed, n, ncl, p, contiguous)
         N = 100.0
         lut = 1.0 - np.arange(101, dtype=np.float64) / N
         threshold, early = lut[9], lut[60]
@@ -505,12 +569,26 @@ def test_native_components_search_equals_the_interpreter_on_random_graphs():
         want = cluster._components(n, row, threshold, early, neighbors, None, local_lists=True)
         took_py = {k: cluster._path_counts[k] - before[k] for k in before}
         before = dict(cluster._path_counts)
+        stats0 = dict(cluster._native_stats)
         got = cluster._components_over_graph(n, ptr, gidx, gcom, 60, row, threshold, early)
         took = {k: cluster._path_counts[k] - before[k] for k in before}
-        assert got == want
+        stats = {k: v - stats0.get(k, 0) for k, v in cluster._native_stats.items()}
+        assert got == want, (seed, n)
         assert took == took_py, (took, took_py)
+        assert stats["searches"] == 1
+        monkeypatch.setenv("CATCHHIP_TEST_HOOKS", "1")
+        monkeypatch.setenv("CATCHHIP_CLUSTER_STEPWISE", "1")
+        before = dict(cluster._path_counts)
+        step = cluster._components_over_graph(n, ptr, gidx, gcom, 60, row, threshold, early)
+        took_step = {k: cluster._path_counts[k] - before[k] for k in before}
+        monkeypatch.delenv("CATCHHIP_CLUSTER_STEPWISE")
+        assert step == want and took_step == took_py, (seed, n)
         if n >= 2500 and ncl < n:
             assert took["copy rank"] > 0 and took["real difference"] > 0 and took["ascending"] > 0, took
+        if n >= 9000 and not contiguous:
+            assert stats["copies"] > 0 and stats["differences built"] > 0, stats
+        if n >= 9000 and contiguous:
+            assert stats["home-slot orders"] > 0, stats
 
 
 def test_prefetch_pool_hands_results_over_in_order_and_discards_what_is_left():

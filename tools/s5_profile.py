@@ -29,7 +29,8 @@ def step():
     print("cluster %.2f s, filters %.2f s (%s), %d clusters" % (t1 - t0, t2 - t1, mode, len(clusters)))
     print("stages (thread seconds):", {k: round(v, 2) for k, v in scf.last_timings.items() if k.endswith("_s")})
     from catch_amd.utils import cluster as _c
-    print("components search:", _c._path_counts)
+    print("components search:", _c._path_counts, _c._native_stats)
+    print("clustering stages:", {k: round(v, 3) for k, v in getattr(pd, "cluster_timings", {}).items()})
 
 
 if len(sys.argv) < 3 or sys.argv[2] != "once":

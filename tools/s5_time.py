@@ -35,7 +35,9 @@ def step():
     if os.environ.get("S5_TIME_EVENTS"):
         for ev in sorted(scf.last_timings.get("pipe_events", []), key=lambda e: e[2]):
             print("   %-8s %3d  %.3f -> %.3f  (%.3f)" % (ev[0], ev[1], ev[2], ev[3], ev[3] - ev[2]))
-    return t1 - t0, t2 - t1, h.hexdigest()[:12], {k: round(v, 2) for k, v in scf.last_timings.items() if k.endswith("_s")}
+    tm = {k: round(v, 2) for k, v in scf.last_timings.items() if k.endswith("_s")}
+    tm["cluster"] = {k: round(v, 3) for k, v in getattr(pd, "cluster_timings", {}).items()}
+    return t1 - t0, t2 - t1, h.hexdigest()[:12], tm
 
 
 step()
