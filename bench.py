@@ -369,21 +369,35 @@ class Stepper:
             self.pool.shutdown()
 
 
-def _pmc_record(workload, scale):
-    """The committed rocprofv3 PMC passes of this same command (profiles/r04_pmc_traffic_<workload>.json, made by
-    tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in separate runs); None when there is none for this
-    workload at this scale: counters cannot be collected from inside the timed run."""
-    for rnd in ("r05", "r04", "r03", "r02"):
-        path = os.path.join(REPO, "profiles", "%s_pmc_traffic_%s.json" % (rnd, workload))
+def _newest_profile(stem, workload, scale):
+    """The newest committed record profiles/r<NN>_<stem>_<workload>.json whose `workload` / `scale` are this run's
+    (rounds in descending order, so nothing has to be re-stamped by hand when a round commits new passes); the
+    record gets `_file` and `_round`.  None when there is none: counters cannot be collected from inside the timed
+    run, so what the line reports as PMC traffic is read back from the committed rocprofv3 passes of this command."""
+    import glob
+    import re
+    found = []
+    for path in glob.glob(os.path.join(REPO, "profiles", "r*_%s_%s.json" % (stem, workload))):
+        m = re.match(r"r(\d+)_", os.path.basename(path))
+        if m:
+            found.append((int(m.group(1)), path))
+    for rnd, path in sorted(found, reverse=True):
         try:
             with open(path) as f:
                 rec = json.load(f)
         except (OSError, ValueError):
             continue
-        if rec.get("workload") == workload and scale == 1.0:
+        if rec.get("workload") == workload and float(rec.get("scale", 1.0)) == float(scale):
             rec["_file"] = os.path.relpath(path, REPO)
+            rec["_round"] = rnd
             return rec
     return None
+
+
+def _pmc_record(workload, scale):
+    """The committed rocprofv3 PMC passes of this same command (profiles/r<NN>_pmc_traffic_<workload>.json, made by
+    tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in separate runs), newest round first."""
+    return _newest_profile("pmc_traffic", workload, scale) if scale == 1.0 else None
 
 
 def pmc_traffic(unit, workload, scale):
@@ -676,14 +690,10 @@ VALU_PEAK_GWIPS = 1024 * 2.4 / 4.0     # wave-instructions / ns: 256 CUs x 4 SIM
 
 
 def units_record(workload, scale):
-    """profiles/r05_pmc_<workload>.json (tools/collect_units.sh): kernel time, FETCH_SIZE / WRITE_SIZE and SQ_INSTS_VALU of
-    the committed rocprofv3 passes of this command, by unit of the hot path; None if there is none for this run."""
-    try:
-        with open(os.path.join(REPO, "profiles", "r05_pmc_%s.json" % workload)) as f:
-            rec = json.load(f)
-    except (OSError, ValueError):
-        return None
-    return rec if rec.get("workload") == workload and rec.get("scale", 1.0) == scale else None
+    """profiles/r<NN>_pmc_<workload>.json of the newest round that has one (tools/collect_units.sh): kernel time,
+    FETCH_SIZE / WRITE_SIZE and SQ_INSTS_VALU of the committed rocprofv3 passes of this command, by unit of the hot
+    path; None if there is none for this run."""
+    return _newest_profile("pmc", workload, scale)
 
 
 def valu_figures(unit, steps_in_run, device_ms_per_step):
@@ -695,7 +705,7 @@ def valu_figures(unit, steps_in_run, device_ms_per_step):
     ach = per_step / (device_ms_per_step * 1e6)
     return dict(bound="valu", achieved=ach, peak=VALU_PEAK_GWIPS, unit="wave-instructions/ns", frac=ach / VALU_PEAK_GWIPS,
                 insts_per_step=per_step, issue_frac_of_busy_cycles=unit.get("valu_issue_frac"),
-                source="profiles/r05_pmc_*.json (rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES, a run of its own)")
+                source="%s (rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES, a run of its own)" % unit.get("_file", "profiles/r*_pmc_*.json"))
 
 
 def closer_roof(roof, vf):
@@ -715,7 +725,7 @@ def closer_roof(roof, vf):
 def s5_roofline(dom, dms, dbytes, dl, args):
     """The roofline object of the configs[4] leg for its dominant unit.  HBM: SURVEY 8(d)'s algorithmic bytes over the
     unit's device time (HIP events on the streams it runs on).  The counters of the committed rocprofv3 passes of this
-    command (profiles/r05_pmc_S5.json, tools/collect_profiles.sh) give the traffic (2 x FETCH_SIZE + WRITE_SIZE per
+    command (the newest profiles/r<NN>_pmc_S5.json, tools/collect_units.sh) give the traffic (2 x FETCH_SIZE + WRITE_SIZE per
     filter call) and, because the near-duplicate filter is neither HBM- nor MFMA-bound, the VALU issue fraction
     SQ_INSTS_VALU x 4 cycles / (256 CUs x 4 SIMDs x busy cycles) beside it."""
     def gbs(b, t_ms):
@@ -724,12 +734,8 @@ def s5_roofline(dom, dms, dbytes, dl, args):
                 frac=gbs(dbytes, dms) / HBM_PEAK_GBS, traffic=None,
                 algorithmic_bytes_per_launch=dbytes / max(dl, 1), avg_launch_ms=dms / max(dl, 1),
                 launches_per_step=dl, device_ms_per_step=dms)
-    try:
-        with open(os.path.join(REPO, "profiles", "r05_pmc_%s.json" % args.workload)) as f:
-            rec = json.load(f)
-    except (OSError, ValueError):
-        return roof
-    if rec.get("workload") != args.workload or rec.get("scale", 1.0) != args.scale:
+    rec = units_record(args.workload, args.scale)
+    if rec is None:
         return roof
     unit = rec["units"].get("ndf" if dom.startswith("MinHash") else
                             "join_verify" if "verify" in dom else "rows_build" if "row build" in dom else "solver_round")
@@ -738,7 +744,9 @@ def s5_roofline(dom, dms, dbytes, dl, args):
         tb = (2.0 * unit["FETCH_SIZE_KB"] + unit["WRITE_SIZE_KB"]) * 1024.0 * per_step
         roof["traffic"] = tb / max(dl, 1)
         roof["traffic_bytes_per_step"] = tb
-        roof["traffic_source"] = "profiles/r05_pmc_%s.json: (2 x FETCH_SIZE + WRITE_SIZE) of the unit's kernels / steps of the run / launches" % args.workload
+        roof["traffic_source"] = "%s: (2 x FETCH_SIZE + WRITE_SIZE) of the unit's kernels / steps of the run / launches" % rec["_file"]
+        roof["traffic_source_round"] = rec["_round"]
+        unit = dict(unit, _file=rec["_file"])
         vf = valu_figures(unit, rec.get("steps_in_run", 1), dms)
         if vf is not None:
             roof = closer_roof(roof, vf)

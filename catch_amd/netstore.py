@@ -17,9 +17,9 @@ Trust (round 5): nothing a stranger sends is ever unpickled, siz
     client answers magic + rank (u32) + its own nonce + HMAC-SHA256(secret, "c" | both nonces | rank); rank 0
     checks it with hmac.compare_digest, checks 1 <= rank < size and that the rank is not connected yet, and
     answers HMAC(secret, "s" | ...) so the client knows it reached ITS rank 0;
-  * the secret is CATCHHIP_STORE_SECRET when the launcher exports one (recommended whenever MASTER_ADDR is not a
-    loopback address), else the launcher's run id + port -- which only keeps apart jobs of one user on one host,
-    hence without an explicit secret rank 0 binds to the loopback interface whenever MASTER_ADDR resolves to it;
+  * the secret is CATCHHIP_STORE_SECRET when the launcher exports one -- REQUIRED whenever MASTER_ADDR is not a
+    loopback address (round 6: the group refuses to start otherwise) --, else the launcher's run id + port, which only
+    keeps apart jobs of one user on one host: without an explicit secret rank 0 binds to the loopback interface;
   * after the handshake every frame is  length (u64, capped) | HMAC(session key, direction | sequence number |
     payload) | payload;  the payload (a pickle, protocol 5) is only deserialised once the MAC holds, so only
     authenticated peers are ever unpickled, and a replayed or reordered frame fails;
@@ -102,6 +102,20 @@ class _Channel:
             pass
 
 
+def _is_closed(sock):
+    """True when the peer has closed `sock` (a pending EOF or error), without consuming data."""
+    import select
+    try:
+        readable, _, _ = select.select([sock], [], [], 0)
+        if not readable:
+            return False
+        return sock.recv(1, socket.MSG_PEEK | socket.MSG_DONTWAIT) == b""
+    except (BlockingIOError, InterruptedError):
+        return False
+    except OSError:
+        return True
+
+
 def _is_loopback(addr):
     try:
         return socket.gethostbyname(addr).startswith("127.")
@@ -127,6 +141,12 @@ class TcpGroup:
             ports = [base + 1 + i for i in range(16)]
         explicit = secret if secret is not None else os.environ.get("CATCHHIP_STORE_SECRET")
         weak = token or (os.environ.get("TORCHELASTIC_RUN_ID", "") + ":" + os.environ.get("MASTER_PORT", ""))
+        if not explicit and not _is_loopback(addr):
+            #  the derived key is guessable -- torchrun's default run id is the literal "none" -- and a
+            # peer that passes the handshake sends frames that are unpickled: off the loopback interface that is
+            # remote code execution for anyone who can reach the port.  No secret, no multi-node rendezvous.
+            raise RuntimeError("catch_amd.netstore: MASTER_ADDR %r is not a loopback address; set CATCHHIP_STORE_SECRET "
+                               "(the same value on every rank) to run the rendezvous across hosts" % (addr,))
         key = hashlib.sha256(b"catchhip-store-key|" + (explicit if explicit else weak).encode()
                              + b"|" + struct.pack("<I", self.size)).digest()
         self._io_timeout = float(os.environ.get("CATCHHIP_STORE_TIMEOUT", "1800"))
@@ -176,7 +196,7 @@ class TcpGroup:
 
     def _admit(self, c, key):
         """Fixed-format challenge/response; returns the channel of a NEW valid rank or None."""
-        c.settimeout(10.0)
+        c.settimeout(2.0)      # (a silent stranger stalls the serial accept loop this long, not 10 s)
         nonce_s = os.urandom(_NONCE)
         c.sendall(_MAGIC + nonce_s)
         hello = bytes(_recv_exact(c, _CLIENT_HELLO))
@@ -189,8 +209,14 @@ class TcpGroup:
         if not hmac.compare_digest(_mac(key, b"c", nonce_s, nonce_c, rank_b), tag):
             return None
         (r,) = struct.unpack("<I", rank_b)
-        if not 1 <= r < self.size or r in self._peers:
-            return None                           # rank 0, a rank beyond the job, or one that is connected already
+        if not 1 <= r < self.size:
+            return None                           # rank 0, or a rank beyond the job
+        if r in self._peers:
+            # connected already -- unless that connection is dead (the client gave up on a slow handshake and came
+            # back: its first socket then reads EOF): an authenticated retry replaces a dead channel
+            if not _is_closed(self._peers[r].sock):
+                return None
+            self._peers.pop(r).close()
         c.sendall(_mac(key, b"s", nonce_c, nonce_s, rank_b))
         c.settimeout(self._io_timeout)
         c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
@@ -272,36 +298,3 @@ class TcpGroup:
                 except OSError:
                     pass
         self._peers, self._root, self._listen = {}, None, None
-
-
-class GlooGroup:
-    """The same interface over torch.distributed (gloo): the second transport -- CATCHHIP_RENDEZVOUS=gloo, and
-    what tests/test_multiproc_gloo.py drives the product's helpers with."""
-
-    def __init__(self, dist):
-        self.dist = dist
-        self.rank, self.size = dist.get_rank(), dist.get_world_size()
-
-    def allgather(self, obj):
-        out = [None] * self.size
-        self.dist.all_gather_object(out, obj)
-        return out
-
-    def broadcast(self, obj, src=0):
-        box = [obj if self.rank == src else None]
-        self.dist.broadcast_object_list(box, src=src)
-        return box[0]
-
-    def barrier(self):
-        self.dist.barrier()
-
-    def allreduce(self, arr, op="sum"):
-        import numpy as np
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(arr).copy())
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
-        return t.numpy()
-
-    def close(self):
-        if self.dist.is_initialized():
-            self.dist.destroy_process_group()

@@ -137,8 +137,8 @@ def plan_with_sharding(group_costs, world, min_cost=0, slack=1.08, eligible=None
 # ---------------------------------------------------------------------------
 # run time: one process per GPU (launched by torch.distributed.run / torchrun or anything else that sets RANK /
 # WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT).  The plumbing -- rendezvous, barriers, small host objects --
-# goes over catch_amd.netstore.TcpGroup (plain sockets; no torch in the product since round 4), or, with
-# CATCHHIP_RENDEZVOUS=gloo, over torch.distributed's gloo backend (netstore.GlooGroup); the data path's exchanges
+# goes over catch_amd.netstore.TcpGroup (plain sockets; no torch anywhere in the product: the gloo stand-in the CPU
+# tests use lives in tests/gloo_group.py since round 6); the data path's exchanges
 # are RCCL all-reduces on device buffers (catchhip_shard_allreduce) over a communicator attached to a context of
 # its own (a context with a communicator switches catchhip_setcover_greedy to the per-pick sharded form, which
 # the whole-group solves must not take).
@@ -219,18 +219,12 @@ def init_from_env():
     import ctypes
     from catch_amd import engine, netstore
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    # RCCL (and gloo) announce themselves on stdout; callers print machine-readable lines
+    # RCCL announces itself on stdout; callers print machine-readable lines
     sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(2, 1)
     try:
-        if os.environ.get("CATCHHIP_RENDEZVOUS", "tcp") == "gloo":
-            import torch.distributed as dist
-            if not dist.is_initialized():
-                dist.init_process_group("gloo", rank=rank, world_size=size)
-            group = netstore.GlooGroup(dist)
-        else:
-            group = netstore.TcpGroup(rank, size, os.environ["MASTER_ADDR"], os.environ.get("CATCHHIP_STORE_PORT"))
+        group = netstore.TcpGroup(rank, size, os.environ["MASTER_ADDR"], os.environ.get("CATCHHIP_STORE_PORT"))
         group.barrier()
         ctypes.CDLL(None).fflush(None)
     finally:
@@ -273,7 +267,7 @@ def init_from_env():
 def host_exchange(group, shards, which):
     """All-reduce of the shards' gain (SUM) or lost (MAX) buffers through host
     memory: over the shards of this process first, then over the process group
-    (None: single process; a netstore group, or a raw torch.distributed module as the gloo test passes it).
+    (None: single process; else anything with netstore.TcpGroup's allreduce -- the CPU tests pass tests/gloo_group.py's).
     Fallback transport and the one the CPU tests use."""
     import numpy as np
     bufs = [sh.buffer_to_host(which) for sh in shards]
@@ -281,9 +275,6 @@ def host_exchange(group, shards, which):
     for b in bufs[1:]:
         acc = acc + b if which == 0 else np.maximum(acc, b)
     if group is not None and acc.size:      # (the size is the same on every rank)
-        if not hasattr(group, "allreduce"):
-            from catch_amd import netstore
-            group = netstore.GlooGroup(group)          # torch.distributed itself
         acc = group.allreduce(acc, "sum" if which == 0 else "max")
     for sh in shards:
         sh.buffer_from_host(which, acc)

@@ -155,9 +155,10 @@ def _worker(rank, world, port, q, transport="gloo"):
     os.environ["MASTER_PORT"] = str(port)
     from catch_amd import netstore, parallel
     if transport == "gloo":
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from gloo_group import GlooGroup  # (torch stays on the test side: the product rendezvouses over netstore only)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        group = dist                      # host_exchange wraps the raw torch module itself
-        coll = netstore.GlooGroup(dist)
+        group = coll = GlooGroup(dist)
     else:
         # the product's own process group (catch_amd.netstore: plain TCP through rank 0, no torch)
         group = coll = netstore.TcpGroup(rank, world, "127.0.0.1", port)
@@ -385,3 +386,87 @@ def test_tcp_group_frames_are_authenticated():
     with pytest.raises(netstore.StoreAuthError):
         rx.recv()
     a.close(); b.close()
+
+
+def test_tcp_group_needs_a_secret_off_the_loopback_interface(monkeypatch):
+    """without CATCHHIP_STORE_SECRET the key is guessable, so a rendezvous on an address that is not a
+    loopback address is refused outright (every rank, before any socket is opened); with a secret, or on 127.0.0.1,
+    the constructor goes on as before."""
+    from catch_amd import netstore
+
+    monkeypatch.delenv("CATCHHIP_STORE_SECRET", raising=False)
+    for rank in (0, 1):
+        with pytest.raises(RuntimeError, match="CATCHHIP_STORE_SECRET"):
+            netstore.TcpGroup(rank, 2, "192.0.2.7", _free_port(), timeout=0.2)
+    # a secret: rank 1 now tries to connect (nobody listens on TEST-NET-1: it times out instead of being refused)
+    with pytest.raises((TimeoutError, OSError)):
+        netstore.TcpGroup(1, 2, "192.0.2.7", _free_port(), secret="s", timeout=0.3)
+    assert netstore.TcpGroup(0, 1, "192.0.2.7").size == 1          # a single process opens nothing
+
+
+def test_tcp_group_lets_a_rank_replace_its_dead_connection():
+    """a rank whose first connection died after rank 0 registered it (it gave up on a slow handshake
+    and came back) is admitted again -- rank 0 sees the first socket at EOF -- while a second LIVE connection of a
+    rank stays refused (test_tcp_group_rejects_strangers_and_bad_ranks)."""
+    import hashlib
+    import socket
+    import struct
+    import threading
+
+    from catch_amd import netstore
+
+    # (with size 2 the accept loop ends at the first admission, so the replacement is exercised on _admit directly)
+    ls = socket.socket(); ls.bind(("127.0.0.1", 0)); ls.listen(4)
+    a1 = socket.create_connection(ls.getsockname()); s1, _ = ls.accept()
+    g0 = netstore.TcpGroup.__new__(netstore.TcpGroup)
+    g0.rank, g0.size, g0._peers, g0._root, g0._listen, g0._io_timeout = 0, 2, {}, None, None, 5.0
+    g0._peers[1] = netstore._Channel(s1, b"k" * 32, True)
+    assert not netstore._is_closed(s1)
+    a1.close()                                       # the client gave up
+    time.sleep(0.05)
+    assert netstore._is_closed(s1)
+    # a fresh, authenticated connection of rank 1 now replaces it
+    res = {}
+
+    def client():
+        g = netstore.TcpGroup.__new__(netstore.TcpGroup)
+        g.rank, g.size, g._peers, g._root, g._listen, g._io_timeout = 1, 2, {}, None, None, 5.0
+        k = hashlib.sha256(b"catchhip-store-key|" + b"s3cret" + b"|" + struct.pack("<I", 2)).digest()
+        g._connect("127.0.0.1", [ls.getsockname()[1]], k, time.time() + 5)
+        res["ok"] = g._root is not None
+        hold.wait(10)                                # (stays connected while a duplicate is tried)
+        g.close()
+
+    hold = threading.Event()
+    th = threading.Thread(target=client)
+    th.start()
+    c2, _ = ls.accept()
+    k = hashlib.sha256(b"catchhip-store-key|" + b"s3cret" + b"|" + struct.pack("<I", 2)).digest()
+    chan = g0._admit(c2, k)
+    time.sleep(0.2)
+    assert chan is not None and g0._peers[1] is chan and res.get("ok")
+    # ... and a third connection while that one is alive is refused
+    th2 = threading.Thread(target=lambda: res.__setitem__("dup", _try_connect(netstore, ls.getsockname()[1])))
+    th2.start()
+    c3, _ = ls.accept()
+    assert g0._admit(c3, k) is None
+    c3.close()
+    ls.close()                                       # (the refused client's retries now fail at once)
+    hold.set()
+    th.join(timeout=10)
+    th2.join(timeout=15)
+    assert res.get("dup") is not True
+    g0.close()
+
+
+def _try_connect(netstore, port):
+    import hashlib
+    import struct
+    g = netstore.TcpGroup.__new__(netstore.TcpGroup)
+    g.rank, g.size, g._peers, g._root, g._listen, g._io_timeout = 1, 2, {}, None, None, 5.0
+    k = hashlib.sha256(b"catchhip-store-key|" + b"s3cret" + b"|" + struct.pack("<I", 2)).digest()
+    try:
+        g._connect("127.0.0.1", [port], k, time.time() + 0.5)
+    except (TimeoutError, OSError):
+        return False
+    return True
