@@ -805,7 +805,11 @@ def bench_design_large(args):
                     os.environ[k] = v
         tm = dict(scf.last_timings)
         tm.update(cluster_s=t1 - t0, filter_s=t2 - t1, merge_s=t3 - t2, wall_s=t3 - t0,
-                  clusters=len(clusters), fragments=sum(len(c) for c in clusters), mode=mode)
+                  clusters=len(clusters), mode=mode,
+                  # (clusters that come as views of the genomes' storage are not iterated: that would build their Genomes)
+                  fragments=(sum(len(c) for c in clusters.clusters) if hasattr(clusters, "clusters") else sum(len(c) for c in clusters)))
+        for k, v in getattr(pd, "cluster_timings", {}).items():
+            tm["cluster_" + k] = v
         return probes, tm
 
     def probes_digest(probes):
@@ -866,7 +870,8 @@ def bench_design_large(args):
                    "front_end": steps[-1]["mode"]},
         "m2_setcoverfilter_wall_s": elapsed / K,
         "wall_s_per_step": {"clustering": per["cluster_s"], "filters (front end + MinHash NDF + scan + solve + strings out)": per["filter_s"],
-                            "merge": per["merge_s"]},
+                            "merge": per["merge_s"],
+                            "clustering_stages": {k[len("cluster_"):]: per[k] for k in per if k.startswith("cluster_") and k != "cluster_s"}},
         "kernel_ms_per_step": {"k1_scan": per.get("scan_ms", 0.0), "k1_seed_verify": per.get("verify_ms", 0.0),
                                "k1_table_lookup": lookup_ms, "rows_build": per.get("rows_ms", 0.0),
                                "k2_greedy": per.get("greedy_ms", 0.0), "k2_greedy_rounds_only": per.get("rounds_ms", 0.0),

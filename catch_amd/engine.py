@@ -42,6 +42,8 @@ def _str_pointers(strs):
     PyUnicode_AsUTF8AndSize hands out that buffer without a copy; it stays valid
     while the str is alive, i.e. for the duration of the call it is passed to."""
     global _as_utf8
+    if isinstance(strs, FragmentTable):
+        return strs.pointers()
     if _as_utf8 is None:
         _as_utf8 = ctypes.pythonapi.PyUnicode_AsUTF8AndSize
         _as_utf8.restype = ctypes.c_void_p
@@ -57,6 +59,58 @@ def _str_pointers(strs):
         arr[i] = _as_utf8(s, ref)
         lens[i] = size.value
     return arr, lens
+
+
+class FragmentTable:
+    """Sequences as VIEWS of their parents' own byte storage: (address, length) per fragment, the parents kept alive
+    beside them.  A clustered design cuts 3.5 Gbases of genomes into 224 k fragments (catch/filter/probe_designer.py:
+    78-184 via Genome.break_into_fragments); slicing them out as str objects and wrapping each in a Genome cost 0.6 s of
+    a 4.3-s step before a single base was looked at, although everything downstream -- the signatures, the targets of
+    the clusters -- only ever hands (pointer, length) pairs to the library.  `parents`: plain-ASCII str objects
+    (others: build() returns None and the caller slices as before); fragment i = parents[parent[i]][start[i] :
+    start[i] + length[i]]."""
+
+    def __init__(self, parents, parent, start, length, addr):
+        self.parents, self.parent, self.start, self.length, self.addr = parents, parent, start, length, addr
+
+    @staticmethod
+    def build(parents, parent, start, length):
+        global _as_utf8
+        if _as_utf8 is None:
+            _as_utf8 = ctypes.pythonapi.PyUnicode_AsUTF8AndSize
+            _as_utf8.restype = ctypes.c_void_p
+            _as_utf8.argtypes = [ctypes.py_object, ctypes.POINTER(ctypes.c_ssize_t)]
+        base = np.zeros(max(len(parents), 1), dtype=np.uint64)
+        size = ctypes.c_ssize_t(0)
+        ref = ctypes.byref(size)
+        for i, s in enumerate(parents):
+            if not isinstance(s, str) or not s.isascii():
+                return None
+            base[i] = _as_utf8(s, ref)
+        parent = np.ascontiguousarray(parent, dtype=np.int64)
+        start = np.ascontiguousarray(start, dtype=np.int64)
+        length = np.ascontiguousarray(length, dtype=np.int64)
+        return FragmentTable(parents, parent, start, length, base[parent] + start.astype(np.uint64))
+
+    def __len__(self):
+        return int(self.length.size)
+
+    def take(self, idx):
+        """The fragments idx (an index array), in that order."""
+        idx = np.asarray(idx, dtype=np.int64)
+        return FragmentTable(self.parents, self.parent[idx], self.start[idx], self.length[idx], self.addr[idx])
+
+    def string(self, i, lo=0, hi=None):
+        """Fragment i (or its characters [lo, hi)) as a str."""
+        a = int(self.start[i])
+        b = a + int(self.length[i])
+        return self.parents[int(self.parent[i])][a + lo:b if hi is None else a + hi]
+
+    def pointers(self):
+        """(void*[n], int64 lengths) as _str_pointers gives them."""
+        arr = (ctypes.c_void_p * max(len(self), 1)).from_buffer_copy(
+            np.ascontiguousarray(self.addr if len(self) else np.zeros(1, dtype=np.uint64)).tobytes())
+        return arr, np.ascontiguousarray(self.length)
 
 
 def pyset_order(hashes):
@@ -257,12 +311,15 @@ class Targets:
 
     def __init__(self, ctx, genomes):
         self.ctx = ctx
-        seqs, sg = [], []
-        for j, g in enumerate(genomes):
-            for s in g:
-                seqs.append(s)
-                sg.append(j)
-        sgn = np.asarray(sg, dtype=np.int32)
+        if isinstance(genomes, FragmentTable):       # every fragment a genome of one sequence
+            seqs, sgn = genomes, np.arange(len(genomes), dtype=np.int32)
+        else:
+            seqs, sg = [], []
+            for j, g in enumerate(genomes):
+                for s in g:
+                    seqs.append(s)
+                    sg.append(j)
+            sgn = np.asarray(sg, dtype=np.int32)
         if sgn.size == 0:
             sgn = np.zeros(1, dtype=np.int32)
         self.nseq = len(seqs)

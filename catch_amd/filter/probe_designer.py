@@ -5,7 +5,10 @@ _cluster_genomes :78-184, _pass_through_filters :186-228, _design_for_genomes
 import itertools
 import logging
 
+import numpy as np
+
 from catch_amd import _lib
+from catch_amd import engine
 from catch_amd import genome
 from catch_amd import probe
 from catch_amd.filter import candidate_probes
@@ -16,6 +19,41 @@ from catch_amd.filter.set_cover_filter import SetCoverFilter
 from catch_amd.utils import cluster
 
 logger = logging.getLogger(__name__)
+
+
+class ClusteredFragments:
+    """The clusters of a clustered design as the reference returns them -- a list of lists of single-sequence Genomes
+    (catch/filter/probe_designer.py:78-184) -- over fragments that are still VIEWS of their parents' storage
+    (engine.FragmentTable).  The device front end reads the views (`table`, `clusters`: index arrays into it) and never
+    builds a Genome or a str per fragment (224 k of them at configs[4]: 0.6 s of the step); everything else indexes or
+    iterates the object like the list it stands for, and gets real Genome objects made on first use."""
+
+    def __init__(self, table, clusters):
+        self.table = table
+        self.clusters = [np.asarray(c, dtype=np.int64) for c in clusters]
+        self._made = {}
+
+    def __len__(self):
+        return len(self.clusters)
+
+    def __getitem__(self, gi):
+        if isinstance(gi, slice):
+            return [self[i] for i in range(*gi.indices(len(self)))]
+        if gi < 0:
+            gi += len(self)
+        got = self._made.get(gi)
+        if got is None:
+            one = genome.Genome.from_one_seq
+            got = self._made[gi] = [one(self.table.string(int(i))) for i in self.clusters[gi]]
+        return got
+
+    def __iter__(self):
+        return (self[gi] for gi in range(len(self)))
+
+    def group_bases(self):
+        """Bases of every cluster (sum of Genome.size() over its members)."""
+        ln = self.table.length
+        return np.array([int(ln[c].sum()) for c in self.clusters], dtype=np.int64)
 
 
 class ProbeDesigner:
@@ -53,6 +91,26 @@ class ProbeDesigner:
                             out.append(s_)
         return out
 
+    def _fragment_table(self):
+        """_sequences_to_cluster as views (engine.FragmentTable): the same fragments in the same order, none of them
+        sliced out -- or None when some sequence is not a plain-ASCII str (the caller then slices)."""
+        parents, par, st, ln = [], [], [], []
+        L, skip = self.cluster_fragment_length, self.seq_length_to_skip
+        for grp in self.genomes:
+            for g in grp:
+                for seq in g.seqs:
+                    n = len(seq)
+                    pi = len(parents)
+                    parents.append(seq)
+                    if L is None or 0 < n <= L:
+                        pieces = ((0, n),)
+                    else:
+                        pieces = [(i, L) if i + L <= n else (max(0, n - L), min(L, n)) for i in range(0, n, L)]
+                    for a, m in pieces:
+                        if skip is None or m > skip:
+                            par.append(pi); st.append(a); ln.append(m)
+        return engine.FragmentTable.build(parents, par, st, ln)
+
     def _resolve_cluster_method(self):
         """'choose' means connected components unless whole long genomes were
         cut into fragments: their pieces would chain into one giant component,
@@ -75,6 +133,19 @@ class ProbeDesigner:
                            len(self.genomes))
         import time
         t0 = time.perf_counter()
+        table = None if _lib.test_env("CATCHHIP_CLUSTER_SLICE_FRAGMENTS") else self._fragment_table()
+        if table is not None:
+            # (round 6) fragments as views of the genomes' own storage, clusters as index arrays: no str, no Genome
+            # per fragment unless somebody asks for one
+            t1 = time.perf_counter()
+            method = self._resolve_cluster_method()
+            logger.info("MinHash clustering of %d sequences (%s, threshold %f)", len(table), method, self.cluster_threshold)
+            clusters = cluster.cluster_with_minhash_signatures(table, threshold=self.cluster_threshold, cluster_method=method)
+            logger.info("%d clusters; sizes %s", len(clusters), [len(c) for c in clusters])
+            t2 = time.perf_counter()
+            out = ClusteredFragments(table, clusters)
+            self.cluster_timings = dict(cluster.last_timings, fragments_s=t1 - t0, genomes_s=time.perf_counter() - t2)
+            return out
         seqs = self._sequences_to_cluster()
         t1 = time.perf_counter()
         method = self._resolve_cluster_method()
@@ -191,6 +262,18 @@ class ProbeDesigner:
             return None
         skip, L = self.seq_length_to_skip, self.probe_length
         total, ngroups = 0, 0
+        if isinstance(genomes, ClusteredFragments):
+            # (views of plain-ASCII strs: the same conditions on the lengths, from the table)
+            ln = genomes.table.length
+            used = np.concatenate(genomes.clusters) if len(genomes) else np.zeros(0, dtype=np.int64)
+            ln = ln[used]
+            if skip is not None:
+                ln = ln[ln > skip]
+            if ln.size and int(ln.min()) < L:
+                return None               # the host path raises the reference's error
+            total = int(ln.sum())
+            ngroups = sum(1 for c in genomes.clusters if len(c))
+            genomes = ()
         for grp in genomes:
             if len(grp) == 0:
                 continue

@@ -825,11 +825,17 @@ class SetCoverFilter(BaseFilter):
                        candidates=0, unique_candidates=0)
         ctx = engine.default_context()
         max_bases = int(float(_lib.test_env("CATCHHIP_UNION_MAX_MBASES", str(max_bases / 1e6))) * 1e6)     # (test hook)
+        # the clusters of a clustered design may come as views of the genomes' storage (probe_designer.
+        # ClusteredFragments: every member a single-sequence genome): sizes, targets and the selected probes' text
+        # are then taken from the table, and no Genome / str is made per fragment
+        views = target_genomes_grouped if hasattr(target_genomes_grouped, "table") else None
+        group_bases = (views.group_bases().tolist() if views is not None
+                       else [sum(g.size() for g in grp) for grp in target_genomes_grouped])
         chunks, at = [], 0
         while at < ngroups:
             chunk, bases = [], 0
             while at < ngroups:
-                b = sum(g.size() for g in target_genomes_grouped[at])
+                b = group_bases[at]
                 if chunk and bases + b > max_bases:
                     break
                 chunk.append(at)
@@ -873,8 +879,12 @@ class SetCoverFilter(BaseFilter):
         def build(chunk, worker=None):
             bctx = ctx if worker is None else engine.upload_context(index=worker)
             t0 = _time.perf_counter()
-            genomes = [g.seqs for gi in chunk for g in target_genomes_grouped[gi]]
-            ngen = [len(target_genomes_grouped[gi]) for gi in chunk]
+            if views is not None:
+                genomes = views.table.take(np.concatenate([views.clusters[gi] for gi in chunk]))
+                ngen = [len(views.clusters[gi]) for gi in chunk]
+            else:
+                genomes = [g.seqs for gi in chunk for g in target_genomes_grouped[gi]]
+                ngen = [len(target_genomes_grouped[gi]) for gi in chunk]
             targets = engine.Targets(bctx, genomes)
             cands = None
             try:
@@ -954,9 +964,16 @@ class SetCoverFilter(BaseFilter):
                 probes = None
                 nrows, ids = 0, np.zeros(0, dtype=np.int64)
                 try:
-                    seqs = [s for gi in chunk for g in target_genomes_grouped[gi] for s in g.seqs]
-                    universe_p = [p for gi in chunk
-                                  for p in self._make_universe_p(target_genomes_grouped[gi])]
+                    if views is not None:
+                        vt = views.table.take(np.concatenate([views.clusters[gi] for gi in chunk]))
+                        if self.coverage <= 1.0:
+                            universe_p = [self.coverage] * len(vt)
+                        else:      # (:761-792: a number of bases per genome)
+                            universe_p = [float(min(self.coverage, n)) / n for n in vt.length.tolist()]
+                    else:
+                        seqs = [s for gi in chunk for g in target_genomes_grouped[gi] for s in g.seqs]
+                        universe_p = [p for gi in chunk
+                                      for p in self._make_universe_p(target_genomes_grouped[gi])]
                     timings["candidates"] += ncand
                     timings["unique_candidates"] += nuniq
                     anch = drawn if drawn is not None else anchors(cands.n)
@@ -970,15 +987,19 @@ class SetCoverFilter(BaseFilter):
                     events.append(("solve", chunk_no[id(chunk)], t0 - t_call, _time.perf_counter() - t_call))
                     # candidate-probe x target-bp of the chunk: every cluster's own candidates x its bases
                     per_group = np.bincount(cands.groups(), minlength=len(chunk)) if cands.n else np.zeros(len(chunk), np.int64)
-                    gbases = np.array([sum(g.size() for g in target_genomes_grouped[gi]) for gi in chunk], dtype=np.float64)
+                    gbases = np.array([group_bases[gi] for gi in chunk], dtype=np.float64)
                     timings["probe_bp_units"] = timings.get("probe_bp_units", 0.0) + float(np.dot(per_group[:len(chunk)], gbases))
                     if ids.size:
                         grp = cands.groups()[ids]
                         pos = cands.positions(ids)
                         which = np.searchsorted(targets.seq_off, pos, side="right") - 1
                         local = pos - targets.seq_off[which]
-                        for g, q, o in zip(grp.tolist(), which.tolist(), local.tolist()):
-                            out[chunk[g]].append(seqs[q][o:o + probe_length])
+                        if views is not None:
+                            for g, q, o in zip(grp.tolist(), which.tolist(), local.tolist()):
+                                out[chunk[g]].append(vt.string(q, o, o + probe_length))
+                        else:
+                            for g, q, o in zip(grp.tolist(), which.tolist(), local.tolist()):
+                                out[chunk[g]].append(seqs[q][o:o + probe_length])
                 finally:
                     if pre is not None:
                         ctx.sync()          # (objects built on the upload context go back to its cache: nothing may still read them)

@@ -473,7 +473,9 @@ def cluster_with_minhash_signatures(seqs, k=12, N=100, threshold=0.1,
                                     cluster_method="simple"):
     """Clusters of sequence names, largest first (:358-430)."""
     num_seqs = len(seqs)
-    names = list(seqs.keys())
+    from catch_amd import engine
+    table = seqs if isinstance(seqs, engine.FragmentTable) else None     # (fragments as views: named 0 .. n - 1)
+    names = range(num_seqs) if table is not None else list(seqs.keys())
     logger.info("Producing signatures of %d sequences", num_seqs)
     family = lsh.MinHashFamily(k, N=N)
     if cluster_method not in ("simple", "hierarchical"):
@@ -486,7 +488,7 @@ def cluster_with_minhash_signatures(seqs, k=12, N=100, threshold=0.1,
     import time as _time
     t0 = _time.perf_counter()
     last_timings.clear()
-    sigs = family.signatures([seqs[n] for n in names])
+    sigs = family.signatures(table if table is not None else [seqs[n] for n in names])
     last_timings["signatures_s"] = _time.perf_counter() - t0
     try:
         if cluster_method == "simple":
@@ -507,4 +509,6 @@ def cluster_with_minhash_signatures(seqs, k=12, N=100, threshold=0.1,
     last_timings["total_s"] = _time.perf_counter() - t0
     last_timings["search_s"] = (last_timings["total_s"] - last_timings["signatures_s"]
                                 - last_timings.get("graph_s", 0.0))
+    if table is not None:
+        return clusters
     return [[names[i] for i in c] for c in clusters]

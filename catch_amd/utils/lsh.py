@@ -53,9 +53,15 @@ class MinHashFamily:
         """engine.Signatures of `seqs` under one freshly drawn hash function
         (or under ab = (a, b))."""
         a, b = ab if ab is not None else self._draw()
-        for s in seqs:
-            assert self.kmer_size <= len(s)
-            self._warn(s)
+        if isinstance(seqs, engine.FragmentTable):
+            # (views of the parents' storage: the same checks on the lengths, the same warnings once per kind)
+            if len(seqs):
+                assert self.kmer_size <= int(seqs.length.min())
+                self._warn(range(int(seqs.length.min())))       # (the shortest one: _warn only looks at the length)
+        else:
+            for s in seqs:
+                assert self.kmer_size <= len(s)
+                self._warn(s)
         ctx = ctx or engine.default_context()
         return engine.Signatures(ctx, seqs, self.kmer_size, self.N, a, b)
 

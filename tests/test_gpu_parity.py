@@ -1212,6 +1212,49 @@ def test_property_checks_at_scale_config5(ctx):
     assert all(c["covered_bases"] == c["universe_bases"] for c in checks)      # -c 1.0
 
 
+def test_clustered_design_over_fragment_views_equals_sliced_fragments(ctx, monkeypatch):
+    """Round 6: the clusters of a clustered design as VIEWS of the genomes' own storage (engine.FragmentTable,
+    probe_designer.ClusteredFragments: no str and no Genome per fragment) == the same design with every fragment sliced
+    out and wrapped (CATCHHIP_CLUSTER_SLICE_FRAGMENTS, the path of rounds 1-5): same clusters, same fragments, same
+    selected probes in the same order, through the union front end and through a generic consumer that iterates the
+    clusters as lists of Genomes; short last fragments, sequences below the skip length and one-fragment genomes in."""
+    import random
+    from catch_amd import genome
+    from catch_amd.filter import near_duplicate_filter, probe_designer, set_cover_filter
+    from catch_amd.utils import synthetic
+    monkeypatch.setenv("CATCHHIP_TEST_HOOKS", "1")
+    genomes = synthetic.dataset("S5", scale=0.01)[0]
+    rng = np.random.RandomState(11)
+    extra = ["".join(rng.choice(list("ACGT"), size=n)) for n in (150, 700, 50001, 99999, 120)]
+    gobjs = [[genome.Genome.from_one_seq(g[0]) for g in genomes] + [genome.Genome.from_one_seq(s) for s in extra]]
+
+    def design(slice_fragments, frag_len, skip):
+        if slice_fragments:
+            monkeypatch.setenv("CATCHHIP_CLUSTER_SLICE_FRAGMENTS", "1")
+        else:
+            monkeypatch.delenv("CATCHHIP_CLUSTER_SLICE_FRAGMENTS", raising=False)
+        random.seed(21)
+        np.random.seed(22)
+        ndf = near_duplicate_filter.NearDuplicateFilterWithMinHash(0.6)
+        scf = set_cover_filter.SetCoverFilter(mismatches=5, lcf_thres=100, coverage=1.0, cover_extension=50,
+                                              kmer_probe_map_k=20)
+        pd = probe_designer.ProbeDesigner(gobjs, [ndf, scf], probe_length=100, probe_stride=50, cluster_threshold=0.15,
+                                          cluster_merge_after=scf, cluster_method="simple",
+                                          cluster_fragment_length=frag_len, seq_length_to_skip=skip)
+        clusters = pd._cluster_genomes()
+        assert isinstance(clusters, probe_designer.ClusteredFragments) == (not slice_fragments)
+        mode = pd._device_front_end_mode(clusters, ndf, scf)
+        assert mode == "union"
+        chosen = scf._filter_genomes_device_union(clusters, 100, 50, skip, ndf)
+        return [[g.seqs[0] for g in cl] for cl in clusters], chosen
+
+    for frag_len, skip in ((50000, None), (20000, 130)):
+        want_clusters, want = design(True, frag_len, skip)
+        got_clusters, got = design(False, frag_len, skip)
+        assert got_clusters == want_clusters
+        assert got == want and sum(len(c) for c in got) > 1000
+
+
 def test_ndf_then_scf_chains_equal_the_live_reference(ctx):
     """Near-duplicate filter -> set cover filter, recorded from the LIVE
     reference under PYTHONHASHSEED=0 (tests/golden/ndf_scf_chains.json): the
