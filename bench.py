@@ -206,7 +206,7 @@ class ShardedGroup:
         t1 = time.perf_counter()
         shard = engine.Shard(rows, self.n_sets)
         try:
-            ids = parallel.sharded_solve([shard], self.W.exchange_for([shard]))
+            ids = parallel.sharded_solve([shard], self.W.exchange_for([shard]), self.W.native_for([shard]))
         finally:
             shard.close()
             nrows = rows.n

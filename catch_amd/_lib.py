@@ -118,6 +118,7 @@ PROTOTYPES = {
     "catchhip_shard_allreduce": (ctypes.c_int, [c_vp, ctypes.c_int32]),
     "catchhip_shard_buffer_copy": (ctypes.c_int, [c_vp, ctypes.c_int32, c_vp, ctypes.c_int32]),
     "catchhip_shard_allreduce_local": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(c_vp), ctypes.c_int32]),
+    "catchhip_shard_solve": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32, c_i32p]),
     "catchhip_ndf_hamming": (ctypes.c_int, [
         c_vp, c_u8p, ctypes.c_int64, ctypes.c_int32, c_i32p, ctypes.c_int32,
         ctypes.c_int32, ctypes.c_int32, c_u8p]),

@@ -57,7 +57,6 @@ struct GreedyState {
     unsigned long long n_wrows, n_recount, n_words;  // work counters
     u32 need_live, ticket;   // row-parallel solver, partial coverage: universes still in need (being counted) / workgroups done
     u32 nwon;                // row-parallel solver, full coverage: sets accepted in this round (listed in FlatArgs::wonlist)
-    u32 nalive[2];           // ... and the sets that still have a gain, by round parity (FlatArgs::alive)
 };
 
 // packed key = (gain << 32) | (0xFFFFFFFF - set id): gains are < 2^32 (a group's

@@ -790,6 +790,20 @@ class Shard:
             pass
 
 
+def shards_solve(shards, transport, rounds_per_sync=4):
+    """catchhip_shard_solve: the whole round loop of the instance under the C ABI, `rounds_per_sync` rounds per host
+    read-back.  transport "rccl": one shard, exchanges over its context's communicator; "local": the shards of this
+    process (one context) exchange among themselves.  Returns the picks in the sequential pick order."""
+    arr = (ctypes.c_void_p * len(shards))(*[s._h for s in shards])
+    done = ctypes.c_int32(0)
+    check(shards[0].ctx._L.catchhip_shard_solve(len(shards), arr, 0 if transport == "rccl" else 1, int(rounds_per_sync),
+                                                 ctypes.byref(done)))
+    out = [sh.picks() for sh in shards]
+    if any(o != out[0] for o in out):
+        raise RuntimeError("sharded solve: shards returned different picks")
+    return out[0]
+
+
 def shards_allreduce_local(shards, which):
     """catchhip_shard_allreduce_local: the exchange between shards that live
     in this process on one device."""

@@ -433,7 +433,7 @@ class SetCoverFilter(BaseFilter):
                         gi + 1, "; ".join("rank %d: %s" % re for re in W_errs)))
                 # every rank must take the same path
                 if all(q for _e, q in status):
-                    selected[gi] = parallel.sharded_solve([shard], W.exchange_for([shard]))
+                    selected[gi] = parallel.sharded_solve([shard], W.exchange_for([shard]), W.native_for([shard]))
                     timings["rows"] += rows.n
                     timings["picks"] += len(selected[gi])
                 else:

@@ -70,11 +70,20 @@ def merge_picks(picks, keys, ranks=None):
 # instance.  The same loop serves one process per GPU (RCCL), several shards in
 # one process (tests on one GPU) and the CPU stand-ins of the gloo tests.
 # ---------------------------------------------------------------------------
-def sharded_solve(shards, exchange):
+def sharded_solve(shards, exchange, native=None):
     """Runs the rounds of one instance over the shards THIS process holds
     (normally one) and returns the picks in the sequential pick order.
     Raises IndexError-like CatchHipError from picks() when the rank list is
-    exhausted, as the unsharded solver does."""
+    exhausted, as the unsharded solver does.
+    native: "rccl" (one shard per process, a communicator on its context) or
+    "local" (the shards of this process, one context): the loop runs under the
+    C ABI (catchhip_shard_solve, round 6: several rounds per host read-back)
+    and `exchange` is not used; None: the loop below, one library call per
+    step and whatever transport `exchange` is (the host / TCP fallback, the
+    CPU stand-ins of the tests)."""
+    if native is not None:
+        from catch_amd import engine
+        return engine.shards_solve(shards, native)
     while True:
         for sh in shards:
             sh.count()
@@ -189,6 +198,15 @@ class World:
                     sh.allreduce(which)
             return exchange
         return lambda which: host_exchange(self.group, shards, which)
+
+    def native_for(self, shards):
+        """What sharded_solve's `native` should be for these shards: "rccl" when the ranks have a communicator (one
+        process per GPU: the whole loop then runs under the C ABI, catchhip_shard_solve), None when the exchange goes
+        through the host (several ranks on one GPU, or the CATCHHIP_SHARD_PYTHON_LOOP test hook)."""
+        from catch_amd import _lib
+        if self.rccl and len(shards) == 1 and not _lib.test_env("CATCHHIP_SHARD_PYTHON_LOOP"):
+            return "rccl"
+        return None
 
     def close(self):
         if self.group is not None:

@@ -356,6 +356,17 @@ int catchhip_shard_buffer_copy(catchhip_shard *shard, int32_t which, void *host,
                                int32_t to_host);
 int catchhip_shard_allreduce_local(int32_t n, catchhip_shard *const *shards,
                                    int32_t which);
+/* The whole round loop of a sharded instance in one call (round 6; catch_amd/parallel.py drove it from the
+ * interpreter, one host synchronisation per round, until then): count -> all-reduce SUM -> claim -> all-reduce MAX ->
+ * [partial coverage: verdict -> all-reduce MAX] -> apply, queued stream-ordered rounds_per_sync rounds at a time; the
+ * exchange buffers keep the capacity of the last read-back, the done flag and the number of sets still alive are read
+ * back once per batch.  shards: the n shards this process holds, fresh (round 0); transport 0: RCCL over the
+ * context's communicator (one shard per process, one process per GPU: the production path, replaces the worker pool
+ * of catch/filter/set_cover_filter.py:848-900 for a group that is sharded), 1: the shards of this process exchange
+ * among themselves (one context; tests, and one-GPU runs of several ranges).  *done: 1 finished, -1 rank list
+ * exhausted; catchhip_shard_picks then returns the picks. */
+int catchhip_shard_solve(int32_t n, catchhip_shard *const *shards, int32_t transport, int32_t rounds_per_sync,
+                         int32_t *done);
 
 /* ---- K3: near-duplicate filter (Hamming LSH) --------------------------- */
 /* Replaces NearDuplicateFilter._filter for NearDuplicateFilterWithHamming

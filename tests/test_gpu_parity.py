@@ -885,6 +885,78 @@ def test_universe_sharded_solver_over_rccl_single_rank(oracle, monkeypatch, flat
     c2.close()
 
 
+@pytest.mark.parametrize("flat", ["0", "1"])
+def test_round_loop_under_the_c_abi_equals_the_interpreters_loop(ctx, oracle, monkeypatch, flat):
+    """catchhip_shard_solve (round 6: the whole round loop of a sharded instance in one call, several rounds queued
+    per host read-back, exchange buffers at the capacity of the last read-back) == parallel.sharded_solve's loop in
+    the interpreter (one read-back per round, exact exchange sizes) == the unsharded picks == the oracle, in pick
+    order: 1, 2, 3 and 5 universe ranges exchanging among themselves (transport "local"), 1 / 3 / 16 rounds per
+    read-back, with and without ranks, full and partial coverage (uniform and mixed fractions; row-parallel kernels),
+    a shard without genomes; and over RCCL on a one-rank communicator (transport "rccl")."""
+    from catch_amd import parallel
+    from catch_amd.utils import synthetic
+    engine, probe = _engine(), _probe_mod()
+    monkeypatch.setenv("CATCHHIP_SHARD_FLAT", flat)
+    rng = np.random.Generator(np.random.PCG64(199))
+    genomes = synthetic.make_species(rng, [6000], 21, 3, 0.06, 0.012)
+    cand = candidates(genomes, 100, 50)
+    k, uniq, owner, ep, eo = probe.anchor_table(cand, 2, 100)
+    p = engine.Probes(ctx, uniq, owner, ep, eo, k)
+    lens = [sum(len(s) for s in g) for g in genomes]
+    glen = [len(g[0]) for g in genomes]
+
+    def solve(c, probes, bounds, ranks, up, native, rounds_per_sync=4):
+        held, shards = [], []
+        try:
+            for v in range(len(bounds) - 1):
+                t = engine.Targets(c, genomes[bounds[v]:bounds[v + 1]])
+                held.append(t)
+                rows = engine.Rows.scan(c, probes, t, 2, 100, 0, 50)
+                held.append(rows)
+                part = up is not None and any(q < 1.0 for q in up)
+                shards.append(engine.Shard(rows, len(cand), ranks, up[bounds[v]:bounds[v + 1]] if part else None,
+                                           instance_partial=part))
+            if native is None:
+                return parallel.sharded_solve(shards, lambda w: engine.shards_allreduce_local(shards, w))
+            return engine.shards_solve(shards, native, rounds_per_sync)
+        finally:
+            for h in shards + held[::-1]:
+                h.close()
+
+    for with_ranks in (False, True):
+        ranks = rng.integers(0, 3, size=len(cand)) if with_ranks else None
+        ups = [None] + ([[0.9] * len(genomes), [0.35, 1.0] * (len(genomes) // 2) + [0.8]] if flat == "1" else [])
+        for up in ups:
+            t = engine.Targets(ctx, genomes)
+            rows = engine.Rows.scan(ctx, p, t, 2, 100, 0, 50)
+            want = rows.greedy(len(cand), ranks, up)
+            sid, un, st, en = rows.fetch()
+            assert want == oracle.lazy_greedy(sid, un, st, en, len(cand), glen, up, ranks) and len(want) > 10
+            rows.close(); t.close()
+            for bounds in ([0, len(genomes)], parallel.split_universes(lens, 2), parallel.split_universes(lens, 3),
+                           parallel.split_universes(lens, 5), [0, 0, 9, 21, 21]):
+                assert solve(ctx, p, bounds, ranks, up, None) == want
+                for rps in (1, 3, 16):
+                    assert solve(ctx, p, bounds, ranks, up, "local", rps) == want, (with_ranks, up and up[:2], bounds, rps)
+    p.close()
+    # transport "rccl": a one-rank communicator on a context of its own
+    c2 = engine.Context(0)
+    c2.comm_init(engine.Context.comm_unique_id(), 1, 0)
+    p2 = engine.Probes(c2, uniq, owner, ep, eo, k)
+    t = engine.Targets(c2, genomes)
+    rows = engine.Rows.scan(c2, p2, t, 2, 100, 0, 50)
+    sid, un, st, en = rows.fetch()
+    want = oracle.lazy_greedy(sid, un, st, en, len(cand), glen, None, None)
+    rows.close(); t.close()
+    for rps in (1, 4):
+        assert solve(c2, p2, [0, len(genomes)], None, None, "rccl", rps) == want
+    if flat == "1":
+        up = [0.9] * len(genomes)
+        assert solve(c2, p2, [0, len(genomes)], None, up, "rccl", 4) == oracle.lazy_greedy(sid, un, st, en, len(cand), glen, up, None)
+    p2.close()
+    c2.close()
+
+
 @pytest.mark.parametrize("nranks", [2, 3])
 def test_plugin_over_several_ranks_selects_what_one_rank_selects(nranks):
     """torch.distributed.run with 2 and 3 ranks (all on this box's one GPU, so

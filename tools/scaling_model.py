@@ -31,6 +31,7 @@ ALPHA_US = 25.0          # one small RCCL all-reduce over xGMI, launch to comple
 SYNC_US = 30.0           # one 4-byte read-back + stream synchronisation per exchange of the packed form (assumed)
 BW_GBS = 100.0           # what a ring all-reduce sustains per link (assumed: ~2/3 of the 153 GB/s link peak)
 NS = (2, 4, 8)
+RPS = 4                  # rounds queued per host read-back (catchhip_shard_solve)
 
 
 def measure():
@@ -99,8 +100,24 @@ def measure():
                 if done[0]:
                     break
             ctx.sync()
-            rec[str(n)] = {"t_scan_ms": scans, "t_rounds_all_shards_ms": (time.perf_counter() - t0) * 1e3, "rounds": rnd,
-                           "gain_elements": gains, "mark_elements": marks, "sets": int(cands.n)}
+            t_py = (time.perf_counter() - t0) * 1e3
+            for sh in shards:
+                sh.close()
+            # the same solve with the round loop under the C ABI (round 6: catchhip_shard_solve, RPS rounds per host
+            # read-back, exchange buffers at the capacity of the last read-back); fresh shards over the same rows
+            shards = [engine.Shard(sh.rows, cands.n) for sh in shards]
+            ctx.sync()
+            t0 = time.perf_counter()
+            engine.shards_solve(shards, "local", RPS)
+            ctx.sync()
+            t_c = (time.perf_counter() - t0) * 1e3
+            cap_g, cap_m = [], []
+            for r in range(rnd):
+                cap_g.append(gains[r - r % RPS])                       # capacity = the alive sets at the last read-back (+ 2)
+                cap_m.append(max(gains[r - r % RPS] - 2, 0))
+            rec[str(n)] = {"t_scan_ms": scans, "t_rounds_all_shards_ms": t_c, "t_rounds_all_shards_python_loop_ms": t_py,
+                           "rounds": rnd, "rounds_per_sync": RPS, "gain_elements": cap_g, "mark_elements": cap_m,
+                           "gain_elements_exact": gains, "mark_elements_exact": marks, "sets": int(cands.n)}
             for sh in shards:
                 sh.close()
         out["sharded"][str(gi)] = rec
@@ -113,8 +130,8 @@ def model(path):
     with open(path) as f:
         d = json.load(f)
     bases, tw = d["bases"], d["t_whole_ms"]
-    print("assumptions: all-reduce latency %.0f us, host read-back per exchange %.0f us, ring bandwidth %.0f GB/s per link"
-          % (ALPHA_US, SYNC_US, BW_GBS))
+    print("assumptions: all-reduce latency %.0f us, host read-back %.0f us (one per exchange in round 4's inputs, one per "
+          "rounds_per_sync rounds since round 6), ring bandwidth %.0f GB/s per link" % (ALPHA_US, SYNC_US, BW_GBS))
     print("| GPUs | sharded groups | busiest rank: whole groups ms | + sharded scan ms | + rounds ms | + exchange ms | step ms | speed-up | efficiency |")
     print("|---|---|---|---|---|---|---|---|---|")
     t1 = sum(tw)
@@ -130,7 +147,9 @@ def model(path):
                 scan += s["t_scan_ms"][r]
                 rounds += s["t_rounds_all_shards_ms"] / n
                 nbytes = 4.0 * sum(s["gain_elements"]) + 1.0 * sum(s["mark_elements"])
-                exch += (s["rounds"] * 2 * (ALPHA_US + SYNC_US) * 1e-3
+                rps = s.get("rounds_per_sync")          # (round 4's inputs: a read-back per exchange)
+                syncs = s["rounds"] * 2 if rps is None else -(-s["rounds"] // rps)
+                exch += ((s["rounds"] * 2 * ALPHA_US + syncs * SYNC_US) * 1e-3
                          + nbytes * 2.0 * (n - 1) / n / (BW_GBS * 1e9) * 1e3)
             tot = whole + scan + rounds + exch
             if best is None or tot > best[-1]:
