@@ -1143,43 +1143,58 @@ def main():
                                  launches=max(nlaunch["claim_launches"], 1) / K, pmc="gr_claim"),
             "rows_build": dict(kernel="bucketed row build (per group: merge, scans, emit)",
                                ms=ms["rows_ms"], bytes=rows_bytes, launches=ninst, pmc="rows_build"),
+            # the K2 UNIT: a frontier round = gr_count + gr_claim + gr_apply + gr_cover, priced with
+            # SURVEY 8(d)'s formula (12 B per row of E_dirty + 8 B per bitmap word read); a "launch" is one round
+            "k2_rounds": dict(kernel="frontier solver round (gr_count + gr_claim + gr_apply + gr_cover; SURVEY 8(d) K2 bytes)",
+                              ms=ms["rounds_ms"], bytes=k2_bytes, launches=max(per.get("greedy_iters", 0), 1), pmc="solver_round"),
         }
-        # The dominant KERNEL by its own HIP-event timer: the join's verify launches (phases 5 + 7), the claim
-        # launches of the row-parallel solver (phase 6: an event pair per launch), or the row build.
-        dom = max(units_roof, key=lambda k: units_roof[k]["ms"])
-        d = units_roof[dom]
-        avg_ms = d["ms"] / max(d["launches"], 1)
-        traffic = pmc_traffic(d["pmc"], args.workload, args.scale)
-        alg_pl = d["bytes"] / max(d["launches"], 1)
-        # `achieved` never prices more bytes than were counted on the memory side: min(model, PMC traffic)
-        priced = alg_pl if traffic is None else min(alg_pl, traffic)
-        roof = dict(bound="hbm", kernel=d["kernel"], achieved=gbs(priced, avg_ms),
-                    peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs(priced, avg_ms) / HBM_PEAK_GBS,
-                    traffic=traffic,
-                    algorithmic_bytes_per_launch=alg_pl,
-                    priced_bytes_per_launch=priced,
-                    avg_launch_ms=avg_ms, launches_per_step=d["launches"],
-                    device_ms_per_step=d["ms"],
-                    note="frac = min(algorithmic bytes of the kernel's model, PMC traffic) / HIP-event time / peak; "
-                         "the K2 round as a whole against SURVEY 8(d)'s formula: roofline_k2")
+        ta_ = {}
+        for st in (alone_stats or []):
+            for k, v in st.items():
+                ta_[k] = ta_.get(k, 0) + v
+        alone_ms_of = {"join_verify": ta_.get("verify_ms", 0.0) + ta_.get("vcount_ms", 0.0), "solver_claim": ta_.get("claim_ms", 0.0),
+                       "rows_build": ta_.get("rows_ms", 0.0), "k2_rounds": ta_.get("rounds_ms", 0.0)}
+
+        def roof_of(name):
+            d = units_roof[name]
+            avg_ms = d["ms"] / max(d["launches"], 1)
+            traffic = pmc_traffic(d["pmc"], args.workload, args.scale)
+            alg_pl = d["bytes"] / max(d["launches"], 1)
+            # `achieved` never prices more bytes than were counted on the memory side: min(model, PMC traffic)
+            priced = alg_pl if traffic is None else min(alg_pl, traffic)
+            roof = dict(bound="hbm", kernel=d["kernel"], achieved=gbs(priced, avg_ms),
+                        peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs(priced, avg_ms) / HBM_PEAK_GBS,
+                        traffic=traffic,
+                        algorithmic_bytes_per_launch=alg_pl,
+                        priced_bytes_per_launch=priced,
+                        avg_launch_ms=avg_ms, launches_per_step=d["launches"],
+                        device_ms_per_step=d["ms"],
+                        note="frac = min(algorithmic bytes, PMC traffic) per launch / HIP-event time per launch / peak")
+            rec = _pmc_record(args.workload, args.scale)
+            if rec is not None:
+                roof["traffic_source"] = rec["_file"]
+                roof["traffic_source_round"] = rec["_round"]
+            if alone_stats:
+                a_ms = alone_ms_of[name]
+                a_avg = a_ms / max(d["launches"], 1)
+                # The line's roofline is priced with the unit's launches when they have the device to themselves (VERDICT
+                # round 4): the timed steps overlap two chains, so a launch's event time there includes the other stream's
+                # kernels.  The overlapped figures stay beside it.
+                roof["overlapped_in_timed_steps"] = dict(avg_launch_ms=roof["avg_launch_ms"], device_ms_per_step=roof["device_ms_per_step"],
+                                                         achieved=roof["achieved"], frac=roof["frac"])
+                roof.update(avg_launch_ms=a_avg, device_ms_per_step=a_ms, achieved=gbs(priced, a_avg), frac=gbs(priced, a_avg) / HBM_PEAK_GBS)
+                roof["note"] += ("; time = the unit's launches in an untimed step that runs the union instance AFTER the large "
+                                 "groups instead of beside them (one chain at a time: what `rocprofv3 --kernel-trace --stats` of "
+                                 "CATCHHIP_BENCH_UNION_BESIDE=0 sums, profiles/r<NN>_bench_kernel_stats_one_chain.csv); "
+                                 "overlapped_in_timed_steps: the same from the timed steps' event times")
+            return roof
+        # The dominant UNIT by its own HIP-event time: the solver's rounds (K2), the join's verify launches, or the row
+        # build -- the K2 unit since round 2.  The claim kernel alone (rounds 2-5's `roofline`) stays beside it.
+        dom = max((k for k in units_roof if k != "solver_claim"), key=lambda k: units_roof[k]["ms"])
+        roof = roof_of(dom)
+        roof_claim = roof_of("solver_claim")
         alone = None
         if alone_stats:
-            ta_ = {}
-            for st in alone_stats:
-                for k, v in st.items():
-                    ta_[k] = ta_.get(k, 0) + v
-            a_ms = {"join_verify": ta_.get("verify_ms", 0.0) + ta_.get("vcount_ms", 0.0), "solver_claim": ta_.get("claim_ms", 0.0),
-                    "rows_build": ta_.get("rows_ms", 0.0)}[dom]
-            a_avg = a_ms / max(d["launches"], 1)
-            # The line's roofline is priced with the kernel's launches when they have the device to themselves (VERDICT
-            # round 4): the timed steps overlap two chains, so a launch's event time there includes the other stream's
-            # kernels.  The overlapped figures stay beside it.
-            roof["overlapped_in_timed_steps"] = dict(avg_launch_ms=roof["avg_launch_ms"], device_ms_per_step=roof["device_ms_per_step"],
-                                                     achieved=roof["achieved"], frac=roof["frac"])
-            roof.update(avg_launch_ms=a_avg, device_ms_per_step=a_ms, achieved=gbs(priced, a_avg), frac=gbs(priced, a_avg) / HBM_PEAK_GBS)
-            roof["note"] += ("; time = the kernel's launches in an untimed step that runs the union instance AFTER the large "
-                             "groups instead of beside them (one chain at a time); overlapped_in_timed_steps: the same from "
-                             "the timed steps' event times")
             alone = {"ms_per_step": alone_ms,
                      "kernel_ms_per_step": {"k1_scan": ta_.get("scan_ms", 0.0), "k1_join_verify_count": ta_.get("vcount_ms", 0.0),
                                             "k1_join_verify_write": ta_.get("verify_ms", 0.0), "rows_build": ta_.get("rows_ms", 0.0),
@@ -1225,6 +1240,7 @@ def main():
                                            "groups in flight overlap, so the sum can exceed ms_per_step"},
             "one_chain_at_a_time": alone,
             "roofline": roof,
+            "roofline_claim_kernel": roof_claim,
             "roofline_k1_verify": dict(bound="hbm", achieved=gbs(verify_bytes, ms["verify_ms"] + ms["vcount_ms"]),
                                        peak=HBM_PEAK_GBS, unit="GB/s",
                                        frac=gbs(verify_bytes, ms["verify_ms"] + ms["vcount_ms"]) / HBM_PEAK_GBS,

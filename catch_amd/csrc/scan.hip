@@ -717,6 +717,7 @@ static seed_verify4_fn pick_seed_verify4(int nw) {
 
 #include "scan_join.inc"
 
+#ifndef CATCHHIP_NO_TILED_SCAN   // (the tests' cross-check scan; see catchhip_cover_scan)
 // The tiled scan kernel (see the comment above full_mismatches).
 __global__ void __launch_bounds__(SF2_THREADS)
 scan_fast3_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const u32 *__restrict__ seq_off,
@@ -763,6 +764,7 @@ scan_fast3_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const 
         }
     }
 }
+#endif
 
 // ------------------------------------------------------------------------
 // general path
@@ -1198,10 +1200,16 @@ static int run_fast(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
         TRY(H.b.reserve(cap));
         HIP_TRY(hipMemsetAsync(H.count.p, 0, sizeof(u32), ctx->stream));
         tm.restart();  // time exactly the scan kernel (HIP events on this stream)
+#ifndef CATCHHIP_NO_TILED_SCAN
         hipLaunchKernelGGL(scan_fast3_kernel, dim3(ntiles, nchunks), dim3(SF2_THREADS), 0, ctx->stream,
                            T->planes.p, T->nwords, (u32)T->total, T->seq_off.p, (u32)T->nseq, P->w0.p,
                            (const uint4 *)P->planes.p, (u32)P->nprobes, ppb, (int)P->L, (int)P->pwords, mm,
                            tailmask, use_n ? 1 : 0, H.a.p, H.b.p, H.count.p, cap);
+#else
+        (void)ntiles; (void)nchunks; (void)ppb; (void)mm; (void)tailmask; (void)use_n;
+        chip_set_error("cover_scan: built without the tiled cross-check scan");
+        return CATCHHIP_EINVAL;
+#endif
         tm.launch();
         tm.stop();
         HIP_TRY(hipGetLastError());
@@ -2094,6 +2102,15 @@ static int cover_scan_impl(catchhip_ctx *ctx, const catchhip_probes *P, const ca
     HIP_TRY(hipSetDevice(ctx->device));
     const bool fast_ok = fast_path_ok(P, T, mismatches, lcf_thres, island);
     const bool seed_ok = seed_path_ok(P, T, mismatches, lcf_thres, island);
+    if (mode == CATCHHIP_SCAN_FAST && !chip_test_env("CATCHHIP_TEST_HOOKS")) {
+        // (round 6: the tiled O(P x G) scan is the tests' independent cross-check of the seed scans, not a product
+        // path -- it answers only under CATCHHIP_TEST_HOOKS=1, and -DCATCHHIP_NO_TILED_SCAN builds a library without it)
+        chip_set_error("cover_scan: CATCHHIP_SCAN_FAST (the tiled cross-check scan) is a test hook (CATCHHIP_TEST_HOOKS=1)");
+        return CATCHHIP_EINVAL;
+    }
+#ifdef CATCHHIP_NO_TILED_SCAN
+    if (mode == CATCHHIP_SCAN_FAST) { chip_set_error("cover_scan: this library was built without the tiled cross-check scan"); return CATCHHIP_EINVAL; }
+#endif
     if (mode == CATCHHIP_SCAN_FAST && !fast_ok) {
         chip_set_error("cover_scan: fast-path preconditions do not hold");
         return CATCHHIP_EINVAL;

@@ -80,13 +80,26 @@ class FragmentTable:
             _as_utf8 = ctypes.pythonapi.PyUnicode_AsUTF8AndSize
             _as_utf8.restype = ctypes.c_void_p
             _as_utf8.argtypes = [ctypes.py_object, ctypes.POINTER(ctypes.c_ssize_t)]
-        base = np.zeros(max(len(parents), 1), dtype=np.uint64)
+        n = len(parents)
+        if n and (set(map(type, parents)) != {str} or not all(map(str.isascii, parents))):
+            return None
+        base = np.zeros(max(n, 1), dtype=np.uint64)
         size = ctypes.c_ssize_t(0)
         ref = ctypes.byref(size)
-        for i, s in enumerate(parents):
-            if not isinstance(s, str) or not s.isascii():
-                return None
-            base[i] = _as_utf8(s, ref)
+        # A plain-ASCII str keeps its characters right behind its header (CPython's "compact ASCII" layout), so the
+        # address is id(s) + the header's size -- one vectorised add instead of 198 k calls through ctypes (0.2 s of a
+        # 4.3-s step).  The header size is MEASURED on this interpreter, and the first and last parents are checked
+        # against PyUnicode_AsUTF8AndSize; any surprise falls back to the call per string.
+        fast = False
+        if n:
+            probe_s = "ACGT" * 3
+            hdr = _as_utf8(probe_s, ref) - id(probe_s)
+            if 0 < hdr <= 128:
+                base[:n] = np.fromiter(map(id, parents), dtype=np.uint64, count=n) + np.uint64(hdr)
+                fast = all(int(base[i]) == _as_utf8(parents[i], ref) for i in {0, n // 2, n - 1})
+        if not fast:
+            for i, s in enumerate(parents):
+                base[i] = _as_utf8(s, ref)
         parent = np.ascontiguousarray(parent, dtype=np.int64)
         start = np.ascontiguousarray(start, dtype=np.int64)
         length = np.ascontiguousarray(length, dtype=np.int64)

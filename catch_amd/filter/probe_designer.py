@@ -94,21 +94,27 @@ class ProbeDesigner:
     def _fragment_table(self):
         """_sequences_to_cluster as views (engine.FragmentTable): the same fragments in the same order, none of them
         sliced out -- or None when some sequence is not a plain-ASCII str (the caller then slices)."""
-        parents, par, st, ln = [], [], [], []
         L, skip = self.cluster_fragment_length, self.seq_length_to_skip
-        for grp in self.genomes:
-            for g in grp:
-                for seq in g.seqs:
-                    n = len(seq)
-                    pi = len(parents)
-                    parents.append(seq)
-                    if L is None or 0 < n <= L:
-                        pieces = ((0, n),)
-                    else:
-                        pieces = [(i, L) if i + L <= n else (max(0, n - L), min(L, n)) for i in range(0, n, L)]
-                    for a, m in pieces:
-                        if skip is None or m > skip:
-                            par.append(pi); st.append(a); ln.append(m)
+        parents = [seq for grp in self.genomes for g in grp for seq in g.seqs]
+        n = np.fromiter(map(len, parents), dtype=np.int64, count=len(parents))
+        if L is None:
+            npieces = np.ones(n.size, dtype=np.int64)
+        else:
+            # (0 < n <= L: the sequence itself; else ceil(n / L) pieces -- none of an empty sequence --, the last one
+            # moved back to be L long)
+            npieces = np.where((n > 0) & (n <= L), 1, -(-n // L))
+        par = np.repeat(np.arange(n.size, dtype=np.int64), npieces)
+        first = np.cumsum(npieces) - npieces
+        j = np.arange(par.size, dtype=np.int64) - first[par]          # piece number inside its parent
+        if L is None:
+            st, ln = np.zeros(par.size, dtype=np.int64), n[par]
+        else:
+            whole = (n[par] <= L)
+            st = np.where(whole, 0, np.minimum(j * L, np.maximum(n[par] - L, 0)))
+            ln = np.where(whole, n[par], L)
+        if skip is not None:
+            keep = ln > skip
+            par, st, ln = par[keep], st[keep], ln[keep]
         return engine.FragmentTable.build(parents, par, st, ln)
 
     def _resolve_cluster_method(self):

@@ -13,6 +13,9 @@ cd /root/repo
 python bench.py --workload $wl > $out/bench.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python /root/repo/bench.py --workload $wl --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure --no-property-checks > $out/bench_under_rocprof.json 2>/dev/null
+# the same with one chain at a time (the union instance after the large groups, not beside them): the summary whose
+# per-kernel times back the line's `roofline` (a unit's launches with the device to themselves)
+CATCHHIP_BENCH_UNION_BESIDE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_one_chain -- python /root/repo/bench.py --workload $wl --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure --no-property-checks --no-also > $out/bench_under_rocprof_one_chain.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python /root/repo/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure --no-property-checks > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python /root/repo/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-m2 --no-partial --no-overlap-figure --no-property-checks > /dev/null 2>&1
 if [ "$extra" = "all" ]; then
@@ -31,6 +34,8 @@ out, wl = os.environ["OUT"], os.environ["WL"]
 ks = max(glob.glob(out + "/trace/*/*kernel_stats.csv"), key=os.path.getmtime)
 ds = sorted(glob.glob(out + "/trace/*/*domain_stats.csv"), key=os.path.getmtime)[-1:]
 shutil.copy(ks, out + "/bench_kernel_stats.csv")
+oc = glob.glob(out + "/trace_one_chain/*/*kernel_stats.csv")
+if oc: shutil.copy(max(oc, key=os.path.getmtime), out + "/bench_kernel_stats_one_chain.csv")
 if ds: shutil.copy(ds[0], out + "/bench_domain_stats.csv")
 def pmc(dirname, counter):
     f = sorted(glob.glob(out + "/" + dirname + "/*/*counter_collection.csv"), key=os.path.getmtime)[-1:]
@@ -60,7 +65,7 @@ k1a = [k for k in kern if k.startswith(("seed_init", "seed_count", "seed_alloc",
 verify = [k for k in kern if k.startswith(("kj_verify", "kj_giant", "seed_verify"))]
 rows = [k for k in kern if k.startswith(("scan1_", "bucket_", "rows_emit", "scan_tiles", "kj_bucket_count", "kj_bases"))]
 setup = [k for k in kern if k.startswith(("gr_tile_", "set_ptr", "gr_bitmap"))]
-solver = [k for k in kern if k.startswith(("gf_count_claim", "gf_check_apply", "gr_count", "gr_claim", "gr_check", "gr_apply"))]
+solver = [k for k in kern if k.startswith(("gf_count_claim", "gf_check_apply", "gr_count", "gr_claim", "gr_check", "gr_apply", "gr_cover"))]
 ndfk = [k for k in kern if k.startswith(("ndf_", "mh_"))]
 rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
                "'python bench.py --workload %s --steps 2 --warmup 1 --no-cpu-baseline --no-property-checks' (3 steps, the two "
