@@ -5,10 +5,12 @@ A set c is accepted in a round iff
   (i)  it holds the largest key (gain, ~id) on every bitmap word where it has uncovered bits, and
   (ii) for every universe u it touches:  K(c) >= T_u  or  K(c) >= M_u,  where
          M_u = largest owner key of a word of u that holds uncovered bits of u,
-         T_u = smallest owner key k of u with  weight(words of u owned by keys > k) <= need[u] - CMAX
-               (CMAX bounds what a set can cover in one universe): nothing picked before c's turn can
-               then bring need[u] below c's count in u, so neither min(need, count) nor its neighbours
-               change c's gain before c is the maximum.
+         T_u = smallest owner key k of u with  weight(words of u owned by keys > k) <= need[u] - B
+               where B bounds what c covers in u: nothing picked before c's turn can then bring need[u]
+               below c's count in u, so neither min(need, count) nor its neighbours change c's gain before
+               c is the maximum.  B = the largest (set, universe) count until round 5; since round 6 the
+               smallest of the levels 8, 16, 32, 64, 128, CMAX that is >= c's own count in u when LEVELS=1
+               is set (gr_usel / gr_passes built with -DGR_UT_LEVELS=6; exact, measured, not the default).
 Gains are exact: sum over universes of min(need[u], count).  Usage: python tests/sim_partial_rounds.py [scale] [groups]
 """
 import sys, time
@@ -17,6 +19,17 @@ import numpy as np
 from catch_amd.filter import candidate_probes
 from catch_amd.utils import synthetic
 from oracle import oracle as orc
+
+
+import os
+LEVELS = os.environ.get("LEVELS", "0") != "0"     # (the library builds with one level, GR_UT_LEVELS; LEVELS=1: six)
+
+
+def level_of(c, bounds):
+    for li, b in enumerate(bounds):
+        if c <= b:
+            return li
+    return len(bounds) - 1
 
 
 def simulate(rs, ru, gs, ge, goff, P, p):
@@ -67,7 +80,8 @@ def simulate(rs, ru, gs, ge, goff, P, p):
             if any(owner[w] != k for w in ws): lost[seg_of_set[row_seg[r]]] = True
         winners = np.nonzero((key > 0) & ~lost)[0]
         # per universe: weights of words by owner, T_u and M_u
-        T = np.full(U, np.iinfo(np.int64).max); M = np.zeros(U, dtype=np.int64)
+        bounds = [cmax] if not LEVELS else [min(b, cmax) for b in (8, 16, 32, 64, 128)] + [cmax]
+        T = np.full((U, len(bounds)), np.iinfo(np.int64).max); M = np.zeros(U, dtype=np.int64)
         for u in range(U):
             if need[u] <= 0 or goff[u + 1] == goff[u]: continue
             w0, w1 = goff[u] >> 6, (goff[u + 1] - 1) >> 6
@@ -79,18 +93,19 @@ def simulate(rs, ru, gs, ge, goff, P, p):
             if not ks: continue
             ks = np.array(ks); wts = np.array(wts)
             M[u] = ks.max()
-            x = need[u] - cmax
-            if x >= 0:
-                o = np.argsort(-ks, kind="stable")
-                cum = np.cumsum(wts[o])
-                j = int(np.searchsorted(cum, x, side="right"))   # first j with cum[j] > x
-                T[u] = 0 if j >= len(o) else ks[o[j]]
+            o = np.argsort(-ks, kind="stable")
+            cum = np.cumsum(wts[o])
+            for li, b in enumerate(bounds):
+                x = need[u] - b
+                if x >= 0:
+                    j = int(np.searchsorted(cum, x, side="right"))   # first j with cum[j] > x
+                    T[u, li] = 0 if j >= len(o) else ks[o[j]]
         accepted = []
         for c in winners:
             k = key[c]
             us = seg_u[setstart[c]:(setstart[c + 1] if c + 1 < len(setstart) else len(segstart))]
             sc = segcnt[setstart[c]:(setstart[c + 1] if c + 1 < len(setstart) else len(segstart))]
-            ok = all((sc[i] == 0) or (k >= T[u]) or (k >= M[u]) for i, u in enumerate(us))
+            ok = all((sc[i] == 0) or (k >= T[u, level_of(sc[i], bounds)]) or (k >= M[u]) for i, u in enumerate(us))
             if ok: accepted.append(c)
         assert accepted, "no progress"
         accepted.sort(key=lambda c: -key[c])
