@@ -1193,6 +1193,7 @@ def main():
         dom = max((k for k in units_roof if k != "solver_claim"), key=lambda k: units_roof[k]["ms"])
         roof = roof_of(dom)
         roof_claim = roof_of("solver_claim")
+        d = units_roof[dom]
         alone = None
         if alone_stats:
             alone = {"ms_per_step": alone_ms,

@@ -236,6 +236,7 @@ struct HammingFamily {       // ndf_near on the padded rows; the earlier tables'
 // launch file round-robin, shard s is drained by the wavefronts with (id & 63) == s, strided.
 struct NdfQueue {
     u32 *dq; u32 *dq_count; u32 segcap;      // shard s: dq[s * segcap ..), its length dq_count[s * ES_STRIDE]
+    u32 *overflow;                           // set (and the entry not filed) if a shard's segment were ever exceeded: the host then fails the call
     u32 *st2;                                // the states once more, 2 bits per probe (see ndf_state); null: polling rounds
 };
 // A mate's state is looked up once per mate examined, at random: the 4-byte words of 5 M probes are 18 MB that miss the
@@ -271,7 +272,7 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
     if (drain) {
         const u32 shard = wave_id & (ES_SHARDS - 1u);
         const u32 w = (wave_id >> 6) + iter * ((gridDim.x * blockDim.x) >> 12);     // (grid wavefronts / ES_SHARDS per stride)
-        if (w >= Q.dq_count[shard * ES_STRIDE]) break;
+        if (w >= min(Q.dq_count[shard * ES_STRIDE], Q.segcap)) break;
         if (lane == 0) {
             valid = true;
             e = Q.dq[(size_t)shard * Q.segcap + w];
@@ -382,7 +383,11 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
             if (lane == 0) base = atomicAdd(&Q.dq_count[shard * ES_STRIDE], (u32)__popcll(db));
             base = __shfl(base, 0, WAVE);
             if (deferred) {
-                Q.dq[(size_t)shard * Q.segcap + base + (u32)__popcll(db & ((1ull << lane) - 1ull))] = e;
+                // (segcap = a shard's share + two wavefronts' worth: cannot be exceeded while the wavefronts file round
+                // robin; guarded all the same -- ADVICE round 5 -- so that a change of the grid shape shows as an error
+                // of the call instead of a write past the segment)
+                const u32 at = base + (u32)__popcll(db & ((1ull << lane) - 1ull));
+                if (at < Q.segcap) Q.dq[(size_t)shard * Q.segcap + at] = e; else *Q.overflow = 1u;
                 cursor_all[(size_t)i * TS + t] = y | (near_known ? NDF_CUR_NEAR : 0u);
             }
         }
@@ -584,7 +589,10 @@ ndf_probe_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 
                 u32 base = 0;
                 if (lane == 0) base = atomicAdd(&Q.dq_count[shard * ES_STRIDE], (u32)__popcll(db));
                 base = __shfl(base, 0, WAVE);
-                if (deferred) Q.dq[(size_t)shard * Q.segcap + base + (u32)__popcll(db & ((1ull << lane) - 1ull))] = t * nslot + x;
+                if (deferred) {
+                    const u32 at = base + (u32)__popcll(db & ((1ull << lane) - 1ull));
+                    if (at < Q.segcap) Q.dq[(size_t)shard * Q.segcap + at] = t * nslot + x; else *Q.overflow = 1u;
+                }
             }
         }
         if (eb && lane == 0) {
@@ -795,8 +803,10 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
         HIP_TRY(hipMemsetAsync(st2.p, 0, sizeof(u32) * (((size_t)nn + 15) / 16 + 1), s));
     }
     const u32 dq_segcap = (u32)(tn / ES_SHARDS) + 64u * 2u;      // (wavefronts file round-robin: a shard gets at most its share + one wavefront's)
-    DevBuf<u32> dq_count;
+    DevBuf<u32> dq_count, dq_overflow;
     if (queued) { TRY(dq.alloc((size_t)dq_segcap * ES_SHARDS)); TRY(dq_count.alloc(ES_SHARDS * ES_STRIDE)); }
+    TRY(dq_overflow.alloc(1));
+    HIP_TRY(hipMemsetAsync(dq_overflow.p, 0, sizeof(u32), s));
     if (wake) {
         TRY(inv.alloc((size_t)nn * TS));
         TRY(left_tables.alloc(nn));
@@ -845,7 +855,7 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
         }
         HIP_TRY(hipMemsetAsync(undecided, 0, 3 * sizeof(u32), s));       // ([2]: the wake-up launch dropped somebody)
         if (queued) HIP_TRY(hipMemsetAsync(dq_count.p, 0, sizeof(u32) * ES_SHARDS * ES_STRIDE, s));
-        Q.dq = queued ? dq.p : (u32 *)nullptr; Q.dq_count = dq_count.p; Q.segcap = dq_segcap; Q.st2 = st2.p;
+        Q.dq = queued ? dq.p : (u32 *)nullptr; Q.dq_count = dq_count.p; Q.segcap = dq_segcap; Q.st2 = st2.p; Q.overflow = dq_overflow.p;
         if (nlist) {
             const u32 *cur_list = round ? (const u32 *)lists[round & 1].p : (const u32 *)nullptr;
             const int mode = (probe_pass && (round || probe_round0)) ? 2 : 0;
@@ -886,9 +896,12 @@ static int ndf_lazy_rounds(catchhip_ctx *ctx, u32 nn, size_t tn, DevBuf<u32> &co
     if (left) { chip_set_error("ndf: %u probes undecided after %u rounds", left, nn + 2); return CATCHHIP_EINVAL; }
     tm.stop();
     std::vector<u64> h_pairs(2 * ES_SHARDS);
+    u32 h_overflow = 0;
     HIP_TRY(hipMemcpyAsync(h_pairs.data(), pairs.p, sizeof(u64) * 2 * ES_SHARDS, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&h_overflow, dq_overflow.p, sizeof(u32), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     tm.finish();
+    if (h_overflow) { chip_set_error("ndf: the queue of deferred walks overflowed a shard's segment"); return CATCHHIP_EINVAL; }
     // pairs compared / of them near (the all-pairs variant reports the length of its edge list there)
     for (int sh = 0; sh < ES_SHARDS; ++sh) { ctx->ndf_counters[2] += (i64)h_pairs[sh]; ctx->ndf_counters[3] += (i64)h_pairs[ES_SHARDS + sh]; }
     return ndf_keep_out(ctx, nn, status.p, keep);

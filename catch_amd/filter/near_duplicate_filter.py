@@ -278,6 +278,33 @@ class NearDuplicateFilterWithMinHash(NearDuplicateFilter):
                 for order, keep in zip(orders, keeps)]
 
 
+_bulk_ok = None
+
+
+def _bulk_draws_match_this_interpreter():
+    """the parse below re-implements CPython's private randint -> _randbelow_with_getrandbits word
+    consumption.  Checked once per process against the real thing -- a private random.Random() given the caller's
+    state draws 64 pairs the slow way; the parse of the same state must give the same pairs and leave the same state
+    (the global generator is put back as it was) -- so another interpreter's algorithm cannot silently change the
+    hash functions: on any difference every call draws through random.randint itself."""
+    global _bulk_ok
+    if _bulk_ok is None:
+        _bulk_ok = True                # (the parse runs below: do not recurse)
+        saved = random.getstate()
+        try:
+            ref = random.Random()
+            ref.setstate(saved)
+            P = 2 ** 31 - 1
+            want = [(ref.randint(1, P), ref.randint(0, P)) for _ in range(64)]
+            got = _randint_pairs_like_random(64, P)
+            _bulk_ok = got == want and random.getstate() == ref.getstate()
+        except Exception:              # noqa: BLE001 -- anything unexpected: the slow way
+            _bulk_ok = False
+        finally:
+            random.setstate(saved)
+    return _bulk_ok
+
+
 def _randint_pairs_like_random(npairs, P):
     """npairs times (random.randint(1, P), random.randint(0, P)) for P = 2**31 - 1, exactly as the interpreter
     draws them, and `random` advanced as those calls would advance it.  randint(1, P) is 1 + getrandbits(31) -- one
@@ -289,6 +316,8 @@ def _randint_pairs_like_random(npairs, P):
     import numpy as np
     st = random.getstate()
     if P != 2 ** 31 - 1 or st[0] != 3 or len(st[1]) != 625:
+        return None
+    if not _bulk_draws_match_this_interpreter():
         return None
     key, pos = np.array(st[1][:-1], dtype=np.uint32), int(st[1][-1])
     bg = np.random.MT19937()

@@ -681,6 +681,8 @@ class SetCoverFilter(BaseFilter):
                 # from host strings: two builders, or lanes balanced by cost instead of size, leave the pass at 0.128-0.133 s
                 # -- the three lanes' kernels share one device, and the pass is within ~10 % of the device work it holds
                 # (96 ms of scans and solves one chain at a time + ~20 ms of front-end kernels + 0.5 GB of uploads).
+                # (keep_input_order is set whenever building draws random numbers -- random anchors, a near-duplicate
+                # filter --: ONE builder then, whatever the hook says, so that the draws stay in production order)
                 nbuilders = 1 if keep_input_order else max(1, int(_lib.test_env("CATCHHIP_BUILDERS", "1")))
                 next_item = [0]
                 take_lock = threading.Lock()
