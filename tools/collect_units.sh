@@ -30,7 +30,7 @@ UNITS = [("ndf", ("ndf_", "mh_", "pyset_", "cand_pyhash")),
          ("rows_build", ("scan1_", "bucket_", "rows_emit", "scan_tiles", "kj_bucket_count", "kj_bases")),
          ("solver_setup", ("gr_tile_", "set_ptr", "gr_bitmap", "gf_build", "gf_universe")),
          ("solver_round", ("gf_count_claim", "gf_check_apply", "gr_count", "gr_claim", "gr_check", "gr_apply", "gr_usel", "gr_finish",
-                           "gr_verdict", "gr_fixup", "gr_seg")),
+                           "gr_verdict", "gr_fixup", "gr_seg", "gr_cover")),
          ("radix_sort", ("radix_",))]
 def unit_of(name):
     n = name.split("(")[0].replace("void ", "").strip()
