@@ -56,7 +56,7 @@ struct GreedyState {
     unsigned long long prof[8];  // shader-clock ticks per phase (thread 0)
     unsigned long long n_wrows, n_recount, n_words;  // work counters
     u32 need_live, ticket;   // row-parallel solver, partial coverage: universes still in need (being counted) / workgroups done
-    u32 nwon;                // row-parallel solver, full coverage: sets accepted in this round (listed in FlatArgs::wonlist)
+    u32 nwon;                // row-parallel solver, full coverage: npicks when this round began -- the sets accepted in it are picks[nwon .. npicks)
 };
 
 // packed key = (gain << 32) | (0xFFFFFFFF - set id): gains are < 2^32 (a group's
