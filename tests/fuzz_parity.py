@@ -152,10 +152,15 @@ def one_case(seed, ctx):
                         shards.append(engine.Shard(rv, len(cands[0]), None,
                                                    None if fractions is None else fractions[b[v]:b[v + 1]]))
                         shards[-1].partial_instance = fractions is not None
-                    got_s = parallel.sharded_solve(shards, lambda w: engine.shards_allreduce_local(shards, w))
+                    # the interpreter's round loop, or the loop under the C ABI with 1-5 rounds per read-back (round 6)
+                    rps = rnd.choice([0, 1, 2, 3, 5])
+                    if rps == 0:
+                        got_s = parallel.sharded_solve(shards, lambda w: engine.shards_allreduce_local(shards, w))
+                    else:
+                        got_s = engine.shards_solve(shards, "local", rps)
                     for h in shards + held[::-1]:
                         h.close()
-                    assert got_s == expect, (desc, "sharded", world, fractions)
+                    assert got_s == expect, (desc, "sharded", world, fractions, "rounds per sync", rps)
         p.close()
     # near-duplicate filters on the first group's candidates (equal lengths)
     strs = [s for s in cands[0] if len(s) == L][:1500]
