@@ -125,6 +125,7 @@ struct SeedTable {
 #define SEED_EMPTY 0xffffffffffffffffull
 #define SEED_DEAD 0xffffffffu   // work-list entry without a seed (the tail of a look-up workgroup's range)
 #define SEED_SIB 3              // other anchors per entry: the filter takes tables of <= 4 anchors per probe
+#define SEED_RSIB 2             // random anchor tables: the anchors just below the entry's that the filter looks at
 #define SEED_KEYBITS 0x3fffffffffffffffull
 #define SEED_SLOT_N 0x80000000u      // sibling / target slot word: the k-mer holds an N
 #define SEED_SLOT_BITS 0x7fffffffu
@@ -263,7 +264,8 @@ seed_alloc_kernel(SeedTable t, u32 *__restrict__ cursor) {
 // table build 3/3: drop the entries into their slot's range
 __global__ void __launch_bounds__(256)
 seed_fill_kernel(u32 nent, SeedTable t, const u32 *__restrict__ slot_of, int nanch,
-                 const u32 *__restrict__ aslot, uint4 *__restrict__ sib) {
+                 const u32 *__restrict__ aslot, uint4 *__restrict__ sib,
+                 const u32 *__restrict__ ent_probe, const u32 *__restrict__ ent_pos) {
     const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nent) return;
     const u32 s = slot_of[e];
@@ -271,7 +273,17 @@ seed_fill_kernel(u32 nent, SeedTable t, const u32 *__restrict__ slot_of, int nan
     const u32 j = atomicSub(&t.cnt[s], 1u) - 1u;
     const u32 idx = t.slot[s].z + j;
     t.ents[idx] = e;
-    if (sib) {
+    if (sib && !nanch) {
+        // random anchors (entries sorted by (probe, position)): the slots of the probe's two anchors just below
+        // this one and how far below they start (<= L - k <= SL_HALO < 256)
+        const u32 p = ent_probe[e], o = ent_pos[e];
+        u32 kk[SEED_RSIB], dd = 0;
+        for (u32 q = 0; q < SEED_RSIB; ++q) {
+            kk[q] = SEED_SLOT_ABSENT;
+            if (e > q && ent_probe[e - 1 - q] == p) { kk[q] = aslot[e - 1 - q]; dd |= (o - ent_pos[e - 1 - q]) << (8 * q); }
+        }
+        sib[idx] = make_uint4(e, kk[0], kk[1], dd);
+    } else if (sib) {
         const u32 a = e % (u32)nanch, e0 = e - a;
         u32 kk[SEED_SIB];
         u32 q = 0;
@@ -409,11 +421,24 @@ seed_lookup_kernel(const u32 *__restrict__ tplanes, i64 nwords, u32 total, const
             const u32 idx = s_rx[lo] + (d - s_off[lo]);
             const uint4 r0 = t.sib[idx];
             ent = r0.x;
-            const u32 a = ent % (u32)nanch;  // the entry's anchor index
-            const u32 sk[SEED_SIB] = {r0.y, r0.z, r0.w};
             bool lower_exact = false, higher = need2 == 0;
+            if (!nanch) {
+                // random anchors: is one of the probe's SEED_RSIB anchors just below this one exact in the same window?
+                const u32 rk[SEED_RSIB] = {r0.y, r0.z};
+#pragma unroll
+                for (u32 j = 0; j < SEED_RSIB; ++j) {
+                    const u32 pk = rk[j];
+                    const int off = (int)lo - (int)((r0.w >> (8 * j)) & 0xffu) + SL_HALO;    // (>= 0: the distance is <= SL_HALO)
+                    const u32 tk = s_slot[off];
+                    const bool same = pk != SEED_SLOT_ABSENT && (tk & SEED_SLOT_BITS) != SEED_SLOT_NONE && ((tk ^ pk) & SEED_SLOT_BITS) == 0u;
+                    lower_exact = lower_exact || (same && !((tk | pk) & SEED_SLOT_N));
+                }
+            }
+            const u32 a = nanch ? ent % (u32)nanch : 0u;  // the entry's anchor index
+            const u32 sk[SEED_SIB] = {r0.y, r0.z, r0.w};
 #pragma unroll
             for (u32 j = 0; j < SEED_SIB; ++j) {
+                if (!nanch) break;
                 const u32 b = j < a ? j : j + 1;
                 if (b >= (u32)nanch) continue;
                 const int off = (int)lo + ((int)b - (int)a) * k + SL_HALO;
@@ -1272,8 +1297,13 @@ static int seed_table_lookup_async(catchhip_ctx *ctx, const catchhip_probes *P, 
     // the anchor-pair filter of the look-up (seed_lookup_kernel): pigeonhole tables of <= 4 anchors per probe
     // whose keys are whole k-mers with room for the N flags
     const int nanch_tab = P->pigeonhole ? (int)(P->L / k) : 0;
-    const bool filt = allow_filter && nanch_tab >= 2 && nanch_tab <= SEED_SIB + 1 && pos_limit != 0xffffffffu && k <= 30 &&
-                      (nanch_tab - 1) * k <= SL_HALO && !chip_test_env("CATCHHIP_SEED_KEEP_ALL");
+    // ... and (round 6) any other table of equal-length probes -- the reference's random anchors, -m 5: a pair is reported
+    // from its LOWEST exact anchor, so a match whose probe has an exact anchor just below in the same window is not a seed
+    const bool filt_random = !P->pigeonhole && P->L > 0 && (i64)P->L - k <= SL_HALO && P->L - k < 256 &&
+                             !chip_test_env("CATCHHIP_SEED_RANDOM_KEEP_ALL");
+    const bool filt = allow_filter && k <= 30 && !chip_test_env("CATCHHIP_SEED_KEEP_ALL") &&
+                      (P->pigeonhole ? nanch_tab >= 2 && nanch_tab <= SEED_SIB + 1 && pos_limit != 0xffffffffu && (nanch_tab - 1) * k <= SL_HALO
+                                     : filt_random);
     const int need2 = filt && nanch_tab - mm >= 2 ? 1 : 0;
     const u32 nblk = (u32)div_up(T->total, SL_TILE);
     S.nranges = filt ? nblk : 0;
@@ -1296,7 +1326,7 @@ static int seed_table_lookup_async(catchhip_ctx *ctx, const catchhip_probes *P, 
                        nanch_tab, k, (int)P->pwords, kb, t, S.slot_of.p, filt ? S.aslot.p : (u32 *)nullptr);
     hipLaunchKernelGGL(seed_alloc_kernel, dim3(capacity / SA_SLOTS), dim3(256), 0, ctx->stream, t, S.ctr.p);
     hipLaunchKernelGGL(seed_fill_kernel, eb, tb, 0, ctx->stream, nent, t, (const u32 *)S.slot_of.p, nanch_tab,
-                       (const u32 *)S.aslot.p, filt ? S.sib.p : nullptr);
+                       (const u32 *)S.aslot.p, filt ? S.sib.p : nullptr, (const u32 *)P->sent_probe.p, (const u32 *)P->sent_pos.p);
     hipLaunchKernelGGL(seed_lookup_kernel, dim3((unsigned)div_up(T->total, SL_TILE)), dim3(SL_THREADS), 0, ctx->stream,
                        (const u32 *)T->planes.p, T->nwords, (u32)T->total, (const u32 *)T->seq_off.p,
                        (u32)T->nseq, k, kb, nanch_tab, need2, T->has_n ? 1 : 0, t, S.spos.p, S.sent.p, S.sseq.p,
@@ -1633,7 +1663,7 @@ static int run_join(catchhip_ctx *ctx, const catchhip_probes *P, const catchhip_
                        (const u32 *)P->sent_pos.p, nent, pos_limit, nanch, k, NW, kb, t, S.slot_of.p, (u32 *)nullptr);
     hipLaunchKernelGGL(seed_alloc_kernel, dim3(capacity / SA_SLOTS), dim3(256), 0, s, t, S.ctr.p);
     hipLaunchKernelGGL(seed_fill_kernel, eb, tb, 0, s, nent, t, (const u32 *)S.slot_of.p, nanch, (const u32 *)nullptr,
-                       (uint4 *)nullptr);
+                       (uint4 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr);
     // ---- hit positions, in position order ------------------------------------------------------------------
     const u32 nblk = (u32)div_up(T->total, KJ_TILE);
     TRY(J.stage_key.reserve((size_t)nblk * KJ_TILE));

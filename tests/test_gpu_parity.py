@@ -44,6 +44,19 @@ def _scan_rows(ctx, probe_strs, genomes, m, thres, island=0, ext=0, mode=0,
     return out
 
 
+def _seed_scan_stats(ctx, probe_strs, genomes, entries, k, m, ext):
+    """Work counters of one seed scan: raw hits and the seeds its verify launch looked at."""
+    engine = _engine()
+    ep = np.array([e[0] for e in entries], dtype=np.int32)
+    eo = np.array([e[1] for e in entries], dtype=np.int32)
+    t = engine.Targets(ctx, genomes)
+    p = engine.Probes(ctx, list(probe_strs), np.arange(len(probe_strs), dtype=np.int32), ep, eo, k)
+    rows = engine.Rows.scan(ctx, p, t, m, len(probe_strs[0]), 0, ext, engine.SCAN_SEED, True)
+    c = ctx.counters()
+    rows.close(); p.close(); t.close()
+    return dict(hits=c["raw_hits"], seeds=c["seed_hits"] - c["seeds_dropped"])
+
+
 def _oracle_rows(oracle, probe_strs, genomes, m, thres, island=0, ext=0,
                  min_k=20):
     k, entries = oracle.anchor_table(probe_strs, m, thres, min_k=min_k, k=min_k)
@@ -136,6 +149,83 @@ def test_seed_lookup_anchor_pair_filter_edge_cases(ctx, oracle):
     finally:
         os.environ.pop("CATCHHIP_SEED_KEEP_ALL", None)
         del os.environ["CATCHHIP_SEED_LIST"]
+
+
+def test_seed_lookup_random_anchor_filter_edge_cases(ctx, oracle):
+    """The look-up's filter for RANDOM anchor tables (round 6; -m 5, k = 20, anchors
+    anywhere in [0, L - k]: a pair is reported from its lowest exact anchor, so a
+    table match whose probe has an exact anchor among the two just below it, in
+    the same window, is dropped before the verify kernel).  Chosen anchor
+    lay-outs (adjacent, overlapping, far apart, at both ends of the probe, a
+    single anchor), copies of a window with mismatches / N's placed inside
+    chosen anchors and between them, windows at the ends of short sequences,
+    copies straddling the look-up's 2,048-position tiles; rows must equal the
+    oracle's and those of the unfiltered look-up and of the general path."""
+    engine = _engine()
+    rng = np.random.Generator(np.random.PCG64(90210))
+    alpha = np.array(list("ACGT"))
+
+    def rnd(n):
+        return "".join(alpha[rng.integers(0, 4, size=n)])
+
+    def mutate(w, positions, to_n=False):
+        w = list(w)
+        for q in positions:
+            w[q] = "N" if to_n else alpha[(list("ACGT").index(w[q]) + 1 + rng.integers(0, 3)) % 4] if w[q] in "ACGT" else "A"
+        return "".join(w)
+
+    base, other, lone = rnd(100), rnd(100), rnd(100)
+    with_n = mutate(base, [12], to_n=True)
+    probes = [base, with_n, other, lone]
+    anchors = {0: [0, 1, 2, 19, 20, 21, 40, 47, 79, 80],     # adjacent, overlapping, both ends
+               1: [0, 5, 13, 30, 31, 60],                    # anchors 0 and 5 hold the probe's N
+               2: [3, 40, 41, 42, 43, 80],
+               3: [37]}
+    entries = sorted((p, a) for p, al in anchors.items() for a in al)
+    copies = []
+    a0 = anchors[0]
+    for mask in range(1 << len(a0)):
+        if mask % 7 not in (0, 3):                            # a spread of the 1,024 patterns
+            continue
+        # break exactly the anchors of `mask` where that is possible with a mismatch of their own
+        pos = []
+        for j, a in enumerate(a0):
+            if mask >> j & 1:
+                pos.append(a + int(rng.integers(0, 20)))
+        pos = sorted(set(pos))[:5]
+        copies.append(mutate(base, pos))
+    for q in ([], [25], [25, 70], [0], [99], [39, 40], [59, 60, 61]):
+        copies.append(mutate(base, q))
+        copies.append(mutate(other, q))
+        copies.append(mutate(lone, q))
+    copies.append(mutate(base, [22], to_n=True))              # N in the target inside anchors 19-21 and 20
+    copies.append(mutate(base, [12], to_n=True))              # the same N as probe 1 has
+    copies.append(mutate(base, [12, 90], to_n=True))
+    copies.append(mutate(with_n, [33]))
+    filler = lambda: rnd(int(rng.integers(1, 70)))
+    seq = filler().join(copies)
+    pad = rnd(2048 * 3 - len(seq) % 2048 - 37)                # the next copies straddle a tile boundary
+    long_seq = seq + pad + base + rnd(11) + mutate(base, [5, 85]) + other + rnd(30)
+    genomes = [[long_seq], [base], [base[:60] + rnd(40) + base], [rnd(20) + other], [mutate(base, [99]) + rnd(9)],
+               [lone[1:] + "A"], [lone]]
+    pr, un, st, en = oracle.make_sets(probes, entries, 20, genomes, 5, 100, 0, 10)
+    exp = rows_as_tuples(pr, un, st, en)
+    assert len(exp) > 60
+    for mode in (engine.SCAN_SEED, engine.SCAN_GENERAL):
+        assert _scan_rows(ctx, probes, genomes, 5, 100, 0, 10, mode, entries=entries, k=20) == exp, mode
+    os.environ["CATCHHIP_SEED_RANDOM_KEEP_ALL"] = "1"
+    try:
+        assert _scan_rows(ctx, probes, genomes, 5, 100, 0, 10, engine.SCAN_SEED, entries=entries, k=20) == exp
+    finally:
+        del os.environ["CATCHHIP_SEED_RANDOM_KEEP_ALL"]
+    # the filter does drop matches: seeds verified with and without it
+    st_f = _seed_scan_stats(ctx, probes, genomes, entries, 20, 5, 10)
+    os.environ["CATCHHIP_SEED_RANDOM_KEEP_ALL"] = "1"
+    try:
+        st_u = _seed_scan_stats(ctx, probes, genomes, entries, 20, 5, 10)
+    finally:
+        del os.environ["CATCHHIP_SEED_RANDOM_KEEP_ALL"]
+    assert st_f["hits"] == st_u["hits"] and 0 < st_f["seeds"] < 0.5 * st_u["seeds"], (st_f, st_u)
 
 
 def test_scan_fast_no_n_two_planes(ctx, oracle):
