@@ -1131,15 +1131,32 @@ mh_other_chars_kernel(const u8 *__restrict__ bytes, u64 total, u32 *__restrict__
     if (__ballot(other) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
+// |x| mod (2^31 - 1) of a 64-bit hash by Mersenne folds (2^31 = 1 mod p) instead of the compiler's 64-bit division by a
+// constant (~30 instructions)
+__device__ __forceinline__ u32 mh_abs_mod_p(long long h) {
+    const u64 x = (u64)(h < 0 ? -h : h);                                     // (never LLONG_MIN: |hash| < 2^63 ... or 2^63 itself, which folds the same)
+    u64 v = (x & MH_P) + ((x >> 31) & MH_P) + (x >> 62);                      // < 2^32 + 2
+    u32 t = (u32)(v & MH_P) + (u32)(v >> 31);                                 // < 2^31 + 2
+    return t >= (u32)MH_P ? t - (u32)MH_P : t;
+}
+
+// KS: the k-mer size at compile time (0: `ks` at run time).  Round 6: with KS known the character loops and SipHash's
+// block loop unroll (the run-time form spent ~12 instructions per character on loop control and shifts by a counter),
+// |hash| mod p is two Mersenne folds, and the rank sort of a probe of A/C/G/T only compares ONE 32-bit word per pair --
+// code << 8 | slot, unique, so that the tie-break of equal k-mers is in the word: a v_cmp + v_addc per (y, slot) with
+// the y's read four at a time as an LDS broadcast (KS <= 12: 24 bits of code + 8 bits of slot).
+template <int KS>
 __global__ void __launch_bounds__(64)
 mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, const u32 *__restrict__ koff, u32 n,
-               int ks, u32 *__restrict__ xs, u64 *__restrict__ id_hi, u64 *__restrict__ id_lo,
+               int ks_rt, u32 *__restrict__ xs, u64 *__restrict__ id_hi, u64 *__restrict__ id_lo,
                u32 *__restrict__ nuniq, unsigned long long *__restrict__ fp, u32 *__restrict__ fp_excess,
                u32 *__restrict__ kc, u32 kstride) {
     __shared__ u64 s_hi[MH_MAXK], s_lo[MH_MAXK];
-    __shared__ u32 s_code[MH_MAXK];
+    __shared__ __attribute__((aligned(16))) u32 s_code[MH_MAXK + 4];
     __shared__ unsigned long long s_fp[MH_FPW];
     const u32 lane = threadIdx.x;
+    const int ks = KS ? KS : ks_rt;
+    constexpr bool WORDKEY = KS > 0 && KS <= 12;      // (code << 8 | slot fits 32 bits; slots < MH_MAXK = 256)
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
         const u8 *p = bytes + probe_off[i];
         const u32 k0 = koff[i], nk = koff[i + 1] - k0;
@@ -1151,17 +1168,20 @@ mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, 
         __syncthreads();
         for (u32 j = lane; j < nk; j += 64) {
             const long long h = mh_pyhash(p + j, ks);
-            xs[k0 + j] = (u32)((u64)(h < 0 ? -h : h) % MH_P);
+            xs[k0 + j] = mh_abs_mod_p(h);
             u64 lo = 0, hi = 0;   // the k-mer's bytes, big endian: order = string order
             u32 code = 0;         // (A < C < G < T in the codes as in the bytes: the same order)
+#pragma unroll
             for (int c = 0; c < ks; ++c) {
                 const u64 ch = p[j + c];
                 if (c < ks - 8) hi = (hi << 8) | ch; else lo = (lo << 8) | ch;
                 code = (code << 2) | (mh_base2((u8)ch) & 3u);
             }
             if (ks <= 8) hi = 0;
-            s_hi[j] = hi; s_lo[j] = lo; s_code[j] = code;
+            s_hi[j] = hi; s_lo[j] = lo; s_code[j] = (WORDKEY && packable) ? (code << 8) | j : code;
         }
+        if (WORDKEY && packable)
+            for (u32 j = nk + lane; j < ((nk + 3u) & ~3u); j += 64) s_code[j] = 0xffffffffu;    // (the last broadcast of four: never less than a key)
         __syncthreads();
         // rank sort; equal k-mers get consecutive ranks, the first of each group is kept.  By the 32-bit codes when the
         // probe has them (round 5: the 128-bit comparisons of all four register slots were 3,300 of the kernel's ~4,500
@@ -1174,7 +1194,21 @@ mh_kmer_kernel(const u8 *__restrict__ bytes, const u32 *__restrict__ probe_off, 
             rk[q] = 0;
             mh[q] = j < nk ? s_hi[j] : 0; ml[q] = j < nk ? s_lo[j] : 0; mc[q] = j < nk ? s_code[j] : 0;
         }
-        if (packable) {
+        if (WORDKEY && packable) {
+            // (the slot count decided outside the loop: a probe of 100 characters has 91 k-mers of 10 = two slots)
+#define MH_RANK_LOOP(NQ)                                                                                              \
+            for (u32 y = 0; y < nk; y += 4) {                                                                         \
+                const uint4 c = *(const uint4 *)&s_code[y];                                                           \
+                _Pragma("unroll") for (int q = 0; q < (NQ); ++q)                                                      \
+                    rk[q] += (u32)(c.x < mc[q]) + (u32)(c.y < mc[q]) + (u32)(c.z < mc[q]) + (u32)(c.w < mc[q]);       \
+            }
+            if (nk <= 64) { MH_RANK_LOOP(1) }
+            else if (nk <= 128) { MH_RANK_LOOP(2) }
+            else { MH_RANK_LOOP(MH_MAXK / 64) }
+#undef MH_RANK_LOOP
+#pragma unroll
+            for (int q = 0; q < MH_MAXK / 64; ++q) mc[q] >>= 8;          // the plain codes from here on
+        } else if (packable) {
             for (u32 y = 0; y < nk; ++y) {
                 const u32 c = s_code[y];
 #pragma unroll
@@ -1749,7 +1783,7 @@ static int ndf_minhash_impl(catchhip_ctx *ctx, const u8 *bytes, const i64 *probe
         HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(u32), s));
     }
     if (want_ids) { TRY(id_hi.alloc(nkm)); TRY(id_lo.alloc(nkm)); }
-    hipLaunchKernelGGL(mh_kmer_kernel, dim3((unsigned)std::min<i64>(n, (i64)1 << 20)), dim3(64), 0, s,
+    hipLaunchKernelGGL(kmer_size == 10 ? mh_kmer_kernel<10> : mh_kmer_kernel<0>, dim3((unsigned)std::min<i64>(n, (i64)1 << 20)), dim3(64), 0, s,
                        (const u8 *)d_bytes.p, (const u32 *)d_off.p, (const u32 *)d_koff.p, nn, (int)kmer_size, xs.p,
                        id_hi.p, id_lo.p, nuniq.p, (unsigned long long *)fp.p, fp_excess.p, wave64 ? kc.p : (u32 *)nullptr, kstride);
     tm.launch(1);

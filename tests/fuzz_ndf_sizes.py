@@ -1,5 +1,5 @@
 """Randomised stress of the near-duplicate filters at the sizes where the lazy resolution compacts its tables (> 4,096
-probes; GPU box):   python tests/fuzz_ndf_sizes.py [seconds] [seed]
+probes; GPU box):   python tests/fuzz_ndf_sizes.py [seconds] [seed]   |   python tests/fuzz_ndf_sizes.py big [probes] [seed]
 Families of near-identical sequences (strains of a few species) next to unrelated ones, 4 k - 80 k candidate probes,
 with and without groups; both LSH families.  The default form (wake-ups, queue, probe passes, packed states, compaction)
 must keep exactly what the polling rounds of round 3 keep (CATCHHIP_NDF_POLL_ROUNDS=1) -- two implementations of the same
@@ -70,7 +70,59 @@ def one_case(seed):
     return len(cands)
 
 
+def big_case(nprobes, seed):
+    """ONE case at the size of an S5 chunk (default 5 M candidate probes: what the control loop of the lazy resolution
+    sees in configs[4] -- tables compacted several times, the deferred-walk queue in use, thousands of parked probes):
+    strains of a few species generated with numpy, both LSH families, the default form against the polling rounds."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    want_bases = nprobes * 50
+    seqs, bases = [], 0
+    while bases < want_bases:
+        n = int(rng.integers(60000, 400000))
+        root = rng.integers(0, 4, size=n, dtype=np.uint8)
+        rate = float(rng.choice([0.002, 0.01, 0.03, 0.08]))
+        for _ in range(int(rng.integers(20, 300))):
+            s = root.copy()
+            m = rng.random(n) < rate
+            s[m] = rng.integers(0, 4, size=int(m.sum()), dtype=np.uint8)
+            seqs.append(lut[s].tobytes().decode())
+            bases += n
+            if bases >= want_bases:
+                break
+    cands = candidate_probes.candidate_strings_from_sequences(seqs, 100, 50)
+    del seqs
+    ngroups = 1 + seed % 3
+    cuts = sorted(int(c) for c in rng.choice(np.arange(1, len(cands)), size=ngroups - 1, replace=False)) if ngroups > 1 else []
+    parts = [cands[a:b] for a, b in zip([0] + cuts, cuts + [len(cands)])]
+
+    def run():
+        t0 = time.time()
+        random.seed(seed)
+        a = NearDuplicateFilterWithMinHash(0.6)._filter_strs_many(parts)
+        t1 = time.time()
+        random.seed(seed + 1)
+        b = [NearDuplicateFilterWithHammingDistance(2, 100)._filter_strs(p) for p in parts]
+        return a, b, t1 - t0, time.time() - t1
+    os.environ.pop("CATCHHIP_NDF_POLL_ROUNDS", None)
+    got = run()
+    os.environ["CATCHHIP_NDF_POLL_ROUNDS"] = "1"
+    try:
+        want = run()
+    finally:
+        os.environ.pop("CATCHHIP_NDF_POLL_ROUNDS", None)
+    assert got[0] == want[0], ("MinHash forms differ", seed, len(cands))
+    assert got[1] == want[1], ("Hamming forms differ", seed, len(cands))
+    print("fuzz_ndf_sizes big: %d probes in %d group(s), seed %d: MinHash keeps %d (%.1f s; polling rounds %.1f s), "
+          "Hamming keeps %d (%.1f s; %.1f s) -- both forms equal"
+          % (len(cands), ngroups, seed, sum(map(len, got[0])), got[2], want[2], sum(map(len, got[1])), got[3], want[3]), flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        big_case(int(sys.argv[2]) if len(sys.argv) > 2 else 5000000, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+        return
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     oracle.build()

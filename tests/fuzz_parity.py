@@ -149,9 +149,11 @@ def one_case(seed, ctx):
                         tv = engine.Targets(ctx, groups[0][b[v]:b[v + 1]])
                         rv = engine.Rows.scan(ctx, p, tv, m, thres, island, ext)
                         held += [tv, rv]
+                        # (instance_partial: the same on every shard -- one with fractions of 1.0 only builds the
+                        # partial kind too, as SetCoverFilter does; catchhip_shard_solve insists on it)
                         shards.append(engine.Shard(rv, len(cands[0]), None,
-                                                   None if fractions is None else fractions[b[v]:b[v + 1]]))
-                        shards[-1].partial_instance = fractions is not None
+                                                   None if fractions is None else fractions[b[v]:b[v + 1]],
+                                                   instance_partial=fractions is not None))
                     # the interpreter's round loop, or the loop under the C ABI with 1-5 rounds per read-back (round 6)
                     rps = rnd.choice([0, 1, 2, 3, 5])
                     if rps == 0:
