@@ -1275,7 +1275,7 @@ __device__ __forceinline__ u32 mh_axb_mod(u32 a, u32 x, u32 b) {     // (a x + b
     u32 t = (u32)(v & MH_P) + (u32)(v >> 31);                       // < 2^31 + 4
     return min(t, t - (u32)MH_P);                                   // (t - p wraps when t < p)
 }
-#define MH_KF 4      // hash functions per pass over the k-mers (k = 3 in the reference)
+#define MH_KF 3      // hash functions per pass over the k-mers = the k of the reference (3); 4 per pass computed a fourth, unused minimum: a quarter of the launch's multiplies
 __global__ void __launch_bounds__(256)
 mh_keys_all_kernel(const u32 *__restrict__ xs, const u32 *__restrict__ koff, u32 n, const u64 *__restrict__ ab,
                    int k, int ntables, int t0, int nt, const u32 *__restrict__ grp, u32 *__restrict__ sig_all,
@@ -1295,6 +1295,9 @@ mh_keys_all_kernel(const u32 *__restrict__ xs, const u32 *__restrict__ koff, u32
         for (int q = 0; q < MH_KF; ++q) {
             const int f = min(f0 + q, k - 1);
             a[q] = (u32)(abt[f * 2] % MH_P); b[q] = (u32)abt[f * 2 + 1];
+            // (opaque: the compiler folds zext(trunc(urem)) back into the 64-bit remainder and then multiplies BOTH of its
+            // words by x in the loop -- two v_mad_u64_u32 per function and k-mer instead of one)
+            asm volatile("" : "+v"(a[q]));
             best[q] = 0xffffffffu;
         }
         for (u32 y = 0; y < nk; ++y) {
