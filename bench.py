@@ -1138,7 +1138,7 @@ def main():
             "join_verify": dict(kernel="kj_verify_kernel<%d, true/false> + kj_giant_kernel (key-grouped join: counting + writing pass)" % nw,
                                 ms=ms["verify_ms"] + ms["vcount_ms"], bytes=verify_bytes,
                                 launches=(nlaunch["verify_launches"] + nlaunch["vcount_launches"]) / K, pmc="join_verify"),
-            "solver_claim": dict(kernel="gr_claim_kernel (row-parallel solver, groups of >= 4 M rows)",
+            "solver_claim": dict(kernel="gr_claim_kernel (row-parallel solver, instances of >= 262,144 rows)",
                                  ms=ms["claim_ms"], bytes=per.get("claim_bytes", 0.0),
                                  launches=max(nlaunch["claim_launches"], 1) / K, pmc="gr_claim"),
             "rows_build": dict(kernel="bucketed row build (per group: merge, scans, emit)",

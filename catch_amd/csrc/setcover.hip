@@ -1114,9 +1114,14 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
 
     int no_retry = 0;
     // large instances: the row-parallel, tile-ordered kernels (setcover_flat.inc).
-    // Measured on S4 (rows: rounds of the fused vs the flat kernels): 272 M: 65 vs
-    // 30 ms; 44 M: 9.9 vs 6.7; 29 M: 6.6 vs 4.5; 19 M: 4.0 vs 3.4; 4 M: 1.5 vs 1.5.
-    const i64 flat_min_rows = chip_test_env("CATCHHIP_FLAT_MIN_ROWS") ? atoll(chip_test_env("CATCHHIP_FLAT_MIN_ROWS")) : (i64)1 << 22;
+    // Measured on S4 in round 2 (rows: rounds of the fused vs the flat kernels): 272 M: 65 vs
+    // 30 ms; 44 M: 9.9 vs 6.7; 29 M: 6.6 vs 4.5; 19 M: 4.0 vs 3.4; 4 M: 1.5 vs 1.5 -- hence 2^22 rows until round 6.
+    // Measured again on S3 x 0.25 / 0.5 / 1.0 with the kernels of round 6 (8-byte records, no count launch in round 0,
+    // four rounds per read-back): 0.48 M rows: 1.56 vs 1.29 ms of solver kernels (step 6.9 vs 6.4 ms); 1.2 M: 2.98 vs
+    // 1.68 (11.1 vs 8.0); 3.4 M (configs[2]): 5.96 vs 3.12 (20.1 vs 13.5 -- the fused family also reads back every
+    // round).  So: 2^18 rows.  (Smaller instances never get here through the fused filter: below ~11 Mbases of
+    // targets it queues scan and solve without a synchronisation, chip_greedy_deferred.)
+    const i64 flat_min_rows = chip_test_env("CATCHHIP_FLAT_MIN_ROWS") ? atoll(chip_test_env("CATCHHIP_FLAT_MIN_ROWS")) : (i64)1 << 18;
     if (batched && R->lmax <= 257 && (i64)nrows >= flat_min_rows && nsets <= GR_MAX_SETS)
         return greedy_flat(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out);
     if (batched) return greedy_frontier(ctx, R, nsets, ranks ? h_rank.data() : nullptr, nrank, out_ids, n_out, &no_retry);
