@@ -1574,10 +1574,18 @@ static int bucket_finish_async(catchhip_ctx *ctx, BucketBuild &B, u32 nrec, cons
                                   3 * BK_BIG * (int)sizeof(u32));
         big_attr_set = true;
     }
-    hipLaunchKernelGGL(bucket_merge_big_kernel, dim3((unsigned)ctx->num_cus), dim3(BKB_THREADS), 3 * BK_BIG * sizeof(u32), s,
-                       (const u32 *)B.bstart.p, B.nb, B.S.p, B.mcnt.p, B.blmax.p, bsum,
-                       B.res.p + 1, dedupe ? 1 : 0);
-    tm.launch(3);
+    // four size classes, each with LDS arrays of its own length: 12 / 24 / 48 / 96 KB = 4 / 4 / 3 / 1 workgroups per CU
+    {
+        u32 lo = BK_SMALL;
+        for (u32 cap = 1024; cap <= (u32)BK_BIG; cap <<= 1) {
+            const unsigned per_cu = cap <= 2048 ? 4u : cap <= 4096 ? 3u : 1u;
+            hipLaunchKernelGGL(bucket_merge_big_kernel, dim3((unsigned)ctx->num_cus * per_cu), dim3(BKB_THREADS), 3 * cap * sizeof(u32), s,
+                               (const u32 *)B.bstart.p, B.nb, B.S.p, B.mcnt.p, B.blmax.p, bsum,
+                               B.res.p + 1, dedupe ? 1 : 0, lo, cap);
+            lo = cap;
+        }
+    }
+    tm.launch(6);
     TRY(bucket_scan(ctx, B, B.mcnt.p, B.rstart.p, B.nb, B.res.p + 4, B.blmax.p, B.res.p + 5, tm));
     return 0;
 }
