@@ -200,7 +200,11 @@ seed_count_kernel(const uint4 *__restrict__ pplanes, const u32 *__restrict__ ent
     u32 s = seed_hash(key) & t.mask;
     bool fresh = false;
     for (;;) {
-        const unsigned long long prev = atomicCAS(t.key_at(s), SEED_EMPTY, key);
+        // (round 6: a look first -- a k-mer is the anchor of ~120 probes on S4, and all but the first of them used to pay
+        // a compare-and-swap on the one address that holds it)
+        unsigned long long prev = *(volatile unsigned long long *)t.key_at(s);
+        if (prev == SEED_EMPTY) prev = atomicCAS(t.key_at(s), SEED_EMPTY, key);
+        else if (prev != key) { s = (s + 1) & t.mask; continue; }
         fresh = prev == SEED_EMPTY;
         if (fresh || prev == key) break;
         s = (s + 1) & t.mask;
