@@ -251,8 +251,19 @@ __device__ __forceinline__ void ndf_mark(u32 *st2, u32 i, u32 v) {
     if (st2) atomicOr(&st2[i >> 4], v << ((i & 15u) * 2u));
 }
 
+// Wavefronts per SIMD the register allocation of the two walking kernels aims at (round 6).  They wait on dependent looks
+// (mate -> state -> signature -> codes), so what hides the waiting is how many wavefronts a SIMD holds: the MinHash instances
+// took 118-126 and 82 vector registers = 4 and 5 wavefronts (the probe pass also held to 5 by 32 KB of LDS per workgroup).
+// Per S5 step with one worker under rocprofv3, round-0 pass / probe passes: as compiled 486 / 424 ms; 5 / 6 wavefronts 354 /
+// 325; 6 / 8: 273 / 284 (80 / 64 registers, ~100 bytes of spill); 8 / 8: 317 / 276.
+#ifndef NDF_LAZY_WAVES
+#define NDF_LAZY_WAVES 6
+#endif
+#ifndef NDF_PROBE_WAVES
+#define NDF_PROBE_WAVES 8
+#endif
 template <class Family, bool WAKE, bool DRAIN = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NDF_LAZY_WAVES)))
 ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *__restrict__ vals_all,
                 u32 *__restrict__ cursor_all, u32 *status, u32 *flags, unsigned long long *__restrict__ pairs,
                 const u32 *__restrict__ list, u32 nlist, u32 *__restrict__ next, u32 *__restrict__ next_count,
@@ -484,7 +495,7 @@ ndf_lazy_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *
 // (64 mates per step there).
 #define NDF_PROBE_STEPS 6
 template <class Family>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NDF_PROBE_WAVES)))
 ndf_probe_kernel(Family fam, u32 n, const u64 *__restrict__ keys_all, const u32 *__restrict__ vals_all,
                  u32 *__restrict__ cursor_all, u32 *status, u32 *flags, unsigned long long *__restrict__ pairs,
                  const u32 *__restrict__ list, u32 nlist, u32 *__restrict__ left, const u32 *__restrict__ inv,
@@ -1454,7 +1465,10 @@ struct MinHashFamily {       // same signature in table t (the key only groups),
     u32 tstride;
     static constexpr bool WAVE_NEAR = true;
     static constexpr bool WAVE64 = true;
-    struct Scratch { u64 h[MH_MAXK], l[MH_MAXK]; u32 tab[MH_TAB]; };
+    // (round 6: the two forms of a wavefront's scratch are never live together -- near_wave stages a MATE's ids / codes per
+    // comparison, the shared walk stages the WALKING probe's table for the length of its loop -- so they share their 4 KB:
+    // 16 instead of 32 KB of LDS per workgroup, which was what held ndf_probe_kernel at 5 wavefronts per SIMD)
+    struct Scratch { union { struct { u64 h[MH_MAXK], l[MH_MAXK]; }; u32 tab[MH_TAB]; }; };
     // The shared walk (round 5).  A wavefront that walks ONE probe's run compares that probe with thousands of mates:
     // its k-mer codes go into an open-addressing table in LDS once (wave64_stage), and a comparison is then every lane
     // looking ITS k-mers of the mate up there -- the mate's row read coalesced, no dependent global loads, ~40
