@@ -1235,7 +1235,16 @@ def test_full_size_config3_matches_oracle_digests(ctx):
     assert _digest_in_order(ids) == g["picks_in_order_sha256"]
 
 
-@pytest.mark.parametrize("scale", [0.01, 0.02, 0.05])
+def _config5_scales():
+    """The scales of S5 that tests/golden/full_size_picks.json pins (x 0.1 = 390 Mbp joins when its oracle run --
+    make_full_size.py S5:0.1, hours of CPU -- has been committed)."""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_picks.json")) as f:
+        keys = json.load(f).keys()
+    return sorted(float(k.split(":")[1]) for k in keys if k.startswith("S5:"))
+
+
+@pytest.mark.parametrize("scale", _config5_scales())
 def test_full_size_config5_design_large_matches_oracle_digest(ctx, tmp_path, capsys, scale):
     """BASELINE configs[4] at real scales (S5 x 0.01: 2,132 genomes, 48 Mbp,
     2,598 fragments -> 1,130 clusters, 826 k candidates after the MinHash
