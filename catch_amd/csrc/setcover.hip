@@ -1055,8 +1055,11 @@ static int greedy_frontier(catchhip_ctx *ctx, const catchhip_rows *R, u32 nsets,
 
 // dense ranks: index into sorted(set(ranks.values())) (set_cover.py:353-354)
 static u32 dense_ranks(const i64 *ranks, u32 nsets, std::vector<u32> &h_rank) {
-    h_rank.assign(nsets, 0);
+    // (no ranks: h_rank stays empty -- a zeroed vector of 4 bytes per set was 16 MB of fresh pages per solve of S4's largest
+    // group, 2.8 ms of host time between the row build and the solver's first launch in which the device sat idle)
+    h_rank.clear();
     if (!ranks) return 1;
+    h_rank.assign(nsets, 0);
     std::vector<i64> vals(ranks, ranks + nsets);
     std::sort(vals.begin(), vals.end());
     vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
@@ -1152,7 +1155,8 @@ extern "C" int catchhip_setcover_greedy(catchhip_ctx *ctx, const catchhip_rows *
         TRY(d_p.alloc(nuniv));
         HIP_TRY(hipMemcpyAsync(d_p.p, universe_p, sizeof(double) * nuniv, hipMemcpyHostToDevice, s));
     }
-    HIP_TRY(hipMemcpyAsync(rank.p, h_rank.data(), sizeof(u32) * nsets, hipMemcpyHostToDevice, s));
+    if (ranks) HIP_TRY(hipMemcpyAsync(rank.p, h_rank.data(), sizeof(u32) * nsets, hipMemcpyHostToDevice, s));
+    else HIP_TRY(hipMemsetAsync(rank.p, 0, sizeof(u32) * nsets, s));
     HIP_TRY(hipMemsetAsync(picked.p, 0, sizeof(u32) * nsets, s));
     HIP_TRY(hipMemsetAsync(bm.p, 0, sizeof(unsigned long long) * nwords, s));
     GreedyState h_st;
