@@ -507,6 +507,51 @@ def test_greedy_random_instances_match_oracle(ctx, oracle, monkeypatch, solver):
         assert got == exp, trial
 
 
+@pytest.mark.parametrize("how", ["by rows", "round robin", "by rows, 2 workgroups per CU", "by rows, 16 tiles at least"])
+def test_flat_solver_tiles_dealt_to_xcds(ctx, oracle, monkeypatch, how):
+    """The row-parallel solver's tiles on the XCDs (round 6): ~250 contiguous tiles of very different row counts --
+    a dense half and a sparse half of the coordinate space, some tiles empty -- dealt by rows (the default: largest
+    tile first, to the XCD with the fewest rows so far, at most 32 tiles per XCD), dealt round robin (tile t on XCD
+    t mod 8, as until round 6), with other grid sizes and tile counts: always the oracle's picks in its order, with
+    and without ranks, at full and at partial coverage."""
+    engine = _engine()
+    monkeypatch.setenv("CATCHHIP_FLAT_MIN_ROWS", "0")
+    monkeypatch.setenv("CATCHHIP_FLAT_TILE_SHIFT", "12")          # (raised by the library until there are < 256 tiles)
+    if how == "round robin":
+        monkeypatch.setenv("CATCHHIP_FLAT_TILES_ROUND_ROBIN", "1")
+    if "2 workgroups" in how:
+        monkeypatch.setenv("CATCHHIP_FLAT_WG_PER_CU", "2")
+    if "16 tiles" in how:
+        monkeypatch.setenv("CATCHHIP_FLAT_MIN_TILES", "16")
+    rng = np.random.Generator(np.random.PCG64(20260930))
+    for trial in range(3):
+        U = 40
+        glen = rng.integers(20000, 60000, size=U)
+        P = int(rng.integers(1500, 3000))
+        rows = []
+        for s in range(P):
+            # sets of the dense half cover many universes of the first 20, the others one or two of the last 20;
+            # universes 30-33 are covered by nobody but one set each (nearly empty tiles)
+            dense = s % 3 != 0
+            us = rng.choice(20, size=int(rng.integers(4, 12)), replace=False) if dense else 20 + rng.choice(10, size=int(rng.integers(1, 3)), replace=False)
+            for u in sorted(int(x) for x in us):
+                pos = int(rng.integers(0, glen[u] - 300))
+                ln = int(rng.integers(30, 257))
+                rows.append((s, u, pos, pos + ln))
+        for u in range(30, 34):
+            rows.append((int(rng.integers(0, P)), u, 100, 180))
+        r = np.array(sorted(set(rows)), dtype=np.int64)
+        ranks = rng.integers(0, 3, size=P) if trial == 1 else None
+        up = [float(rng.choice([1.0, 0.9, 0.5])) for _ in range(U)] if trial == 2 else None
+        exp = oracle.approx_multiuniverse(r[:, 0], r[:, 1], r[:, 2], r[:, 3], P, U, None, up, ranks)
+        dev = engine.Rows.from_host(ctx, r[:, 0], r[:, 1], r[:, 2], r[:, 3], glen)
+        got = dev.greedy(P, ranks, up)
+        cn = ctx.counters()
+        dev.close()
+        assert cn["flat_rows_streamed"] > 0
+        assert got == exp, (how, trial)
+
+
 @pytest.mark.parametrize("flat", [False, True, "lds", "contiguous", "contiguous-lds"])
 def test_greedy_batched_rounds_restore_sequential_order(ctx, oracle, monkeypatch, flat):
     """Larger full-coverage instances (many locally maximal sets per round,
