@@ -662,8 +662,13 @@ class SetCoverFilter(BaseFilter):
                 else:
                     # the order in which the lanes will ask for their groups if time goes as cost
                     production, at, clock = [], [0] * nl, [0.0] * nl
+                    # (the lanes' FIRST items, all wanted at time zero, smallest first: the device has work after the few
+                    # milliseconds a small item takes to pack instead of after the ~21 ms of the largest;
+                    # CATCHHIP_PRODUCE_LARGEST_FIRST=1, a test hook: lane order as until round 6)
+                    small_first = _lib.test_env("CATCHHIP_PRODUCE_LARGEST_FIRST", "0") in ("", "0")
                     while len(production) < len(order):
-                        li = min((l for l in range(nl) if at[l] < len(lists[l])), key=lambda l: (clock[l], l))
+                        li = min((l for l in range(nl) if at[l] < len(lists[l])),
+                                 key=lambda l: (clock[l], cost[lists[l][at[l]]] if (small_first and at[l] == 0) else 0.0, l))
                         gi = lists[li][at[li]]
                         production.append(gi)
                         clock[li] += cost[gi]

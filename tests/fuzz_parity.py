@@ -99,6 +99,11 @@ def one_case(seed, ctx):
         return genome.Genome.from_chrs(dict(("c%d" % i, x) for i, x in enumerate(gen)))
     got = f._filter_strs(cands, [[mk(gen) for gen in g] for g in groups])
     assert [sorted(a) for a in got] == [sorted(b) for b in want], desc
+    if not cands[0]:
+        # (seed 1200792: the first group's only sequence of probe length or more is cut by a run of N's into pieces shorter
+        # than a probe -- catch/filter/candidate_probes.py makes no candidate then; the filters above agreed on the empty
+        # selection, and the checks below need a first group with candidates)
+        return
     # rows of the first group through every scan mode that applies
     np.random.seed(np_seed)
     k, entries = oracle.anchor_table(cands[0], m, thres)
