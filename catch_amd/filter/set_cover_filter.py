@@ -661,14 +661,11 @@ class SetCoverFilter(BaseFilter):
                     production = list(order)
                 else:
                     # the order in which the lanes will ask for their groups if time goes as cost
+                    # (round 6, measured and dropped: the lanes' first items produced smallest first, so that the device has
+                    # work after a few milliseconds instead of the ~21 ms the largest group takes to pack: 0.1206 vs 0.1220 s)
                     production, at, clock = [], [0] * nl, [0.0] * nl
-                    # (the lanes' FIRST items, all wanted at time zero, smallest first: the device has work after the few
-                    # milliseconds a small item takes to pack instead of after the ~21 ms of the largest;
-                    # CATCHHIP_PRODUCE_LARGEST_FIRST=1, a test hook: lane order as until round 6)
-                    small_first = _lib.test_env("CATCHHIP_PRODUCE_LARGEST_FIRST", "0") in ("", "0")
                     while len(production) < len(order):
-                        li = min((l for l in range(nl) if at[l] < len(lists[l])),
-                                 key=lambda l: (clock[l], cost[lists[l][at[l]]] if (small_first and at[l] == 0) else 0.0, l))
+                        li = min((l for l in range(nl) if at[l] < len(lists[l])), key=lambda l: (clock[l], l))
                         gi = lists[li][at[li]]
                         production.append(gi)
                         clock[li] += cost[gi]
