@@ -232,6 +232,9 @@ struct catchhip_rows {
     // words": [1] overflow, [2] hits, [4] rows, [5] longest row), info[8..11] =
     // seed counters ([9] seeds), info[12] = seed capacity
     bool deferred = false;
+    // the scan's probes / targets carried group numbers (a union of independent instances, catchhip_*_set_groups): its
+    // coordinate space is a row of unlike groups, which the row-parallel solver cuts into more, smaller tiles
+    bool grouped = false;
     DevBuf<u32> info;
     mutable double seed_ratio_seen = 0.0;   // filled by the deferred solve: seeds per target base of the scan
     DevBuf<i32> set_id;

@@ -2037,6 +2037,7 @@ int chip_cover_scan_nosync(catchhip_ctx *ctx, const catchhip_probes *P, const ca
     R->total = T->total;
     R->ngenomes = T->ngenomes;
     R->h_genome_off = T->h_genome_off;
+    R->grouped = P->has_groups && T->has_groups;
     R->deferred = true;
     R->n = O.S.scap;   // capacity; the row count is info[4]
     int rc = 0;
@@ -2170,6 +2171,7 @@ static int cover_scan_impl(catchhip_ctx *ctx, const catchhip_probes *P, const ca
     R->total = T->total;
     R->ngenomes = T->ngenomes;
     R->h_genome_off = T->h_genome_off;
+    R->grouped = P->has_groups && T->has_groups;
     int rc = 0;
     do {
         if ((rc = R->genome_off.alloc((size_t)T->ngenomes + 1))) break;
